@@ -1,0 +1,111 @@
+"""ctypes binding of lib2dod_hip.so (C ABI: include/frcnn_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a symbol does not resolve
+this module raises, and every op raises on a non-zero status with frcnn_last_error().
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib2dod_hip.so")
+
+
+class ConvDesc(Structure):
+    """frcnn_conv_desc"""
+    _fields_ = [(n, c_int) for n in (
+        "n", "hi", "wi", "in_pix_stride", "cin", "kh", "kw", "stride", "pad_h", "pad_w",
+        "ho", "wo", "cout", "out_h", "out_w", "out_scatter", "flags", "split_k")]
+
+
+CONV_BIAS, CONV_RELU, CONV_OUT_F32, CONV_ADD_RES, CONV_STATS, CONV_SPLITK_ATOMIC = 1, 2, 4, 8, 16, 32
+
+P = c_void_p
+_SIGNATURES = {
+    # name: (restype, [argtypes])
+    "frcnn_abi_version": (c_int, []),
+    "frcnn_last_error": (c_char_p, []),
+    "frcnn_conv2d_stat_tiles": (c_int, [POINTER(ConvDesc)]),
+    "frcnn_conv2d_fprop": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
+    "frcnn_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
+    "frcnn_weights_transpose_flip": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "frcnn_cast_f32_bf16": (c_int, [P, P, c_int64, P]),
+    "frcnn_stem_pack_weights": (c_int, [P, P, c_int, P]),
+    "frcnn_stem_unpack_grad": (c_int, [P, P, c_int, P]),
+    "frcnn_preprocess_u8_bgr_mean": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "frcnn_bn_finalize_train": (c_int, [P, c_int, c_int, c_int64, P, P, P, P, c_float, c_float, P, P, P, P, P]),
+    "frcnn_bn_finalize_eval": (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
+    "frcnn_bn_apply": (c_int, [P, P, P, P, c_int, P, c_int64, c_int, P]),
+    "frcnn_bn_bwd_blocks": (c_int, [c_int64]),
+    "frcnn_bn_bwd_reduce": (c_int, [P, P, P, P, P, P, c_int64, c_int, P]),
+    "frcnn_bn_bwd_finalize": (c_int, [P, c_int, c_int, c_int64, P, P, P, P, P]),
+    "frcnn_bn_bwd_apply": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int64, c_int, P]),
+    "frcnn_relu_bwd": (c_int, [P, P, P, c_int64, P]),
+    "frcnn_colsum_bf16": (c_int, [P, c_int64, c_int, c_int, P, P]),
+    "frcnn_maxpool3x3s2_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "frcnn_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "frcnn_sgd_momentum": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, P, P, P, c_int, P]),
+    "frcnn_step_increment": (c_int, [P, P]),
+    "frcnn_anchors_generate": (c_int, [P, c_int, c_int, POINTER(c_float), c_int, POINTER(c_float), c_int,
+                                       c_float, c_float, c_float, c_float, P]),
+    "frcnn_rpn_head_post": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P]),
+    "frcnn_clip_to_window": (c_int, [P, P, c_int64, c_float, c_float, c_float, c_float, P]),
+    "frcnn_decode_boxes": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_float, c_float, P]),
+    "frcnn_nms_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "frcnn_nms_combined": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                   P, P, P, P, P, c_size_t, P]),
+    "frcnn_roi_crop_pool_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "frcnn_roi_crop_pool_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "frcnn_rcnn_head_post": (c_int, [P, c_int, P, c_int, c_int, P, P, P]),
+    "frcnn_boxes_scale": (c_int, [P, P, c_int64, c_float, c_float, P]),
+    "frcnn_assign_targets": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
+                                     c_float, c_float, c_float, P, P, P]),
+    "frcnn_sample_indices": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_uint64, P, c_int, P, P, P, P]),
+    "frcnn_losses": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P]),
+    "frcnn_rpn_head_grad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
+    "frcnn_rcnn_head_grad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (after torch, so that both share one libamdhip64) and bind every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            "%s not found: build it with `python 2d_object_detection_amd/csrc/build.py` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (loads torch's bundled libamdhip64.so.7 first; same SONAME is then reused)
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError("symbol %s missing from %s" % (name, LIB_PATH)) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().frcnn_last_error()
+        raise RuntimeError("%s failed (%d): %s" % (what or "frcnn call", rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on error."""
+    rc = getattr(load(), name)(*args)
+    check(rc, name)

@@ -1,0 +1,398 @@
+// Anchors, RPN head post-processing, box decode and the batched per-class NMS
+// (tf.image.combined_non_max_suppression as used by the reference's utils/post_processing.py).
+//
+// Box arithmetic is compiled with -ffp-contract=off so that IoU comparisons are bit-identical
+// to the C oracle (no FMA contraction).
+//
+// NMS design (wavefront primitives, one 1024-thread workgroup per (image, class)):
+//   1. keys = (score bits << 32 | ~index) for score > threshold, else 0; bitonic sort descending
+//      in LDS (n_pad <= 16384) or in a global scratch slab (larger N);
+//   2. greedy selection in chunks of 64 sorted candidates: every candidate is tested against the
+//      kept list (16 threads per candidate striding the list, reduced with a 16-lane OR), then the
+//      64x64 intra-chunk suppression matrix is built with one __ballot per row and resolved by a
+//      64-step scalar scan in wave 0; survivors are appended to the kept list in LDS.
+//      The loop ends when max_per_class boxes are kept or candidates run out -- no host sync.
+//   3. one workgroup per image merges the classes: bitonic sort of the <= C*max_per_class kept
+//      (score, class, slot) keys, top max_total written clipped to [0,1], remainder zero.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ---------------------------------------------------------------- anchors
+struct AnchorShapes { float w[64]; float h[64]; int na; };
+
+__global__ void anchors_kernel(float* __restrict__ out, int gh, int gw, AnchorShapes sh, float stride_h, float stride_w) {
+    const int total = gh * gw * sh.na;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int k = i % sh.na;
+        const int loc = i / sh.na;
+        const int x = loc % gw, y = loc / gw;
+        const float xc = (float)x * stride_w, yc = (float)y * stride_h;
+        const float hw = 0.5f * sh.w[k], hh = 0.5f * sh.h[k];
+        f32x4 b = {xc - hw, yc - hh, xc + hw, yc + hh};
+        *reinterpret_cast<f32x4*>(out + (int64_t)i * 4) = b;
+    }
+}
+
+// ---------------------------------------------------------------- RPN head post
+__global__ void rpn_head_post_kernel(const float* __restrict__ head, int ld, int B, int A_total, int apl, const int* __restrict__ keep,
+                                     int n, float* __restrict__ scores, float* __restrict__ deltas) {
+    const int total = B * n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / n, j = i - b * n;
+        const int a = keep ? keep[j] : j;
+        const int loc = a / apl, k = a - loc * apl;
+        const int locs = A_total / apl;
+        const float* row = head + ((int64_t)b * locs + loc) * ld;
+        const float l0 = row[2 * k], l1 = row[2 * k + 1];
+        const float mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        const float inv = 1.f / (e0 + e1);
+        scores[(int64_t)i * 2] = e0 * inv;
+        scores[(int64_t)i * 2 + 1] = e1 * inv;
+        const float* d = row + 2 * apl + 4 * k;
+        *reinterpret_cast<f32x4*>(deltas + (int64_t)i * 4) = f32x4{d[0], d[1], d[2], d[3]};
+    }
+}
+
+__global__ void clip_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, float x0, float y0, float x1, float y1) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(in + i * 4);
+        b[0] = fmaxf(fminf(b[0], x1), x0);
+        b[1] = fmaxf(fminf(b[1], y1), y0);
+        b[2] = fmaxf(fminf(b[2], x1), x0);
+        b[3] = fmaxf(fminf(b[3], y1), y0);
+        *reinterpret_cast<f32x4*>(out + i * 4) = b;
+    }
+}
+
+__global__ void scale_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, float sx, float sy) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(in + i * 4);
+        b[0] *= sx; b[1] *= sy; b[2] *= sx; b[3] *= sy;
+        *reinterpret_cast<f32x4*>(out + i * 4) = b;
+    }
+}
+
+// utils/boxes.py:20-41 + :86-93
+__global__ void decode_kernel(const float* __restrict__ regions, int rpi, const float* __restrict__ deltas, float* __restrict__ out, int B,
+                              int R, int C, float W, float H) {
+    const int64_t total = (int64_t)B * R * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t br = i / C;
+        const int r = (int)(br % R);
+        const int b = (int)(br / R);
+        const f32x4 ref = *reinterpret_cast<const f32x4*>(regions + ((rpi ? (int64_t)b * R : 0) + r) * 4);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(deltas + i * 4);
+        const float cxr = (ref[2] + ref[0]) / 2.0f, cyr = (ref[3] + ref[1]) / 2.0f;
+        const float wr = ref[2] - ref[0], hr = ref[3] - ref[1];
+        const float cx = d[0] * wr + cxr, cy = d[1] * hr + cyr;
+        const float w = expf(d[2]) * wr, h = expf(d[3]) * hr;
+        f32x4 o = {(cx - 0.5f * w) / W, (cy - 0.5f * h) / H, (cx + 0.5f * w) / W, (cy + 0.5f * h) / H};
+        *reinterpret_cast<f32x4*>(out + i * 4) = o;
+    }
+}
+
+// ---------------------------------------------------------------- NMS
+__device__ __forceinline__ float nms_iou(const f32x4 a, const f32x4 b) {
+    const float y0i = fminf(a[0], a[2]), x0i = fminf(a[1], a[3]);
+    const float y1i = fmaxf(a[0], a[2]), x1i = fmaxf(a[1], a[3]);
+    const float y0j = fminf(b[0], b[2]), x0j = fminf(b[1], b[3]);
+    const float y1j = fmaxf(b[0], b[2]), x1j = fmaxf(b[1], b[3]);
+    const float area_i = (y1i - y0i) * (x1i - x0i);
+    const float area_j = (y1j - y0j) * (x1j - x0j);
+    if (area_i <= 0.0f || area_j <= 0.0f) return 0.0f;
+    const float iy0 = fmaxf(y0i, y0j), ix0 = fmaxf(x0i, x0j);
+    const float iy1 = fminf(y1i, y1j), ix1 = fminf(x1i, x1j);
+    const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
+    return inter / (area_i + area_j - inter);
+}
+
+// order-preserving float -> uint (handles negatives too)
+__device__ __forceinline__ unsigned int float_key(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned int k) {
+    const unsigned int u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+
+constexpr int NMS_T = 1024;
+constexpr int NMS_LDS_KEYS = 16384;
+
+// descending bitonic sort of n_pad (power of two) u64 keys by NMS_T threads
+__device__ void bitonic_desc(unsigned long long* keys, int n_pad) {
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (n_pad >> 1); t += blockDim.x) {
+                const int i = ((t / j) * 2 * j) + (t % j);     // lower index of the pair
+                const int l = i + j;
+                const bool desc = ((i & k) == 0);
+                const unsigned long long a = keys[i], b = keys[l];
+                if ((a < b) == desc) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+struct NmsParams {
+    const float* boxes; const float* scores;
+    int N, q, C, score_stride, score_offset, max_per_class, n_pad;
+    float iou_thr, score_thr;
+    unsigned long long* gkeys;       // global scratch [B*C][n_pad] (only when n_pad > NMS_LDS_KEYS)
+    unsigned long long* kept_keys;   // [B][C*max_per_class]: (score key << 32 | ~(class*max_per_class + slot)) or 0
+    int* kept_idx;                   // [B][C*max_per_class] box index
+};
+
+__global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS: [kept boxes f32x4 * max_per_class][chunk boxes 64 f32x4][chunk alive/sup 64 u64 x2][misc][keys...]
+    f32x4* kept_box = reinterpret_cast<f32x4*>(smem);
+    f32x4* chunk_box = kept_box + p.max_per_class;
+    unsigned long long* sup_by = reinterpret_cast<unsigned long long*>(chunk_box + 64);   // [64] mask of earlier chunk members suppressing me
+    int* dead = reinterpret_cast<int*>(sup_by + 64);                                      // [64] suppressed by kept list
+    int* misc = dead + 64;                                                                 // [0]=kept count [1]=num valid
+    unsigned long long* lkeys = reinterpret_cast<unsigned long long*>(misc + 4);
+
+    const int b = blockIdx.x / p.C, c = blockIdx.x % p.C;
+    const int bc = (p.q == 1) ? 0 : c;
+    const float* boxes = p.boxes + (int64_t)b * p.N * p.q * 4;
+    unsigned long long* keys = (p.n_pad <= NMS_LDS_KEYS) ? lkeys : p.gkeys + (int64_t)blockIdx.x * p.n_pad;
+
+    for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) {
+        unsigned long long k = 0ull;
+        if (i < p.N) {
+            const float s = p.scores[((int64_t)b * p.N + i) * p.score_stride + p.score_offset + c];
+            if (s > p.score_thr) k = ((unsigned long long)float_key(s) << 32) | (unsigned int)(~(unsigned int)i);
+        }
+        keys[i] = k;
+    }
+    if (threadIdx.x == 0) { misc[0] = 0; }
+    __syncthreads();
+    bitonic_desc(keys, p.n_pad);
+
+    const int lane = threadIdx.x & 63;
+    int kept = 0;
+    for (int base = 0; base < p.n_pad; base += 64) {
+        // ---- load chunk (first 64 threads)
+        if (threadIdx.x < 64) {
+            const unsigned long long k = keys[base + threadIdx.x];
+            f32x4 bx = {0.f, 0.f, 0.f, 0.f};
+            if (k != 0ull) {
+                const unsigned int idx = ~(unsigned int)(k & 0xFFFFFFFFull);
+                bx = *reinterpret_cast<const f32x4*>(boxes + ((int64_t)idx * p.q + bc) * 4);
+            }
+            chunk_box[threadIdx.x] = bx;
+            dead[threadIdx.x] = (k == 0ull) ? 1 : 0;
+        }
+        __syncthreads();
+        if (keys[base] == 0ull) break;        // sorted: nothing valid left (uniform: same value for all threads)
+        // ---- test against the kept list: 16 threads per candidate
+        {
+            const int cand = threadIdx.x >> 4, sub = threadIdx.x & 15;
+            const f32x4 cb = chunk_box[cand];
+            int hit = 0;
+            for (int j = sub; j < kept; j += 16)
+                if (nms_iou(cb, kept_box[j]) > p.iou_thr) { hit = 1; break; }
+            // OR over the 16 sub-lanes
+            hit |= __shfl_xor(hit, 1); hit |= __shfl_xor(hit, 2); hit |= __shfl_xor(hit, 4); hit |= __shfl_xor(hit, 8);
+            if (sub == 0 && hit) dead[cand] = 1;
+        }
+        // ---- intra-chunk suppression matrix: wave w handles rows w, w+16, ...
+        {
+            const int wave = threadIdx.x >> 6;
+            const f32x4 mine = chunk_box[lane];
+            for (int r = wave; r < 64; r += NMS_T / 64) {
+                // row r: which earlier members j < r suppress r?  lane j evaluates iou(j, r)
+                const bool s = (lane < r) && (nms_iou(mine, chunk_box[r]) > p.iou_thr);
+                const unsigned long long m = __ballot(s);
+                if (lane == 0) sup_by[r] = m;
+            }
+        }
+        __syncthreads();
+        // ---- sequential resolve in wave 0: 64 scalar steps on readlane'd (SGPR) values
+        if (threadIdx.x < 64) {
+            const unsigned long long my_sup = sup_by[lane];
+            const int sup_lo = (int)(unsigned int)my_sup, sup_hi = (int)(unsigned int)(my_sup >> 32);
+            const int my_dead = dead[lane];
+            unsigned long long kept_mask = 0ull;
+            int k_now = kept;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const unsigned int slo = (unsigned int)__builtin_amdgcn_readlane(sup_lo, i);
+                const unsigned int shi = (unsigned int)__builtin_amdgcn_readlane(sup_hi, i);
+                const int d_i = __builtin_amdgcn_readlane(my_dead, i);
+                const unsigned long long s_i = ((unsigned long long)shi << 32) | slo;
+                if (!d_i && (s_i & kept_mask) == 0ull && k_now < p.max_per_class) { kept_mask |= (1ull << i); ++k_now; }
+            }
+            if ((kept_mask >> lane) & 1ull) {
+                const int slot = kept + __popcll(kept_mask & ((1ull << lane) - 1ull));
+                kept_box[slot] = chunk_box[lane];
+                const unsigned long long k = keys[base + lane];
+                const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + slot;
+                p.kept_keys[o] = (k & 0xFFFFFFFF00000000ull) | (unsigned int)(~(unsigned int)(c * p.max_per_class + slot));
+                p.kept_idx[o] = (int)(~(unsigned int)(k & 0xFFFFFFFFull));
+            }
+            if (lane == 0) misc[0] = k_now;
+        }
+        __syncthreads();
+        kept = misc[0];
+        if (kept >= p.max_per_class) break;
+    }
+    // zero the unused kept slots of this (image, class)
+    for (int s = kept + threadIdx.x; s < p.max_per_class; s += blockDim.x) {
+        const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + s;
+        p.kept_keys[o] = 0ull;
+        p.kept_idx[o] = 0;
+    }
+}
+
+struct MergeParams {
+    const float* boxes; const unsigned long long* kept_keys; const int* kept_idx;
+    int N, q, C, max_per_class, max_total, m_pad;
+    float* out_boxes; float* out_scores; int* out_classes; int* out_valid;
+};
+
+__global__ __launch_bounds__(NMS_T) void nms_merge_kernel(const MergeParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    int& nvalid = *reinterpret_cast<int*>(keys + p.m_pad);
+    const int b = blockIdx.x;
+    const int total = p.C * p.max_per_class;
+    if (threadIdx.x == 0) nvalid = 0;
+    for (int i = threadIdx.x; i < p.m_pad; i += blockDim.x) keys[i] = i < total ? p.kept_keys[(int64_t)b * total + i] : 0ull;
+    __syncthreads();
+    bitonic_desc(keys, p.m_pad);
+    int cnt = 0;
+    for (int t = threadIdx.x; t < p.max_total; t += blockDim.x) {
+        const unsigned long long k = keys[t];
+        f32x4 bx = {0.f, 0.f, 0.f, 0.f};
+        float s = 0.f;
+        int cls = 0;
+        if (k != 0ull) {
+            const unsigned int cs = ~(unsigned int)(k & 0xFFFFFFFFull);          // class*max_per_class + slot
+            cls = (int)(cs / (unsigned)p.max_per_class);
+            const int idx = p.kept_idx[(int64_t)b * total + cs];
+            const int bc = (p.q == 1) ? 0 : cls;
+            bx = *reinterpret_cast<const f32x4*>(p.boxes + (((int64_t)b * p.N + idx) * p.q + bc) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bx[e] = fminf(fmaxf(bx[e], 0.0f), 1.0f);
+            s = key_float((unsigned int)(k >> 32));
+            ++cnt;
+        }
+        *reinterpret_cast<f32x4*>(p.out_boxes + ((int64_t)b * p.max_total + t) * 4) = bx;
+        p.out_scores[(int64_t)b * p.max_total + t] = s;
+        p.out_classes[(int64_t)b * p.max_total + t] = cls;
+    }
+    if (cnt) atomicAdd(&nvalid, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) p.out_valid[b] = nvalid;
+}
+
+int next_pow2(int v) { int p = 64; while (p < v) p <<= 1; return p; }
+
+}  // namespace
+
+#define S_(stream) reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int frcnn_anchors_generate(float* anchors, int gh, int gw, const float* scales, int ns, const float* ratios, int nr,
+                                      float base_h, float base_w, float stride_h, float stride_w, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(anchors && scales && ratios && ns * nr <= 64 && ns > 0 && nr > 0, "anchors_generate: bad arguments");
+    AnchorShapes sh;
+    sh.na = ns * nr;
+    for (int r = 0; r < nr; ++r)
+        for (int s = 0; s < ns; ++s) {
+            // rpn_detector.py:182-184 in fp32: heights = scales / sqrt(ratio) * base[0]; widths = scales * sqrt(ratio) * base[1]
+            const float rs = sqrtf(ratios[r]);
+            volatile float hq = scales[s] / rs;
+            volatile float wq = scales[s] * rs;
+            sh.h[r * ns + s] = hq * base_h;
+            sh.w[r * ns + s] = wq * base_w;
+        }
+    const int total = gh * gw * sh.na;
+    hipLaunchKernelGGL(anchors_kernel, dim3(cdiv(total, 256)), dim3(256), 0, S_(stream), anchors, gh, gw, sh, stride_h, stride_w);
+    FRCNN_CHECK_LAUNCH("anchors_generate");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_rpn_head_post(const float* head, int ld, int b, int num_anchors_total, int a_per_loc, const int32_t* keep, int n,
+                                   float* scores, float* deltas, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(head && scores && deltas && ld >= 6 * a_per_loc && num_anchors_total % a_per_loc == 0 && n > 0, "rpn_head_post: bad arguments");
+    hipLaunchKernelGGL(rpn_head_post_kernel, dim3(cdiv((int64_t)b * n, 256)), dim3(256), 0, S_(stream), head, ld, b, num_anchors_total,
+                       a_per_loc, keep, n, scores, deltas);
+    FRCNN_CHECK_LAUNCH("rpn_head_post");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_clip_to_window(const float* boxes, float* out, int64_t n, float x0, float y0, float x1, float y1, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(boxes && out, "clip_to_window: null pointer");
+    hipLaunchKernelGGL(clip_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), boxes, out, n, x0, y0, x1, y1);
+    FRCNN_CHECK_LAUNCH("clip_to_window");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_boxes_scale(const float* in, float* out, int64_t n, float sx, float sy, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(in && out, "boxes_scale: null pointer");
+    hipLaunchKernelGGL(scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), in, out, n, sx, sy);
+    FRCNN_CHECK_LAUNCH("boxes_scale");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_decode_boxes(const float* regions, int regions_per_image, const float* deltas, float* out, int b, int r, int c,
+                                  float img_w, float img_h, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(regions && deltas && out && b > 0 && r > 0 && c > 0, "decode_boxes: bad arguments");
+    const int64_t total = (int64_t)b * r * c;
+    hipLaunchKernelGGL(decode_kernel, dim3(cdiv(total, 256)), dim3(256), 0, S_(stream), regions, regions_per_image, deltas, out, b, r, c,
+                       img_w, img_h);
+    FRCNN_CHECK_LAUNCH("decode_boxes");
+    return FRCNN_OK;
+}
+
+extern "C" size_t frcnn_nms_workspace_bytes(int b, int n, int c, int max_per_class, int max_total) {
+    (void)max_total;
+    const int n_pad = next_pow2(n);
+    size_t bytes = (size_t)b * c * max_per_class * (sizeof(unsigned long long) + sizeof(int));
+    if (n_pad > NMS_LDS_KEYS) bytes += (size_t)b * c * n_pad * sizeof(unsigned long long);
+    return (bytes + 255) & ~(size_t)255;
+}
+
+extern "C" int frcnn_nms_combined(const float* boxes, const float* scores, int b, int n, int q, int c, int score_stride, int score_offset,
+                                  int max_per_class, int max_total, float iou_thr, float score_thr, float* out_boxes, float* out_scores,
+                                  int32_t* out_classes, int32_t* out_valid, void* workspace, size_t workspace_bytes,
+                                  frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(boxes && scores && out_boxes && out_scores && out_classes && out_valid && workspace, "nms_combined: null pointer");
+    FRCNN_CHECK_ARG(b > 0 && n > 0 && c > 0 && (q == 1 || q == c) && max_per_class > 0 && max_total > 0, "nms_combined: bad sizes");
+    FRCNN_CHECK_ARG(workspace_bytes >= frcnn_nms_workspace_bytes(b, n, c, max_per_class, max_total), "nms_combined: workspace too small");
+    FRCNN_CHECK_ARG(max_per_class <= 4096, "nms_combined: max_output_size_per_class=%d > 4096 unsupported", max_per_class);
+    const int n_pad = next_pow2(n);
+    FRCNN_CHECK_ARG(n_pad <= (1 << 20), "nms_combined: N too large");
+    const int m_pad = next_pow2(c * max_per_class);
+    FRCNN_CHECK_ARG(m_pad <= NMS_LDS_KEYS, "nms_combined: C*max_per_class=%d too large", c * max_per_class);
+
+    unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+    NmsParams p;
+    p.boxes = boxes; p.scores = scores; p.N = n; p.q = q; p.C = c; p.score_stride = score_stride; p.score_offset = score_offset;
+    p.max_per_class = max_per_class; p.n_pad = n_pad; p.iou_thr = iou_thr; p.score_thr = score_thr;
+    p.kept_keys = reinterpret_cast<unsigned long long*>(ws);
+    p.kept_idx = reinterpret_cast<int*>(ws + (size_t)b * c * max_per_class * sizeof(unsigned long long));
+    p.gkeys = reinterpret_cast<unsigned long long*>(ws + (size_t)b * c * max_per_class * (sizeof(unsigned long long) + sizeof(int)));
+    // keep the u64 scratch 8-byte aligned
+    if (((size_t)b * c * max_per_class * sizeof(int)) % 8) p.gkeys = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(p.gkeys) + 4);
+    size_t smem = (size_t)max_per_class * 16 + 64 * 16 + 64 * 8 + 64 * 4 + 16;
+    if (n_pad <= NMS_LDS_KEYS) smem += (size_t)n_pad * 8;
+    FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(nms_class_kernel), smem) == 0, "nms_combined: cannot reserve %zu B of LDS", smem);
+    hipLaunchKernelGGL(nms_class_kernel, dim3(b * c), dim3(NMS_T), smem, S_(stream), p);
+    FRCNN_CHECK_LAUNCH("nms_combined(class)");
+
+    MergeParams m;
+    m.boxes = boxes; m.kept_keys = p.kept_keys; m.kept_idx = p.kept_idx; m.N = n; m.q = q; m.C = c; m.max_per_class = max_per_class;
+    m.max_total = max_total; m.m_pad = m_pad; m.out_boxes = out_boxes; m.out_scores = out_scores; m.out_classes = out_classes;
+    m.out_valid = out_valid;
+    hipLaunchKernelGGL(nms_merge_kernel, dim3(b), dim3(NMS_T), (size_t)m_pad * 8 + 16, S_(stream), m);
+    FRCNN_CHECK_LAUNCH("nms_combined(merge)");
+    return FRCNN_OK;
+}

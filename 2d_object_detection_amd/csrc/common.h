@@ -1,0 +1,82 @@
+// Shared device/host helpers for the gfx950 Faster-RCNN kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/frcnn_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+void frcnn_set_error(const char* fmt, ...);
+
+#define FRCNN_CHECK_ARG(cond, ...)                 \
+    do {                                           \
+        if (!(cond)) {                             \
+            frcnn_set_error(__VA_ARGS__);          \
+            return FRCNN_EINVAL;                   \
+        }                                          \
+    } while (0)
+
+#define FRCNN_CHECK_LAUNCH(name)                                                   \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            frcnn_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return FRCNN_ELAUNCH;                                                  \
+        }                                                                          \
+    } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Dynamic LDS above 64 KiB must be opted into per kernel (gfx950 has 160 KiB per CU).  Not a
+// stream operation and idempotent, so it is safe under graph capture.
+static inline int frcnn_allow_big_lds(const void* func, size_t bytes) {
+    if (bytes <= 65536) return 0;
+    if (bytes > 163840) return -1;
+    return hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned int)b) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    bf16_t h = (bf16_t)f;                       // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf16_round(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
+
+// unpack 8 bf16 (one 16-byte vector) to floats and back
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xFFFF0000u);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v[i] = (unsigned int)f32_to_bf16_bits(f[2 * i]) | ((unsigned int)f32_to_bf16_bits(f[2 * i + 1]) << 16);
+    return v;
+}
+
+// Philox4x32-10 (shared by the sampler; oracle/philox.py is the numpy twin)
+__device__ __forceinline__ unsigned int philox_first(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
+                                                     unsigned int k0, unsigned int k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0;
+        const unsigned long long p1 = 0xCD9E8D57ull * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (unsigned int)p1; c2 = n2; c3 = (unsigned int)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}

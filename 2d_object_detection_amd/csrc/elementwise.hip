@@ -1,0 +1,540 @@
+// HBM-bound elementwise / reduction kernels of the backbone: preprocess, BatchNorm (apply,
+// backward reduce / apply), ReLU backward, max-pool, SGD, weight re-layouts.
+// All activations are NHWC bf16 and are moved as 16-byte vectors (8 channels per lane), rows
+// grid-strided over <= 2048 workgroups.
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+void frcnn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* frcnn_last_error(void) { return g_err; }
+extern "C" int frcnn_abi_version(void) { return 1; }
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+inline int grid_for(int64_t work_items, int threads) {
+    int64_t b = (work_items + threads - 1) / threads;
+    if (b < 1) b = 1;
+    return (int)(b > kMaxBlocks ? kMaxBlocks : b);
+}
+
+// ---------------------------------------------------------------- preprocess
+__global__ void preprocess_kernel(const uint8_t* __restrict__ img, bf16_t* __restrict__ out, int B, int H, int W, int Hp,
+                                  int Wp, int pad) {
+    const int64_t total = (int64_t)B * Hp * Wp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xp = (int)(i % Wp);
+        const int64_t t = i / Wp;
+        const int yp = (int)(t % Hp);
+        const int b = (int)(t / Hp);
+        const int x = xp - pad, y = yp - pad;
+        u32x2 v = {0u, 0u};
+        if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+            const uint8_t* px = img + (((int64_t)b * H + y) * W + x) * 3;
+            const float bl = (float)px[2] - 103.939f, g = (float)px[1] - 116.779f, r = (float)px[0] - 123.68f;
+            v[0] = (unsigned)f32_to_bf16_bits(bl) | ((unsigned)f32_to_bf16_bits(g) << 16);
+            v[1] = (unsigned)f32_to_bf16_bits(r);
+        }
+        *reinterpret_cast<u32x2*>(out + i * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------- BN finalize
+__global__ void bn_finalize_train_kernel(const float* __restrict__ part, int tiles, int C, float inv_count, float unbias,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
+                                         float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
+                                         float* __restrict__ invstd_o) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int t = 0; t < tiles; ++t) {
+        s += (double)part[((int64_t)t * 2) * C + c];
+        ss += (double)part[((int64_t)t * 2 + 1) * C + c];
+    }
+    const double mean = s * inv_count;
+    double var = ss * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    mean_o[c] = (float)mean;
+    invstd_o[c] = invstd;
+    mm[c] = mm[c] * momentum + (float)mean * (1.f - momentum);
+    mv[c] = mv[c] * momentum + (float)(var * unbias) * (1.f - momentum);
+}
+
+__global__ void bn_finalize_eval_kernel(int C, const float* gamma, const float* beta, const float* mm, const float* mv,
+                                        float eps, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(mv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - mm[c] * sc;
+}
+
+// ---------------------------------------------------------------- BN apply (+res, +relu)
+__global__ void bn_apply_kernel(const bf16_t* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
+                                const bf16_t* __restrict__ res, int relu, bf16_t* __restrict__ out, int64_t nvec, int C8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8) * 8;
+        float v[8], r[8];
+        unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), v);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + c), s1 = *reinterpret_cast<const f32x4*>(scale + c + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + c), h1 = *reinterpret_cast<const f32x4*>(shift + c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = v[e] * s0[e] + h0[e];
+            v[e + 4] = v[e + 4] * s1[e] + h1[e];
+        }
+        if (res) {
+            unpack8(*reinterpret_cast<const u32x4*>(res + i * 8), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<u32x4*>(out + i * 8) = pack8(v);
+    }
+}
+
+// ---------------------------------------------------------------- BN backward
+// Block = 256 threads arranged as (C8 lanes over channel vectors) x (256/C8 row lanes) when C8 <= 256.
+// Generic layout: thread handles channel-vector cv = tid % C8L and rows rl, rl+RL, ... of its block slab.
+constexpr int kBwdRowsPerBlock = 256;   // rows per reduce block
+template <bool MASK>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ act,
+                                                            const bf16_t* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* __restrict__ part,
+                                                            int64_t M, int C) {
+    // one block reduces kBwdRowsPerBlock rows for all channels; channel vectors are looped when C8 > 256
+    extern __shared__ float red[];      // [256][16] floats
+    const int C8 = C / 8;
+    const int64_t row_begin = (int64_t)blockIdx.x * kBwdRowsPerBlock;
+    const int64_t row_end = min(M, row_begin + kBwdRowsPerBlock);
+    const int lanes_c = C8 < 256 ? C8 : 256;
+    const int RL = 256 / lanes_c;       // row lanes
+    for (int cv0 = 0; cv0 < C8; cv0 += lanes_c) {
+        const int cl = threadIdx.x % lanes_c, rl = threadIdx.x / lanes_c;
+        const int cv = cv0 + cl;
+        float sg[8], sgx[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sg[e] = sgx[e] = 0.f;
+        if (cv < C8 && rl < RL) {
+            float mu[8], is[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { mu[e] = mean[cv * 8 + e]; is[e] = invstd[cv * 8 + e]; }
+            for (int64_t r = row_begin + rl; r < row_end; r += RL) {
+                float g[8], zz[8];
+                unpack8(*reinterpret_cast<const u32x4*>(gout + (r * C8 + cv) * 8), g);
+                unpack8(*reinterpret_cast<const u32x4*>(z + (r * C8 + cv) * 8), zz);
+                if (MASK) {
+                    float a[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(act + (r * C8 + cv) * 8), a);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sg[e] += g[e];
+                    sgx[e] += g[e] * ((zz[e] - mu[e]) * is[e]);
+                }
+            }
+        }
+        // reduce over row lanes through LDS
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = sg[e]; red[threadIdx.x * 16 + 8 + e] = sgx[e]; }
+        __syncthreads();
+        if (threadIdx.x < lanes_c && cv0 + threadIdx.x < C8) {
+            float a[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[e] = 0.f;
+            for (int k = 0; k < RL; ++k)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) a[e] += red[(k * lanes_c + threadIdx.x) * 16 + e];
+            float* dst = part + ((int64_t)blockIdx.x * 2) * C + (cv0 + threadIdx.x) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dst[e] = a[e]; dst[C + e] = a[8 + e]; }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int blocks, int C, float inv_m, float* dgamma,
+                                       float* dbeta, float* c1, float* c2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sx = 0.0;
+    for (int t = 0; t < blocks; ++t) {
+        s += (double)part[((int64_t)t * 2) * C + c];
+        sx += (double)part[((int64_t)t * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)sx;
+    c1[c] = (float)(s * inv_m);
+    c2[c] = (float)(sx * inv_m);
+}
+
+template <bool MASK>
+__global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ act, const bf16_t* __restrict__ z,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ c1, const float* __restrict__ c2,
+                                    bf16_t* __restrict__ dz, bf16_t* __restrict__ gpre, int64_t nvec, int C8) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8) * 8;
+        float g[8], zz[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4*>(gout + i * 8), g);
+        unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), zz);
+        if (MASK) {
+            float a[8];
+            unpack8(*reinterpret_cast<const u32x4*>(act + i * 8), a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float is = invstd[c + e];
+            const float xh = (zz[e] - mean[c + e]) * is;
+            o[e] = gamma[c + e] * is * (g[e] - c1[c + e] - xh * c2[c + e]);
+        }
+        *reinterpret_cast<u32x4*>(dz + i * 8) = pack8(o);
+        if (gpre) *reinterpret_cast<u32x4*>(gpre + i * 8) = pack8(g);
+    }
+}
+
+__global__ void relu_bwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ act, bf16_t* __restrict__ out, int64_t nvec) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        unpack8(*reinterpret_cast<const u32x4*>(g + i * 8), a);
+        unpack8(*reinterpret_cast<const u32x4*>(act + i * 8), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = b[e] > 0.f ? a[e] : 0.f;
+        *reinterpret_cast<u32x4*>(out + i * 8) = pack8(a);
+    }
+}
+
+// column sums of a bf16 matrix [m, ld] (first c columns): one block per 64 columns, 256 threads = 4 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int64_t m, int c, int ld, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (col < c)
+        for (int64_t r = rl; r < m; r += 4) s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(x + r * ld + col));
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && col < c) out[col] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+}
+
+// ---------------------------------------------------------------- max pool 3x3 / 2 with zero pad 1
+__global__ void maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, uint8_t* __restrict__ amax, int N, int H,
+                                   int W, int C8, int Ho, int Wo) {
+    const int64_t total = (int64_t)N * Ho * Wo * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % C8);
+        int64_t t = i / C8;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float best[8];
+        unsigned char arg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -1.f; arg[e] = 0; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int iy = oy * 2 - 1 + k / 3, ix = ox * 2 - 1 + k % 3;
+            float v[8];
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                unpack8(*reinterpret_cast<const u32x4*>(x + ((((int64_t)n * H + iy) * W + ix) * C8 + cv) * 8), v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;     // ZeroPadding2D: the pad value takes part in the max
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (v[e] > best[e]) { best[e] = v[e]; arg[e] = (unsigned char)k; }
+        }
+        *reinterpret_cast<u32x4*>(y + i * 8) = pack8(best);
+        u32x2 a;
+        a[0] = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
+        a[1] = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
+        *reinterpret_cast<u32x2*>(amax + i * 8) = a;
+    }
+}
+
+// gather form: input pixel (iy,ix) receives gy of every window whose argmax points at it (deterministic)
+__global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ gy, const uint8_t* __restrict__ amax, bf16_t* __restrict__ gx, int N,
+                                   int H, int W, int C8, int Ho, int Wo) {
+    const int64_t total = (int64_t)N * H * W * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % C8);
+        int64_t t = i / C8;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H);
+        const int n = (int)(t / H);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        // windows oy with oy*2-1 <= iy <= oy*2+1
+        const int oy_lo = (iy) / 2, oy_hi = (iy + 1) / 2;
+        const int ox_lo = (ix) / 2, ox_hi = (ix + 1) / 2;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (oy >= Ho) continue;
+            const int ky = iy - (oy * 2 - 1);
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ox >= Wo) continue;
+                const int kx = ix - (ox * 2 - 1);
+                const unsigned k = (unsigned)(ky * 3 + kx);
+                const int64_t o = (((int64_t)n * Ho + oy) * Wo + ox) * C8 + cv;
+                const u32x2 a = *reinterpret_cast<const u32x2*>(amax + o * 8);
+                float g[8];
+                unpack8(*reinterpret_cast<const u32x4*>(gy + o * 8), g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned ak = (a[e >> 2] >> ((e & 3) * 8)) & 0xFFu;
+                    if (ak == k) acc[e] += g[e];
+                }
+            }
+        }
+        *reinterpret_cast<u32x4*>(gx + i * 8) = pack8(acc);
+    }
+}
+
+// ---------------------------------------------------------------- SGD + bf16 refresh
+__global__ void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, bf16_t* __restrict__ wb,
+                           int64_t n, float momentum, float l2x2, float gscale, const int64_t* __restrict__ step,
+                           const int64_t* __restrict__ bounds, const float* __restrict__ values, int nb) {
+    const int64_t st = *step;
+    int k = 0;
+    while (k < nb && st >= bounds[k]) ++k;
+    const float lr = values[k];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float wi = w[i];
+        const float gi = g[i] * gscale + l2x2 * wi;
+        const float vi = momentum * v[i] - lr * gi;
+        const float wn = wi + vi;
+        v[i] = vi;
+        w[i] = wn;
+        if (wb) wb[i] = (bf16_t)wn;
+    }
+}
+__global__ void step_inc_kernel(int64_t* step) { *step += 1; }
+
+__global__ void cast_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (bf16_t)s[i];
+}
+
+// w[co][kh][kw][ci] fp32 -> wt[ci][KH-1-kh][KW-1-kw][co] bf16
+__global__ void transpose_flip_kernel(const float* __restrict__ w, bf16_t* __restrict__ wt, int Cout, int KH, int KW, int Cin) {
+    const int64_t total = (int64_t)Cout * KH * KW * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // i enumerates the OUTPUT (coalesced writes): [ci][kh'][kw'][co]
+        const int co = (int)(i % Cout);
+        int64_t t = i / Cout;
+        const int kwp = (int)(t % KW);
+        t /= KW;
+        const int khp = (int)(t % KH);
+        const int ci = (int)(t / KH);
+        const int kh = KH - 1 - khp, kw = KW - 1 - kwp;
+        wt[i] = (bf16_t)w[(((int64_t)co * KH + kh) * KW + kw) * Cin + ci];
+    }
+}
+
+__global__ void stem_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int Cout) {
+    const int total = Cout * 7 * 8 * 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i & 3, kw = (i >> 2) & 7, kh = (i >> 5) % 7, co = i / (7 * 32);
+        float v = 0.f;
+        if (c < 3 && kw < 7) v = w[((co * 7 + kh) * 7 + kw) * 3 + c];
+        wp[i] = (bf16_t)v;
+    }
+}
+__global__ void stem_unpack_grad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout) {
+    const int total = Cout * 7 * 7 * 3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i % 3, kw = (i / 3) % 7, kh = (i / 21) % 7, co = i / 147;
+        dw[i] = dwp[((co * 7 + kh) * 8 + kw) * 4 + c];
+    }
+}
+
+}  // namespace
+
+#define S_(stream) reinterpret_cast<hipStream_t>(stream)
+#define BF(p) reinterpret_cast<bf16_t*>(p)
+#define CBF(p) reinterpret_cast<const bf16_t*>(p)
+
+extern "C" int frcnn_preprocess_u8_bgr_mean(const uint8_t* images, frcnn_bf16* out, int b, int h, int w, int hp, int wp, int pad,
+                                            frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(images && out && b > 0 && hp >= h + pad && wp >= w + pad, "preprocess: bad arguments");
+    const int64_t total = (int64_t)b * hp * wp;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total, 256)), dim3(256), 0, S_(stream), images, BF(out), b, h, w, hp, wp, pad);
+    FRCNN_CHECK_LAUNCH("preprocess");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_bn_finalize_train(const float* stats_partial, int tiles, int c, int64_t count, const float* gamma,
+                                       const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
+                                       float* scale, float* shift, float* mean, float* invstd, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(stats_partial && gamma && beta && moving_mean && moving_var && scale && shift && mean && invstd && count > 0,
+                    "bn_finalize_train: bad arguments");
+    const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(cdiv(c, 64)), dim3(64), 0, S_(stream), stats_partial, tiles, c,
+                       (float)(1.0 / (double)count), unbias, gamma, beta, moving_mean, moving_var, momentum, eps, scale, shift,
+                       mean, invstd);
+    FRCNN_CHECK_LAUNCH("bn_finalize_train");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_bn_finalize_eval(int c, const float* gamma, const float* beta, const float* moving_mean,
+                                      const float* moving_var, float eps, float* scale, float* shift, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale && shift, "bn_finalize_eval: null pointer");
+    hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3(cdiv(c, 64)), dim3(64), 0, S_(stream), c, gamma, beta, moving_mean,
+                       moving_var, eps, scale, shift);
+    FRCNN_CHECK_LAUNCH("bn_finalize_eval");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_bn_apply(const frcnn_bf16* z, const float* scale, const float* shift, const frcnn_bf16* res, int relu,
+                              frcnn_bf16* out, int64_t m, int c, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(z && scale && shift && out && c % 8 == 0, "bn_apply: bad arguments (c %% 8 != 0?)");
+    const int64_t nvec = m * (c / 8);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, S_(stream), CBF(z), scale, shift, CBF(res), relu,
+                       BF(out), nvec, c / 8);
+    FRCNN_CHECK_LAUNCH("bn_apply");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_bn_bwd_blocks(int64_t m) { return (int)((m + kBwdRowsPerBlock - 1) / kBwdRowsPerBlock); }
+
+extern "C" int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act, const frcnn_bf16* z, const float* mean,
+                                   const float* invstd, float* partial, int64_t m, int c, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(gout && z && mean && invstd && partial && c % 8 == 0, "bn_bwd_reduce: bad arguments");
+    const int c8 = c / 8;
+    FRCNN_CHECK_ARG(c8 >= 256 ? (c8 % 256 == 0) : (256 % c8 == 0), "bn_bwd_reduce: c/8=%d must divide or be a multiple of 256", c8);
+    const int blocks = frcnn_bn_bwd_blocks(m);
+    const size_t smem = 256 * 16 * sizeof(float);
+    if (act)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), smem, S_(stream), CBF(gout), CBF(act), CBF(z), mean,
+                           invstd, partial, m, c);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), smem, S_(stream), CBF(gout), CBF(act), CBF(z), mean,
+                           invstd, partial, m, c);
+    FRCNN_CHECK_LAUNCH("bn_bwd_reduce");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_bn_bwd_finalize(const float* partial, int blocks, int c, int64_t m, float* dgamma, float* dbeta, float* c1,
+                                     float* c2, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(partial && dgamma && dbeta && c1 && c2 && m > 0, "bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, S_(stream), partial, blocks, c,
+                       (float)(1.0 / (double)m), dgamma, dbeta, c1, c2);
+    FRCNN_CHECK_LAUNCH("bn_bwd_finalize");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_bn_bwd_apply(const frcnn_bf16* gout, const frcnn_bf16* act, const frcnn_bf16* z, const float* mean,
+                                  const float* invstd, const float* gamma, const float* c1, const float* c2, frcnn_bf16* dz,
+                                  frcnn_bf16* gpre, int64_t m, int c, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(gout && z && mean && invstd && gamma && c1 && c2 && dz && c % 8 == 0, "bn_bwd_apply: bad arguments");
+    const int64_t nvec = m * (c / 8);
+    if (act)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(nvec, 256)), dim3(256), 0, S_(stream), CBF(gout), CBF(act), CBF(z),
+                           mean, invstd, gamma, c1, c2, BF(dz), BF(gpre), nvec, c / 8);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(nvec, 256)), dim3(256), 0, S_(stream), CBF(gout), CBF(act), CBF(z),
+                           mean, invstd, gamma, c1, c2, BF(dz), BF(gpre), nvec, c / 8);
+    FRCNN_CHECK_LAUNCH("bn_bwd_apply");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, int64_t n, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(g && act && out && n % 8 == 0, "relu_bwd: bad arguments");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, S_(stream), CBF(g), CBF(act), BF(out), n / 8);
+    FRCNN_CHECK_LAUNCH("relu_bwd");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_colsum_bf16(const frcnn_bf16* x, int64_t m, int c, int ld, float* out, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(x && out && c > 0 && ld >= c, "colsum: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(c, 64)), dim3(256), 0, S_(stream), CBF(x), m, c, ld, out);
+    FRCNN_CHECK_LAUNCH("colsum");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_maxpool3x3s2_fwd(const frcnn_bf16* x, frcnn_bf16* y, uint8_t* argmax, int n, int h, int w, int c, int ho,
+                                      int wo, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(x && y && argmax && c % 8 == 0 && ho == (h + 2 - 3) / 2 + 1 && wo == (w + 2 - 3) / 2 + 1, "maxpool_fwd: bad arguments");
+    const int64_t total = (int64_t)n * ho * wo * (c / 8);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, S_(stream), CBF(x), BF(y), argmax, n, h, w, c / 8,
+                       ho, wo);
+    FRCNN_CHECK_LAUNCH("maxpool_fwd");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_maxpool3x3s2_bwd(const frcnn_bf16* gy, const uint8_t* argmax, frcnn_bf16* gx, int n, int h, int w, int c, int ho,
+                                      int wo, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(gy && gx && argmax && c % 8 == 0, "maxpool_bwd: bad arguments");
+    const int64_t total = (int64_t)n * h * w * (c / 8);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, S_(stream), CBF(gy), argmax, BF(gx), n, h, w, c / 8,
+                       ho, wo);
+    FRCNN_CHECK_LAUNCH("maxpool_bwd");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_sgd_momentum(float* w, const float* g, float* v, frcnn_bf16* w_bf16, int64_t n, float momentum, float l2,
+                                  float grad_scale, const int64_t* step, const int64_t* boundaries, const float* values, int nb,
+                                  frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(w && g && v && step && values && (nb == 0 || boundaries), "sgd_momentum: null pointer");
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, S_(stream), w, g, v, BF(w_bf16), n, momentum, 2.f * l2,
+                       grad_scale, step, boundaries, values, nb);
+    FRCNN_CHECK_LAUNCH("sgd_momentum");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_step_increment(int64_t* step, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(step, "step_increment: null pointer");
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, S_(stream), step);
+    FRCNN_CHECK_LAUNCH("step_increment");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_cast_f32_bf16(const float* src, frcnn_bf16* dst, int64_t n, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(src && dst, "cast: null pointer");
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n, 256)), dim3(256), 0, S_(stream), src, BF(dst), n);
+    FRCNN_CHECK_LAUNCH("cast");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_weights_transpose_flip(const float* w, frcnn_bf16* w_t, int cout, int kh, int kw, int cin, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(w && w_t, "weights_transpose_flip: null pointer");
+    const int64_t total = (int64_t)cout * kh * kw * cin;
+    hipLaunchKernelGGL(transpose_flip_kernel, dim3(grid_for(total, 256)), dim3(256), 0, S_(stream), w, BF(w_t), cout, kh, kw, cin);
+    FRCNN_CHECK_LAUNCH("weights_transpose_flip");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_stem_pack_weights(const float* w, frcnn_bf16* w_packed, int cout, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(w && w_packed, "stem_pack_weights: null pointer");
+    hipLaunchKernelGGL(stem_pack_kernel, dim3(cdiv(cout * 224, 256)), dim3(256), 0, S_(stream), w, BF(w_packed), cout);
+    FRCNN_CHECK_LAUNCH("stem_pack_weights");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_stem_unpack_grad(const float* dw_packed, float* dw, int cout, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(dw_packed && dw, "stem_unpack_grad: null pointer");
+    hipLaunchKernelGGL(stem_unpack_grad_kernel, dim3(cdiv(cout * 147, 256)), dim3(256), 0, S_(stream), dw_packed, dw, cout);
+    FRCNN_CHECK_LAUNCH("stem_unpack_grad");
+    return FRCNN_OK;
+}

@@ -1,0 +1,137 @@
+// Fused RoI pooling of the reference's ROIPooling layer (fast_rcnn_detector.py:133-177):
+// tf.image.crop_and_resize (bilinear, 14x14, extrapolation 0) + MaxPool 2x2 in ONE pass that never
+// materialises the 14x14 crop (241 MB / image in the reference): HBM traffic is the feature map
+// (L2 / Infinity-Cache resident) plus the pooled output.
+//
+// Forward: one workgroup per RoI; lanes run over 8-channel vectors (16-byte loads of the NHWC
+// feature map), each work item evaluates the 2x2 bilinear samples of one pooled bin and keeps the
+// max and its window position.  Backward: one workgroup per *sampled* RoI row, lanes over single
+// channels so that every float-atomic wave instruction adds 256 contiguous bytes of one
+// feature-map pixel.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct RoiGeom { float y1s, x1s, hs, ws; };   // in = y1s + i*hs  (TF crop_and_resize coordinate map)
+
+__device__ __forceinline__ RoiGeom roi_geom(const float* roi /*x1,y1,x2,y2 rel*/, int Hf, int Wf, int crop) {
+    const float x1 = roi[0], y1 = roi[1], x2 = roi[2], y2 = roi[3];
+    const float hm1 = (float)(Hf - 1), wm1 = (float)(Wf - 1);
+    RoiGeom g;
+    g.hs = (y2 - y1) * hm1 / (float)(crop - 1);
+    g.ws = (x2 - x1) * wm1 / (float)(crop - 1);
+    g.y1s = y1 * hm1;
+    g.x1s = x1 * wm1;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ rois, int P, int Hf, int Wf,
+                                                      int C8, int ps, int ks, bf16_t* __restrict__ pooled, uint8_t* __restrict__ amax) {
+    const int row = blockIdx.x;               // b*P + p
+    const int b = row / P;
+    const int crop = ps * ks;
+    const RoiGeom g = roi_geom(rois + (int64_t)row * 4, Hf, Wf, crop);
+    const float hm1 = (float)(Hf - 1), wm1 = (float)(Wf - 1);
+    const bf16_t* fb = feat + (int64_t)b * Hf * Wf * C8 * 8;
+    const int items = ps * ps * C8;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int cv = it % C8;
+        const int bin = it / C8;
+        const int ph = bin / ps, pw = bin - ph * ps;
+        float best[8];
+        unsigned char arg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = 0; }
+        for (int s = 0; s < ks * ks; ++s) {
+            const int i = ph * ks + s / ks, j = pw * ks + s % ks;
+            const float in_y = g.y1s + (float)i * g.hs;
+            const float in_x = g.x1s + (float)j * g.ws;
+            float v[8];
+            if (!(in_y >= 0.f && in_y <= hm1 && in_x >= 0.f && in_x <= wm1)) {   // NaN-safe
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            } else {
+                const float ty = floorf(in_y), by = ceilf(in_y), ly = in_y - ty;
+                const float lx_ = floorf(in_x), rx = ceilf(in_x), lx = in_x - lx_;
+                const int t = (int)ty, bo = (int)by, l = (int)lx_, r = (int)rx;
+                float tl[8], tr[8], bl[8], br[8];
+                unpack8(*reinterpret_cast<const u32x4*>(fb + (((int64_t)t * Wf + l) * C8 + cv) * 8), tl);
+                unpack8(*reinterpret_cast<const u32x4*>(fb + (((int64_t)t * Wf + r) * C8 + cv) * 8), tr);
+                unpack8(*reinterpret_cast<const u32x4*>(fb + (((int64_t)bo * Wf + l) * C8 + cv) * 8), bl);
+                unpack8(*reinterpret_cast<const u32x4*>(fb + (((int64_t)bo * Wf + r) * C8 + cv) * 8), br);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float top = tl[e] + (tr[e] - tl[e]) * lx;
+                    const float bot = bl[e] + (br[e] - bl[e]) * lx;
+                    v[e] = top + (bot - top) * ly;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (v[e] > best[e]) { best[e] = v[e]; arg[e] = (unsigned char)s; }
+        }
+        const int64_t o = ((int64_t)row * ps * ps + bin) * C8 + cv;
+        *reinterpret_cast<u32x4*>(pooled + o * 8) = pack8(best);
+        u32x2 a;
+        a[0] = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
+        a[1] = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
+        *reinterpret_cast<u32x2*>(amax + o * 8) = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void roi_bwd_kernel(const bf16_t* __restrict__ gpooled, const uint8_t* __restrict__ amax,
+                                                      const float* __restrict__ rois, const int* __restrict__ rows, int P, int Hf, int Wf,
+                                                      int C, int ps, int ks, float* __restrict__ gfeat) {
+    const int r = blockIdx.x;                 // dense row of gpooled
+    const int row = rows[r];                  // RoI row b*P + p
+    const int b = row / P;
+    const int crop = ps * ks;
+    const RoiGeom g = roi_geom(rois + (int64_t)row * 4, Hf, Wf, crop);
+    const float hm1 = (float)(Hf - 1), wm1 = (float)(Wf - 1);
+    float* gb = gfeat + (int64_t)b * Hf * Wf * C;
+    const int items = ps * ps * C;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int c = it % C;
+        const int bin = it / C;
+        const int ph = bin / ps, pw = bin - ph * ps;
+        const float gv = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(gpooled + (int64_t)r * items + it));
+        if (gv == 0.f) continue;
+        const int s = amax[(int64_t)row * items + it];
+        const int i = ph * ks + s / ks, j = pw * ks + s % ks;
+        const float in_y = g.y1s + (float)i * g.hs;
+        const float in_x = g.x1s + (float)j * g.ws;
+        if (!(in_y >= 0.f && in_y <= hm1 && in_x >= 0.f && in_x <= wm1)) continue;
+        const float ty = floorf(in_y), by = ceilf(in_y), ly = in_y - ty;
+        const float lx_ = floorf(in_x), rx = ceilf(in_x), lx = in_x - lx_;
+        const int t = (int)ty, bo = (int)by, l = (int)lx_, rr = (int)rx;
+        const float dtop = (1.f - ly) * gv, dbot = ly * gv;
+        atomicAdd(gb + ((int64_t)t * Wf + l) * C + c, (1.f - lx) * dtop);
+        atomicAdd(gb + ((int64_t)t * Wf + rr) * C + c, lx * dtop);
+        atomicAdd(gb + ((int64_t)bo * Wf + l) * C + c, (1.f - lx) * dbot);
+        atomicAdd(gb + ((int64_t)bo * Wf + rr) * C + c, lx * dbot);
+    }
+}
+
+}  // namespace
+
+extern "C" int frcnn_roi_crop_pool_fwd(const frcnn_bf16* feat, const float* rois, int b, int p, int hf, int wf, int c, int ps, int ks,
+                                       frcnn_bf16* pooled, uint8_t* argmax, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(feat && rois && pooled && argmax, "roi_crop_pool_fwd: null pointer");
+    FRCNN_CHECK_ARG(b > 0 && p > 0 && c % 8 == 0 && ps >= 1 && ks >= 1 && ps * ks >= 2 && ks * ks <= 255 && hf > 1 && wf > 1,
+                    "roi_crop_pool_fwd: bad sizes");
+    hipLaunchKernelGGL(roi_fwd_kernel, dim3(b * p), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16_t*>(feat), rois, p, hf, wf, c / 8, ps, ks, reinterpret_cast<bf16_t*>(pooled), argmax);
+    FRCNN_CHECK_LAUNCH("roi_crop_pool_fwd");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_roi_crop_pool_bwd(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows, int nrows,
+                                       int p, int hf, int wf, int c, int ps, int ks, float* gfeat, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(gpooled && argmax && rois && rows && gfeat && nrows > 0, "roi_crop_pool_bwd: bad arguments");
+    hipLaunchKernelGGL(roi_bwd_kernel, dim3(nrows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16_t*>(gpooled), argmax, rois, rows, p, hf, wf, c, ps, ks, gfeat);
+    FRCNN_CHECK_LAUNCH("roi_crop_pool_bwd");
+    return FRCNN_OK;
+}

@@ -1,0 +1,426 @@
+// Target assignment, sampling, losses and loss gradients of the reference's training path
+// (utils/training.py, utils/losses.py, get_training_samples of both detectors).
+// One workgroup per image; box arithmetic without FMA contraction so that IoUs (hence the
+// discrete fg/bg decisions) are bit-identical to the fp32 oracle.
+#include <math.h>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kMaxGt = 128;
+constexpr int kMaxC1 = 32;
+
+// utils/metrics.py:136-208
+__device__ __forceinline__ float ref_iou(const f32x4 a, const float area_a, const f32x4 b, const float area_b) {
+    const float dw = fminf(a[2], b[2]) - fmaxf(a[0], b[0]);
+    const float dh = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
+    const float inter = fmaxf(0.0f, dw) * fmaxf(0.0f, dh);
+    const float uni = area_a + area_b - inter;
+    return inter == 0.0f ? 0.0f : inter / uni;
+}
+
+struct AssignParams {
+    const float* regions; int rpi;
+    const float* gt_labels; const float* gt_boxes;
+    int R, G, C1g, C1, objectness;
+    float W, H, fg_lo, fg_hi, bg_lo, bg_hi;
+    float* tl; float* tb;
+};
+
+__global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams p) {
+    __shared__ f32x4 gbox[kMaxGt];
+    __shared__ float garea[kMaxGt];
+    __shared__ int gsrc[kMaxGt];          // original gt row of compacted entry
+    __shared__ int gobj[kMaxGt];          // objectness class (0/1, -1 = none) of original row
+    __shared__ int nvalid;
+    __shared__ float red_v[1024];
+    __shared__ int red_i[1024];
+    const int b = blockIdx.x;
+    const float* gl = p.gt_labels + (int64_t)b * p.G * p.C1g;
+    const float* gbx = p.gt_boxes + (int64_t)b * p.G * 4;
+    const float* regions = p.regions + (p.rpi ? (int64_t)b * p.R * 4 : 0);
+    float* tl = p.tl + (int64_t)b * p.R * p.C1;
+    float* tb = p.tb + (int64_t)b * p.R * (p.C1 - 1) * 4;
+    const int C = p.C1 - 1;
+
+    // ---- compact the non-padding ground truth in order (training.py:43-45), absolute coords (:48)
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int g = 0; g < p.G; ++g) {
+            float s = 0.f;
+            for (int c = 0; c < p.C1g; ++c) s += gl[g * p.C1g + c];
+            bool keep;
+            int obj = -1;
+            if (p.objectness) {                       // rpn_detector.py:141: one_hot(int(sum), 2)
+                const int k = (int)s;
+                obj = (k == 0 || k == 1) ? k : -1;
+                keep = obj >= 0;                      // one-hot row sums to 1 != 0 (an out-of-range index gives a zero row)
+            } else {
+                keep = s != 0.0f;
+            }
+            if (keep && n < kMaxGt) {
+                f32x4 bx = {gbx[g * 4] * p.W, gbx[g * 4 + 1] * p.H, gbx[g * 4 + 2] * p.W, gbx[g * 4 + 3] * p.H};
+                gbox[n] = bx;
+                garea[n] = (bx[2] - bx[0]) * (bx[3] - bx[1]);
+                gsrc[n] = g;
+                gobj[n] = obj;
+                ++n;
+            }
+        }
+        nvalid = n;
+    }
+    __syncthreads();
+    const int ng = nvalid;
+
+    // ---- pass 1: per-region max IoU / first argmax; stash them in the output buffers
+    float best_v = -1.f;
+    int best_i = 0x7FFFFFFF;
+    for (int r = threadIdx.x; r < p.R; r += blockDim.x) {
+        const f32x4 rb = *reinterpret_cast<const f32x4*>(regions + (int64_t)r * 4);
+        const float ra = (rb[2] - rb[0]) * (rb[3] - rb[1]);
+        float mx = -INFINITY;
+        int am = 0;
+        for (int g = 0; g < ng; ++g) {
+            const float v = ref_iou(rb, ra, gbox[g], garea[g]);
+            if (v > mx) { mx = v; am = g; }
+        }
+        if (ng == 0) mx = 0.f;
+        tl[(int64_t)r * p.C1] = mx;
+        tl[(int64_t)r * p.C1 + 1] = __int_as_float(am);
+        if (mx > best_v || (mx == best_v && r < best_i)) { best_v = mx; best_i = r; }
+    }
+    red_v[threadIdx.x] = best_v;
+    red_i[threadIdx.x] = best_i;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float ov = red_v[threadIdx.x + s];
+            const int oi = red_i[threadIdx.x + s];
+            if (ov > red_v[threadIdx.x] || (ov == red_v[threadIdx.x] && oi < red_i[threadIdx.x])) {
+                red_v[threadIdx.x] = ov;
+                red_i[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int force_idx = red_i[0];       // first region attaining the global max (training.py:137-138)
+
+    // ---- pass 2: labels + encoded target boxes
+    for (int r = threadIdx.x; r < p.R; r += blockDim.x) {
+        const float mx = tl[(int64_t)r * p.C1];
+        const int am = __float_as_int(tl[(int64_t)r * p.C1 + 1]);
+        const bool bg = (mx >= p.bg_lo) && (mx < p.bg_hi);
+        const bool fg = ((mx >= p.fg_lo) && (mx < p.fg_hi)) || (r == force_idx);
+        float lab[kMaxC1];
+#pragma unroll 1
+        for (int c = 0; c < p.C1; ++c) lab[c] = 0.f;
+        if (bg) lab[0] = 1.f;
+        if (fg && ng > 0) {
+            if (p.objectness) {
+                for (int c = 0; c < p.C1; ++c) lab[c] = (c == gobj[am]) ? 1.f : 0.f;
+            } else {
+                const float* src = gl + gsrc[am] * p.C1g;
+                for (int c = 0; c < p.C1; ++c) lab[c] = src[c];
+            }
+        }
+        for (int c = 0; c < p.C1; ++c) tl[(int64_t)r * p.C1 + c] = lab[c];
+        // encode (utils/boxes.py:44-73) of the argmax gt against this region
+        f32x4 enc = {0.f, 0.f, 0.f, 0.f};
+        if (ng > 0) {
+            const f32x4 rb = *reinterpret_cast<const f32x4*>(regions + (int64_t)r * 4);
+            const f32x4 gb = gbox[am];
+            const float cxr = (rb[2] + rb[0]) / 2.0f, cyr = (rb[3] + rb[1]) / 2.0f;
+            const float wr = rb[2] - rb[0], hr = rb[3] - rb[1];
+            const float cx = (gb[2] + gb[0]) / 2.0f, cy = (gb[3] + gb[1]) / 2.0f;
+            const float w = gb[2] - gb[0], h = gb[3] - gb[1];
+            enc[0] = (cx - cxr) / wr;
+            enc[1] = (cy - cyr) / hr;
+            enc[2] = logf(w / wr);
+            enc[3] = logf(h / hr);
+        }
+        for (int c = 0; c < C; ++c) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(tb + ((int64_t)r * C + c) * 4) = (lab[c + 1] != 0.f) ? enc : z;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- sampling
+struct SampleParams {
+    const float* tl; int R, C1, S, max_fg;
+    unsigned int k0, k1; const int64_t* step; int stream_base;
+    int* out; int* ws; int* status;
+};
+constexpr int kFgLds = 8192;
+
+__global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
+    __shared__ int cnt_fg[256], cnt_bg[256];
+    __shared__ int fg_lds[kFgLds];
+    __shared__ int tot[2];
+    const int b = blockIdx.x;
+    const float* tl = p.tl + (int64_t)b * p.R * p.C1;
+    int* fg_list = p.ws + (int64_t)b * 2 * p.R;
+    int* bg_list = fg_list + p.R;
+    const int seg = (p.R + 255) / 256;
+    const int r0 = threadIdx.x * seg, r1 = min(p.R, r0 + seg);
+    int nf = 0, nb = 0;
+    for (int r = r0; r < r1; ++r) {
+        float s = 0.f;
+        for (int c = 0; c < p.C1; ++c) s += tl[(int64_t)r * p.C1 + c];
+        const float l0 = tl[(int64_t)r * p.C1];
+        if (s != 0.0f && l0 == 0.0f) ++nf;
+        if (s != 0.0f && l0 == 1.0f) ++nb;
+    }
+    cnt_fg[threadIdx.x] = nf;
+    cnt_bg[threadIdx.x] = nb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int af = 0, ab = 0;
+        for (int t = 0; t < 256; ++t) {
+            const int f = cnt_fg[t], g = cnt_bg[t];
+            cnt_fg[t] = af; cnt_bg[t] = ab;
+            af += f; ab += g;
+        }
+        tot[0] = af; tot[1] = ab;
+    }
+    __syncthreads();
+    int of = cnt_fg[threadIdx.x], ob = cnt_bg[threadIdx.x];
+    for (int r = r0; r < r1; ++r) {
+        float s = 0.f;
+        for (int c = 0; c < p.C1; ++c) s += tl[(int64_t)r * p.C1 + c];
+        const float l0 = tl[(int64_t)r * p.C1];
+        if (s != 0.0f && l0 == 0.0f) fg_list[of++] = r;
+        if (s != 0.0f && l0 == 1.0f) bg_list[ob++] = r;
+    }
+    __syncthreads();
+    const int nfg = tot[0], nbg = tot[1];
+    const int n_fg = min(nfg, p.max_fg);
+    const int n_bg = p.S - n_fg;
+    const unsigned int step = (unsigned int)(*p.step);
+    int* out = p.out + (int64_t)b * p.S;
+    // fg: partial Fisher-Yates (== shuffle then take), sequential by construction
+    const bool in_lds = nfg <= kFgLds;
+    if (in_lds)
+        for (int i = threadIdx.x; i < nfg; i += blockDim.x) fg_lds[i] = fg_list[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int* lst = in_lds ? fg_lds : fg_list;
+        for (int i = 0; i < n_fg; ++i) {
+            const unsigned int rnd = philox_first((unsigned)i, (unsigned)b, step, (unsigned)(p.stream_base + 0), p.k0, p.k1);
+            const int j = i + (int)(rnd % (unsigned)(nfg - i));
+            const int a = lst[i], c = lst[j];
+            lst[i] = c; lst[j] = a;
+            out[i] = c;
+        }
+        if (n_bg > 0 && nbg == 0) atomicOr(p.status, 1);
+    }
+    for (int i = threadIdx.x; i < n_bg; i += blockDim.x) {
+        int v = 0;
+        if (nbg > 0) {
+            const unsigned int rnd = philox_first((unsigned)i, (unsigned)b, step, (unsigned)(p.stream_base + 1), p.k0, p.k1);
+            v = bg_list[rnd % (unsigned)nbg];
+        }
+        out[n_fg + i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- losses + per-sample gradients
+struct LossParams {
+    const float* scores; const float* deltas; const float* tl; const float* tb; const int* idx;
+    int B, R, C1, S; float cls_scale, reg_scale;
+    float* losses; float* dlog; float* ddel;
+};
+
+__global__ __launch_bounds__(256) void losses_kernel(const LossParams p) {
+    __shared__ float red[2][256];
+    const int C = p.C1 - 1;
+    const int rows = p.B * p.S;
+    const float inv_rows = 1.0f / (float)rows;
+    float cls = 0.f, reg = 0.f;
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+        const int b = i / p.S;
+        const int r = p.idx[i];
+        const float* sc = p.scores + ((int64_t)b * p.R + r) * p.C1;
+        const float* t = p.tl + ((int64_t)b * p.R + r) * p.C1;
+        // Keras categorical_crossentropy on probabilities: renormalise, clip, -sum t log p
+        float pr[kMaxC1], gq[kMaxC1];
+        float s = 0.f;
+        for (int c = 0; c < p.C1; ++c) { pr[c] = sc[c]; s += pr[c]; }
+        float row_loss = 0.f, dot = 0.f;
+        for (int c = 0; c < p.C1; ++c) {
+            const float q = pr[c] / s;
+            const float qc = fminf(fmaxf(q, 1e-7f), 1.0f - 1e-7f);
+            row_loss -= t[c] * logf(qc);
+            const bool pass = (q >= 1e-7f) && (q <= 1.0f - 1e-7f);
+            gq[c] = pass ? -t[c] / qc : 0.f;
+            dot += gq[c] * pr[c];
+        }
+        cls += row_loss;
+        if (p.dlog) {
+            // d/dp_j = gq_j/s - dot/s^2 ; softmax backward: dz_i = p_i (dp_i - sum_j p_j dp_j)
+            float dp[kMaxC1];
+            float pdot = 0.f;
+            for (int c = 0; c < p.C1; ++c) { dp[c] = gq[c] / s - dot / (s * s); pdot += pr[c] * dp[c]; }
+            for (int c = 0; c < p.C1; ++c) p.dlog[(int64_t)i * p.C1 + c] = p.cls_scale * inv_rows * pr[c] * (dp[c] - pdot);
+        }
+        // Huber(delta=1), mean over the 4 coords, rows with sum(target) != 0, summed (losses.py:35-41)
+        for (int c = 0; c < C; ++c) {
+            const f32x4 tv = *reinterpret_cast<const f32x4*>(p.tb + (((int64_t)b * p.R + r) * C + c) * 4);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(p.deltas + (((int64_t)b * p.R + r) * C + c) * 4);
+            const bool keep = (tv[0] + tv[1] + tv[2] + tv[3]) != 0.0f;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            if (keep) {
+                float h = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = pv[e] - tv[e];
+                    const float ad = fabsf(d);
+                    h += (ad <= 1.0f) ? 0.5f * d * d : ad - 0.5f;
+                    g[e] = p.reg_scale * 0.25f * ((ad <= 1.0f) ? d : (d > 0.f ? 1.f : -1.f));
+                }
+                reg += h * 0.25f;
+            }
+            if (p.ddel) *reinterpret_cast<f32x4*>(p.ddel + ((int64_t)i * C + c) * 4) = g;
+        }
+    }
+    red[0][threadIdx.x] = cls;
+    red[1][threadIdx.x] = reg;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        p.losses[0] = red[0][0] * inv_rows;
+        p.losses[1] = red[1][0];
+    }
+}
+
+// RPN: scatter-add per-sample gradients into the dense fp32 head-gradient matrix
+__global__ void rpn_head_grad_kernel(const float* __restrict__ dlog, const float* __restrict__ ddel, const int* __restrict__ idx,
+                                     const int* __restrict__ keep, int B, int S, int locs, int apl, float* __restrict__ dhead, int ld) {
+    const int total = B * S;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / S;
+        const int j = idx[i];
+        const int a = keep ? keep[j] : j;
+        const int loc = a / apl, k = a - loc * apl;
+        float* row = dhead + ((int64_t)b * locs + loc) * ld;
+        atomicAdd(row + 2 * k, dlog[(int64_t)i * 2]);
+        atomicAdd(row + 2 * k + 1, dlog[(int64_t)i * 2 + 1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(row + 2 * apl + 4 * k + e, ddel[(int64_t)i * 4 + e]);
+    }
+}
+
+// RCNN: per-sample gradient rows -> bf16 [B*S, ld] (zero padded) + RoI row ids
+__global__ void rcnn_head_grad_kernel(const float* __restrict__ dlog, const float* __restrict__ ddel, const int* __restrict__ idx, int B,
+                                      int R, int C1, int S, bf16_t* __restrict__ dhead, int ld, int* __restrict__ rows_out) {
+    const int total = B * S * ld;
+    const int nreg = 4 * (C1 - 1);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int col = i % ld, row = i / ld;
+        float v = 0.f;
+        if (col < C1) v = dlog[(int64_t)row * C1 + col];
+        else if (col < C1 + nreg) v = ddel[(int64_t)row * nreg + (col - C1)];
+        dhead[i] = (bf16_t)v;
+        if (col == 0) rows_out[row] = (row / S) * R + idx[row];
+    }
+}
+
+// RCNN head post: bias + softmax / split
+__global__ void rcnn_head_post_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ bias, int R, int C1,
+                                      float* __restrict__ scores, float* __restrict__ deltas) {
+    const int nreg = 4 * (C1 - 1);
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        const float* row = logits + (int64_t)r * ld;
+        float l[kMaxC1];
+        float mx = -INFINITY;
+        for (int c = 0; c < C1; ++c) { l[c] = row[c] + bias[c]; mx = fmaxf(mx, l[c]); }
+        float s = 0.f;
+        for (int c = 0; c < C1; ++c) { l[c] = expf(l[c] - mx); s += l[c]; }
+        const float inv = 1.f / s;
+        for (int c = 0; c < C1; ++c) scores[(int64_t)r * C1 + c] = l[c] * inv;
+        for (int c = 0; c < nreg; ++c) deltas[(int64_t)r * nreg + c] = row[C1 + c] + bias[C1 + c];
+    }
+}
+
+}  // namespace
+
+#define S_(stream) reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int frcnn_assign_targets(const float* regions, int regions_per_image, const float* gt_labels, const float* gt_boxes, int b,
+                                    int r, int g, int c1g, int objectness, float img_w, float img_h, float fg_lo, float fg_hi,
+                                    float bg_lo, float bg_hi, float* target_labels, float* target_boxes, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(regions && gt_labels && gt_boxes && target_labels && target_boxes, "assign_targets: null pointer");
+    const int c1 = objectness ? 2 : c1g;
+    FRCNN_CHECK_ARG(b > 0 && r > 0 && g > 0 && g <= kMaxGt && c1 >= 2 && c1 <= kMaxC1 && c1g <= kMaxC1, "assign_targets: bad sizes (G<=%d, C+1<=%d)", kMaxGt, kMaxC1);
+    AssignParams p;
+    p.regions = regions; p.rpi = regions_per_image; p.gt_labels = gt_labels; p.gt_boxes = gt_boxes;
+    p.R = r; p.G = g; p.C1g = c1g; p.C1 = c1; p.objectness = objectness;
+    p.W = img_w; p.H = img_h; p.fg_lo = fg_lo; p.fg_hi = fg_hi; p.bg_lo = bg_lo; p.bg_hi = bg_hi;
+    p.tl = target_labels; p.tb = target_boxes;
+    hipLaunchKernelGGL(assign_targets_kernel, dim3(b), dim3(1024), 0, S_(stream), p);
+    FRCNN_CHECK_LAUNCH("assign_targets");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_sample_indices(const float* target_labels, int b, int r, int c1, int num_samples, float fg_proportion, uint64_t seed,
+                                    const int64_t* step, int stream_base, int32_t* indices, int32_t* workspace, int32_t* status,
+                                    frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(target_labels && step && indices && workspace && status && b > 0 && r > 0 && num_samples > 0, "sample_indices: bad arguments");
+    SampleParams p;
+    p.tl = target_labels; p.R = r; p.C1 = c1; p.S = num_samples;
+    p.max_fg = (int)nearbyint((double)num_samples * (double)fg_proportion);   // tf.math.round: half to even
+    p.k0 = (unsigned int)(seed & 0xFFFFFFFFull); p.k1 = (unsigned int)(seed >> 32);
+    p.step = step; p.stream_base = stream_base; p.out = indices; p.ws = workspace; p.status = status;
+    hipLaunchKernelGGL(sample_kernel, dim3(b), dim3(256), 0, S_(stream), p);
+    FRCNN_CHECK_LAUNCH("sample_indices");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_losses(const float* scores, const float* deltas, const float* target_labels, const float* target_boxes,
+                            const int32_t* indices, int b, int r, int c1, int s, float cls_scale, float reg_scale, float* losses,
+                            float* dlogits_s, float* ddeltas_s, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(scores && deltas && target_labels && target_boxes && indices && losses, "losses: null pointer");
+    FRCNN_CHECK_ARG(c1 >= 2 && c1 <= kMaxC1 && b > 0 && s > 0, "losses: bad sizes");
+    LossParams p;
+    p.scores = scores; p.deltas = deltas; p.tl = target_labels; p.tb = target_boxes; p.idx = indices;
+    p.B = b; p.R = r; p.C1 = c1; p.S = s; p.cls_scale = cls_scale; p.reg_scale = reg_scale;
+    p.losses = losses; p.dlog = dlogits_s; p.ddel = ddeltas_s;
+    hipLaunchKernelGGL(losses_kernel, dim3(1), dim3(256), 0, S_(stream), p);
+    FRCNN_CHECK_LAUNCH("losses");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_rpn_head_grad(const float* dlogits_s, const float* ddeltas_s, const int32_t* indices, const int32_t* keep, int b, int s,
+                                   int num_anchors_total, int a_per_loc, float* dhead, int ld, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(dlogits_s && ddeltas_s && indices && dhead && ld >= 6 * a_per_loc, "rpn_head_grad: bad arguments");
+    hipLaunchKernelGGL(rpn_head_grad_kernel, dim3(cdiv((int64_t)b * s, 256)), dim3(256), 0, S_(stream), dlogits_s, ddeltas_s, indices, keep,
+                       b, s, num_anchors_total / a_per_loc, a_per_loc, dhead, ld);
+    FRCNN_CHECK_LAUNCH("rpn_head_grad");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_rcnn_head_grad(const float* dlogits_s, const float* ddeltas_s, const int32_t* indices, int b, int r, int c1, int s,
+                                    frcnn_bf16* dhead_s, int ld, int32_t* rows_out, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(dlogits_s && ddeltas_s && indices && dhead_s && rows_out && ld >= c1 + 4 * (c1 - 1), "rcnn_head_grad: bad arguments");
+    hipLaunchKernelGGL(rcnn_head_grad_kernel, dim3(cdiv((int64_t)b * s * ld, 256)), dim3(256), 0, S_(stream), dlogits_s, ddeltas_s, indices,
+                       b, r, c1, s, reinterpret_cast<bf16_t*>(dhead_s), ld, rows_out);
+    FRCNN_CHECK_LAUNCH("rcnn_head_grad");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_rcnn_head_post(const float* logits, int ld, const float* bias, int r, int nc1, float* scores, float* deltas,
+                                    frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(logits && bias && scores && deltas && nc1 >= 2 && nc1 <= kMaxC1 && ld >= nc1 + 4 * (nc1 - 1), "rcnn_head_post: bad arguments");
+    hipLaunchKernelGGL(rcnn_head_post_kernel, dim3(cdiv(r, 256)), dim3(256), 0, S_(stream), logits, ld, bias, r, nc1, scores, deltas);
+    FRCNN_CHECK_LAUNCH("rcnn_head_post");
+    return FRCNN_OK;
+}

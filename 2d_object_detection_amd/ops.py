@@ -1,0 +1,204 @@
+"""Torch-tensor front end of the C ABI (include/frcnn_hip.h).
+
+PyTorch is plumbing only (device memory, streams): every function here hands raw device pointers
+to lib2dod_hip.so on the current torch stream and launches hand-written gfx950 kernels.  Nothing
+here computes with torch ops, and nothing falls back to them.
+"""
+import ctypes
+from ctypes import byref, c_float, c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import (CONV_ADD_RES, CONV_BIAS, CONV_OUT_F32, CONV_RELU, CONV_SPLITK_ATOMIC, CONV_STATS, ConvDesc, call)
+
+BF16 = torch.bfloat16
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError("%s must be a CUDA (HIP) tensor: the HIP path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s: expected %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+def conv_desc(n, hi, wi, cin, kh, kw, stride, pad_h, pad_w, ho, wo, cout, in_pix_stride=None, out_h=None, out_w=None,
+              out_scatter=1, flags=0, split_k=1):
+    return ConvDesc(n, hi, wi, cin if in_pix_stride is None else in_pix_stride, cin, kh, kw, stride, pad_h, pad_w, ho, wo, cout,
+                    ho if out_h is None else out_h, wo if out_w is None else out_w, out_scatter, flags, split_k)
+
+
+def conv_stat_tiles(d):
+    return _lib.load().frcnn_conv2d_stat_tiles(byref(d))
+
+
+def conv2d_fprop(d, x, w, y, bias=None, res=None, stats=None):
+    call("frcnn_conv2d_fprop", byref(d), _p(x), _p(w), _p(bias), _p(res), _p(y), _p(stats), _stream())
+
+
+def conv2d_wgrad(d, x, dz, dw, dz_stride=None, row_index=None):
+    call("frcnn_conv2d_wgrad", byref(d), _p(x), _p(dz), d.cout if dz_stride is None else dz_stride, _p(row_index), _p(dw), _stream())
+
+
+def weights_transpose_flip(w, w_t, cout, kh, kw, cin):
+    call("frcnn_weights_transpose_flip", _p(w), _p(w_t), cout, kh, kw, cin, _stream())
+
+
+def cast_f32_bf16(src, dst, n=None):
+    call("frcnn_cast_f32_bf16", _p(src), _p(dst), src.numel() if n is None else n, _stream())
+
+
+def stem_pack_weights(w, w_packed, cout=64):
+    call("frcnn_stem_pack_weights", _p(w), _p(w_packed), cout, _stream())
+
+
+def stem_unpack_grad(dw_packed, dw, cout=64):
+    call("frcnn_stem_unpack_grad", _p(dw_packed), _p(dw), cout, _stream())
+
+
+def preprocess(images_u8, out, pad=3):
+    _chk(images_u8, torch.uint8, "images")
+    b, h, w, _ = images_u8.shape
+    _, hp, wp, _ = out.shape
+    call("frcnn_preprocess_u8_bgr_mean", _p(images_u8), _p(out), b, h, w, hp, wp, pad, _stream())
+
+
+def bn_finalize_train(stats, tiles, c, count, gamma, beta, mm, mv, momentum, eps, scale, shift, mean, invstd):
+    call("frcnn_bn_finalize_train", _p(stats), tiles, c, count, _p(gamma), _p(beta), _p(mm), _p(mv), momentum, eps,
+         _p(scale), _p(shift), _p(mean), _p(invstd), _stream())
+
+
+def bn_finalize_eval(c, gamma, beta, mm, mv, eps, scale, shift):
+    call("frcnn_bn_finalize_eval", c, _p(gamma), _p(beta), _p(mm), _p(mv), eps, _p(scale), _p(shift), _stream())
+
+
+def bn_apply(z, scale, shift, out, m, c, res=None, relu=True):
+    call("frcnn_bn_apply", _p(z), _p(scale), _p(shift), _p(res), 1 if relu else 0, _p(out), m, c, _stream())
+
+
+def bn_bwd_blocks(m):
+    return _lib.load().frcnn_bn_bwd_blocks(m)
+
+
+def bn_bwd_reduce(gout, act, z, mean, invstd, partial, m, c):
+    call("frcnn_bn_bwd_reduce", _p(gout), _p(act), _p(z), _p(mean), _p(invstd), _p(partial), m, c, _stream())
+
+
+def bn_bwd_finalize(partial, blocks, c, m, dgamma, dbeta, c1, c2):
+    call("frcnn_bn_bwd_finalize", _p(partial), blocks, c, m, _p(dgamma), _p(dbeta), _p(c1), _p(c2), _stream())
+
+
+def bn_bwd_apply(gout, act, z, mean, invstd, gamma, c1, c2, dz, gpre, m, c):
+    call("frcnn_bn_bwd_apply", _p(gout), _p(act), _p(z), _p(mean), _p(invstd), _p(gamma), _p(c1), _p(c2), _p(dz), _p(gpre), m, c,
+         _stream())
+
+
+def relu_bwd(g, act, out, n=None):
+    call("frcnn_relu_bwd", _p(g), _p(act), _p(out), g.numel() if n is None else n, _stream())
+
+
+def colsum_bf16(x, m, c, ld, out):
+    call("frcnn_colsum_bf16", _p(x), m, c, ld, _p(out), _stream())
+
+
+def maxpool_fwd(x, y, argmax, n, h, w, c, ho, wo):
+    call("frcnn_maxpool3x3s2_fwd", _p(x), _p(y), _p(argmax), n, h, w, c, ho, wo, _stream())
+
+
+def maxpool_bwd(gy, argmax, gx, n, h, w, c, ho, wo):
+    call("frcnn_maxpool3x3s2_bwd", _p(gy), _p(argmax), _p(gx), n, h, w, c, ho, wo, _stream())
+
+
+def sgd_momentum(w, g, v, w_bf16, n, momentum, l2, grad_scale, step, boundaries, values, nb):
+    call("frcnn_sgd_momentum", _p(w), _p(g), _p(v), _p(w_bf16), n, momentum, l2, grad_scale, _p(step), _p(boundaries), _p(values), nb,
+         _stream())
+
+
+def step_increment(step):
+    call("frcnn_step_increment", _p(step), _stream())
+
+
+def anchors_generate(out, gh, gw, scales, ratios, base_h, base_w, stride_h=16.0, stride_w=16.0):
+    sc = (c_float * len(scales))(*scales)
+    ra = (c_float * len(ratios))(*ratios)
+    call("frcnn_anchors_generate", _p(out), gh, gw, sc, len(scales), ra, len(ratios), base_h, base_w, stride_h, stride_w, _stream())
+
+
+def rpn_head_post(head, ld, b, num_anchors_total, a_per_loc, keep, n, scores, deltas):
+    call("frcnn_rpn_head_post", _p(head), ld, b, num_anchors_total, a_per_loc, _p(keep), n, _p(scores), _p(deltas), _stream())
+
+
+def clip_to_window(boxes, out, window):
+    x0, y0, x1, y1 = [float(v) for v in window]
+    call("frcnn_clip_to_window", _p(boxes), _p(out), boxes.numel() // 4, x0, y0, x1, y1, _stream())
+
+
+def boxes_scale(inp, out, sx, sy):
+    call("frcnn_boxes_scale", _p(inp), _p(out), inp.numel() // 4, sx, sy, _stream())
+
+
+def decode_boxes(regions, deltas, out, b, r, c, img_w, img_h):
+    call("frcnn_decode_boxes", _p(regions), 1 if regions.dim() == 3 else 0, _p(deltas), _p(out), b, r, c, float(img_w), float(img_h),
+         _stream())
+
+
+def nms_workspace_bytes(b, n, c, max_per_class, max_total):
+    return int(_lib.load().frcnn_nms_workspace_bytes(b, n, c, max_per_class, max_total))
+
+
+def nms_combined(boxes, scores, b, n, q, c, score_stride, score_offset, max_per_class, max_total, iou_thr, score_thr, out_boxes,
+                 out_scores, out_classes, out_valid, workspace):
+    call("frcnn_nms_combined", _p(boxes), _p(scores), b, n, q, c, score_stride, score_offset, max_per_class, max_total, iou_thr,
+         score_thr, _p(out_boxes), _p(out_scores), _p(out_classes), _p(out_valid), _p(workspace), workspace.numel() * workspace.element_size(),
+         _stream())
+
+
+def roi_crop_pool_fwd(feat, rois, b, p, hf, wf, c, ps, ks, pooled, argmax):
+    call("frcnn_roi_crop_pool_fwd", _p(feat), _p(rois), b, p, hf, wf, c, ps, ks, _p(pooled), _p(argmax), _stream())
+
+
+def roi_crop_pool_bwd(gpooled, argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, gfeat):
+    call("frcnn_roi_crop_pool_bwd", _p(gpooled), _p(argmax), _p(rois), _p(rows), nrows, p, hf, wf, c, ps, ks, _p(gfeat), _stream())
+
+
+def rcnn_head_post(logits, ld, bias, r, nc1, scores, deltas):
+    call("frcnn_rcnn_head_post", _p(logits), ld, _p(bias), r, nc1, _p(scores), _p(deltas), _stream())
+
+
+def assign_targets(regions, gt_labels, gt_boxes, b, r, g, c1g, objectness, img_w, img_h, fg_interval, bg_interval, target_labels,
+                   target_boxes):
+    call("frcnn_assign_targets", _p(regions), 1 if regions.dim() == 3 else 0, _p(gt_labels), _p(gt_boxes), b, r, g, c1g,
+         1 if objectness else 0, float(img_w), float(img_h), float(fg_interval[0]), float(fg_interval[1]), float(bg_interval[0]),
+         float(bg_interval[1]), _p(target_labels), _p(target_boxes), _stream())
+
+
+def sample_indices(target_labels, b, r, c1, num_samples, fg_proportion, seed, step, stream_base, indices, workspace, status):
+    call("frcnn_sample_indices", _p(target_labels), b, r, c1, num_samples, float(fg_proportion), ctypes.c_uint64(seed), _p(step),
+         stream_base, _p(indices), _p(workspace), _p(status), _stream())
+
+
+def losses(scores, deltas, target_labels, target_boxes, indices, b, r, c1, s, cls_scale, reg_scale, out_losses, dlogits_s=None,
+           ddeltas_s=None):
+    call("frcnn_losses", _p(scores), _p(deltas), _p(target_labels), _p(target_boxes), _p(indices), b, r, c1, s, float(cls_scale),
+         float(reg_scale), _p(out_losses), _p(dlogits_s), _p(ddeltas_s), _stream())
+
+
+def rpn_head_grad(dlogits_s, ddeltas_s, indices, keep, b, s, num_anchors_total, a_per_loc, dhead, ld):
+    call("frcnn_rpn_head_grad", _p(dlogits_s), _p(ddeltas_s), _p(indices), _p(keep), b, s, num_anchors_total, a_per_loc, _p(dhead), ld,
+         _stream())
+
+
+def rcnn_head_grad(dlogits_s, ddeltas_s, indices, b, r, c1, s, dhead_s, ld, rows_out):
+    call("frcnn_rcnn_head_grad", _p(dlogits_s), _p(ddeltas_s), _p(indices), b, r, c1, s, _p(dhead_s), ld, _p(rows_out), _stream())

@@ -1,0 +1,226 @@
+/* frcnn_hip.h -- C ABI of the MI355X-native (gfx950) Faster-RCNN hot path.
+ *
+ * The reference (antoineBarbez/2D_object_detection) is 100% Python on TensorFlow and has no
+ * FFI of its own; the boundary it offers is the Python call surface of
+ * models/faster_rcnn.py, models/feature_extractor.py, models/detectors/{rpn,fast_rcnn}_detector.py and
+ * utils/post_processing.py.  Each entry point below names the reference call site (file:line)
+ * whose TensorFlow op(s) it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer unless marked "host";
+ *   - `stream` is a hipStream_t passed as void*; nothing here synchronises the host,
+ *     allocates, or keeps global mutable state (graph-capture safe, re-entrant);
+ *   - activations are NHWC, bf16 (uint16 storage) unless noted; parameters are fp32 masters
+ *     with bf16 working copies; boxes are [x_min, y_min, x_max, y_max] fp32;
+ *   - return value: 0 = ok, <0 = error (see frcnn_last_error(), thread-local).
+ */
+#ifndef FRCNN_HIP_H
+#define FRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* frcnn_stream_t;
+typedef uint16_t frcnn_bf16;
+
+#define FRCNN_OK 0
+#define FRCNN_EINVAL (-1)      /* bad argument / unsupported shape */
+#define FRCNN_ELAUNCH (-2)     /* kernel launch failed */
+
+int frcnn_abi_version(void);
+const char* frcnn_last_error(void);
+
+/* ------------------------------------------------------------------ dense tensor ops */
+
+/* Implicit-GEMM convolution, bf16 MFMA, fp32 accumulate.
+ * Replaces every Conv2D of the Keras ResNet50 graph (models/feature_extractor.py:8-10), the RPN
+ * convs (models/detectors/rpn_detector.py:26-58,79-86), the Dense heads
+ * (fast_rcnn_detector.py:25-41,62-65, as 1x1 "convs" over RoI rows) and -- with transposed,
+ * tap-flipped weights -- their data gradients (tape.gradient, models/faster_rcnn.py:103).
+ *
+ * out[(n,oy,ox), co] = sum_{kh,kw,ci} x[n, oy*stride-pad_h+kh, ox*stride-pad_w+kw, ci] * w[co,kh,kw,ci]
+ * x rows outside the input are zero.  `cin` must be a multiple of 32 (64 unless kh*kw*cin/32 is odd),
+ * `cout` a multiple of 8.  in_pix_stride is the element distance between input pixels (== cin
+ * for ordinary NHWC; the stem reads its 4-channel padded image with in_pix_stride 4, cin 32).
+ * The output pixel (n,oy,ox) is stored at row ((n*out_h + oy*out_scatter)*out_w + ox*out_scatter)
+ * (out_scatter 2 scatters a stride-2 1x1 data gradient into the larger input grid). */
+#define FRCNN_CONV_BIAS       1   /* add bias[cout] */
+#define FRCNN_CONV_RELU       2   /* max(.,0) */
+#define FRCNN_CONV_OUT_F32    4   /* y is fp32 instead of bf16 */
+#define FRCNN_CONV_ADD_RES    8   /* y = conv + res (res bf16, same addressing as y; may alias y) */
+#define FRCNN_CONV_STATS      16  /* write per-M-tile column sum / sum-of-squares of the (bf16-rounded) output */
+#define FRCNN_CONV_SPLITK_ATOMIC 32 /* y (fp32, pre-zeroed) accumulated with atomics over split_k K-slices */
+typedef struct {
+    int n, hi, wi, in_pix_stride, cin;
+    int kh, kw, stride, pad_h, pad_w;
+    int ho, wo, cout;
+    int out_h, out_w, out_scatter;
+    int flags, split_k;
+} frcnn_conv_desc;
+/* number of M tiles == rows of the stats_partial buffer [tiles][2][cout] */
+int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d);
+int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
+                       const frcnn_bf16* res, void* y, float* stats_partial, frcnn_stream_t stream);
+
+/* Weight gradient: dw[co,kh,kw,ci] (fp32, accumulated with atomics into a pre-zeroed buffer) =
+ * sum_pixels dz[(n,oy,ox), co] * x[n, oy*stride-pad_h+kh, ox*stride-pad_w+kw, ci].
+ * Same descriptor as the forward conv (out_* / flags ignored).  `row_index` (optional int32[M])
+ * replaces the im2col row of output pixel p by input row row_index[p] (1x1 only; used for the Dense
+ * heads, whose gradient only involves the sampled RoI rows).  dz row stride is dz_stride elements. */
+int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* dz, int dz_stride,
+                       const int32_t* row_index, float* dw, frcnn_stream_t stream);
+
+/* w_t[ci][KH-1-kh][KW-1-kw][co] (bf16) = w[co][kh][kw][ci] (fp32 master) : data-gradient weights. */
+int frcnn_weights_transpose_flip(const float* w, frcnn_bf16* w_t, int cout, int kh, int kw, int cin,
+                                 frcnn_stream_t stream);
+/* plain fp32 -> bf16 cast of n elements */
+int frcnn_cast_f32_bf16(const float* src, frcnn_bf16* dst, int64_t n, frcnn_stream_t stream);
+/* stem weights: master [64][7][7][3] fp32 <-> padded GEMM form [64][7][8][4]
+ * (pack: -> bf16; unpack_grad: padded fp32 grad -> compact fp32 grad, overwriting). */
+int frcnn_stem_pack_weights(const float* w, frcnn_bf16* w_packed, int cout, frcnn_stream_t stream);
+int frcnn_stem_unpack_grad(const float* dw_packed, float* dw, int cout, frcnn_stream_t stream);
+
+/* uint8 RGB [B,H,W,3] -> bf16 BGR minus caffe mean, zero-padded to [B,Hp,Wp,4] with the image at
+ * offset (pad,pad); channel 3 = 0.  models/feature_extractor.py:6-7 (+ the ZeroPadding2D(3)
+ * of Keras ResNet50). */
+int frcnn_preprocess_u8_bgr_mean(const uint8_t* images, frcnn_bf16* out, int b, int h, int w, int hp, int wp,
+                                 int pad, frcnn_stream_t stream);
+
+/* BatchNormalization (Keras ResNet50 BN layers, training and inference mode).
+ * finalize_train: reduce conv stats partials [tiles][2][c] -> mean/invstd, fused scale/shift
+ * (scale = gamma*invstd, shift = beta - mean*scale), and update the moving averages
+ * (moving = moving*momentum + batch*(1-momentum), variance unbiased as FusedBatchNormV3). */
+int frcnn_bn_finalize_train(const float* stats_partial, int tiles, int c, int64_t count, const float* gamma,
+                            const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
+                            float* scale, float* shift, float* mean, float* invstd, frcnn_stream_t stream);
+int frcnn_bn_finalize_eval(int c, const float* gamma, const float* beta, const float* moving_mean,
+                           const float* moving_var, float eps, float* scale, float* shift, frcnn_stream_t stream);
+/* out = [relu]( z*scale + shift [+ res] )  over m rows of c channels (c % 8 == 0) */
+int frcnn_bn_apply(const frcnn_bf16* z, const float* scale, const float* shift, const frcnn_bf16* res, int relu,
+                   frcnn_bf16* out, int64_t m, int c, frcnn_stream_t stream);
+/* backward: g = gout * (act > 0) if act != NULL else gout;  xhat = (z-mean)*invstd
+ * reduce  : partial[blk][0][c] = sum g, partial[blk][1][c] = sum g*xhat   (blk = frcnn_bn_bwd_blocks(m))
+ * finalize: dgamma = sum g*xhat, dbeta = sum g, c1 = dbeta/m, c2 = dgamma/m
+ * apply   : dz = gamma*invstd*(g - c1 - xhat*c2);  gpre (optional) = g */
+int frcnn_bn_bwd_blocks(int64_t m);
+int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act, const frcnn_bf16* z, const float* mean,
+                        const float* invstd, float* partial, int64_t m, int c, frcnn_stream_t stream);
+int frcnn_bn_bwd_finalize(const float* partial, int blocks, int c, int64_t m, float* dgamma, float* dbeta,
+                          float* c1, float* c2, frcnn_stream_t stream);
+int frcnn_bn_bwd_apply(const frcnn_bf16* gout, const frcnn_bf16* act, const frcnn_bf16* z, const float* mean,
+                       const float* invstd, const float* gamma, const float* c1, const float* c2,
+                       frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, frcnn_stream_t stream);
+/* g_out = g * (act > 0): ReLU backward without BN (RPN intermediate layer) */
+int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, int64_t n, frcnn_stream_t stream);
+/* per-channel column sum of a bf16 [m,c] matrix -> fp32 out[c] (bias gradients); overwrites out */
+int frcnn_colsum_bf16(const frcnn_bf16* x, int64_t m, int c, int ld, float* out, frcnn_stream_t stream);
+
+/* ZeroPadding2D(1) + MaxPool 3x3/2 valid of Keras ResNet50 (pool1_pad/pool1_pool); input >= 0.
+ * argmax (uint8, 0..8 window position, first max wins) feeds the backward gather. */
+int frcnn_maxpool3x3s2_fwd(const frcnn_bf16* x, frcnn_bf16* y, uint8_t* argmax, int n, int h, int w, int c,
+                           int ho, int wo, frcnn_stream_t stream);
+int frcnn_maxpool3x3s2_bwd(const frcnn_bf16* gy, const uint8_t* argmax, frcnn_bf16* gx, int n, int h, int w, int c,
+                           int ho, int wo, frcnn_stream_t stream);
+
+/* Keras SGD(momentum) step on a flat parameter range (train_faster_rcnn.py:109-112,
+ * models/faster_rcnn.py:104) fused with the L2 kernel regulariser gradient 2*l2*w
+ * (models/faster_rcnn.py:101) and the bf16 working-copy refresh:
+ *   g' = g*grad_scale + 2*l2*w ; v = momentum*v - lr*g' ; w += v ; w_bf16 = bf16(w)
+ * lr = values[i] for the first i with step < boundaries[i] (values has nb+1 entries):
+ * tf.keras.optimizers.schedules.PiecewiseConstantDecay evaluated on the device step counter. */
+int frcnn_sgd_momentum(float* w, const float* g, float* v, frcnn_bf16* w_bf16, int64_t n, float momentum, float l2,
+                       float grad_scale, const int64_t* step, const int64_t* boundaries, const float* values, int nb,
+                       frcnn_stream_t stream);
+int frcnn_step_increment(int64_t* step, frcnn_stream_t stream);
+
+/* ------------------------------------------------------------------ boxes / RPN / NMS */
+
+/* models/detectors/rpn_detector.py:162-199: anchors[(y*gw+x)*A + k] , k = ratio-major. */
+int frcnn_anchors_generate(float* anchors, int gh, int gw, const float* scales /*host*/, int ns,
+                           const float* ratios /*host*/, int nr, float base_h, float base_w, float stride_h,
+                           float stride_w, frcnn_stream_t stream);
+/* rpn_detector.py:81-91 after the two 1x1 convs: head [B*gh*gw, ld] fp32 with columns
+ * [0,2A) = cls logits (k*2+{bg,fg}) and [2A,6A) = deltas (k*4+..).  For each kept anchor index
+ * keep[i] (or all anchors when keep == NULL): pair softmax -> scores[B,n,2]; deltas[B,n,4]. */
+int frcnn_rpn_head_post(const float* head, int ld, int b, int num_anchors_total, int a_per_loc, const int32_t* keep,
+                        int n, float* scores, float* deltas, frcnn_stream_t stream);
+/* utils/boxes.py:4-17 */
+int frcnn_clip_to_window(const float* boxes, float* out, int64_t n, float x0, float y0, float x1, float y1,
+                         frcnn_stream_t stream);
+/* utils/post_processing.py:39-49: decode(pred_boxes, tiled regions) / [W,H,W,H].
+ * regions [R,4] (regions_per_image = 0) or [B,R,4]; deltas [B,R,C,4] -> out [B,R,C,4]. */
+int frcnn_decode_boxes(const float* regions, int regions_per_image, const float* deltas, float* out, int b, int r,
+                       int c, float img_w, float img_h, frcnn_stream_t stream);
+/* tf.image.combined_non_max_suppression as called at utils/post_processing.py:53-55.
+ * boxes [B,N,q,4] (q = 1 or C), scores [B,N,*] with row stride score_stride, class c at column
+ * score_offset + c.  Outputs [B,T,4], [B,T], int32 [B,T], int32 [B]. */
+size_t frcnn_nms_workspace_bytes(int b, int n, int c, int max_per_class, int max_total);
+int frcnn_nms_combined(const float* boxes, const float* scores, int b, int n, int q, int c, int score_stride,
+                       int score_offset, int max_per_class, int max_total, float iou_thr, float score_thr,
+                       float* out_boxes, float* out_scores, int32_t* out_classes, int32_t* out_valid,
+                       void* workspace, size_t workspace_bytes, frcnn_stream_t stream);
+
+/* ------------------------------------------------------------------ RoI pooling + heads */
+
+/* fast_rcnn_detector.py:154-175: crop_and_resize(14x14 bilinear, extrapolation 0) + MaxPool 2x2,
+ * fused; rois [B,P,4] relative [x1,y1,x2,y2]; pooled [B*P, ps*ps*C] in (h,w,c) order; argmax
+ * uint8 (0..ks*ks-1) per pooled element.  `row_index` (optional int32[nrows]) selects which RoI rows
+ * (b*P+p) to process and writes them densely (used to re-pool only sampled rows). */
+int frcnn_roi_crop_pool_fwd(const frcnn_bf16* feat, const float* rois, int b, int p, int hf, int wf, int c, int ps,
+                            int ks, frcnn_bf16* pooled, uint8_t* argmax, frcnn_stream_t stream);
+/* gradient w.r.t. the feature map only (CropAndResizeGradImage o MaxPoolGrad): for each listed
+ * row r (RoI rows[r] = b*P+p) scatter-add gpooled[r] into gfeat (fp32, pre-zeroed). */
+int frcnn_roi_crop_pool_bwd(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,
+                            int nrows, int p, int hf, int wf, int c, int ps, int ks, float* gfeat,
+                            frcnn_stream_t stream);
+/* fast_rcnn_detector.py:62-65 after the GEMM: logits [R, ld] fp32 (+bias): softmax over the first
+ * nc1 columns -> scores [R,nc1]; columns [nc1, nc1+4*(nc1-1)) -> deltas. */
+int frcnn_rcnn_head_post(const float* logits, int ld, const float* bias, int r, int nc1, float* scores, float* deltas,
+                         frcnn_stream_t stream);
+/* rois_abs = rois_rel * [W,H,W,H]  (utils/boxes.py:76-83, fast_rcnn_detector.py:67) */
+int frcnn_boxes_scale(const float* in, float* out, int64_t n, float sx, float sy, frcnn_stream_t stream);
+
+/* ------------------------------------------------------------------ targets / sampling / losses */
+
+/* utils/training.py:7-77 (+ rpn_detector.py:141 objectness conversion when objectness != 0).
+ * regions [R,4] (regions_per_image = 0) or [B,R,4] absolute; gt_labels [B,G,C1g], gt_boxes [B,G,4]
+ * relative.  Writes target_labels [B,R,C1] and target_boxes [B,R,C1-1,4] (C1 = 2 when objectness). */
+int frcnn_assign_targets(const float* regions, int regions_per_image, const float* gt_labels, const float* gt_boxes,
+                         int b, int r, int g, int c1g, int objectness, float img_w, float img_h, float fg_lo,
+                         float fg_hi, float bg_lo, float bg_hi, float* target_labels, float* target_boxes,
+                         frcnn_stream_t stream);
+/* utils/training.py:80-120 with a counter-based RNG (Philox4x32-10; counter = (i, image, step,
+ * stream_base + {0 fg, 1 bg}), key = seed).  indices int32 [B,S].  status[0] |= 1 on an empty
+ * background set (the reference raises there).  workspace: int32 [B, 2*R]. */
+int frcnn_sample_indices(const float* target_labels, int b, int r, int c1, int num_samples, float fg_proportion,
+                         uint64_t seed, const int64_t* step, int stream_base, int32_t* indices, int32_t* workspace,
+                         int32_t* status, frcnn_stream_t stream);
+/* utils/losses.py + gathers of get_training_samples (rpn_detector.py:156-159,
+ * fast_rcnn_detector.py:126-129) + their gradients.
+ * scores [B,R,C1] (probabilities), deltas [B,R,C,4], targets as written by frcnn_assign_targets,
+ * indices [B,S].  losses[0] = CCE mean, losses[1] = Huber sum.  If dlogits_s / ddeltas_s != NULL
+ * they receive the PER-SAMPLE gradient of (cls_scale*CCE + reg_scale*Huber) w.r.t. the
+ * PRE-softmax logits [B,S,C1] and the deltas [B,S,C,4] of the sampled rows (duplicated samples
+ * stay separate rows; no atomics, deterministic). */
+int frcnn_losses(const float* scores, const float* deltas, const float* target_labels, const float* target_boxes,
+                 const int32_t* indices, int b, int r, int c1, int s, float cls_scale, float reg_scale, float* losses,
+                 float* dlogits_s, float* ddeltas_s, frcnn_stream_t stream);
+/* RPN: scatter-ADD the per-sample gradients (dlogits_s [B,S,2], ddeltas_s [B,S,4]) into the dense
+ * fp32 head-gradient matrix dhead [B*gh*gw, ld] (pre-zeroed).  Sample (b,s) refers to kept anchor
+ * indices[b,s], i.e. anchor keep[indices[b,s]] (keep == NULL: identity). */
+int frcnn_rpn_head_grad(const float* dlogits_s, const float* ddeltas_s, const int32_t* indices, const int32_t* keep,
+                        int b, int s, int num_anchors_total, int a_per_loc, float* dhead, int ld,
+                        frcnn_stream_t stream);
+/* RCNN: per-sample gradient rows -> dhead_s [B*S, ld] (bf16, zero padded to ld columns);
+ * rows_out[b*S+s] = b*R + indices[b,s] (the RoI row each sample came from). */
+int frcnn_rcnn_head_grad(const float* dlogits_s, const float* ddeltas_s, const int32_t* indices, int b, int r, int c1,
+                         int s, frcnn_bf16* dhead_s, int ld, int32_t* rows_out, frcnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRCNN_HIP_H */

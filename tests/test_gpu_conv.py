@@ -1,0 +1,212 @@
+"""GPU parity of the MFMA conv family (through the C ABI) against torch-CPU fp32 on the same
+bf16-rounded inputs.  Tolerances: outputs are bf16 (8 significand bits -> 2^-9 relative
+rounding) of fp32-accumulated sums; fp32 outputs only differ by accumulation order."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _rt(t):
+    return t.to(BF).to(torch.float32)
+
+
+def _ohwi(w_oihw):
+    return w_oihw.permute(0, 2, 3, 1).contiguous()
+
+
+def _close(a, b, rtol, atol, what):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    bad = int((err > bound).sum())
+    assert bad == 0, "%s: %d/%d mismatches, max err %g (ref max %g)" % (what, bad, a.numel(), float(err.max()), float(b.abs().max()))
+
+
+CASES = [
+    # n, h, w, cin, cout, k, stride, pad, flags
+    dict(n=2, h=13, w=17, cin=64, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    dict(n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1, bias=True, relu=True, stats=False),
+    dict(n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0, bias=False, relu=False, stats=True),
+    dict(n=4, h=64, w=64, cin=64, cout=512, k=1, s=1, p=0, bias=True, relu=False, stats=True),   # 128x128 tiles
+    dict(n=1, h=9, w=11, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+    dict(n=2, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fprop(ops, case):
+    g = torch.Generator().manual_seed(0)
+    n, h, w, cin, cout, k, s, p = (case[x] for x in ("n", "h", "w", "cin", "cout", "k", "s", "p"))
+    x = _rt(torch.randn(n, h, w, cin, generator=g))
+    wt = _rt(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5)
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), wt, bias if case["bias"] else None, stride=s, padding=p)
+    if case["relu"]:
+        ref = F.relu(ref)
+    ref = ref.permute(0, 2, 3, 1).contiguous()
+    ho, wo = ref.shape[1], ref.shape[2]
+    flags = (ops.CONV_BIAS if case["bias"] else 0) | (ops.CONV_RELU if case["relu"] else 0) | (ops.CONV_STATS if case["stats"] else 0)
+    d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout, flags=flags)
+    xd, wd, bd = x.to(BF).cuda(), _ohwi(wt).to(BF).cuda(), bias.cuda()
+    y = torch.full((n, ho, wo, cout), float("nan"), dtype=BF, device="cuda")
+    tiles = ops.conv_stat_tiles(d)
+    stats = torch.zeros(tiles, 2, cout, device="cuda")
+    ops.conv2d_fprop(d, xd, wd, y, bias=bd, stats=stats if case["stats"] else None)
+    torch.cuda.synchronize()
+    _close(y, ref, 2 ** -7, 2e-2, "conv output")
+    if case["stats"]:
+        yb = y.float().cpu().reshape(-1, cout)
+        _close(stats[:, 0].sum(0), yb.sum(0), 1e-4, 1e-2, "stats sum")
+        _close(stats[:, 1].sum(0), (yb * yb).sum(0), 1e-4, 1e-2, "stats sumsq")
+
+
+def test_conv_stem(ops):
+    """uint8 image -> preprocess kernel (BGR - mean, pad 3, 4 channels) -> 7x7/2 conv as a K=7x32 row-gather GEMM."""
+    g = torch.Generator().manual_seed(1)
+    n, h, w = 2, 37, 45
+    img = torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8)
+    wt = _rt(torch.randn(64, 3, 7, 7, generator=g) * 0.05)
+    bias = torch.randn(64, generator=g)
+    mean = torch.tensor([103.939, 116.779, 123.68])
+    xp = _rt(img.float()[..., [2, 1, 0]] - mean)
+    ref = F.conv2d(xp.permute(0, 3, 1, 2), wt, bias, stride=2, padding=3).permute(0, 2, 3, 1)
+    ho, wo = ref.shape[1], ref.shape[2]
+    hp, wp = h + 6, max(w + 6, 2 * (wo - 1) + 8)
+    xpad = torch.full((n * hp * wp * 4 + 64,), float("nan"), dtype=BF, device="cuda")
+    xpad[n * hp * wp * 4:] = 0
+    ops.preprocess(img.cuda(), xpad[: n * hp * wp * 4].view(n, hp, wp, 4), pad=3)
+    pre = xpad[: n * hp * wp * 4].view(n, hp, wp, 4).float().cpu()
+    assert torch.equal(pre[:, 3:3 + h, 3:3 + w, :3], xp), "preprocess interior"
+    assert float(pre[:, :3].abs().sum()) == 0 and float(pre[..., 3].abs().sum()) == 0, "preprocess padding"
+    w_master = _ohwi(wt).cuda()                         # [64,7,7,3] fp32
+    w_packed = torch.empty(64, 7, 8, 4, dtype=BF, device="cuda")
+    ops.stem_pack_weights(w_master, w_packed)
+    d = ops.conv_desc(n, hp, wp, 32, 7, 1, 2, 0, 0, ho, wo, 64, in_pix_stride=4, flags=ops.CONV_BIAS)
+    y = torch.empty(n, ho, wo, 64, dtype=BF, device="cuda")
+    ops.conv2d_fprop(d, xpad, w_packed, y, bias=bias.cuda())
+    torch.cuda.synchronize()
+    _close(y, ref, 2 ** -7, 0.5, "stem conv")          # |x| up to 150 -> outputs O(100)
+
+
+def test_conv_dgrad_3x3_with_residual(ops):
+    g = torch.Generator().manual_seed(2)
+    n, h, w, cin, cout = 2, 11, 9, 64, 128
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = _rt(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5)
+    dz = _rt(torch.randn(n, cout, h, w, generator=g))
+    res = _rt(torch.randn(n, h, w, cin, generator=g))
+    F.conv2d(x, wt, padding=1).backward(dz)
+    ref = x.grad.permute(0, 2, 3, 1) + res
+    w_t = torch.empty(cin, 3, 3, cout, dtype=BF, device="cuda")
+    ops.weights_transpose_flip(_ohwi(wt).cuda(), w_t, cout, 3, 3, cin)
+    d = ops.conv_desc(n, h, w, cout, 3, 3, 1, 1, 1, h, w, cin, flags=ops.CONV_ADD_RES)
+    out = res.to(BF).cuda()                                # in-place accumulate: res aliases y
+    ops.conv2d_fprop(d, dz.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), w_t, out, res=out)
+    torch.cuda.synchronize()
+    _close(out, ref, 2 ** -7, 3e-2, "dgrad 3x3 + residual")
+
+
+def test_conv_dgrad_stride2_scatter(ops):
+    g = torch.Generator().manual_seed(3)
+    n, h, w, cin, cout = 2, 15, 21, 64, 128
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = _rt(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5)
+    y = F.conv2d(x, wt, stride=2)
+    ho, wo = y.shape[2], y.shape[3]
+    dz = _rt(torch.randn(n, cout, ho, wo, generator=g))
+    y.backward(dz)
+    ref = x.grad.permute(0, 2, 3, 1)
+    w_t = torch.empty(cin, 1, 1, cout, dtype=BF, device="cuda")
+    ops.weights_transpose_flip(_ohwi(wt).cuda(), w_t, cout, 1, 1, cin)
+    d = ops.conv_desc(n, ho, wo, cout, 1, 1, 1, 0, 0, ho, wo, cin, out_h=h, out_w=w, out_scatter=2)
+    out = torch.zeros(n, h, w, cin, dtype=BF, device="cuda")
+    ops.conv2d_fprop(d, dz.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), w_t, out)
+    torch.cuda.synchronize()
+    _close(out, ref, 2 ** -7, 3e-2, "dgrad stride-2 scatter")
+
+
+def test_conv_f32_out_and_splitk(ops):
+    g = torch.Generator().manual_seed(4)
+    m, k, cout = 300, 6400, 64
+    x = _rt(torch.randn(m, k, generator=g))
+    wt = _rt(torch.randn(cout, k, generator=g) / k ** 0.5)
+    wt[36:] = 0
+    bias = torch.randn(cout, generator=g)
+    ref = x @ wt.t()
+    xd, wd = x.to(BF).cuda(), wt.to(BF).cuda()
+    d = ops.conv_desc(1, 1, m, k, 1, 1, 1, 0, 0, 1, m, cout, flags=ops.CONV_OUT_F32 | ops.CONV_BIAS)
+    y = torch.empty(m, cout, device="cuda")
+    ops.conv2d_fprop(d, xd, wd, y, bias=bias.cuda())
+    _close(y, ref + bias, 1e-4, 1e-3, "fp32 output")
+    d2 = ops.conv_desc(1, 1, m, k, 1, 1, 1, 0, 0, 1, m, cout, flags=ops.CONV_SPLITK_ATOMIC, split_k=8)
+    y2 = torch.zeros(m, cout, device="cuda")
+    ops.conv2d_fprop(d2, xd, wd, y2)
+    torch.cuda.synchronize()
+    _close(y2, ref, 1e-4, 1e-3, "split-K atomic output")
+
+
+WGRAD_CASES = [
+    dict(n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1),
+    dict(n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0),
+    dict(n=2, h=9, w=13, cin=128, cout=256, k=1, s=1, p=0),
+    dict(n=3, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1),
+    dict(n=2, h=30, w=40, cin=64, cout=256, k=1, s=1, p=0),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(ops, case):
+    g = torch.Generator().manual_seed(5)
+    n, h, w, cin, cout, k, s, p = (case[x] for x in ("n", "h", "w", "cin", "cout", "k", "s", "p"))
+    x = _rt(torch.randn(n, cin, h, w, generator=g))
+    wt = torch.zeros(cout, cin, k, k, requires_grad=True)
+    y = F.conv2d(x, wt, stride=s, padding=p)
+    ho, wo = y.shape[2], y.shape[3]
+    dz = _rt(torch.randn(n, cout, ho, wo, generator=g))
+    y.backward(dz)
+    ref = _ohwi(wt.grad)
+    d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout)
+    dw = torch.zeros(cout, k, k, cin, device="cuda")
+    ops.conv2d_wgrad(d, x.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dz.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dw)
+    torch.cuda.synchronize()
+    _close(dw, ref, 2e-4, 2e-3 * (n * ho * wo) ** 0.5, "wgrad")
+
+
+def test_conv_wgrad_stem_and_rowindex(ops):
+    g = torch.Generator().manual_seed(6)
+    # stem: packed [64][7][8][4] gradient, then unpack to [64][7][7][3]
+    n, h, w = 2, 37, 45
+    xp = _rt(torch.randn(n, 3, h, w, generator=g))
+    wt = torch.zeros(64, 3, 7, 7, requires_grad=True)
+    y = F.conv2d(xp, wt, stride=2, padding=3)
+    ho, wo = y.shape[2], y.shape[3]
+    dz = _rt(torch.randn(n, 64, ho, wo, generator=g))
+    y.backward(dz)
+    ref = _ohwi(wt.grad)
+    hp, wp = h + 6, max(w + 6, 2 * (wo - 1) + 8)
+    xpad = torch.zeros(n, hp, wp, 4)
+    xpad[:, 3:3 + h, 3:3 + w, :3] = xp.permute(0, 2, 3, 1)
+    xflat = torch.zeros(n * hp * wp * 4 + 64, dtype=BF, device="cuda")
+    xflat[: n * hp * wp * 4] = xpad.reshape(-1).to(BF).cuda()
+    d = ops.conv_desc(n, hp, wp, 32, 7, 1, 2, 0, 0, ho, wo, 64, in_pix_stride=4)
+    dwp = torch.zeros(64, 7, 8, 4, device="cuda")
+    ops.conv2d_wgrad(d, xflat, dz.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dwp)
+    dw = torch.empty(64, 7, 7, 3, device="cuda")
+    ops.stem_unpack_grad(dwp, dw)
+    torch.cuda.synchronize()
+    _close(dw, ref, 2e-4, 2e-3 * (n * ho * wo) ** 0.5, "stem wgrad")
+    # Dense-head form: rows gathered through row_index, dz padded to 64 columns
+    R, K, S = 40, 1024, 24
+    pooled = _rt(torch.randn(R, K, generator=g))
+    rows = torch.randint(0, R, (S,), generator=g, dtype=torch.int32)
+    dl = torch.zeros(S, 64)
+    dl[:, :36] = _rt(torch.randn(S, 36, generator=g))
+    ref2 = dl.t() @ pooled[rows.long()]
+    d2 = ops.conv_desc(1, 1, S, K, 1, 1, 1, 0, 0, 1, S, 64)
+    dw2 = torch.zeros(64, K, device="cuda")
+    ops.conv2d_wgrad(d2, pooled.to(BF).cuda(), dl.to(BF).cuda(), dw2, dz_stride=64, row_index=rows.cuda())
+    torch.cuda.synchronize()
+    _close(dw2, ref2, 2e-4, 1e-2, "head wgrad (row_index)")

@@ -1,0 +1,434 @@
+"""GPU parity (through the C ABI) of the non-GEMM kernels against the CPU oracle.
+Integer / index / discrete outputs: bit-exact.  Float outputs: tolerance stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import boxes as oboxes
+from oracle import faster_rcnn as O
+from oracle import losses as olosses
+from oracle import nms as onms
+from oracle import roi as oroi
+from oracle import training as otraining
+from oracle.philox import rand_u32
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _rt(t):
+    return t.to(BF).to(torch.float32)
+
+
+def _close(a, b, rtol, atol, what):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    bad = int((err > atol + rtol * b.abs()).sum())
+    assert bad == 0, "%s: %d/%d mismatches, max err %g" % (what, bad, a.numel(), float(err.max()))
+
+
+# ------------------------------------------------------------------ BN / pool / SGD
+def test_bn_forward_backward(ops):
+    g = torch.Generator().manual_seed(0)
+    m, c = 1000, 64
+    z = _rt(torch.randn(m, c, generator=g) * 2 + 0.5)
+    res = _rt(torch.randn(m, c, generator=g))
+    gamma = 1 + 0.1 * torch.randn(c, generator=g)
+    beta = 0.1 * torch.randn(c, generator=g)
+    zz = z.clone().requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    out_ref = F.relu(F.batch_norm(zz, rm, rv, gm, bt, training=True, momentum=0.01, eps=1.001e-5) + res)
+    gout = _rt(torch.randn(m, c, generator=g))
+    out_ref.backward(gout)
+
+    dev = "cuda"
+    zd = z.to(BF).to(dev)
+    # stats partials as the conv epilogue would write them: 4 row blocks
+    parts = torch.zeros(4, 2, c, device=dev)
+    for i, blk in enumerate(z.chunk(4)):
+        parts[i, 0] = blk.sum(0).to(dev)
+        parts[i, 1] = (blk * blk).sum(0).to(dev)
+    mm, mv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    scale, shift, mean, invstd = (torch.empty(c, device=dev) for _ in range(4))
+    ops.bn_finalize_train(parts, 4, c, m, gamma.to(dev), beta.to(dev), mm, mv, 0.99, 1.001e-5, scale, shift, mean, invstd)
+    out = torch.empty(m, c, dtype=BF, device=dev)
+    ops.bn_apply(zd, scale, shift, out, m, c, res=res.to(BF).to(dev), relu=True)
+    torch.cuda.synchronize()
+    _close(mm, rm, 1e-4, 1e-5, "moving mean")
+    _close(mv, rv, 1e-4, 1e-5, "moving variance")
+    _close(out, out_ref.detach(), 2 ** -7, 1e-2, "bn apply")
+    # backward (mask from the ORACLE's activation so both sides use the same ReLU mask)
+    act = out_ref.detach().to(BF).to(dev)
+    nb = ops.bn_bwd_blocks(m)
+    partial = torch.empty(nb, 2, c, device=dev)
+    gd = gout.to(BF).to(dev)
+    ops.bn_bwd_reduce(gd, act, zd, mean, invstd, partial, m, c)
+    dgamma, dbeta, c1, c2 = (torch.empty(c, device=dev) for _ in range(4))
+    ops.bn_bwd_finalize(partial, nb, c, m, dgamma, dbeta, c1, c2)
+    dz = torch.empty(m, c, dtype=BF, device=dev)
+    gpre = torch.empty(m, c, dtype=BF, device=dev)
+    ops.bn_bwd_apply(gd, act, zd, mean, invstd, gamma.to(dev), c1, c2, dz, gpre, m, c)
+    torch.cuda.synchronize()
+    _close(dgamma, gm.grad, 1e-3, 1e-2, "dgamma")
+    _close(dbeta, bt.grad, 1e-3, 1e-2, "dbeta")
+    _close(dz, zz.grad, 2 ** -6, 2e-3, "dz")
+    _close(gpre, gout * (out_ref.detach() > 0), 0, 0, "gpre")
+
+
+def test_bn_wide_channels_and_eval(ops):
+    g = torch.Generator().manual_seed(1)
+    m, c = 300, 1024
+    z = _rt(torch.randn(m, c, generator=g))
+    gout = _rt(torch.randn(m, c, generator=g))
+    mean, invstd = torch.randn(c, generator=g) * 0.1, 1 + 0.1 * torch.rand(c, generator=g)
+    dev = "cuda"
+    nb = ops.bn_bwd_blocks(m)
+    partial = torch.empty(nb, 2, c, device=dev)
+    ops.bn_bwd_reduce(gout.to(BF).to(dev), None, z.to(BF).to(dev), mean.to(dev), invstd.to(dev), partial, m, c)
+    torch.cuda.synchronize()
+    xh = (z - mean) * invstd
+    _close(partial[:, 0].sum(0), gout.sum(0), 1e-4, 1e-3, "sum g")
+    _close(partial[:, 1].sum(0), (gout * xh).sum(0), 1e-4, 1e-3, "sum g*xhat")
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    scale, shift = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    ops.bn_finalize_eval(c, gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev), 1.001e-5, scale, shift)
+    out = torch.empty(m, c, dtype=BF, device=dev)
+    ops.bn_apply(z.to(BF).to(dev), scale, shift, out, m, c, relu=False)
+    torch.cuda.synchronize()
+    _close(out, F.batch_norm(z, rm, rv, gamma, beta, training=False, eps=1.001e-5), 2 ** -7, 1e-2, "bn eval")
+
+
+def test_maxpool(ops):
+    g = torch.Generator().manual_seed(2)
+    n, h, w, c = 2, 19, 23, 64
+    x = F.relu(_rt(torch.randn(n, h, w, c, generator=g)))
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = F.max_pool2d(F.pad(xr, (1, 1, 1, 1)), 3, 2)
+    ho, wo = yr.shape[2], yr.shape[3]
+    gy = _rt(torch.randn(n, ho, wo, c, generator=g))
+    yr.backward(gy.permute(0, 3, 1, 2))
+    dev = "cuda"
+    y = torch.empty(n, ho, wo, c, dtype=BF, device=dev)
+    am = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=dev)
+    ops.maxpool_fwd(x.to(BF).to(dev), y, am, n, h, w, c, ho, wo)
+    gx = torch.empty(n, h, w, c, dtype=BF, device=dev)
+    ops.maxpool_bwd(gy.to(BF).to(dev), am, gx, n, h, w, c, ho, wo)
+    torch.cuda.synchronize()
+    _close(y, yr.detach().permute(0, 2, 3, 1), 0, 0, "maxpool fwd")
+    # gradient routing can differ only where a window has tied maxima (zeros after ReLU); compare where x > 0
+    ref = xr.grad.permute(0, 2, 3, 1)
+    mask = x > 0
+    _close(gx.float().cpu()[mask], ref[mask], 2 ** -7, 1e-2, "maxpool bwd")
+
+
+def test_sgd_and_lr_schedule(ops):
+    g = torch.Generator().manual_seed(3)
+    n = 10007
+    w, gr, v = torch.randn(n, generator=g), torch.randn(n, generator=g), torch.randn(n, generator=g)
+    dev = "cuda"
+    wd, gd, vd = w.to(dev), gr.to(dev), v.to(dev)
+    wb = torch.empty(n, dtype=BF, device=dev)
+    bounds = torch.tensor([40000, 80000], dtype=torch.int64, device=dev)
+    values = torch.tensor([1e-3, 1e-4, 1e-5], device=dev)
+    for step_val, lr in ((0, 1e-3), (39999, 1e-3), (40000, 1e-4), (80000, 1e-5)):
+        step = torch.tensor([step_val], dtype=torch.int64, device=dev)
+        w0, v0 = wd.clone().cpu(), vd.clone().cpu()
+        ops.sgd_momentum(wd, gd, vd, wb, n, 0.9, 0.0005, 1.0, step, bounds, values, 2)
+        torch.cuda.synchronize()
+        gp = gr + 2 * 0.0005 * w0
+        v1 = 0.9 * v0 - np.float32(lr) * gp
+        _close(vd, v1, 1e-5, 1e-7, "velocity @%d" % step_val)
+        _close(wd, w0 + v1, 1e-5, 1e-7, "weights @%d" % step_val)
+        _close(wb, (w0 + v1), 2 ** -8, 0, "bf16 copy")
+    step = torch.tensor([5], dtype=torch.int64, device=dev)
+    ops.step_increment(step)
+    assert int(step.item()) == 6
+
+
+# ------------------------------------------------------------------ boxes / NMS
+def test_anchors_and_decode(ops):
+    cfg = O.default_config()
+    gh, gw = O.feature_grid(cfg["image_shape"])
+    ref = O.generate_anchors((gh, gw), **cfg["rpn"]["anchors"])
+    a = cfg["rpn"]["anchors"]
+    out = torch.empty(gh * gw * 12, 4, device="cuda")
+    ops.anchors_generate(out, gh, gw, a["scales"], a["aspect_ratios"], a["base_anchor_shape"][0], a["base_anchor_shape"][1])
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref), "anchors must be bit-exact"
+    g = torch.Generator().manual_seed(4)
+    B, R, C = 2, 500, 7
+    regions = ref[1000:1000 + R]
+    deltas = torch.randn(B, R, C, 4, generator=g) * 0.3
+    exp = oboxes.to_relative(oboxes.decode(deltas, regions[None, :, None, :]), cfg["image_shape"])
+    got = torch.empty(B, R, C, 4, device="cuda")
+    ops.decode_boxes(regions.cuda(), deltas.cuda(), got, B, R, C, 1242, 375)
+    clipped = torch.empty(R, 4, device="cuda")
+    ops.clip_to_window(regions.cuda(), clipped, [0, 0, 1242, 375])
+    torch.cuda.synchronize()
+    _close(got, exp, 1e-5, 1e-6, "decode")
+    assert torch.equal(clipped.cpu(), oboxes.clip_to_window(regions, [0, 0, 1242, 375]))
+
+
+def _random_boxes(g, B, N, q):
+    ctr = torch.rand(B, N, q, 2, generator=g)
+    sz = torch.rand(B, N, q, 2, generator=g) * 0.3 + 0.02
+    return torch.cat([ctr - sz / 2, ctr + sz / 2], -1)
+
+
+@pytest.mark.parametrize("B,N,q,C,mpc,mt,thr", [
+    (2, 300, 7, 7, 100, 300, 0.6),       # RCNN configuration
+    (2, 8768, 1, 1, 300, 300, 0.7),      # RPN train configuration (LDS sort, 16384 pad)
+    (1, 22464, 1, 1, 300, 300, 0.7),     # RPN eval configuration (global-scratch sort)
+    (3, 1000, 1, 1, 50, 20, 0.3),        # max_total < kept, heavy suppression
+    (1, 70, 3, 3, 100, 300, 0.5),        # fewer candidates than any cap
+])
+def test_nms_combined_bit_exact(ops, B, N, q, C, mpc, mt, thr):
+    g = torch.Generator().manual_seed(N + C)
+    boxes = _random_boxes(g, B, N, q)
+    # distinct scores (ties are implementation-defined in TF), with a few <= threshold
+    perm = torch.stack([torch.randperm(N * C, generator=g) for _ in range(B)]).reshape(B, N, C)
+    scores = (perm.float() + 1) / (N * C + 1)
+    scores[:, ::17, :] = 0.0
+    exp = onms.combined_nms(boxes, scores, mpc, mt, thr, 0.0)
+    dev = "cuda"
+    ob = torch.full((B, mt, 4), -1.0, device=dev)
+    os_ = torch.full((B, mt), -1.0, device=dev)
+    oc = torch.full((B, mt), -1, dtype=torch.int32, device=dev)
+    ov = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    ws = torch.empty(ops.nms_workspace_bytes(B, N, C, mpc, mt), dtype=torch.uint8, device=dev)
+    ops.nms_combined(boxes.to(dev), scores.to(dev), B, N, q, C, C, 0, mpc, mt, thr, 0.0, ob, os_, oc, ov, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(ov.cpu(), exp[3]), "num_valid_detections"
+    assert torch.equal(os_.cpu(), exp[1]), "scores"
+    assert torch.equal(oc.cpu(), exp[2]), "classes"
+    assert torch.equal(ob.cpu(), exp[0]), "boxes"
+
+
+def test_nms_with_background_column_and_threshold(ops):
+    """scores given WITH the background column (stride C+1, offset 1), threshold > 0."""
+    g = torch.Generator().manual_seed(9)
+    B, N, C = 2, 400, 4
+    boxes = _random_boxes(g, B, N, C)
+    full = torch.rand(B, N, C + 1, generator=g)
+    exp = onms.combined_nms(boxes, full[..., 1:].contiguous(), 30, 50, 0.5, 0.4)
+    dev = "cuda"
+    ob, os_ = torch.empty(B, 50, 4, device=dev), torch.empty(B, 50, device=dev)
+    oc, ov = torch.empty(B, 50, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
+    ws = torch.empty(ops.nms_workspace_bytes(B, N, C, 30, 50), dtype=torch.uint8, device=dev)
+    ops.nms_combined(boxes.to(dev), full.to(dev), B, N, C, C, C + 1, 1, 30, 50, 0.5, 0.4, ob, os_, oc, ov, ws)
+    torch.cuda.synchronize()
+    for got, e, name in ((ov, exp[3], "valid"), (os_, exp[1], "scores"), (oc, exp[2], "classes"), (ob, exp[0], "boxes")):
+        assert torch.equal(got.cpu(), e), name
+
+
+def test_rpn_head_post(ops):
+    g = torch.Generator().manual_seed(5)
+    B, locs, apl, ld = 2, 30, 12, 128
+    head = torch.randn(B * locs, ld, generator=g)
+    keep = torch.randperm(locs * apl, generator=g)[:100].sort().values.to(torch.int32)
+    cls = head[:, :24].reshape(B, locs * apl, 2)
+    reg = head[:, 24:72].reshape(B, locs * apl, 4)
+    exp_s = torch.softmax(cls, -1)[:, keep.long()]
+    exp_d = reg[:, keep.long()]
+    s, d = torch.empty(B, 100, 2, device="cuda"), torch.empty(B, 100, 4, device="cuda")
+    ops.rpn_head_post(head.cuda(), ld, B, locs * apl, apl, keep.cuda(), 100, s, d)
+    torch.cuda.synchronize()
+    _close(s, exp_s, 1e-5, 1e-6, "rpn scores")
+    assert torch.equal(d.cpu(), exp_d)
+
+
+# ------------------------------------------------------------------ RoI
+def test_roi_crop_pool_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(6)
+    B, P, Hf, Wf, C = 2, 20, 24, 78, 64
+    feat = _rt(torch.randn(B, Hf, Wf, C, generator=g))
+    x0, y0 = torch.rand(B, P, generator=g) * 0.8, torch.rand(B, P, generator=g) * 0.8
+    rois = torch.stack([x0, y0, x0 + torch.rand(B, P, generator=g) * 0.4, y0 + torch.rand(B, P, generator=g) * 0.4], -1)
+    rois[0, 0] = 0.0                                    # NMS padding row: samples pixel (0,0) everywhere
+    rois[0, 1] = torch.tensor([0.0, 0.0, 1.0, 1.0])     # full image
+    rois[1, 0] = torch.tensor([0.9, 0.9, 1.3, 1.2])     # partly outside -> extrapolation 0
+    fr = feat.clone().requires_grad_(True)
+    exp = oroi.roi_pooling(fr, rois, 7, 2)              # [B,P,49*C]
+    dev = "cuda"
+    pooled = torch.empty(B * P, 49 * C, dtype=BF, device=dev)
+    am = torch.empty(B * P, 49 * C, dtype=torch.uint8, device=dev)
+    ops.roi_crop_pool_fwd(feat.to(BF).to(dev), rois.to(dev), B, P, Hf, Wf, C, 7, 2, pooled, am)
+    torch.cuda.synchronize()
+    _close(pooled.view(B, P, -1), exp.detach(), 2 ** -7, 2e-2, "roi pooled")
+    # backward on a sampled subset with duplicates
+    rows = torch.tensor([0, 1, 5, 5, 20, 21, 39, 39, 39], dtype=torch.int32)
+    gp = _rt(torch.randn(len(rows), 49 * C, generator=g))
+    gfull = torch.zeros(B * P, 49 * C)
+    gfull.index_add_(0, rows.long(), gp)
+    exp.backward(gfull.view(B, P, -1))
+    gfeat = torch.zeros(B, Hf, Wf, C, device=dev)
+    ops.roi_crop_pool_bwd(gp.to(BF).to(dev), am, rois.to(dev), rows.to(dev), len(rows), P, Hf, Wf, C, 7, 2, gfeat)
+    torch.cuda.synchronize()
+    # argmax ties between the oracle (fp32) and the kernel can differ only where samples are equal
+    _close(gfeat, fr.grad, 1e-3, 5e-2, "roi grad")
+
+
+# ------------------------------------------------------------------ targets / sampling / losses
+def _targets_case(seed, B, R, rpn):
+    g = torch.Generator().manual_seed(seed)
+    cfg = O.default_config()
+    _, gl, gb = O.synthetic_batch(B, (8, 8, 3), seed=seed)
+    if rpn:
+        anchors = O.generate_anchors((24, 78), **cfg["rpn"]["anchors"])
+        regions = anchors[O.inside_indices(anchors, cfg["image_shape"])][:R]
+    else:
+        ctr = torch.rand(B, R, 2, generator=g) * torch.tensor([1242.0, 375.0])
+        sz = torch.rand(B, R, 2, generator=g) * torch.tensor([300.0, 200.0]) + 5
+        regions = torch.cat([ctr - sz / 2, ctr + sz / 2], -1)
+        regions[:, -3:] = 0.0                           # zero-size NMS padding rows
+        regions[0, 0] = oboxes.to_absolute(gb[0, 0], cfg["image_shape"])   # an exact match: IoU == 1.0
+    return cfg, gl, gb, regions
+
+
+@pytest.mark.parametrize("rpn", [True, False])
+def test_assign_targets(ops, rpn):
+    B, R = 3, 8768 if rpn else 300
+    cfg, gl, gb, regions = _targets_case(11, B, R, rpn)
+    samp = cfg["rpn" if rpn else "rcnn"]["sampling"]
+    c1 = 2 if rpn else 8
+    exp_l, exp_b = [], []
+    for b in range(B):
+        labels = F.one_hot(gl[b].sum(-1).long(), 2).float() if rpn else gl[b]
+        l, t = otraining.generate_targets(labels, gb[b], regions if rpn else regions[b], cfg["image_shape"],
+                                          samp["foreground_iou_interval"], samp["background_iou_interval"])
+        exp_l.append(l)
+        exp_b.append(t)
+    exp_l, exp_b = torch.stack(exp_l), torch.stack(exp_b)
+    dev = "cuda"
+    tl = torch.full((B, R, c1), -7.0, device=dev)
+    tb = torch.full((B, R, c1 - 1, 4), -7.0, device=dev)
+    ops.assign_targets(regions.to(dev), gl.to(dev), gb.to(dev), B, R, 100, 8, rpn, 1242, 375,
+                       samp["foreground_iou_interval"], samp["background_iou_interval"], tl, tb)
+    torch.cuda.synchronize()
+    assert torch.equal(tl.cpu(), exp_l), "target labels must be bit-exact"
+    fin = torch.isfinite(exp_b)
+    assert torch.equal(torch.isfinite(tb.cpu()), fin)
+    _close(tb.cpu()[fin], exp_b[fin], 1e-5, 1e-5, "target boxes")   # logf ulp differences only
+
+
+def test_sample_indices_matches_oracle_and_contract(ops):
+    B, R, c1, S, prop = 4, 5000, 8, 64, 0.25
+    g = torch.Generator().manual_seed(12)
+    tl = torch.zeros(B, R, c1)
+    kind = torch.rand(B, R, generator=g)
+    tl[..., 0][kind < 0.3] = 1.0                                         # background
+    fgm = kind > 0.995
+    tl[..., 3][fgm] = 1.0                                                # foreground (class 3)
+    tl[3] = 0
+    tl[3, :, 0] = 1.0
+    tl[3, 5, 0], tl[3, 5, 2] = 0.0, 1.0                                  # a single foreground
+    dev = "cuda"
+    for step_val, base, seed in ((0, 0, 0), (7, 2, 0x123456789ABCDEF)):
+        idx = torch.empty(B, S, dtype=torch.int32, device=dev)
+        ws = torch.empty(B, 2 * R, dtype=torch.int32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        step = torch.tensor([step_val], dtype=torch.int64, device=dev)
+        ops.sample_indices(tl.to(dev), B, R, c1, S, prop, seed, step, base, idx, ws, status)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        for b in range(B):
+            exp = otraining.get_sample_indices(tl[b], S, prop, image=b, step=step_val, seed=seed, stream_base=base)
+            assert torch.equal(idx[b].cpu().long(), exp), "sample indices image %d" % b
+            fg, bg = otraining.split_fg_bg(tl[b])
+            n_fg = min(len(fg), 16)
+            got = idx[b].cpu().long()
+            assert set(got[:n_fg].tolist()) <= set(fg.tolist()) and len(set(got[:n_fg].tolist())) == n_fg   # w/o replacement
+            assert set(got[n_fg:].tolist()) <= set(bg.tolist())
+    # empty background set -> status flag (the reference raises)
+    tl2 = torch.zeros(1, 100, c1)
+    tl2[0, :, 2] = 1.0
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.sample_indices(tl2.to(dev), 1, 100, c1, S, prop, 0, torch.zeros(1, dtype=torch.int64, device=dev), 0,
+                       torch.empty(1, S, dtype=torch.int32, device=dev), torch.empty(1, 200, dtype=torch.int32, device=dev), status)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 1
+
+
+@pytest.mark.parametrize("c1,C", [(2, 1), (8, 7)])
+def test_losses_and_gradients(ops, c1, C):
+    g = torch.Generator().manual_seed(13 + c1)
+    B, R, S = 3, 400, 64
+    logits = torch.randn(B, R, c1, generator=g).requires_grad_(True)
+    deltas = (torch.randn(B, R, C, 4, generator=g) * 1.5).requires_grad_(True)
+    scores = torch.softmax(logits, -1)
+    tl = F.one_hot(torch.randint(0, c1, (B, R), generator=g), c1).float()
+    tb = torch.zeros(B, R, C, 4)
+    fg = tl[..., 0] == 0
+    cls = tl[..., 1:].argmax(-1)
+    tb[fg, cls[fg]] = torch.randn(int(fg.sum()), 4, generator=g)
+    idx = torch.randint(0, R, (B, S), generator=g)
+    idx[:, 1] = idx[:, 0]                                                 # duplicates
+    ar = torch.arange(B)[:, None]
+    lc = olosses.classification_loss(tl[ar, idx], scores[ar, idx])
+    lr = olosses.regression_loss(tb[ar, idx], deltas[ar, idx])
+    (0.5 * lc + 2.0 * lr).backward()
+    dev = "cuda"
+    out = torch.empty(2, device=dev)
+    dl = torch.empty(B, S, c1, device=dev)
+    dd = torch.empty(B, S, C, 4, device=dev)
+    ops.losses(scores.detach().to(dev), deltas.detach().to(dev), tl.to(dev), tb.to(dev), idx.to(torch.int32).to(dev),
+               B, R, c1, S, 0.5, 2.0, out, dl, dd)
+    torch.cuda.synchronize()
+    _close(out[0], lc.detach(), 1e-5, 1e-6, "cls loss")
+    _close(out[1], lr.detach(), 1e-5, 1e-5, "reg loss")
+    dense_l = torch.zeros(B, R, c1)
+    dense_d = torch.zeros(B, R, C, 4)
+    for b in range(B):
+        dense_l[b].index_add_(0, idx[b], dl[b].cpu())
+        dense_d[b].index_add_(0, idx[b], dd[b].cpu())
+    _close(dense_l, logits.grad, 1e-4, 1e-7, "dlogits")
+    _close(dense_d, deltas.grad, 1e-5, 1e-7, "ddeltas")
+
+
+def test_head_grad_scatter_gather(ops):
+    g = torch.Generator().manual_seed(14)
+    dev = "cuda"
+    B, S, locs, apl, ld = 2, 32, 40, 12, 128
+    A = locs * apl
+    keep = torch.randperm(A, generator=g)[:200].sort().values.to(torch.int32)
+    idx = torch.randint(0, 200, (B, S), generator=g, dtype=torch.int32)
+    idx[:, 3] = idx[:, 2]
+    dl, dd = torch.randn(B, S, 2, generator=g), torch.randn(B, S, 4, generator=g)
+    exp = torch.zeros(B * locs, ld)
+    for b in range(B):
+        for s in range(S):
+            a = int(keep[int(idx[b, s])])
+            loc, k = a // apl, a % apl
+            exp[b * locs + loc, 2 * k:2 * k + 2] += dl[b, s]
+            exp[b * locs + loc, 24 + 4 * k:24 + 4 * k + 4] += dd[b, s]
+    dhead = torch.zeros(B * locs, ld, device=dev)
+    ops.rpn_head_grad(dl.to(dev), dd.to(dev), idx.to(dev), keep.to(dev), B, S, A, apl, dhead, ld)
+    torch.cuda.synchronize()
+    _close(dhead, exp, 1e-6, 1e-6, "rpn head grad scatter")
+    R, c1 = 300, 8
+    idx2 = torch.randint(0, R, (B, S), generator=g, dtype=torch.int32)
+    dl2, dd2 = torch.randn(B, S, c1, generator=g), torch.randn(B, S, 7, 4, generator=g)
+    out = torch.empty(B * S, 64, dtype=BF, device=dev)
+    rows = torch.empty(B * S, dtype=torch.int32, device=dev)
+    ops.rcnn_head_grad(dl2.to(dev), dd2.to(dev), idx2.to(dev), B, R, c1, S, out, 64, rows)
+    torch.cuda.synchronize()
+    exp2 = torch.zeros(B * S, 64)
+    exp2[:, :8] = dl2.reshape(-1, 8)
+    exp2[:, 8:36] = dd2.reshape(-1, 28)
+    _close(out, exp2, 2 ** -8, 0, "rcnn head grad rows")
+    assert torch.equal(rows.cpu().long(), (torch.arange(B)[:, None] * R + idx2.long()).reshape(-1))
+
+
+def test_rcnn_head_post(ops):
+    g = torch.Generator().manual_seed(15)
+    R, ld = 77, 64
+    logits = torch.randn(R, ld, generator=g)
+    bias = torch.randn(36, generator=g)
+    s, d = torch.empty(R, 8, device="cuda"), torch.empty(R, 28, device="cuda")
+    ops.rcnn_head_post(logits.cuda(), ld, bias.cuda(), R, 8, s, d)
+    torch.cuda.synchronize()
+    _close(s, torch.softmax(logits[:, :8] + bias[:8], -1), 1e-5, 1e-6, "rcnn scores")
+    _close(d, logits[:, 8:36] + bias[8:], 0, 1e-6, "rcnn deltas")
