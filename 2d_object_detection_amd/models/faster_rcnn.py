@@ -1,0 +1,280 @@
+"""Faster-RCNN with the call surface of reference models/faster_rcnn.py, MI355X-native.
+
+    model = FasterRCNN(config)
+    losses, preds = model.train_step(images, gt_labels, gt_boxes, optimizer)
+    losses, preds = model.test_step(images, gt_labels, gt_boxes)
+    rpn_output, rcnn_output = model(images, training)
+
+The whole train step (forward, RPN NMS, RoI pooling, target assignment, sampling, losses,
+backward, SGD, prediction NMS) is one static launch plan over pre-allocated HBM buffers, replayed
+as hipGraphs: no host synchronisation inside a step, ~zero launch overhead.  The RPN proposals are
+computed once per step (the reference computes them twice with identical inputs,
+faster_rcnn.py:53,106).
+"""
+import torch
+
+from .. import ops
+from ..optimizers import SGD
+from ..runtime import ParamStore, Plan
+from ..utils.post_processing import NmsBuffers, postprocess_plan
+from .detectors.fast_rcnn_detector import FastRCNNDetector
+from .detectors.rpn_detector import RPNDetector
+from .feature_extractor import FeatureExtractor, get_feature_extractor_model
+
+BF16 = torch.bfloat16
+LOSS_NAMES = ("rpn_cls", "rpn_reg", "rcnn_cls", "rcnn_reg")
+
+
+class _Modules:
+    """One set of module instances (= one set of activation buffers) attached to the shared store."""
+
+    def __init__(self, config, depth, store, device, first):
+        image_shape = config["image_shape"]
+        # registration order = gradient-bucket order: regularised kernels, head biases, then backbone
+        fe_shape = _feature_shape(image_shape, depth)
+        self.rcnn = FastRCNNDetector(image_shape, config["num_classes"], config["rcnn"], feature_channels=fe_shape[3], store=store,
+                                     device=device)
+        self.rpn = RPNDetector(image_shape, fe_shape, config["rpn"], store=store, device=device)
+        self.rcnn.register_biases()
+        self.rpn.register_biases()
+        store.end_bucket("heads")
+        self.fe = get_feature_extractor_model(image_shape, depth=depth, store=store, device=device)
+        assert tuple(self.fe.output_shape) == tuple(fe_shape)
+
+
+def _feature_shape(image_shape, depth):
+    h, w = image_shape[0], image_shape[1]
+    f1 = lambda n: (n + 6 - 7) // 2 + 1
+    f2 = lambda n: (n + 2 - 3) // 2 + 1
+    f3 = lambda n: (n - 1) // 2 + 1
+    return (None, f3(f3(f2(f1(h)))), f3(f3(f2(f1(w)))), 1024)
+
+
+class FasterRCNN:
+    def __init__(self, config, name="faster_rcnn", depth=50, device="cuda", seed=0, sampling_seed=0, world_size=1):
+        """reference faster_rcnn.py:11-37.  `config`: dict with the reference's config.json schema."""
+        self.name = name
+        self.config = config
+        self._image_shape = tuple(config["image_shape"])
+        self._rpn_config = config["rpn"]
+        self._rcnn_config = config["rcnn"]
+        self.depth = depth
+        self.device = torch.device(device)
+        self.sampling_seed = int(sampling_seed)
+        self.world_size = int(world_size)
+        self.store = ParamStore(self.device)
+        self._train = _Modules(config, depth, self.store, self.device, True)
+        self.store.finalize()
+        self._eval = None
+        self.feature_extractor, self.rpn_detector, self.rcnn_detector = self._train.fe, self._train.rpn, self._train.rcnn
+        self.init_weights(seed)
+        self._train_plan = None
+        self._eval_plan = None
+        self._fwd_plans = {}
+        self._eval_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.status = torch.zeros(4, dtype=torch.int32, device=self.device)     # [0] |= 1: empty background set while sampling
+        self.use_graphs = True
+
+    # ------------------------------------------------------------------ parameters
+    def init_weights(self, seed=0):
+        self.feature_extractor.init_weights(seed)
+        self.rpn_detector.init_weights(seed + 1)
+        self.rcnn_detector.init_weights(seed + 2)
+        self._weights_dirty = True
+
+    def set_weights(self, weights):
+        """dict Keras-variable-name -> array in Keras layout (see oracle/faster_rcnn.py for the names)."""
+        self.feature_extractor.set_weights(weights)
+        self.rpn_detector.set_weights(weights)
+        self.rcnn_detector.set_weights(weights)
+        self._weights_dirty = True
+
+    def get_weights(self):
+        out = {}
+        for m in (self.feature_extractor, self.rpn_detector, self.rcnn_detector):
+            out.update(m.get_weights())
+        return out
+
+    def save_weights(self, path):
+        """reference train_faster_rcnn.py:242-243 (torch.save of the Keras-named weight dict)."""
+        torch.save(self.get_weights(), path)
+
+    def load_weights(self, path):
+        self.set_weights(torch.load(path))
+
+    @property
+    def trainable_variables(self):
+        return self.store.order
+
+    def _sync_derived_weights(self, mods):
+        """fp32 masters -> bf16 working copies, transposed data-gradient weights, packed stem."""
+        p = Plan("refresh")
+        p.add(self.store.refresh_bf16)
+        mods.fe.refresh_weights(p)
+        mods.rpn.refresh_weights(p)
+        mods.rcnn.refresh_weights(p)
+        p.run()
+
+    # ------------------------------------------------------------------ plan builders
+    def _build(self, mods, batch, training, optimizer):
+        cfg = self.config
+        dev = self.device
+        H, W = self._image_shape[0], self._image_shape[1]
+        nc1 = cfg["num_classes"] + 1
+        plan = Plan("train_step" if training else "test_step")
+        io = {}
+        io["images"] = mods.fe.setup(batch, training)
+        _, gh, gw, cf = mods.fe.output_shape
+        G = 100
+        io["gt_labels"] = torch.zeros(batch, G, nc1, device=dev)
+        io["gt_boxes"] = torch.zeros(batch, G, 4, device=dev)
+        mods.rpn.setup(batch, training)
+        P = int(self._rpn_config["nms"]["max_total_size"])
+        rs, cs = self._rpn_config["sampling"], self._rcnn_config["sampling"]
+        S_rpn, S_rcnn = int(rs["num_samples"]), int(cs["num_samples"])
+        mods.rcnn.setup(batch, P, gh, gw, training, S_rcnn)
+        step = optimizer.iterations if training else self._eval_step
+
+        if training:
+            plan.add(self.store.g.zero_)
+        feat = mods.fe.forward_plan(plan, training)
+        feat2d = feat.view(batch * gh * gw, cf)
+        rpn_out = mods.rpn.forward_plan(plan, feat2d, training)
+        n = rpn_out["pred_scores"].shape[1]
+        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"])
+        rois = nms_rpn["pred_boxes"]
+        rcnn_out = mods.rcnn.forward_plan(plan, feat, rois)
+
+        # ---- targets, sampling, losses (+ per-sample gradients)
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        t = {}
+        t["rpn_tl"], t["rpn_tb"] = torch.empty(batch, n, 2, **f32), torch.empty(batch, n, 1, 4, **f32)
+        t["rpn_idx"], t["rpn_ws"] = torch.empty(batch, S_rpn, **i32), torch.empty(batch, 2 * n, **i32)
+        t["rcnn_tl"], t["rcnn_tb"] = torch.empty(batch, P, nc1, **f32), torch.empty(batch, P, nc1 - 1, 4, **f32)
+        t["rcnn_idx"], t["rcnn_ws"] = torch.empty(batch, S_rcnn, **i32), torch.empty(batch, 2 * P, **i32)
+        losses = torch.zeros(4, **f32)
+        if training:
+            t["rpn_dl"], t["rpn_dd"] = torch.empty(batch, S_rpn, 2, **f32), torch.empty(batch, S_rpn, 1, 4, **f32)
+            t["rcnn_dl"], t["rcnn_dd"] = torch.empty(batch, S_rcnn, nc1, **f32), torch.empty(batch, S_rcnn, nc1 - 1, 4, **f32)
+        plan.hold(t)
+        # data-parallel: classification losses are means over the GLOBAL batch (scale 1/world before the SUM
+        # all-reduce); regression losses are sums over rows (utils/losses.py:40) -> scale 1
+        cls_scale = 1.0 / self.world_size
+        plan.add(ops.assign_targets, rpn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
+                 rs["foreground_iou_interval"], rs["background_iou_interval"], t["rpn_tl"], t["rpn_tb"])
+        plan.add(ops.sample_indices, t["rpn_tl"], batch, n, 2, S_rpn, rs["foreground_proportion"], self.sampling_seed, step, 0,
+                 t["rpn_idx"], t["rpn_ws"], self.status)
+        plan.add(ops.losses, rpn_out["pred_scores"], rpn_out["pred_boxes"], t["rpn_tl"], t["rpn_tb"], t["rpn_idx"], batch, n, 2, S_rpn,
+                 cls_scale, 1.0, losses[0:2], t.get("rpn_dl"), t.get("rpn_dd"))
+        plan.add(ops.assign_targets, rcnn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, P, G, nc1, False, W, H,
+                 cs["foreground_iou_interval"], cs["background_iou_interval"], t["rcnn_tl"], t["rcnn_tb"])
+        plan.add(ops.sample_indices, t["rcnn_tl"], batch, P, nc1, S_rcnn, cs["foreground_proportion"], self.sampling_seed, step, 2,
+                 t["rcnn_idx"], t["rcnn_ws"], self.status)
+        plan.add(ops.losses, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"], batch, P, nc1,
+                 S_rcnn, cls_scale, 1.0, losses[2:4], t.get("rcnn_dl"), t.get("rcnn_dd"))
+
+        if training:
+            g_feat = torch.empty(batch * gh * gw, cf, dtype=BF16, device=dev)
+            plan.hold(g_feat)
+            mods.rcnn.backward_plan(plan, t["rcnn_dl"], t["rcnn_dd"], t["rcnn_idx"], S_rcnn, rois, g_feat)
+            mods.rpn.backward_plan(plan, t["rpn_dl"], t["rpn_dd"], t["rpn_idx"], S_rpn, feat2d, g_feat)
+            plan.cut("bwd_conv4")
+            mods.fe.backward_plan(plan, g_feat)
+            plan.cut("update")
+            optimizer.apply_plan(plan)
+            mods.fe.refresh_weights(plan)
+            mods.rpn.refresh_weights(plan)
+            mods.rcnn.refresh_weights(plan)
+            plan.add(ops.step_increment, optimizer.iterations)
+        nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
+        preds = {"rpn_boxes": nms_rpn["pred_boxes"], "rpn_scores": nms_rpn["pred_scores"], "rcnn_boxes": nms_rcnn["pred_boxes"],
+                 "rcnn_scores": nms_rcnn["pred_scores"], "rcnn_classes": nms_rcnn["pred_classes"]}
+        aux = {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn, "nms_rcnn": nms_rcnn, "targets": t, "feature_maps": feat}
+        return {"plan": plan, "io": io, "losses": losses, "preds": preds, "aux": aux, "batch": batch}
+
+    def _feed(self, built, images, gt_labels, gt_boxes):
+        io = built["io"]
+        io["images"].copy_(images, non_blocking=True)
+        io["gt_labels"].copy_(gt_labels, non_blocking=True)
+        io["gt_boxes"].copy_(gt_boxes, non_blocking=True)
+
+    def _losses_dict(self, built):
+        l = built["losses"]
+        return {k: l[i] for i, k in enumerate(LOSS_NAMES)}
+
+    # ------------------------------------------------------------------ reference call surface
+    def train_step(self, images, gt_labels, gt_boxes, optimizer, sync_fn=None):
+        """reference faster_rcnn.py:59-117.  images uint8 [B,H,W,3]; gt_labels fp32 [B,100,C+1];
+        gt_boxes fp32 [B,100,4] relative (CUDA tensors).  Returns (losses, preds): device tensors
+        living in static buffers (valid until the next step; clone to keep).
+        sync_fn(segment_index) is the data-parallel hook called after each backward segment."""
+        b = int(images.shape[0])
+        if self._train_plan is None or self._train_plan["batch"] != b or self._train_plan["optimizer"] is not optimizer:
+            optimizer.bind(self.store)
+            built = self._build(self._train, b, True, optimizer)
+            built["optimizer"] = optimizer
+            self._train_plan = built
+            self._sync_derived_weights(self._train)
+            self._weights_dirty = False
+            self._feed(built, images, gt_labels, gt_boxes)
+            if self.use_graphs:
+                # warm-up eagerly on a scratch copy of the mutable state, then capture
+                state = self._snapshot(optimizer)
+                built["plan"].run()
+                torch.cuda.synchronize()
+                self._restore(state, optimizer)
+                built["plan"].capture()
+                self._restore(state, optimizer)
+        built = self._train_plan
+        if self._weights_dirty:
+            self._sync_derived_weights(self._train)
+            self._weights_dirty = False
+        self._feed(built, images, gt_labels, gt_boxes)
+        plan = built["plan"]
+        nseg = len(plan.segments)
+        for i in range(nseg):
+            if plan.captured:
+                plan.replay_segment(i)
+            else:
+                plan.run_segment(i)
+            if sync_fn is not None and i < nseg - 1:
+                sync_fn(i, nseg)
+        return self._losses_dict(built), built["preds"]
+
+    def _snapshot(self, optimizer):
+        st = self.store
+        return {"w": st.w.clone(), "wb": st.wb.clone(), "v": optimizer.velocity.clone(), "it": optimizer.iterations.clone(),
+                "stats": {k: v.clone() for k, v in st.stats.items()}}
+
+    def _restore(self, s, optimizer):
+        st = self.store
+        st.w.copy_(s["w"])
+        st.wb.copy_(s["wb"])
+        optimizer.velocity.copy_(s["v"])
+        optimizer.iterations.copy_(s["it"])
+        for k, v in s["stats"].items():
+            st.stats[k].copy_(v)
+        self._sync_derived_weights(self._train)
+
+    def test_step(self, images, gt_labels, gt_boxes):
+        """reference faster_rcnn.py:119-169 (BN in inference mode, all anchors clipped to the image)."""
+        b = int(images.shape[0])
+        if self._eval is None:
+            self._eval = _Modules(self.config, self.depth, self.store, self.device, False)
+        if self._eval_plan is None or self._eval_plan["batch"] != b:
+            self._eval_plan = self._build(self._eval, b, False, None)
+        built = self._eval_plan
+        self._sync_derived_weights(self._eval)
+        self._feed(built, images, gt_labels, gt_boxes)
+        built["plan"].run()
+        return self._losses_dict(built), built["preds"]
+
+    def __call__(self, images, training=False):
+        """reference faster_rcnn.py:39-57: returns (rpn_output, rcnn_output) dicts."""
+        if training:
+            raise NotImplementedError("use train_step for the training-mode forward (BN statistics are updated there)")
+        z = torch.zeros
+        b = int(images.shape[0])
+        self.test_step(images, z(b, 100, self.config["num_classes"] + 1, device=self.device), z(b, 100, 4, device=self.device))
+        return self._eval_plan["aux"]["rpn_out"], self._eval_plan["aux"]["rcnn_out"]

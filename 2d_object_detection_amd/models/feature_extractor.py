@@ -1,0 +1,350 @@
+"""Backbone: Keras-applications ResNet50 (v1) truncated at conv4_block6_out, on hand-written
+gfx950 kernels.  Mirrors reference models/feature_extractor.py:4-11:
+
+    m = get_feature_extractor_model(image_shape)
+    feature_maps = m(images_uint8[B,H,W,3], training=bool)     # bf16 [B, gh, gw, 1024]
+    m.output_shape == (None, gh, gw, 1024)
+
+Layout: NHWC bf16 activations.  conv -> (bias) -> BN statistics are fused into the implicit-GEMM
+epilogue; BN-apply(+residual)(+ReLU) is one elementwise pass.  Backward is an explicit reverse
+plan (bn_bwd reduce/apply, data gradient as an implicit GEMM with transposed tap-flipped weights,
+weight gradient with transposing LDS reads).
+"""
+import math
+
+import torch
+
+from .. import ops
+from ..runtime import ParamStore, Plan
+
+BF16 = torch.bfloat16
+BN_EPS = 1.001e-5          # Keras ResNet50 BatchNormalization epsilon [TF-ext]
+BN_MOMENTUM = 0.99
+STACKS = {50: ((64, 3, 1), (128, 4, 2), (256, 6, 2)), 101: ((64, 3, 1), (128, 4, 2), (256, 23, 2))}
+
+
+def _out_hw(h, w):
+    f1 = lambda n: (n + 6 - 7) // 2 + 1
+    f2 = lambda n: (n + 2 - 3) // 2 + 1
+    return f1(h), f1(w), f2(f1(h)), f2(f1(w))
+
+
+class _ConvBN:
+    """One conv + BatchNorm unit (Keras names <name>_conv / <name>_bn)."""
+
+    def __init__(self, store, name, cin, cout, k, stride, pad):
+        self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
+        self.store = store
+        store.register(name + "_conv/kernel", (cout, k, k, cin))          # OHWI (Keras: HWIO)
+        store.register(name + "_conv/bias", (cout,))
+        store.register(name + "_bn/gamma", (cout,))
+        store.register(name + "_bn/beta", (cout,))
+        self.mm = store.register_stat(name + "_bn/moving_mean", (cout,), 0.0)
+        self.mv = store.register_stat(name + "_bn/moving_variance", (cout,), 1.0)
+        self.is_stem = (k == 7)
+
+    # -- buffers for a fixed input geometry
+    def setup(self, n, hi, wi, device, training):
+        s, p, k = self.stride, self.pad, self.k
+        self.n, self.hi, self.wi = n, hi, wi
+        if self.is_stem:
+            self.ho, self.wo = (hi + 6 - 7) // 2 + 1, (wi + 6 - 7) // 2 + 1
+            self.hp, self.wp = hi + 6, max(wi + 6, 2 * (self.wo - 1) + 8)
+            self.desc = ops.conv_desc(n, self.hp, self.wp, 32, 7, 1, 2, 0, 0, self.ho, self.wo, self.cout, in_pix_stride=4,
+                                      flags=ops.CONV_BIAS | (ops.CONV_STATS if training else 0))
+            self.w_packed = torch.zeros(self.cout, 7, 8, 4, dtype=BF16, device=device)
+            self.dw_packed = torch.zeros(self.cout, 7, 8, 4, dtype=torch.float32, device=device)
+        else:
+            self.ho, self.wo = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
+            self.desc = ops.conv_desc(n, hi, wi, self.cin, k, k, s, p, p, self.ho, self.wo, self.cout,
+                                      flags=ops.CONV_BIAS | (ops.CONV_STATS if training else 0))
+            self.w_t = torch.zeros(self.cin, k, k, self.cout, dtype=BF16, device=device)   # data-gradient weights
+        self.m = n * self.ho * self.wo
+        c = self.cout
+        f32 = dict(dtype=torch.float32, device=device)
+        self.z = torch.empty(self.m, c, dtype=BF16, device=device)
+        self.scale, self.shift = torch.empty(c, **f32), torch.empty(c, **f32)
+        if training:
+            self.tiles = ops.conv_stat_tiles(self.desc)
+            self.stats = torch.empty(self.tiles, 2, c, **f32)
+            self.mean, self.invstd = torch.empty(c, **f32), torch.empty(c, **f32)
+            self.bwd_blocks = ops.bn_bwd_blocks(self.m)
+            self.bwd_partial = torch.empty(self.bwd_blocks, 2, c, **f32)
+            self.c1, self.c2 = torch.empty(c, **f32), torch.empty(c, **f32)
+            self.dz = torch.empty(self.m, c, dtype=BF16, device=device)
+
+    def refresh_weights(self, plan):
+        """(re)build the derived bf16 weight forms from the fp32 masters."""
+        st = self.store
+        if self.is_stem:
+            plan.add(ops.stem_pack_weights, st.weight(self.name + "_conv/kernel"), self.w_packed, self.cout)
+        else:
+            plan.add(ops.weights_transpose_flip, st.weight(self.name + "_conv/kernel"), self.w_t, self.cout, self.k, self.k, self.cin)
+
+    def w_fwd(self):
+        return self.w_packed if self.is_stem else self.store.weight_bf16(self.name + "_conv/kernel")
+
+    # -- forward: x -> z (raw conv output) -> scale/shift
+    def forward(self, plan, x, training):
+        st = self.store
+        plan.add(ops.conv2d_fprop, self.desc, x, self.w_fwd(), self.z, bias=st.weight(self.name + "_conv/bias"),
+                 stats=self.stats if training else None)
+        g, b = st.weight(self.name + "_bn/gamma"), st.weight(self.name + "_bn/beta")
+        if training:
+            plan.add(ops.bn_finalize_train, self.stats, self.tiles, self.cout, self.m, g, b, self.mm, self.mv, BN_MOMENTUM, BN_EPS,
+                     self.scale, self.shift, self.mean, self.invstd)
+        else:
+            plan.add(ops.bn_finalize_eval, self.cout, g, b, self.mm, self.mv, BN_EPS, self.scale, self.shift)
+
+    def apply(self, plan, out, res=None, relu=True):
+        plan.add(ops.bn_apply, self.z, self.scale, self.shift, out, self.m, self.cout, res=res, relu=relu)
+
+    # -- backward: gout (grad of the BN[+res][+relu] output), act = that output (None when no ReLU)
+    def backward_bn(self, plan, gout, act, gpre=None):
+        st = self.store
+        plan.add(ops.bn_bwd_reduce, gout, act, self.z, self.mean, self.invstd, self.bwd_partial, self.m, self.cout)
+        plan.add(ops.bn_bwd_finalize, self.bwd_partial, self.bwd_blocks, self.cout, self.m, st.grad(self.name + "_bn/gamma"),
+                 st.grad(self.name + "_bn/beta"), self.c1, self.c2)
+        plan.add(ops.bn_bwd_apply, gout, act, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"), self.c1, self.c2,
+                 self.dz, gpre, self.m, self.cout)
+        # the conv bias feeds a training-mode BN: its gradient is identically zero (flat grad buffer is pre-zeroed)
+
+    def backward_weights(self, plan, x):
+        st = self.store
+        if self.is_stem:
+            plan.add(self.dw_packed.zero_)
+            plan.add(ops.conv2d_wgrad, self.desc, x, self.dz, self.dw_packed)
+            plan.add(ops.stem_unpack_grad, self.dw_packed, st.grad(self.name + "_conv/kernel"), self.cout)
+        else:
+            plan.add(ops.conv2d_wgrad, self.desc, x, self.dz, st.grad(self.name + "_conv/kernel"))
+
+    def backward_data(self, plan, gx, res=None):
+        """gx[n,hi,wi,cin] = conv_transpose(dz) (+ res); stride-2 1x1 scatters into a pre-zeroed gx."""
+        k, s = self.k, self.stride
+        if s == 1:
+            d = ops.conv_desc(self.n, self.ho, self.wo, self.cout, k, k, 1, self.pad, self.pad, self.hi, self.wi, self.cin,
+                              flags=ops.CONV_ADD_RES if res is not None else 0)
+        else:
+            assert k == 1
+            d = ops.conv_desc(self.n, self.ho, self.wo, self.cout, 1, 1, 1, 0, 0, self.ho, self.wo, self.cin, out_h=self.hi,
+                              out_w=self.wi, out_scatter=s, flags=ops.CONV_ADD_RES if res is not None else 0)
+        plan.hold(d)
+        plan.add(ops.conv2d_fprop, d, self.dz, self.w_t, gx, res=res)
+
+
+class FeatureExtractor:
+    """ResNet-50/101 C4 backbone (callable like the Keras model returned by the reference)."""
+
+    def __init__(self, image_shape, depth=50, store=None, device="cuda"):
+        self.image_shape = tuple(image_shape)
+        self.depth = depth
+        self.device = torch.device(device)
+        self.own_store = store is None
+        self.store = store if store is not None else ParamStore(self.device)
+        h, w = image_shape[0], image_shape[1]
+        h1, w1, h2, w2 = _out_hw(h, w)
+        # registration in reverse execution order (gradient-bucket order): conv4 .. conv2, stem
+        self.blocks = []            # (name, [conv0?], conv1, conv2, conv3, stride)
+        cin = 64
+        specs = []
+        for si, (f, nb, s1) in enumerate(STACKS[depth]):
+            for b in range(1, nb + 1):
+                specs.append(("conv%d_block%d" % (si + 2, b), cin, f, s1 if b == 1 else 1, b == 1))
+                cin = 4 * f
+        units = {}
+        stage_of = lambda n: int(n[4])
+        last_stage = None
+        for (n, ci, f, s, first) in reversed(specs):
+            if last_stage is not None and stage_of(n) != last_stage:
+                self.store.end_bucket("conv%d" % last_stage)
+            last_stage = stage_of(n)
+            u = {}
+            if first:
+                u[0] = _ConvBN(self.store, n + "_0", ci, 4 * f, 1, s, 0)
+            u[1] = _ConvBN(self.store, n + "_1", ci, f, 1, s, 0)
+            u[2] = _ConvBN(self.store, n + "_2", f, f, 3, 1, 1)
+            u[3] = _ConvBN(self.store, n + "_3", f, 4 * f, 1, 1, 0)
+            units[n] = u
+        self.stem = _ConvBN(self.store, "conv1", 3, 64, 7, 2, 3)
+        self.store.end_bucket("conv2+stem")
+        self.specs = specs
+        self.units = units
+        self.out_channels = cin
+        gh, gw = h2, w2
+        for (_, _, _, s, _) in specs:
+            if s == 2:
+                gh, gw = (gh - 1) // 2 + 1, (gw - 1) // 2 + 1
+        self.output_shape = (None, gh, gw, cin)
+        self._plans = {}
+        if self.own_store:
+            self.store.finalize()
+            self.init_weights(0)
+
+    # ------------------------------------------------------------------ parameters
+    def conv_units(self):
+        yield self.stem
+        for (n, _, _, _, _) in self.specs:
+            for k in sorted(self.units[n]):
+                yield self.units[n][k]
+
+    def init_weights(self, seed=0):
+        """He-normal conv kernels, zero bias, gamma 1 / beta 0 (no ImageNet download possible here)."""
+        g = torch.Generator().manual_seed(seed)
+        st = self.store
+        for u in self.conv_units():
+            fan_in = u.k * u.k * u.cin
+            w = torch.randn(u.cout, u.k, u.k, u.cin, generator=g) * math.sqrt(2.0 / fan_in)
+            st.weight(u.name + "_conv/kernel").copy_(w)
+            st.weight(u.name + "_conv/bias").zero_()
+            st.weight(u.name + "_bn/gamma").fill_(1.0)
+            st.weight(u.name + "_bn/beta").zero_()
+            u.mm.zero_()
+            u.mv.fill_(1.0)
+
+    def set_weights(self, weights):
+        """weights: dict Keras-name -> array in Keras layout (conv kernel HWIO)."""
+        st = self.store
+        for u in self.conv_units():
+            st.weight(u.name + "_conv/kernel").copy_(torch.as_tensor(weights[u.name + "_conv/kernel"]).permute(3, 0, 1, 2))
+            for s in ("_conv/bias", "_bn/gamma", "_bn/beta"):
+                st.weight(u.name + s).copy_(torch.as_tensor(weights[u.name + s]))
+            u.mm.copy_(torch.as_tensor(weights[u.name + "_bn/moving_mean"]))
+            u.mv.copy_(torch.as_tensor(weights[u.name + "_bn/moving_variance"]))
+
+    def get_weights(self):
+        st, out = self.store, {}
+        for u in self.conv_units():
+            out[u.name + "_conv/kernel"] = st.weight(u.name + "_conv/kernel").permute(1, 2, 3, 0).contiguous().cpu()
+            for s in ("_conv/bias", "_bn/gamma", "_bn/beta"):
+                out[u.name + s] = st.weight(u.name + s).clone().cpu()
+            out[u.name + "_bn/moving_mean"] = u.mm.clone().cpu()
+            out[u.name + "_bn/moving_variance"] = u.mv.clone().cpu()
+        return out
+
+    def refresh_weights(self, plan):
+        for u in self.conv_units():
+            u.refresh_weights(plan)
+
+    # ------------------------------------------------------------------ plans
+    def setup(self, batch, training):
+        """Allocate activations for a batch size; returns the static input buffer [B,H,W,3] uint8."""
+        dev = self.device
+        h, w = self.image_shape[0], self.image_shape[1]
+        self.batch = batch
+        self.images = torch.zeros(batch, h, w, 3, dtype=torch.uint8, device=dev)
+        st = self.stem
+        st.setup(batch, h, w, dev, training)
+        npad = batch * st.hp * st.wp * 4
+        self.xpad_flat = torch.zeros(npad + 256, dtype=BF16, device=dev)        # slack for the 8-wide tap reads
+        self.xpad = self.xpad_flat[:npad].view(batch, st.hp, st.wp, 4)
+        self.a_stem = torch.empty(st.m, 64, dtype=BF16, device=dev)
+        self.hp1, self.wp1 = (st.ho + 2 - 3) // 2 + 1, (st.wo + 2 - 3) // 2 + 1
+        self.pool = torch.empty(batch * self.hp1 * self.wp1, 64, dtype=BF16, device=dev)
+        self.pool_arg = torch.empty(batch * self.hp1 * self.wp1, 64, dtype=torch.uint8, device=dev)
+        hi, wi = self.hp1, self.wp1
+        self.acts = {}
+        for (n, ci, f, s, first) in self.specs:
+            u = self.units[n]
+            if first:
+                u[0].setup(batch, hi, wi, dev, training)
+            u[1].setup(batch, hi, wi, dev, training)
+            ho, wo = u[1].ho, u[1].wo
+            u[2].setup(batch, ho, wo, dev, training)
+            u[3].setup(batch, ho, wo, dev, training)
+            m = batch * ho * wo
+            a = {"a1": torch.empty(m, f, dtype=BF16, device=dev), "a2": torch.empty(m, f, dtype=BF16, device=dev),
+                 "out": torch.empty(m, 4 * f, dtype=BF16, device=dev)}
+            if first:
+                a["sc"] = torch.empty(m, 4 * f, dtype=BF16, device=dev)
+            if training:
+                a["g1"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a1
+                a["g2"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a2
+                a["gpre"] = torch.empty(m, 4 * f, dtype=BF16, device=dev)
+                a["gin"] = torch.empty(batch * hi * wi, ci, dtype=BF16, device=dev)   # grad wrt the block input
+            self.acts[n] = a
+            hi, wi = ho, wo
+        if training:
+            self.g_stem = torch.empty(st.m, 64, dtype=BF16, device=dev)
+        self.feature_maps = self.acts[self.specs[-1][0]]["out"].view(batch, hi, wi, self.out_channels)
+        return self.images
+
+    def forward_plan(self, plan, training):
+        st = self.stem
+        plan.add(ops.preprocess, self.images, self.xpad, 3)
+        st.forward(plan, self.xpad_flat, training)
+        st.apply(plan, self.a_stem, relu=True)
+        plan.add(ops.maxpool_fwd, self.a_stem, self.pool, self.pool_arg, self.batch, st.ho, st.wo, 64, self.hp1, self.wp1)
+        x = self.pool
+        for (n, ci, f, s, first) in self.specs:
+            u, a = self.units[n], self.acts[n]
+            if first:
+                u[0].forward(plan, x, training)
+                u[0].apply(plan, a["sc"], relu=False)
+                res = a["sc"]
+            else:
+                res = x
+            u[1].forward(plan, x, training)
+            u[1].apply(plan, a["a1"])
+            u[2].forward(plan, a["a1"], training)
+            u[2].apply(plan, a["a2"])
+            u[3].forward(plan, a["a2"], training)
+            u[3].apply(plan, a["out"], res=res, relu=True)
+            x = a["out"]
+        return self.feature_maps
+
+    def backward_plan(self, plan, g_feat):
+        """g_feat: bf16 gradient w.r.t. feature_maps [B*gh*gw, C].  Cuts the plan after each stage."""
+        gout = g_feat
+        prev_stage = None
+        xs = {}
+        x = self.pool
+        for (n, ci, f, s, first) in self.specs:
+            xs[n] = x
+            x = self.acts[n]["out"]
+        for (n, ci, f, s, first) in reversed(self.specs):
+            stage = int(n[4])
+            if prev_stage is not None and stage != prev_stage:
+                plan.cut("bwd_conv%d" % stage)
+            prev_stage = stage
+            u, a, xin = self.units[n], self.acts[n], xs[n]
+            u[3].backward_bn(plan, gout, a["out"], gpre=a["gpre"])
+            u[3].backward_weights(plan, a["a2"])
+            u[3].backward_data(plan, a["g2"])
+            u[2].backward_bn(plan, a["g2"], a["a2"])
+            u[2].backward_weights(plan, a["a1"])
+            u[2].backward_data(plan, a["g1"])
+            u[1].backward_bn(plan, a["g1"], a["a1"])
+            u[1].backward_weights(plan, xin)
+            if first:
+                u[0].backward_bn(plan, a["gpre"], None)
+                u[0].backward_weights(plan, xin)
+                if s != 1:
+                    plan.add(a["gin"].zero_)
+                u[1].backward_data(plan, a["gin"])
+                u[0].backward_data(plan, a["gin"], res=a["gin"])
+            else:
+                u[1].backward_data(plan, a["gin"], res=a["gpre"])
+            gout = a["gin"]
+        st = self.stem
+        plan.add(ops.maxpool_bwd, gout, self.pool_arg, self.g_stem, self.batch, st.ho, st.wo, 64, self.hp1, self.wp1)
+        st.backward_bn(plan, self.g_stem, self.a_stem)
+        st.backward_weights(plan, self.xpad_flat)
+
+    # ------------------------------------------------------------------ Keras-model-like call
+    def __call__(self, images, training=False):
+        key = (int(images.shape[0]), bool(training))
+        if key not in self._plans:
+            self.setup(key[0], training)
+            self.store.refresh_bf16()
+            plan = Plan("feature_extractor")
+            self.refresh_weights(plan)
+            self.forward_plan(plan, training)
+            self._plans = {key: plan}           # buffers are re-created per geometry: keep only the live plan
+        self.images.copy_(images)
+        self._plans[key].run()
+        return self.feature_maps
+
+
+def get_feature_extractor_model(image_shape, depth=50, store=None, device="cuda"):
+    """reference models/feature_extractor.py:4 (weights: seeded synthetic init; load real ones with set_weights)."""
+    return FeatureExtractor(image_shape, depth=depth, store=store, device=device)

@@ -1,0 +1,159 @@
+"""Host-side runtime: static launch plans, hipGraph capture and the flat parameter store.
+
+The whole Faster-RCNN step is shape-static (fixed anchors, NMS outputs padded to max_total_size,
+fixed sample counts), so it is compiled ONCE into a `Plan`: an ordered list of C-ABI kernel
+launches over pre-allocated HBM buffers.  A plan can be replayed eagerly (tests, profiling) or
+captured into hipGraphs (training: no per-kernel host cost, no host sync anywhere in the step).
+Plans are cut into *segments* so that a data-parallel driver can interleave RCCL all-reduces of
+finished gradient buckets with the remaining backward segments.
+"""
+import numpy as np
+import torch
+
+
+class Plan:
+    def __init__(self, name="plan"):
+        self.name = name
+        self.segments = [[]]
+        self.segment_names = ["main"]
+        self.keep = []            # buffers owned by the plan
+        self._graphs = None
+
+    # -- construction
+    def add(self, fn, *args, **kwargs):
+        self.segments[-1].append((fn, args, kwargs))
+
+    def cut(self, name):
+        """Start a new segment (a gradient bucket of the previous segment is complete here)."""
+        if self.segments[-1]:
+            self.segments.append([])
+            self.segment_names.append(name)
+        else:
+            self.segment_names[-1] = name
+
+    def hold(self, *tensors):
+        self.keep.extend(tensors)
+        return tensors[0] if len(tensors) == 1 else tensors
+
+    @property
+    def num_launches(self):
+        return sum(len(s) for s in self.segments)
+
+    # -- execution
+    def run_segment(self, i):
+        for fn, args, kwargs in self.segments[i]:
+            fn(*args, **kwargs)
+
+    def run(self):
+        for i in range(len(self.segments)):
+            self.run_segment(i)
+
+    def capture(self):
+        """Capture every segment into its own hipGraph (after one eager warm-up run)."""
+        graphs = []
+        pool = None
+        for i in range(len(self.segments)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self.run_segment(i)
+            pool = g.pool()
+            graphs.append(g)
+        self._graphs = graphs
+        return graphs
+
+    def replay_segment(self, i):
+        self._graphs[i].replay()
+
+    def replay(self):
+        for g in self._graphs:
+            g.replay()
+
+    @property
+    def captured(self):
+        return self._graphs is not None
+
+
+class ParamStore:
+    """All trainable parameters in ONE flat fp32 buffer (+ gradient, momentum and bf16 working
+    copy of identical layout).  Registration order is the order gradients become final during
+    backward (heads first, stem last), so contiguous slices are all-reduce buckets; parameters
+    carrying the L2 kernel regulariser are registered first (one contiguous SGD range)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}          # name -> (offset, shape, decay)
+        self.order = []
+        self.size = 0
+        self.finalized = False
+        self.buckets = []          # (name, begin, end)
+        self._bucket_start = 0
+        self.stats = {}            # non-trainable fp32 tensors (BN moving statistics)
+
+    def register(self, name, shape, decay=0.0):
+        if name in self.entries:                  # a second module instance (eval twin) re-attaching to the same store
+            assert self.entries[name][1] == tuple(shape), name
+            return name
+        assert not self.finalized, "ParamStore already finalized: cannot add %s" % name
+        n = int(np.prod(shape))
+        self.entries[name] = (self.size, tuple(shape), float(decay))
+        self.order.append(name)
+        self.size += (n + 63) // 64 * 64          # 256-byte aligned slices
+        return name
+
+    def end_bucket(self, name):
+        if self.size > self._bucket_start:
+            self.buckets.append((name, self._bucket_start, self.size))
+            self._bucket_start = self.size
+
+    def register_stat(self, name, shape, fill):
+        if name in self.stats:
+            return self.stats[name]
+        self.stats[name] = torch.full(tuple(shape), float(fill), dtype=torch.float32, device=self.device)
+        return self.stats[name]
+
+    def finalize(self):
+        if self.finalized:
+            return
+        self.end_bucket("tail")
+        self.w = torch.zeros(self.size, dtype=torch.float32, device=self.device)
+        self.g = torch.zeros(self.size, dtype=torch.float32, device=self.device)
+        self.wb = torch.zeros(self.size, dtype=torch.bfloat16, device=self.device)
+        self.finalized = True
+
+    def _view(self, buf, name):
+        off, shape, _ = self.entries[name]
+        return buf[off:off + int(np.prod(shape))].view(shape)
+
+    def weight(self, name):
+        return self._view(self.w, name)
+
+    def grad(self, name):
+        return self._view(self.g, name)
+
+    def weight_bf16(self, name):
+        return self._view(self.wb, name)
+
+    def offset(self, name):
+        return self.entries[name][0]
+
+    def decay_ranges(self):
+        """Contiguous (begin, end, l2) ranges covering the whole buffer."""
+        ranges = []
+        for name in self.order:
+            off, shape, decay = self.entries[name]
+            end = off + (int(np.prod(shape)) + 63) // 64 * 64
+            if ranges and ranges[-1][2] == decay and ranges[-1][1] == off:
+                ranges[-1] = (ranges[-1][0], end, decay)
+            else:
+                ranges.append((off, end, decay))
+        return ranges
+
+    def refresh_bf16(self):
+        from . import ops
+        ops.cast_f32_bf16(self.w, self.wb)
+
+
+def dev_tensor(shape, dtype, device, fill=None):
+    if fill is None:
+        return torch.empty(shape, dtype=dtype, device=device)
+    return torch.full(shape, fill, dtype=dtype, device=device)
