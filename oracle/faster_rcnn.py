@@ -131,12 +131,14 @@ def trainable_names(params):
 
 
 # --------------------------------------------------------------------------- model pieces
-def rpn_forward(p, feature_maps, anchors, image_shape, training):
+def rpn_forward(p, feature_maps, anchors, image_shape, training, quant=None):
     """reference RPNDetector.call (rpn_detector.py:60-96).  feature_maps NHWC."""
     x = feature_maps.permute(0, 3, 1, 2)
     w = p["rpn_intermediate_layer/kernel"].permute(3, 2, 0, 1)
     pad = w.shape[-1] // 2
     f = F.relu(F.conv2d(x, w, p["rpn_intermediate_layer/bias"], padding=pad))
+    if quant is not None:
+        f = quant(f)
     cls = F.conv2d(f, p["rpn_classification_head/kernel"].permute(3, 2, 0, 1), p["rpn_classification_head/bias"])
     reg = F.conv2d(f, p["rpn_regression_head/kernel"].permute(3, 2, 0, 1), p["rpn_regression_head/bias"])
     B = x.shape[0]
@@ -152,10 +154,12 @@ def rpn_forward(p, feature_maps, anchors, image_shape, training):
     return {"regions": regions, "pred_scores": pred_scores, "pred_boxes": pred_boxes}
 
 
-def rcnn_forward(p, feature_maps, rois, image_shape, config):
+def rcnn_forward(p, feature_maps, rois, image_shape, config, quant=None):
     """reference FastRCNNDetector.call (fast_rcnn_detector.py:43-69)."""
     rp = config["rcnn"]["roi_pooling"]
     flat = roi_pooling(feature_maps, rois, rp["pooled_size"], rp["kernel_size"])
+    if quant is not None:
+        flat = quant(flat)
     logits = flat @ p["fast_rcnn_classification_head/kernel"] + p["fast_rcnn_classification_head/bias"]
     pred_scores = torch.softmax(logits, dim=-1)
     reg = flat @ p["fast_rcnn_regression_head/kernel"] + p["fast_rcnn_regression_head/bias"]
@@ -201,23 +205,23 @@ def _training_samples(gt_labels, gt_boxes, regions, pred_scores, pred_boxes, ima
             "sample_indices": idx, "all_target_labels": tl, "all_target_boxes": tb}
 
 
-def forward(p, config, images, training, depth=50, taps=None):
+def forward(p, config, images, training, depth=50, taps=None, quant=None):
     """reference FasterRCNN.call (faster_rcnn.py:39-57)."""
     image_shape = config["image_shape"]
-    feature_maps, new_stats = resnet.forward(p, images, training, depth, taps)
+    feature_maps, new_stats = resnet.forward(p, images, training, depth, taps, quant)
     anchors = generate_anchors(feature_maps.shape[1:3], **config["rpn"]["anchors"])
-    rpn_out = rpn_forward(p, feature_maps, anchors, image_shape, training)
+    rpn_out = rpn_forward(p, feature_maps, anchors, image_shape, training, quant)
     nmsed_rpn = postprocess_output(image_shape, **rpn_out, **config["rpn"]["nms"])
-    rcnn_out = rcnn_forward(p, feature_maps, nmsed_rpn["pred_boxes"], image_shape, config)
+    rcnn_out = rcnn_forward(p, feature_maps, nmsed_rpn["pred_boxes"], image_shape, config, quant)
     if taps is not None:
         taps["feature_maps"] = feature_maps
     return rpn_out, rcnn_out, nmsed_rpn, new_stats
 
 
 def compute_losses(p, config, images, gt_labels, gt_boxes, training, step=0, seed=0, depth=50,
-                   rpn_sample_indices=None, rcnn_sample_indices=None, taps=None):
+                   rpn_sample_indices=None, rcnn_sample_indices=None, taps=None, quant=None):
     image_shape = config["image_shape"]
-    rpn_out, rcnn_out, nmsed_rpn, new_stats = forward(p, config, images, training, depth, taps)
+    rpn_out, rcnn_out, nmsed_rpn, new_stats = forward(p, config, images, training, depth, taps, quant)
     gt_obj = F.one_hot(gt_labels.sum(-1).to(torch.int64), 2).to(torch.float32)       # rpn_detector.py:141
     rs = _training_samples(gt_obj, gt_boxes, **rpn_out, image_shape=image_shape, sampling=config["rpn"]["sampling"],
                            step=step, seed=seed, stream_base=0, sample_indices=rpn_sample_indices)
@@ -239,7 +243,7 @@ def compute_losses(p, config, images, gt_labels, gt_boxes, training, step=0, see
 
 
 def train_step(p, velocity, config, images, gt_labels, gt_boxes, lr, step=0, seed=0, depth=50,
-               rpn_sample_indices=None, rcnn_sample_indices=None, taps=None):
+               rpn_sample_indices=None, rcnn_sample_indices=None, taps=None, quant=None):
     """reference FasterRCNN.train_step (faster_rcnn.py:59-117) + Keras SGD(momentum=.9)
     (train_faster_rcnn.py:109-112).  Updates `p` and `velocity` in place.  Returns
     (losses, preds, grads, aux)."""
@@ -247,7 +251,7 @@ def train_step(p, velocity, config, images, gt_labels, gt_boxes, lr, step=0, see
     for n in names:
         p[n].requires_grad_(True)
     losses, preds, aux = compute_losses(p, config, images, gt_labels, gt_boxes, True, step, seed, depth,
-                                        rpn_sample_indices, rcnn_sample_indices, taps)
+                                        rpn_sample_indices, rcnn_sample_indices, taps, quant)
     wd = {n: (config["rpn"]["weight_decay"] if n.startswith("rpn") else config["rcnn"]["weight_decay"]) for n in REGULARIZED}
     reg = sum(wd[n] * (p[n] ** 2).sum() for n in REGULARIZED)                  # faster_rcnn.py:101 self.losses
     total = sum(losses.values()) + reg
@@ -265,10 +269,10 @@ def train_step(p, velocity, config, images, gt_labels, gt_boxes, lr, step=0, see
     return losses, preds, grads, aux
 
 
-def test_step(p, config, images, gt_labels, gt_boxes, step=0, seed=0, depth=50):
+def test_step(p, config, images, gt_labels, gt_boxes, step=0, seed=0, depth=50, quant=None):
     """reference FasterRCNN.test_step (faster_rcnn.py:119-169)."""
     with torch.no_grad():
-        losses, preds, aux = compute_losses(p, config, images, gt_labels, gt_boxes, False, step, seed, depth)
+        losses, preds, aux = compute_losses(p, config, images, gt_labels, gt_boxes, False, step, seed, depth, quant=quant)
     return losses, preds, aux
 
 
