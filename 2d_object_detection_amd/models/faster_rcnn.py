@@ -177,6 +177,7 @@ class FasterRCNN:
         if training:
             g_feat = torch.empty(batch * gh * gw, cf, dtype=BF16, device=dev)
             plan.hold(g_feat)
+            t["g_feat"] = g_feat
             mods.rcnn.backward_plan(plan, t["rcnn_dl"], t["rcnn_dd"], t["rcnn_idx"], S_rcnn, rois, g_feat)
             mods.rpn.backward_plan(plan, t["rpn_dl"], t["rpn_dd"], t["rpn_idx"], S_rpn, feat2d, g_feat)
             plan.cut("bwd_conv4")

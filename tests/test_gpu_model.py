@@ -50,6 +50,12 @@ def setup():
     for k in params:
         if k.endswith("/kernel"):
             params[k] = params[k].to(BF).float()
+        if k.endswith("_3_bn/gamma"):
+            # Residual-branch scale 0.25 (trained nets / zero-init-residual are in this regime).  With gamma = 1 a
+            # random-init ResNet in training-mode BN amplifies ANY perturbation ~100x by conv4 (a one-LSB change of
+            # one input pixel moves the fp32 oracle's own output by 4e-4; bf16 storage moves it by 23%), which makes
+            # end-to-end comparisons meaningless; per-layer bit-level parity for gamma = 1 is test_backbone_teacher_forced.
+            params[k] = params[k] * 0.25
     images, gl, gb = O.synthetic_batch(2, cfg["image_shape"], seed=5)
     model = M.FasterRCNN(cfg, sampling_seed=11)
     model.use_graphs = False
@@ -77,7 +83,9 @@ def test_feature_extractor_module(setup):
         torch.cuda.synchronize()
         assert got.shape == ref.shape
         print("feature maps training=%s rel err %.4f" % (training, _rel(got, ref)))
-        assert _rel(got, ref) < (0.10 if training else 0.03), "feature maps training=%s rel err %g" % (training, _rel(got, ref))
+        assert _rel(got, ref) < 0.02, "feature maps training=%s rel err %g" % (training, _rel(got, ref))
+        ref32, _ = oresnet.forward({k: v.clone() for k, v in setup["params"].items()}, setup["images"], training)
+        assert _rel(got, ref32) < 0.05, "vs fp32 oracle: %g" % _rel(got, ref32)
         if training:
             w = m.get_weights()
             for k, v in new_stats.items():
@@ -100,7 +108,7 @@ def test_train_step_stagewise(setup):
     p = {k: v.clone() for k, v in params.items()}
     feat_ref, _ = oresnet.forward(p, images, True, quant=oresnet.bf16_storage)
     feat = aux["feature_maps"].float().cpu()
-    assert _rel(feat, feat_ref) < 0.10, _rel(feat, feat_ref)
+    assert _rel(feat, feat_ref) < 0.02, _rel(feat, feat_ref)
     # 2. RPN on the HIP feature maps
     anchors = O.generate_anchors(feat.shape[1:3], **cfg["rpn"]["anchors"])
     rpn_ref = O.rpn_forward(p, feat, anchors, ishape, True, quant=oresnet.bf16_storage)
@@ -140,7 +148,13 @@ def test_train_step_stagewise(setup):
 
 
 def test_train_step_gradients_and_update(setup):
-    """Full oracle train step (fp32, autograd) with the HIP path's sampled indices injected."""
+    """Full oracle train step (bf16-storage forward, autograd) with the HIP path's sampled indices injected.
+
+    Gradients of this net are NOT a smooth function of rounding noise: ReLU masks and the RoI max-pool argmax flip
+    under bf16-level perturbations.  Calibration (CPU, same inputs): the oracle's OWN gradients, fp32 forward vs
+    bf16-storage forward, agree only to cosine 0.91 (conv4_block6_3 kernel) / 0.86 (conv1 kernel).  The end-to-end
+    gate is therefore: head gradients tight, backbone gradients at least as close as that calibration; the strict
+    per-layer backward parity is tests/test_gpu_backbone_layers.py::test_backbone_backward_teacher_forced."""
     cfg, params = setup["cfg"], setup["params"]
     images, gl, gb = setup["images"], setup["gl"], setup["gb"]
     model = setup["M"].FasterRCNN(cfg, sampling_seed=11)
@@ -154,65 +168,77 @@ def test_train_step_gradients_and_update(setup):
     vel = {}
     ol, _, grads, _ = O.train_step(p, vel, cfg, images, gl, gb, lr=0.01, seed=11, rpn_sample_indices=t["rpn_idx"].cpu(),
                                    rcnn_sample_indices=t["rcnn_idx"].cpu(), quant=oresnet.bf16_storage)
-    print("losses hip", {k: float(v) for k, v in losses.items()}, "oracle", {k: float(v) for k, v in ol.items()})
     for k in ol:
-        assert abs(float(losses[k]) - float(ol[k])) < 0.08 * max(1.0, abs(float(ol[k]))), (k, float(losses[k]), float(ol[k]))
+        assert abs(float(losses[k]) - float(ol[k])) < 0.03 * max(1.0, abs(float(ol[k]))), (k, float(losses[k]), float(ol[k]))
     st = model.store
-    g_hip = {
+    heads = {
         "rpn_intermediate_layer/kernel": st.grad("rpn_intermediate_layer/kernel").permute(1, 2, 3, 0),
         "rpn_intermediate_layer/bias": st.grad("rpn_intermediate_layer/bias"),
         "rpn_classification_head/kernel": st.grad("rpn_heads/kernel")[:24].permute(1, 2, 3, 0),
         "rpn_regression_head/kernel": st.grad("rpn_heads/kernel")[24:72].permute(1, 2, 3, 0),
+        "rpn_classification_head/bias": st.grad("rpn_heads/bias")[:24],
+        "rpn_regression_head/bias": st.grad("rpn_heads/bias")[24:72],
         "fast_rcnn_classification_head/kernel": st.grad("fast_rcnn_heads/kernel").view(64, -1)[:8].t(),
         "fast_rcnn_regression_head/kernel": st.grad("fast_rcnn_heads/kernel").view(64, -1)[8:36].t(),
         "fast_rcnn_classification_head/bias": st.grad("fast_rcnn_heads/bias")[:8],
+        "fast_rcnn_regression_head/bias": st.grad("fast_rcnn_heads/bias")[8:36],
     }
+    backbone = {}
     for name in ("conv4_block6_3", "conv4_block1_0", "conv4_block1_1", "conv3_block1_2", "conv2_block1_0", "conv2_block3_2", "conv1"):
-        g_hip[name + "_conv/kernel"] = st.grad(name + "_conv/kernel").permute(1, 2, 3, 0)
-        g_hip[name + "_bn/gamma"] = st.grad(name + "_bn/gamma")
-        g_hip[name + "_bn/beta"] = st.grad(name + "_bn/beta")
-    # the L2 regulariser gradient is applied inside the SGD kernel: remove it from the oracle gradient
-    report = []
-    for k, g in g_hip.items():
-        ref = grads[k]
-        if k in O.REGULARIZED:
-            ref = ref - 2 * 0.0005 * params[k]
-        report.append((k, _cos(g, ref), _rel(g, ref)))
-    print("\n".join("%-45s cos %.4f rel %.4f" % r for r in report))
-    bad = [r for r in report if not (r[1] > 0.90 and r[2] < 0.5)]
-    assert not bad, "gradient mismatch (name, cosine, rel err): %s" % bad
-    # parameters after the update
+        backbone[name + "_conv/kernel"] = st.grad(name + "_conv/kernel").permute(1, 2, 3, 0)
+        backbone[name + "_bn/gamma"] = st.grad(name + "_bn/gamma")
+        backbone[name + "_bn/beta"] = st.grad(name + "_bn/beta")
+
+    def ref_of(k):   # the L2 regulariser gradient is applied inside the SGD kernel: remove it from the oracle gradient
+        return grads[k] - 2 * 0.0005 * params[k] if k in O.REGULARIZED else grads[k]
+
+    rep_h = [(k, _cos(g, ref_of(k)), _rel(g, ref_of(k))) for k, g in heads.items()]
+    rep_b = [(k, _cos(g, ref_of(k)), _rel(g, ref_of(k))) for k, g in backbone.items()]
+    print("\n".join("%-45s cos %.4f rel %.4f" % r for r in rep_h + rep_b))
+    assert not [r for r in rep_h if not (r[1] > 0.98 and r[2] < 0.2)], rep_h
+    assert not [r for r in rep_b if not r[1] > 0.85], rep_b
+    # parameters after the update (momentum SGD, lr schedule, L2 on the five regularised kernels)
     w = model.get_weights()
-    for k in ("rpn_intermediate_layer/kernel", "fast_rcnn_regression_head/kernel", "conv4_block6_3_conv/kernel", "conv1_conv/kernel",
-              "conv3_block2_1_bn/gamma"):
-        delta_ref = p[k] - params[k]
-        delta = w[k] - params[k]
-        assert _cos(delta, delta_ref) > 0.90, (k, _cos(delta, delta_ref))
+    for k in ("rpn_intermediate_layer/kernel", "rpn_classification_head/kernel", "fast_rcnn_regression_head/kernel"):
+        assert _cos(w[k] - params[k], p[k] - params[k]) > 0.98, (k, _cos(w[k] - params[k], p[k] - params[k]))
+    # exact SGD arithmetic on the HIP path's own gradient: w1 = w0 + (-lr * (g + 2*l2*w0))
+    g = st.grad("rpn_intermediate_layer/kernel").permute(1, 2, 3, 0).cpu()
+    k = "rpn_intermediate_layer/kernel"
+    exp = params[k] - 0.01 * (g + 2 * 0.0005 * params[k])
+    assert _rel(w[k], exp) < 1e-6
 
 
 def test_graph_replay_matches_eager(setup):
     cfg, params = setup["cfg"], setup["params"]
     images, gl, gb = (x.cuda() for x in (setup["images"], setup["gl"], setup["gb"]))
-    outs = []
+    res = []
     for graphs in (False, True):
         model = setup["M"].FasterRCNN(cfg, sampling_seed=11)
         model.use_graphs = graphs
         model.set_weights(params)
         opt = setup["OPT"].SGD(learning_rate=1e-5, momentum=0.9)
-        hist = []
-        for _ in range(3):
-            losses, preds = model.train_step(images, gl, gb, opt)
-            hist.append({k: float(v) for k, v in losses.items()})
+        l1, _ = model.train_step(images, gl, gb, opt)
+        l1 = {k: float(v) for k, v in l1.items()}
         torch.cuda.synchronize()
-        assert int(opt.iterations.item()) == 3
+        w1 = model.get_weights()
+        l2, _ = model.train_step(images, gl, gb, opt)
+        l2 = {k: float(v) for k, v in l2.items()}
+        torch.cuda.synchronize()
+        assert int(opt.iterations.item()) == 2
         assert model._train_plan["plan"].captured == graphs
-        outs.append(hist)
-    print("eager", outs[0], "\ngraph", outs[1])
-    for k in outs[0][0]:
+        res.append((l1, w1, l2))
+    (l1e, w1e, l2e), (l1g, w1g, l2g) = res
+    for k in l1e:
         # step 1: identical weights and inputs -> only float-atomic ordering differs
-        assert abs(outs[0][0][k] - outs[1][0][k]) <= 1e-3 * max(1.0, abs(outs[0][0][k])), (k, outs[0][0][k], outs[1][0][k])
-        # later steps: the (random-init, training-mode BN) net amplifies the atomics' rounding noise
-        assert abs(outs[0][2][k] - outs[1][2][k]) <= 0.05 * max(1.0, abs(outs[0][2][k])), (k, outs[0][2][k], outs[1][2][k])
+        assert abs(l1e[k] - l1g[k]) <= 1e-5 * max(1.0, abs(l1e[k])), (k, l1e[k], l1g[k])
+        # step 2: a 1e-7 difference can flip a near-tied NMS order / IoU threshold (one sampled row = 1/32 of the mean)
+        assert abs(l2e[k] - l2g[k]) <= 0.15 * max(1.0, abs(l2e[k])), (k, l2e[k], l2g[k])
+    # the state after the first (replayed) update must be the same: weights, BN moving statistics
+    for k in w1e:
+        d = (w1e[k] - w1g[k]).abs().max()
+        assert float(d) <= 1e-5 * max(1.0, float(w1e[k].abs().max())), (k, float(d))
+        if k.endswith("/kernel") or k.endswith("moving_mean"):
+            assert not torch.equal(w1e[k], params[k]), "%s did not change" % k
 
 
 def test_test_step_runs_and_matches_stagewise(setup):
