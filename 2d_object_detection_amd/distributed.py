@@ -1,0 +1,89 @@
+"""Data parallelism: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI).
+
+The reference is single-device; the natural shard is the image.  Each rank runs
+the same static train plan on its own images; the only exchange is a SUM all-reduce of the flat
+fp32 gradient buffer, cut into the buckets the ParamStore registered in backward-completion order
+(heads+RPN, conv4, conv3, conv2+stem).  Bucket i is reduced on a side stream right after backward
+segment i, overlapping with the remaining backward segments; the update segment waits for the
+last bucket.  xGMI is point-to-point, so buckets are few and large (51 MB fp32 total, 4 buckets)
+rather than many small ones.
+
+Loss semantics (so that N ranks x b images == the reference's single batch of N*b images):
+classification losses are MEANS over all sampled rows of the global batch -> each rank scales its
+classification gradient by 1/world (FasterRCNN(world_size=...)) and the all-reduce SUMs;
+regression losses are SUMS over rows (utils/losses.py:40) -> scale 1, SUM.  BatchNorm statistics
+stay per replica (documented deviation from a single big batch).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+class GradientSynchronizer:
+    """Bucketed, overlapped all-reduce of a flat gradient buffer.
+
+    `grad` is the flat fp32 gradient tensor, `buckets` a list of (name, begin, end) in the order the
+    buckets become final.  Use `after_segment` as the `sync_fn` of FasterRCNN.train_step."""
+
+    def __init__(self, grad, buckets, group=None):
+        self.grad = grad
+        self.buckets = list(buckets)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.on_gpu = grad.is_cuda
+        self.comm_stream = torch.cuda.Stream() if (self.on_gpu and self.world > 1) else None
+        self.bytes_per_step = sum(e - b for _, b, e in self.buckets) * grad.element_size()
+
+    def reduce_bucket(self, i):
+        if self.world == 1:
+            return
+        _, b, e = self.buckets[i]
+        view = self.grad[b:e]
+        if self.on_gpu:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ready)
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+
+    def wait_all(self):
+        if self.world > 1 and self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def after_segment(self, seg, nseg):
+        """Hook for FasterRCNN.train_step: backward segment `seg` has been enqueued; segments 0..nb-1
+        complete buckets 0..nb-1, the last segment (update) must see every reduced bucket."""
+        if seg < len(self.buckets):
+            self.reduce_bucket(seg)
+        if seg == nseg - 2:
+            for j in range(seg + 1, len(self.buckets)):     # fewer segments than buckets (should not happen)
+                self.reduce_bucket(j)
+            self.wait_all()
+
+
+def shard_batch(global_batch, rank, world):
+    """Image range [begin, end) of the global batch owned by `rank` (input_pipeline sharding)."""
+    per = global_batch // world
+    assert per * world == global_batch, "global batch must be divisible by the world size"
+    return rank * per, (rank + 1) * per

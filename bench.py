@@ -1,0 +1,198 @@
+"""Headline benchmark: images/sec of the full Faster-RCNN training step (ResNet-50, 375x1242
+synthetic KITTI batches, bf16) on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = forward + RPN NMS + RoI pooling + target assignment + sampling + losses + backward +
+SGD-momentum + prediction NMS for one batch already resident in HBM (the reference's
+FasterRCNN.train_step, models/faster_rcnn.py:59-117).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+METRIC = "images/sec training, ResNet-50 Faster-RCNN KITTI 1242x375, 1/2/4/8 GPU"
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def conv_flops(d, true_cin=None, true_cout=None):
+    """Algorithmic FLOPs (2*MAC) of one implicit-GEMM launch with its unpadded channel counts."""
+    m = d.n * d.ho * d.wo
+    k = d.kh * d.kw * (true_cin if true_cin is not None else d.cin)
+    return 2.0 * m * k * (true_cout if true_cout is not None else d.cout)
+
+
+def profile_conv_kernels(model, built, steps=3):
+    """Eager replay of the train plan with HIP events (torch events on the launch stream) around every
+    MFMA conv launch.  Returns per-family {launches, seconds, flops} per step."""
+    ops = importlib.import_module("2d_object_detection_amd.ops")
+    plan = built["plan"]
+    fam = {}
+    records = []
+
+    def true_dims(d, kind):
+        """un-padded channel counts: stem taps 7x(8x4) carry 7x7x3 real values; RPN heads 72 of 128; RCNN heads 36 of 64"""
+        cin, cout = d.cin, d.cout
+        if d.in_pix_stride == 4 and d.cin == 32:
+            return 21.0, cout
+        if d.kh == 1 and d.cin == 256 and d.cout == 128:
+            cout = 72
+        if d.kh == 1 and d.cin == 128 and d.cout == 256:
+            cin = 72
+        if d.cout == 64 and d.cin > 4096:
+            cout = 36
+        if d.cin == 64 and d.cout > 4096:
+            cin = 36
+        return cin, cout
+
+    for seg in plan.segments:
+        for fn, args, kwargs in seg:
+            if fn is ops.conv2d_fprop or fn is ops.conv2d_wgrad:
+                d = args[0]
+                cin, cout = true_dims(d, fn)
+                name = "igemm_kernel(fprop/dgrad)" if fn is ops.conv2d_fprop else "wgrad_kernel"
+                records.append((fn, args, kwargs, name, conv_flops(d, cin, cout)))
+            else:
+                records.append((fn, args, kwargs, None, 0.0))
+    state = model._snapshot(built["optimizer"])
+    events = []
+    for it in range(steps + 1):
+        for fn, args, kwargs, name, fl in records:
+            if name is None:
+                fn(*args, **kwargs)
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn(*args, **kwargs)
+                e1.record()
+                if it > 0:
+                    events.append((name, fl, e0, e1))
+    torch.cuda.synchronize()
+    model._restore(state, built["optimizer"])
+    for name, fl, e0, e1 in events:
+        f = fam.setdefault(name, {"launches": 0, "seconds": 0.0, "flops": 0.0})
+        f["launches"] += 1
+        f["seconds"] += e0.elapsed_time(e1) * 1e-3
+        f["flops"] += fl
+    for f in fam.values():
+        for k in f:
+            f[k] /= steps
+    return fam
+
+
+def cpu_baseline(cfg, steps=2):
+    """The CPU oracle (fp32 restatement of the reference path, kind "port") timed on this host's cores at
+    BASELINE config 1: batch 1, full train step.  Bounded sample: 1 warm-up + `steps` timed steps."""
+    from oracle import faster_rcnn as O
+    torch.manual_seed(0)
+    p = O.init_params(cfg, seed=0)
+    vel = {}
+    images, gl, gb = O.synthetic_batch(1, cfg["image_shape"], seed=1234)
+    O.train_step(p, vel, cfg, images, gl, gb, lr=1e-5, step=0, seed=0)
+    t0 = time.perf_counter()
+    for s in range(steps):
+        O.train_step(p, vel, cfg, images, gl, gb, lr=1e-5, step=s + 1, seed=0)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": 1.0 / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle (PyTorch-CPU fp32 + C NMS) full train step, batch 1, 375x1242, 1 warm-up + %d timed steps, %.2f s/step" % (steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    D = importlib.import_module("2d_object_detection_amd.distributed")
+    M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
+    OPT = importlib.import_module("2d_object_detection_amd.optimizers")
+    C = importlib.import_module("2d_object_detection_amd.config")
+    import torch.distributed as dist
+
+    rank, world, local_rank = D.init_from_env()
+    assert world == args.gpus, "launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    cfg = C.default_config()                                   # 375 x 1242, 7 classes, reference hyper-parameters
+    B = args.batch_per_gpu
+    model = M.FasterRCNN(cfg, device=dev, seed=0, sampling_seed=0, world_size=world)
+    model.use_graphs = not args.no_graphs
+    opt = OPT.SGD(learning_rate=OPT.PiecewiseConstantDecay([40000, 80000], [1e-3, 1e-4, 1e-5]), momentum=0.9)
+
+    # synthetic KITTI-like batch, resident in HBM, per-rank seed
+    DATA = importlib.import_module("2d_object_detection_amd.data")
+    images, gl, gb = DATA.synthetic_batch(B, cfg["image_shape"], seed=1234 + rank, device=dev)
+
+    sync = None
+    if world > 1:
+        sync = D.GradientSynchronizer(model.store.g, model.store.buckets)
+    hook = sync.after_segment if sync is not None else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        losses, preds = model.train_step(images, gl, gb, opt, sync_fn=hook)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses, preds = model.train_step(images, gl, gb, opt, sync_fn=hook)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_vals = {k: float(v) for k, v in losses.items()}
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    out = {
+        "metric": METRIC, "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": "ResNet-50(C4) Faster-RCNN full train step, bf16, batch %d per GPU, 375x1242 synthetic KITTI, "
+                               "300 proposals, 7 classes (BASELINE.json configs[%d])" % (B, 1 if world == 1 else 2),
+                   "global_batch": world * B, "image_shape": cfg["image_shape"], "parallelism": "dp%d" % world,
+                   "hip_graphs": model.use_graphs, "kernel_launches_per_step": model._train_plan["plan"].num_launches},
+        "final_losses": loss_vals,
+    }
+    if rank == 0:
+        fam = profile_conv_kernels(model, model._train_plan, args.profile_steps) if args.profile_steps > 0 else {}
+        if fam:
+            dom = max(fam, key=lambda k: fam[k]["seconds"])
+            f = fam[dom]
+            achieved = f["flops"] / f["seconds"] / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "traffic": None,
+                               "launches_per_step": f["launches"], "avg_launch_us": round(f["seconds"] / f["launches"] * 1e6, 2),
+                               "algorithmic_gflop_per_launch": round(f["flops"] / f["launches"] / 1e9, 4),
+                               "families": {k: {"launches_per_step": v["launches"], "ms_per_step": round(v["seconds"] * 1e3, 4),
+                                                "tflops": round(v["flops"] / v["seconds"] / 1e12, 2)} for k, v in fam.items()}}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
