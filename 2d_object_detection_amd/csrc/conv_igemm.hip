@@ -279,9 +279,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const ConvParams p) 
                 s += v;
                 ss += v * v;
             }
-            float* dst = p.stats + ((long long)(tile_m * PARTS + part) * 2) * p.Cout + n0 + col;
-            dst[0] = s;
-            dst[p.Cout] = ss;
+            // 64 accumulation slots (pre-zeroed by the caller) keep the finalize pass short; a slot sees
+            // tiles/64 float atomics per address, each wave instruction adding 256 contiguous bytes
+            float* dst = p.stats + ((long long)((tile_m * PARTS + part) & (FRCNN_STAT_SLOTS - 1)) * 2) * p.Cout + n0 + col;
+            atomicAdd(dst, s);
+            atomicAdd(dst + p.Cout, ss);
         }
     }
 }
@@ -316,9 +318,7 @@ int stats_parts(const TileCfg& t) { return 256 / t.bn; }
 
 extern "C" int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d) {
     if (!d) return FRCNN_EINVAL;
-    const TileCfg t = pick_tile(d);
-    const long long M = (long long)d->n * d->ho * d->wo;
-    return (int)((M + t.bm - 1) / t.bm) * stats_parts(t);
+    return FRCNN_STAT_SLOTS;
 }
 
 extern "C" int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,

@@ -52,13 +52,22 @@ __global__ void bn_finalize_train_kernel(const float* __restrict__ part, int til
                                          float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
                                          float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
                                          float* __restrict__ invstd_o) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // block = 64 channels x 4 slot lanes
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s = 0.0, ss = 0.0;
-    for (int t = 0; t < tiles; ++t) {
-        s += (double)part[((int64_t)t * 2) * C + c];
-        ss += (double)part[((int64_t)t * 2 + 1) * C + c];
-    }
+    if (c < C)
+        for (int t = sl; t < tiles; t += 4) {
+            s += (double)part[((int64_t)t * 2) * C + c];
+            ss += (double)part[((int64_t)t * 2 + 1) * C + c];
+        }
+    red[0][sl][cl] = s;
+    red[1][sl][cl] = ss;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    ss = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
     const double mean = s * inv_count;
     double var = ss * inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -162,9 +171,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
             for (int k = 0; k < RL; ++k)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) a[e] += red[(k * lanes_c + threadIdx.x) * 16 + e];
-            float* dst = part + ((int64_t)blockIdx.x * 2) * C + (cv0 + threadIdx.x) * 8;
+            // accumulate into one of FRCNN_STAT_SLOTS pre-zeroed slots (keeps the finalize pass short)
+            float* dst = part + ((int64_t)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2) * C + (cv0 + threadIdx.x) * 8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { dst[e] = a[e]; dst[C + e] = a[8 + e]; }
+            for (int e = 0; e < 8; ++e) { atomicAdd(dst + e, a[e]); atomicAdd(dst + C + e, a[8 + e]); }
         }
         __syncthreads();
     }
@@ -172,13 +182,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
 
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int blocks, int C, float inv_m, float* dgamma,
                                        float* dbeta, float* c1, float* c2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s = 0.0, sx = 0.0;
-    for (int t = 0; t < blocks; ++t) {
-        s += (double)part[((int64_t)t * 2) * C + c];
-        sx += (double)part[((int64_t)t * 2 + 1) * C + c];
-    }
+    if (c < C)
+        for (int t = sl; t < blocks; t += 4) {
+            s += (double)part[((int64_t)t * 2) * C + c];
+            sx += (double)part[((int64_t)t * 2 + 1) * C + c];
+        }
+    red[0][sl][cl] = s;
+    red[1][sl][cl] = sx;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    sx = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
     dbeta[c] = (float)s;
     dgamma[c] = (float)sx;
     c1[c] = (float)(s * inv_m);
@@ -225,15 +243,18 @@ __global__ void relu_bwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __re
 
 // column sums of a bf16 matrix [m, ld] (first c columns): one block per 64 columns, 256 threads = 4 row lanes
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int64_t m, int c, int ld, float* __restrict__ out) {
+    // grid = (column groups of 64, row chunks of 256); each block adds its partial with one atomic per column
     __shared__ float red[256];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 256, r1 = min(m, r0 + 256);
     float s = 0.f;
     if (col < c)
-        for (int64_t r = rl; r < m; r += 4) s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(x + r * ld + col));
+        for (int64_t r = r0 + rl; r < r1; r += 4) s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(x + r * ld + col));
     red[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < 64 && col < c) out[col] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+    if (threadIdx.x < 64 && col < c)
+        atomicAdd(out + col, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 // ---------------------------------------------------------------- max pool 3x3 / 2 with zero pad 1
@@ -390,7 +411,7 @@ extern "C" int frcnn_bn_finalize_train(const float* stats_partial, int tiles, in
     FRCNN_CHECK_ARG(stats_partial && gamma && beta && moving_mean && moving_var && scale && shift && mean && invstd && count > 0,
                     "bn_finalize_train: bad arguments");
     const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(cdiv(c, 64)), dim3(64), 0, S_(stream), stats_partial, tiles, c,
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(cdiv(c, 64)), dim3(256), 0, S_(stream), stats_partial, tiles, c,
                        (float)(1.0 / (double)count), unbias, gamma, beta, moving_mean, moving_var, momentum, eps, scale, shift,
                        mean, invstd);
     FRCNN_CHECK_LAUNCH("bn_finalize_train");
@@ -416,14 +437,14 @@ extern "C" int frcnn_bn_apply(const frcnn_bf16* z, const float* scale, const flo
     return FRCNN_OK;
 }
 
-extern "C" int frcnn_bn_bwd_blocks(int64_t m) { return (int)((m + kBwdRowsPerBlock - 1) / kBwdRowsPerBlock); }
+extern "C" int frcnn_bn_bwd_blocks(int64_t m) { (void)m; return FRCNN_STAT_SLOTS; }
 
 extern "C" int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act, const frcnn_bf16* z, const float* mean,
                                    const float* invstd, float* partial, int64_t m, int c, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(gout && z && mean && invstd && partial && c % 8 == 0, "bn_bwd_reduce: bad arguments");
     const int c8 = c / 8;
     FRCNN_CHECK_ARG(c8 >= 256 ? (c8 % 256 == 0) : (256 % c8 == 0), "bn_bwd_reduce: c/8=%d must divide or be a multiple of 256", c8);
-    const int blocks = frcnn_bn_bwd_blocks(m);
+    const int blocks = (int)((m + kBwdRowsPerBlock - 1) / kBwdRowsPerBlock);   // row blocks; they fold into FRCNN_STAT_SLOTS slots
     const size_t smem = 256 * 16 * sizeof(float);
     if (act)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), smem, S_(stream), CBF(gout), CBF(act), CBF(z), mean,
@@ -438,7 +459,7 @@ extern "C" int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act
 extern "C" int frcnn_bn_bwd_finalize(const float* partial, int blocks, int c, int64_t m, float* dgamma, float* dbeta, float* c1,
                                      float* c2, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(partial && dgamma && dbeta && c1 && c2 && m > 0, "bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, S_(stream), partial, blocks, c,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 64)), dim3(256), 0, S_(stream), partial, blocks, c,
                        (float)(1.0 / (double)m), dgamma, dbeta, c1, c2);
     FRCNN_CHECK_LAUNCH("bn_bwd_finalize");
     return FRCNN_OK;
@@ -468,7 +489,7 @@ extern "C" int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_
 
 extern "C" int frcnn_colsum_bf16(const frcnn_bf16* x, int64_t m, int c, int ld, float* out, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(x && out && c > 0 && ld >= c, "colsum: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(c, 64)), dim3(256), 0, S_(stream), CBF(x), m, c, ld, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(c, 64), cdiv(m, 256)), dim3(256), 0, S_(stream), CBF(x), m, c, ld, out);
     FRCNN_CHECK_LAUNCH("colsum");
     return FRCNN_OK;
 }

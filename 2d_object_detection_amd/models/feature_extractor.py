@@ -66,10 +66,10 @@ class _ConvBN:
         self.scale, self.shift = torch.empty(c, **f32), torch.empty(c, **f32)
         if training:
             self.tiles = ops.conv_stat_tiles(self.desc)
-            self.stats = torch.empty(self.tiles, 2, c, **f32)
+            self.stats = torch.zeros(self.tiles, 2, c, **f32)          # atomically accumulated: zeroed every step
             self.mean, self.invstd = torch.empty(c, **f32), torch.empty(c, **f32)
             self.bwd_blocks = ops.bn_bwd_blocks(self.m)
-            self.bwd_partial = torch.empty(self.bwd_blocks, 2, c, **f32)
+            self.bwd_partial = torch.zeros(self.bwd_blocks, 2, c, **f32)
             self.c1, self.c2 = torch.empty(c, **f32), torch.empty(c, **f32)
             self.dz = torch.empty(self.m, c, dtype=BF16, device=device)
 
@@ -270,6 +270,11 @@ class FeatureExtractor:
 
     def forward_plan(self, plan, training):
         st = self.stem
+        if training:
+            # BN statistics / backward partial sums are accumulated with atomics: one multi-tensor zero per step
+            acc = [t for u in self.conv_units() for t in (u.stats, u.bwd_partial)]
+            plan.hold(acc)
+            plan.add(torch._foreach_zero_, acc)
         plan.add(ops.preprocess, self.images, self.xpad, 3)
         st.forward(plan, self.xpad_flat, training)
         st.apply(plan, self.a_stem, relu=True)

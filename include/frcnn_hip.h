@@ -52,7 +52,9 @@ const char* frcnn_last_error(void);
 #define FRCNN_CONV_RELU       2   /* max(.,0) */
 #define FRCNN_CONV_OUT_F32    4   /* y is fp32 instead of bf16 */
 #define FRCNN_CONV_ADD_RES    8   /* y = conv + res (res bf16, same addressing as y; may alias y) */
-#define FRCNN_CONV_STATS      16  /* write per-M-tile column sum / sum-of-squares of the (bf16-rounded) output */
+#define FRCNN_CONV_STATS      16  /* accumulate (float atomics) the column sum / sum-of-squares of the bf16-rounded
+                                     output into stats_partial [FRCNN_STAT_SLOTS][2][cout], which must be pre-zeroed */
+#define FRCNN_STAT_SLOTS      64
 #define FRCNN_CONV_SPLITK_ATOMIC 32 /* y (fp32, pre-zeroed) accumulated with atomics over split_k K-slices */
 typedef struct {
     int n, hi, wi, in_pix_stride, cin;
@@ -61,7 +63,7 @@ typedef struct {
     int out_h, out_w, out_scatter;
     int flags, split_k;
 } frcnn_conv_desc;
-/* number of M tiles == rows of the stats_partial buffer [tiles][2][cout] */
+/* rows of the stats_partial buffer [rows][2][cout] (== FRCNN_STAT_SLOTS) */
 int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d);
 int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
                        const frcnn_bf16* res, void* y, float* stats_partial, frcnn_stream_t stream);
@@ -103,7 +105,8 @@ int frcnn_bn_finalize_eval(int c, const float* gamma, const float* beta, const f
 int frcnn_bn_apply(const frcnn_bf16* z, const float* scale, const float* shift, const frcnn_bf16* res, int relu,
                    frcnn_bf16* out, int64_t m, int c, frcnn_stream_t stream);
 /* backward: g = gout * (act > 0) if act != NULL else gout;  xhat = (z-mean)*invstd
- * reduce  : partial[blk][0][c] = sum g, partial[blk][1][c] = sum g*xhat   (blk = frcnn_bn_bwd_blocks(m))
+ * reduce  : partial[slot][0][c] += sum g, partial[slot][1][c] += sum g*xhat over row blocks (float atomics into a
+ *           PRE-ZEROED [frcnn_bn_bwd_blocks(m)][2][c] buffer; the row count is FRCNN_STAT_SLOTS)
  * finalize: dgamma = sum g*xhat, dbeta = sum g, c1 = dbeta/m, c2 = dgamma/m
  * apply   : dz = gamma*invstd*(g - c1 - xhat*c2);  gpre (optional) = g */
 int frcnn_bn_bwd_blocks(int64_t m);
@@ -116,7 +119,8 @@ int frcnn_bn_bwd_apply(const frcnn_bf16* gout, const frcnn_bf16* act, const frcn
                        frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, frcnn_stream_t stream);
 /* g_out = g * (act > 0): ReLU backward without BN (RPN intermediate layer) */
 int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, int64_t n, frcnn_stream_t stream);
-/* per-channel column sum of a bf16 [m,c] matrix -> fp32 out[c] (bias gradients); overwrites out */
+/* per-channel column sum of a bf16 [m,c] matrix ADDED (float atomics) to fp32 out[c] (bias gradients;
+ * the flat gradient buffer is zeroed at the start of a step) */
 int frcnn_colsum_bf16(const frcnn_bf16* x, int64_t m, int c, int ld, float* out, frcnn_stream_t stream);
 
 /* ZeroPadding2D(1) + MaxPool 3x3/2 valid of Keras ResNet50 (pool1_pad/pool1_pool); input >= 0.

@@ -62,7 +62,7 @@ def test_bn_forward_backward(ops):
     # backward (mask from the ORACLE's activation so both sides use the same ReLU mask)
     act = out_ref.detach().to(BF).to(dev)
     nb = ops.bn_bwd_blocks(m)
-    partial = torch.empty(nb, 2, c, device=dev)
+    partial = torch.zeros(nb, 2, c, device=dev)          # slots are accumulated with atomics: pre-zeroed
     gd = gout.to(BF).to(dev)
     ops.bn_bwd_reduce(gd, act, zd, mean, invstd, partial, m, c)
     dgamma, dbeta, c1, c2 = (torch.empty(c, device=dev) for _ in range(4))
@@ -85,9 +85,12 @@ def test_bn_wide_channels_and_eval(ops):
     mean, invstd = torch.randn(c, generator=g) * 0.1, 1 + 0.1 * torch.rand(c, generator=g)
     dev = "cuda"
     nb = ops.bn_bwd_blocks(m)
-    partial = torch.empty(nb, 2, c, device=dev)
+    partial = torch.zeros(nb, 2, c, device=dev)
     ops.bn_bwd_reduce(gout.to(BF).to(dev), None, z.to(BF).to(dev), mean.to(dev), invstd.to(dev), partial, m, c)
+    colsum = torch.full((c,), 1.0, device=dev)                           # colsum ADDS into its output
+    ops.colsum_bf16(gout.to(BF).to(dev), m, c, c, colsum)
     torch.cuda.synchronize()
+    _close(colsum, gout.sum(0) + 1.0, 1e-4, 1e-3, "colsum")
     xh = (z - mean) * invstd
     _close(partial[:, 0].sum(0), gout.sum(0), 1e-4, 1e-3, "sum g")
     _close(partial[:, 1].sum(0), (gout * xh).sum(0), 1e-4, 1e-3, "sum g*xhat")
