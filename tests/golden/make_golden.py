@@ -57,20 +57,22 @@ KNOWN = {
         ],
     },
     "target_assignment": {
-        "derivation": "utils/training.py:7-77,123-143 on a 100x100 image (rel == abs/100); fg [0.5,1), bg [0,0.3). "
-                      "gt0 = [10,10,50,50] class 2, gt1 = [60,60,100,100] class 1, one padding row. regions: "
-                      "r0 == gt0 (IoU 1.0: NOT in [0.5,1) but is the global max -> forced fg, :137-138); "
-                      "r1 = [10,10,50,40] (IoU 0.75 with gt0 -> fg class 2); r2 = [60,60,100,80] (IoU .5 with gt1 -> fg class 1); "
-                      "r3 = [0,0,20,20] (inter 100, union 400+1600-100 -> 1/19 -> bg); r4 = [10,10,50,26] (IoU .4: ignored); "
-                      "r5 = [200,200,210,210] (IoU 0 -> bg, interval is closed at 0)",
+        "derivation": "utils/training.py:7-77,123-143 on a 100x100 image; all coordinates are exact binary fractions so that fp32 "
+                      "IoUs hit the thresholds exactly; fg [0.5,1), bg [0,0.3). gt0 = [12.5,12.5,50,50] class 2 (area 1406.25), "
+                      "gt1 = [50,50,100,100] class 1, one padding row. regions: r0 == gt0 (IoU 1.0: NOT in [0.5,1) but it is the "
+                      "global max -> forced fg, :137-138); r1 = [12.5,12.5,50,40] (1031.25/1406.25 = .7333 -> fg class 2); "
+                      "r2 = [50,50,100,75] (1250/2500 = .5 exactly -> fg class 1, interval closed at .5); r3 = [0,0,20,20] "
+                      "(56.25/1750 -> bg); r4 = [12.5,12.5,50,27.5] (562.5/1406.25 = .4: ignored); r5 = [200,200,210,210] "
+                      "(IoU 0 -> bg, interval closed at 0)",
         "image_shape": [100, 100, 3],
-        "gt_boxes": [[0.1, 0.1, 0.5, 0.5], [0.6, 0.6, 1.0, 1.0], [0, 0, 0, 0]],
+        "gt_boxes": [[0.125, 0.125, 0.5, 0.5], [0.5, 0.5, 1.0, 1.0], [0, 0, 0, 0]],
         "gt_labels": [[0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 0]],
-        "regions": [[10, 10, 50, 50], [10, 10, 50, 40], [60, 60, 100, 80], [0, 0, 20, 20], [10, 10, 50, 26], [200, 200, 210, 210]],
+        "regions": [[12.5, 12.5, 50, 50], [12.5, 12.5, 50, 40], [50, 50, 100, 75], [0, 0, 20, 20], [12.5, 12.5, 50, 27.5],
+                    [200, 200, 210, 210]],
         "fg_interval": [0.5, 1.0], "bg_interval": [0.0, 0.3],
         "target_labels": [[0, 0, 1, 0], [0, 0, 1, 0], [0, 1, 0, 0], [1, 0, 0, 0], [0, 0, 0, 0], [1, 0, 0, 0]],
-        "target_box_r1_class2": [0.0, (30 - 25) / 30.0, 0.0, math.log(40.0 / 30.0)],
-        "target_box_r2_class1": [0.0, (80 - 70) / 20.0, 0.0, math.log(40.0 / 20.0)],
+        "target_box_r1_class2": [0.0, (31.25 - 26.25) / 27.5, 0.0, math.log(37.5 / 27.5)],
+        "target_box_r2_class1": [0.0, (75 - 62.5) / 25.0, 0.0, math.log(50.0 / 25.0)],
     },
     "rpn_objectness_padding_quirk": {
         "derivation": "rpn_detector.py:141 + training.py:43-45 (SURVEY A.6): one_hot(int(sum(labels)),2) maps padding rows to [1,0], "
