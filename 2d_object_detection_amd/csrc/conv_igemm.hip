@@ -1,19 +1,27 @@
 // Implicit-GEMM convolution for gfx950 (CDNA4): bf16 MFMA 16x16x32, fp32 accumulate.
 //
-// GEMM view: C[M = N*Ho*Wo pixels][Cout] = A[M][K = KH*KW*Cin] * W[Cout][K]^T, A gathered on the
-// fly from the NHWC input (im2col never materialised).  One workgroup = 4 waves computes a
-// BM x BN tile; K is walked in BK-wide slices that never straddle a filter tap (Cin % BK == 0),
-// so every A-tile row is one contiguous 64/128-byte run of an input pixel (or zeros in the
-// padding halo).  Tiles are staged global -> registers -> LDS (16 B per lane, XOR-swizzled so the
-// ds_read_b128 fragment reads are bank-conflict free), double buffered with one barrier per
-// K-slice: the next slice's global loads are issued before the MFMAs of the current one and
-// written to the other LDS buffer after them.
+// GEMM view: C[M = N*Ho*Wo pixels][Cout] = A[M][K = KH*KW*Cin] * W[Cout][K]^T, A gathered on the fly
+// from the NHWC input (im2col never materialised).  K is walked in BK-wide slices that never
+// straddle a filter tap (Cin % BK == 0), so every A-tile row is one contiguous 64/128-byte run of an
+// input pixel (or zeros in the padding halo / M tail).
 //
-// The MFMA is issued with swapped operands (A-op = weights, B-op = pixels) so that each lane
-// ends up with 4 consecutive output channels of one pixel: the epilogue packs them to bf16,
-// stages the tile in LDS and writes full 16-byte/lane coalesced rows, optionally fusing bias,
-// ReLU, a residual add, a stride-2 scatter (data gradient of strided 1x1 convs) and the
-// per-tile BatchNorm statistics (column sum / sum of squares of the bf16-rounded outputs).
+// Structure (v2): PERSISTENT workgroups (4 waves) walk a list of work items (tile x K-split) and
+// stream (item, K-slice) pairs through an S-deep LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPR staging).  The loader runs S-1
+// slices ahead of the MFMA consumer ACROSS item boundaries, so the next tile's operands are already
+// in flight while the current tile's epilogue runs -- the small-K (1x1, K = 64..256) layers of
+// conv2/conv3, which are HBM-bound, get the same latency hiding as the long-K 3x3 layers.
+// Synchronisation per slice: counted s_waitcnt vmcnt(N) (never 0 in steady state) + one raw
+// s_barrier; a ring slot is refilled only after the barrier that follows its last read.
+// The LDS image is lane-linear (DMA constraint), the XOR bank swizzle is applied to the per-lane
+// SOURCE address and to the ds_read_b128 fragment reads.  Rows outside the input read a 16-byte zero
+// page.
+//
+// The MFMA is issued with swapped operands (A-op = weights, B-op = pixels) so that each lane ends
+// with 4 consecutive output channels of one pixel: the epilogue adds bias / ReLU, packs to bf16,
+// reduces the BatchNorm statistics (sum, sum of squares of the ROUNDED outputs) in registers with
+// 16-lane butterflies, stages the tile in a dedicated LDS region and writes 16-byte/lane coalesced
+// rows, optionally adding a residual and scattering with stride 2 (data gradient of strided 1x1).
 #include "common.h"
 
 namespace {
@@ -27,8 +35,10 @@ struct ConvParams {
     float* stats;
     int Hi, Wi, in_pix_stride, Cin, KW, stride, pad_h, pad_w;
     int Ho, Wo, Cout, out_h, out_w, out_scatter, flags;
-    int M, Ktot, k_tiles, k_tiles_per_split;
-    int tiles_m, tiles_n;
+    int M, Ktot, k_tiles, k_tiles_per_split, split, taps, linear_a;
+    int in_row_stride32;                    // in_row_stride (elements); the whole tensor stays below 2 GiB
+    unsigned x_bytes, w_bytes;              // buffer descriptor sizes (x incl. the leading halo shift)
+    int tiles_m, tiles_n, items;            // items = tiles_m * tiles_n * split
     long long in_row_stride, in_img_stride;
 };
 
@@ -48,129 +58,322 @@ __device__ __forceinline__ long long out_row_of(const ConvParams& p, int m) {
     return ((long long)n * p.out_h + (long long)oy * p.out_scatter) * p.out_w + (long long)ox * p.out_scatter;
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const ConvParams p) {
-    constexpr int T = WM * WN * 64;
-    constexpr int CPR = BK / 8;               // 16-byte chunks per tile row
-    constexpr int RPP = T / CPR;              // rows loaded per pass
-    constexpr int A_IT = BM / RPP;
-    constexpr int B_IT = BN / RPP;
+// gfx950 retires loads, LDS-DMA, stores and atomics through ONE in-order vmcnt: "slice q landed" is
+// "at most n younger vector-memory ops are still outstanding", where n must count the DMA of the
+// younger slices AND the epilogue stores issued after slice q's DMA (waiting for those acknowledgements
+// would serialise every small-K tile on a store round trip).  n is data dependent, the immediate is not:
+// dispatch over the possible values (an under-estimate only waits longer, never too little).
+#define FRCNN_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+__device__ __forceinline__ void wait_vmcnt_at_most(int n) {
+    switch (n < 48 ? n : 48) {
+        FRCNN_VMCNT_CASE(0) FRCNN_VMCNT_CASE(1) FRCNN_VMCNT_CASE(2) FRCNN_VMCNT_CASE(3) FRCNN_VMCNT_CASE(4) FRCNN_VMCNT_CASE(5)
+        FRCNN_VMCNT_CASE(6) FRCNN_VMCNT_CASE(7) FRCNN_VMCNT_CASE(8) FRCNN_VMCNT_CASE(9) FRCNN_VMCNT_CASE(10) FRCNN_VMCNT_CASE(11)
+        FRCNN_VMCNT_CASE(12) FRCNN_VMCNT_CASE(13) FRCNN_VMCNT_CASE(14) FRCNN_VMCNT_CASE(15) FRCNN_VMCNT_CASE(16) FRCNN_VMCNT_CASE(17)
+        FRCNN_VMCNT_CASE(18) FRCNN_VMCNT_CASE(19) FRCNN_VMCNT_CASE(20) FRCNN_VMCNT_CASE(21) FRCNN_VMCNT_CASE(22) FRCNN_VMCNT_CASE(23)
+        FRCNN_VMCNT_CASE(24) FRCNN_VMCNT_CASE(25) FRCNN_VMCNT_CASE(26) FRCNN_VMCNT_CASE(27) FRCNN_VMCNT_CASE(28) FRCNN_VMCNT_CASE(29)
+        FRCNN_VMCNT_CASE(30) FRCNN_VMCNT_CASE(31) FRCNN_VMCNT_CASE(32) FRCNN_VMCNT_CASE(33) FRCNN_VMCNT_CASE(34) FRCNN_VMCNT_CASE(35)
+        FRCNN_VMCNT_CASE(36) FRCNN_VMCNT_CASE(37) FRCNN_VMCNT_CASE(38) FRCNN_VMCNT_CASE(39) FRCNN_VMCNT_CASE(40) FRCNN_VMCNT_CASE(41)
+        FRCNN_VMCNT_CASE(42) FRCNN_VMCNT_CASE(43) FRCNN_VMCNT_CASE(44) FRCNN_VMCNT_CASE(45) FRCNN_VMCNT_CASE(46) FRCNN_VMCNT_CASE(47)
+        default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    }
+}
+#undef FRCNN_VMCNT_CASE
+
+// Epilogue LDS writes go through inline asm: hipcc orders every DS *write/atomic* it emits behind ALL pending
+// LDS-DMA (s_waitcnt vmcnt(0)), although staging tile / statistics array and DMA ring never overlap; that would
+// drain the prefetch ring once per tile.  The asm forms are invisible to that pass; their completion is awaited
+// explicitly (s_waitcnt lgkmcnt(0)) before the barrier that publishes them.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void lds_write_b64(unsigned addr, u32x2 v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_add_f32(unsigned addr, float v) {
+    asm volatile("ds_add_f32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// Block -> work-item schedule.  Blocks b, b+8, ... share an XCD (its L2): every XCD owns a contiguous chunk
+// of the item list (item = tile * split + k-split, tile = tile_m * tiles_n + tile_n) and its blocks interleave
+// inside it, so concurrently running blocks of one XCD touch neighbouring tiles (shared A rows / weight panels
+// come out of that L2).  A block walks its items with a constant stride; (tile_m, tile_n, ks) advance by
+// carry-propagating adds -- no division per item.
+struct ItemWalk {
+    int left;                 // items still to take
+    int tm, tn, ks;           // current item
+    int dm, dn, dk;           // per-step increments (stride decomposed)
+    __device__ __forceinline__ void init(const int items, const int tiles_n, const int split, const int bid, const int nblocks) {
+        const int xcd = bid & 7, local = bid >> 3;
+        const int stride = (nblocks >> 3) + ((nblocks & 7) > xcd ? 1 : 0);
+        const int q = items >> 3, r = items & 7;
+        const int begin = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int end = begin + q + (xcd < r ? 1 : 0);
+        const int first = begin + local;
+        left = first < end ? (end - first + stride - 1) / stride : 0;
+        int t = first / split;
+        ks = first - t * split;
+        tm = t / tiles_n;
+        tn = t - tm * tiles_n;
+        int st = stride / split;
+        dk = stride - st * split;
+        dm = st / tiles_n;
+        dn = st - dm * tiles_n;
+    }
+    __device__ __forceinline__ void advance(const int tiles_n, const int split) {
+        --left;
+        ks += dk;
+        int carry = 0;
+        if (ks >= split) { ks -= split; carry = 1; }
+        tn += dn + carry;
+        carry = 0;
+        if (tn >= tiles_n) { tn -= tiles_n; carry = 1; }
+        if (tn >= tiles_n) { tn -= tiles_n; ++carry; }
+        tm += dm + carry;
+    }
+};
+
+constexpr unsigned kOob = 0xFFFFFFF0u;       // voffset beyond every buffer: the hardware range check returns zeros
+
+template <int BM, int BN, int BK, int S, int NW>
+__global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only types/builtins (buffer resources, LDS-DMA): the host pass only needs the stub
+    constexpr int T = NW * 64, WM = 2, WN = NW / 2;   // 8 waves: 2 per SIMD, partner waves overlap DMA issue / LDS reads / epilogue
+    constexpr int CPR = BK / 8;                  // 16-byte chunks per tile row
+    constexpr int RPI = 64 / CPR;                // rows written by one DMA wave instruction (1 KiB)
+    constexpr int A_INSTR = BM / RPI, B_INSTR = BN / RPI;            // DMA instructions per slice
+    constexpr int A_IT = (A_INSTR + NW - 1) / NW, B_IT = (B_INSTR + NW - 1) / NW;
+    constexpr bool UNIFORM_L = (A_INSTR % NW == 0) && (B_INSTR % NW == 0);
+    constexpr int LC = A_INSTR / NW + B_INSTR / NW;                    // DMA instructions per wave and slice when uniform
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = WTM / 16, NI = WTN / 16;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-    constexpr int ROWB = BN * 2 + 16;         // epilogue staging row pitch (bytes)
-    static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for the thread count");
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int ROWB = BN * 2 + 16;            // epilogue staging row pitch (bytes)
+    static_assert(MI >= 1 && NI >= 1 && S >= 2 && S <= 4, "unsupported tile");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;                 // [2][A_BYTES]
-    unsigned char* sB = smem + 2 * A_BYTES;   // [2][B_BYTES]
-
-    // XCD-aware tile order: blocks b, b+8, ... share an XCD (its L2); give each XCD a contiguous
-    // run of tiles, N-tiles fastest, so the gathered A rows are re-used out of that L2.
-    const int nwg = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_m = bid / p.tiles_n;
-    const int tile_n = bid - tile_m * p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    unsigned char* ring = smem;                              // [S][A tile | B tile]
+    unsigned char* stage = smem + S * STAGE_BYTES;           // [BM][ROWB] epilogue staging
+    float* bias_s = reinterpret_cast<float*>(stage + BM * ROWB);                      // [Cout]    (BIAS, bf16 path)
+    float* stat_s = bias_s + ((p.flags & FRCNN_CONV_BIAS) ? p.Cout : 0);             // [2][Cout] (STATS)
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
-    const int chunk = tid % CPR, row0 = tid / CPR;
+    const int flags = p.flags;
+    const bool bf16_path = !(flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC));
+    const unsigned stage_a = lds_addr(stage), stat_a = lds_addr(stat_s);
+    if (bf16_path) {
+        // bias and the per-block BN partial sums live in LDS: no ordinary global load in the loop (the compiler would
+        // drain the DMA ring with vmcnt(0) for it) and ONE global atomic flush per block instead of one per tile
+        if (flags & FRCNN_CONV_BIAS)
+            for (int c = tid; c < p.Cout; c += T) bias_s[c] = p.bias[c];
+        if (flags & FRCNN_CONV_STATS)
+            for (int c = tid; c < 2 * p.Cout; c += T) stat_s[c] = 0.f;
+        __syncthreads();
+    }
 
-    // per-thread im2col row state
-    long long a_base[A_IT];
+    // ------------------------------------------------------------------ loader (LDS-DMA producer) state
+    // buffer_load_dwordx4 ... lds: address = base + soffset (scalar: filter tap / K offset, advanced per slice) +
+    // voffset (per lane: pixel row + swizzled chunk, fixed per item).  Lanes of rows outside the input / tile use an
+    // out-of-range voffset: the buffer range check writes zeros, so halo, M tail and N tail need no branches.
+    // The x descriptor starts pad rows/pixels BEFORE the tensor so that voffset (pixel oy*s, ox*s) and soffset
+    // (tap kh, kw) are both non-negative; taps that fall outside the image are masked per lane.
+    const long long halo = (long long)p.pad_h * p.in_row_stride + (long long)p.pad_w * p.in_pix_stride;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - halo), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    ItemWalk ld_items;
+    ld_items.init(p.items, p.tiles_n, p.split, blockIdx.x, gridDim.x);
+    ItemWalk cp_items = ld_items;
+    int ld_left = 0;                             // K-slices left in the loader's current item
+    int ld_c0 = 0, ld_kh = 0, ld_kw = 0;         // filter tap / channel offset of the next slice
+    unsigned ld_soff_a = 0, ld_soff_b = 0;       // scalar byte offsets of the next slice
+    unsigned a_voff[A_IT], b_voff[B_IT];
     int a_iy0[A_IT], a_ix0[A_IT];
+    const int lrow = lane / CPR, lslot = lane % CPR;
     const int hw = p.Ho * p.Wo;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + row0 + i * RPP;
-        if (m < p.M) {
-            const int n = m / hw;
-            const int rem = m - n * hw;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            a_iy0[i] = oy * p.stride - p.pad_h;
-            a_ix0[i] = ox * p.stride - p.pad_w;
-            a_base[i] = (long long)n * p.in_img_stride + (long long)a_iy0[i] * p.in_row_stride +
-                        (long long)a_ix0[i] * p.in_pix_stride + chunk * 8;
+    const int Lw = [&]() {                       // DMA instructions THIS wave issues per slice (vmcnt units)
+        int l = 0;
+        for (int i = 0; i < A_IT; ++i) l += (wave + NW * i < A_INSTR) ? 1 : 0;
+        for (int i = 0; i < B_IT; ++i) l += (wave + NW * i < B_INSTR) ? 1 : 0;
+        return l;
+    }();
+
+    auto loader_next_item = [&]() {
+        const int m0 = ld_items.tm * BM, n0 = ld_items.tn * BN;
+        const int kt = ld_items.ks * p.k_tiles_per_split;
+        ld_left = min(p.k_tiles, kt + p.k_tiles_per_split) - kt;
+        if (p.taps == 1) {
+            ld_kh = ld_kw = 0;
+            ld_c0 = kt * BK;
         } else {
-            a_iy0[i] = -0x40000000;           // never valid
-            a_ix0[i] = 0;
-            a_base[i] = 0;
+            const int k0 = kt * BK;
+            const int tap = k0 / p.Cin;
+            ld_c0 = k0 - tap * p.Cin;
+            ld_kh = tap / p.KW;
+            ld_kw = tap - ld_kh * p.KW;
         }
-    }
-    long long b_base[B_IT];
-    bool b_ok[B_IT];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-        const int n = n0 + row0 + i * RPP;
-        b_ok[i] = n < p.Cout;
-        b_base[i] = (long long)n * p.Ktot + chunk * 8;
-    }
-
-    const int kt_begin = blockIdx.z * p.k_tiles_per_split;
-    const int kt_end = min(p.k_tiles, kt_begin + p.k_tiles_per_split);
-
-    u32x4 areg[A_IT], breg[B_IT];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
-        const int tap = k0 / p.Cin;
-        const int c0 = k0 - tap * p.Cin;
-        const int kh = tap / p.KW;
-        const int kw = tap - kh * p.KW;
-        const long long tap_off = (long long)kh * p.in_row_stride + (long long)kw * p.in_pix_stride + c0;
+        ld_soff_a = (unsigned)((ld_kh * p.in_row_stride32 + ld_kw * p.in_pix_stride + ld_c0) * 2);
+        ld_soff_b = (unsigned)(kt * BK * 2);
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
-            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u32x4*>(p.x + a_base[i] + tap_off);
-            areg[i] = v;
+            const int r = (wave + NW * i) * RPI + lrow;
+            const int m = m0 + r;
+            const unsigned chunk_b = (unsigned)swz<BK>(lslot, r) * 16u;     // LDS slot lslot of row r must hold this chunk
+            const bool ok = m < p.M && r < BM;
+            if (p.linear_a) {                                // 1x1 stride-1: output pixel m reads input pixel m
+                a_voff[i] = ok ? (unsigned)m * (unsigned)(p.in_pix_stride * 2) + chunk_b : kOob;
+                a_iy0[i] = a_ix0[i] = 0;
+            } else if (ok) {
+                const int n = m / hw;
+                const int rem = m - n * hw;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                a_iy0[i] = oy * p.stride - p.pad_h;
+                a_ix0[i] = ox * p.stride - p.pad_w;
+                a_voff[i] = (unsigned)(((n * p.Hi + oy * p.stride) * p.Wi + ox * p.stride) * p.in_pix_stride * 2) + chunk_b;
+            } else {
+                a_voff[i] = kOob;
+                a_iy0[i] = a_ix0[i] = 0;
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (b_ok[i]) v = *reinterpret_cast<const u32x4*>(p.w + b_base[i] + k0);
-            breg[i] = v;
+            const int r = (wave + NW * i) * RPI + lrow;
+            const int n = n0 + r;
+            b_voff[i] = (n < p.Cout && r < BN) ? (unsigned)n * (unsigned)(p.Ktot * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
         }
+        ld_items.advance(p.tiles_n, p.split);
     };
-    auto store_tile = [&](int buf) {
+
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto issue_slice = [&](const int slot) {     // DMA one K-slice of the loader's item into ring slot
+        unsigned char* sa = ring + slot * STAGE_BYTES;
+        unsigned char* sb = sa + A_BYTES;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int r = row0 + i * RPP;
-            *reinterpret_cast<u32x4*>(sA + buf * A_BYTES + r * (BK * 2) + swz<BK>(chunk, r) * 16) = areg[i];
+            if (wave + NW * i < A_INSTR) {       // wave-uniform
+                unsigned vo = a_voff[i];
+                if (!p.linear_a) {
+                    const int iy = a_iy0[i] + ld_kh, ix = a_ix0[i] + ld_kw;
+                    vo = ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) ? vo : kOob;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(sa + (wave + NW * i) * 1024), 16, vo, ld_soff_a, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int r = row0 + i * RPP;
-            *reinterpret_cast<u32x4*>(sB + buf * B_BYTES + r * (BK * 2) + swz<BK>(chunk, r) * 16) = breg[i];
+            if (wave + NW * i < B_INSTR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (wave + NW * i) * 1024), 16, b_voff[i], ld_soff_b, 0, 0);
+        }
+        --ld_left;
+        ld_soff_b += BK * 2;
+        ld_soff_a += BK * 2;
+        ld_c0 += BK;
+        if (ld_c0 == p.Cin) {                    // next filter tap
+            ld_c0 = 0;
+            if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
+            ld_soff_a = (unsigned)((ld_kh * p.in_row_stride32 + ld_kw * p.in_pix_stride) * 2);
         }
     };
+    // total slices this block will stream (every item has >= 1 slice; only the last K-split of a tile can be shorter)
+    int total_slices = 0;
+    {
+        ItemWalk it = ld_items;
+        while (it.left > 0) {
+            const int kb = it.ks * p.k_tiles_per_split;
+            total_slices += min(p.k_tiles, kb + p.k_tiles_per_split) - kb;
+            it.advance(p.tiles_n, p.split);
+        }
+    }
 
+    // ------------------------------------------------------------------ consumer (MFMA) state
+    int cp_left = 0;                             // slices left in the consumer's current item
+    int cp_m0 = 0, cp_n0 = 0, cp_ks = 0;
     f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-    }
-    __syncthreads();
-
     const int frow = lane & 15, fchunk = lane >> 4;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        const bool more = kt + 1 < kt_end;
-        if (more) load_tile(kt + 1);
-        const unsigned char* cA = sA + cur * A_BYTES;
-        const unsigned char* cB = sB + cur * B_BYTES;
+    // BN statistics stay in registers across all tiles of this block that share an n-tile (the usual case: the item
+    // stride of a block is a multiple of tiles_n); they are reduced and flushed only when n0 changes / at the end
+    float ssum[NI][4], ssq[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssum[j][e] = ssq[j][e] = 0.f;
+    int stats_n0 = -1;
+    auto flush_stats = [&]() {                   // all lanes active here
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = ssum[j][e], b = ssq[j][e];
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) {
+                    a += __shfl_xor(a, sh);
+                    b += __shfl_xor(b, sh);
+                }
+                const int c = stats_n0 + wn * WTN + j * 16 + fchunk * 4 + e;
+                if (frow == 0 && c < p.Cout) {
+                    lds_add_f32(stat_a + c * 4, a);
+                    lds_add_f32(stat_a + (p.Cout + c) * 4, b);
+                }
+                ssum[j][e] = ssq[j][e] = 0.f;
+            }
+    };
+
+    int issued = 0, consumed = 0, ld_slot = 0, cp_slot = 0;
+    int ep_sum = 0, ep_hist[3] = {0, 0, 0};      // epilogue vector-memory ops of this wave in the last 3 iterations
+    // prologue: fill S-1 ring slots
+    for (int s = 0; s < S - 1; ++s) {
+        if (issued < total_slices) {
+            if (ld_left == 0) loader_next_item();
+            issue_slice(ld_slot);
+            ld_slot = ld_slot + 1 == S ? 0 : ld_slot + 1;
+            ++issued;
+        }
+    }
+
+    while (consumed < total_slices) {
+        if (cp_left == 0) {                      // start the next item
+            cp_ks = cp_items.ks;
+            cp_m0 = cp_items.tm * BM;
+            cp_n0 = cp_items.tn * BN;
+            const int kb = cp_ks * p.k_tiles_per_split;
+            cp_left = min(p.k_tiles, kb + p.k_tiles_per_split) - kb;
+            cp_items.advance(p.tiles_n, p.split);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((flags & FRCNN_CONV_STATS) && bf16_path && cp_n0 != stats_n0) {
+                if (stats_n0 >= 0) flush_stats();
+                stats_n0 = cp_n0;
+            }
+        }
+        // slice `consumed` must have landed.  Ops this wave issued AFTER that slice's DMA: the DMA of the younger
+        // slices and the epilogue stores of the last S-1 iterations (ep_sum; under-estimates are safe).
+        const int younger = issued - consumed - 1;
+        if (UNIFORM_L && younger == S - 2 && ep_sum == 0) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LC) : "memory");       // steady state: one immediate, no dispatch
+        } else {
+            wait_vmcnt_at_most(younger * Lw + ep_sum);
+        }
+        __builtin_amdgcn_s_barrier();            // everyone's DMA of this slice landed; everyone finished reading the previous slot
+        // age the epilogue history: the slice consumed next was issued one iteration later than this one
+        if (ep_sum != 0) {
+            if (S == 4) { ep_hist[2] = ep_hist[1]; ep_hist[1] = ep_hist[0]; }
+            else if (S == 3) { ep_hist[1] = ep_hist[0]; }
+            ep_hist[0] = 0;
+            ep_sum = ep_hist[1] + ep_hist[2];
+        }
+        if (issued < total_slices) {             // refill the slot that was read in the previous iteration
+            if (ld_left == 0) loader_next_item();
+            issue_slice(ld_slot);
+            ld_slot = ld_slot + 1 == S ? 0 : ld_slot + 1;
+            ++issued;
+        }
+        const unsigned char* cA = ring + cp_slot * STAGE_BYTES;
+        const unsigned char* cB = cA + A_BYTES;
+        cp_slot = cp_slot + 1 == S ? 0 : cp_slot + 1;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 af[MI], bfr[NI];
@@ -190,129 +393,169 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const ConvParams p) 
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
-    }
+        ++consumed;
+        if (--cp_left != 0) continue;
 
-    // ------------------------------------------------------------------ epilogue
-    // lane holds, for tile (i,j): pixel = wm*WTM + i*16 + (lane&15); couts = wn*WTN + j*16 + (lane>>4)*4 + 0..3
-    const int flags = p.flags;
-    if (flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC)) {
-        float* y = reinterpret_cast<float*>(p.y);
-        const bool add_bias = (flags & FRCNN_CONV_BIAS) && blockIdx.z == 0;
+        // ------------------------------------------------------------------ epilogue of the finished item
+        // lane holds, for tile (i,j): pixel = wm*WTM + i*16 + (lane&15); couts = wn*WTN + j*16 + (lane>>4)*4 + 0..3
+        const int m0 = cp_m0, n0 = cp_n0;
+        if (!bf16_path) {
+            float* y = reinterpret_cast<float*>(p.y);
+            const bool add_bias = (flags & FRCNN_CONV_BIAS) && cp_ks == 0;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * WTM + i * 16 + frow;
-            if (m >= p.M) continue;
-            const long long orow = out_row_of(p, m);
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * WTM + i * 16 + frow;
+                if (m >= p.M) continue;
+                const long long orow = out_row_of(p, m);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int c = n0 + wn * WTN + j * 16 + fchunk * 4;
+                for (int j = 0; j < NI; ++j) {
+                    const int c = n0 + wn * WTN + j * 16 + fchunk * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (c + e >= p.Cout) continue;
-                    float v = acc[i][j][e];
-                    if (add_bias) v += p.bias[c + e];
-                    if (flags & FRCNN_CONV_RELU) v = fmaxf(v, 0.f);
-                    if (flags & FRCNN_CONV_SPLITK_ATOMIC)
-                        atomicAdd(y + orow * p.Cout + c + e, v);
-                    else
-                        y[orow * p.Cout + c + e] = v;
+                    for (int e = 0; e < 4; ++e) {
+                        if (c + e >= p.Cout) continue;
+                        float v = acc[i][j][e];
+                        if (add_bias) v += p.bias[c + e];
+                        if (flags & FRCNN_CONV_RELU) v = fmaxf(v, 0.f);
+                        if (flags & FRCNN_CONV_SPLITK_ATOMIC)
+                            atomicAdd(y + orow * p.Cout + c + e, v);
+                        else
+                            y[orow * p.Cout + c + e] = v;
+                    }
                 }
             }
+            continue;
         }
-        return;
-    }
 
-    unsigned char* stage = smem;              // [BM][ROWB]; all waves are past the last barrier
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int r = wm * WTM + i * 16 + frow;
+        for (int i = 0; i < MI; ++i) {
+            const int r = wm * WTM + i * 16 + frow;
+            const bool row_ok = m0 + r < p.M;
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int cl = wn * WTN + j * 16 + fchunk * 4;
-            float v[4];
+            for (int j = 0; j < NI; ++j) {
+                const int cl = wn * WTN + j * 16 + fchunk * 4;
+                unsigned short hb[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = acc[i][j][e];
-                if (flags & FRCNN_CONV_BIAS) v[e] += (n0 + cl + e < p.Cout) ? p.bias[n0 + cl + e] : 0.f;
-                if (flags & FRCNN_CONV_RELU) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][e];
+                    if (flags & FRCNN_CONV_BIAS) v += (n0 + cl + e < p.Cout) ? bias_s[n0 + cl + e] : 0.f;
+                    if (flags & FRCNN_CONV_RELU) v = fmaxf(v, 0.f);
+                    hb[e] = f32_to_bf16_bits(v);
+                    if (flags & FRCNN_CONV_STATS) {
+                        const float q = row_ok ? bf16_bits_to_f32(hb[e]) : 0.f;
+                        ssum[j][e] += q;
+                        ssq[j][e] += q * q;
+                    }
+                }
+                u32x2 pk;
+                pk[0] = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
+                pk[1] = (unsigned)hb[2] | ((unsigned)hb[3] << 16);
+                lds_write_b64(stage_a + r * ROWB + cl * 2, pk);
             }
-            u32x2 pk;
-            pk[0] = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-            pk[1] = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-            *reinterpret_cast<u32x2*>(stage + r * ROWB + cl * 2) = pk;
         }
-    }
-    __syncthreads();
+        // staging tile complete: LDS writes are tracked by lgkmcnt; a raw barrier does NOT drain the DMA ring
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
 
-    bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
-    constexpr int C8 = BN / 8;
-    for (int idx = tid; idx < BM * C8; idx += T) {
-        const int r = idx / C8, c8 = idx - r * C8;
-        const int m = m0 + r, c = n0 + c8 * 8;
-        if (m >= p.M || c >= p.Cout) continue;
-        u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + c8 * 16);
-        const long long off = out_row_of(p, m) * p.Cout + c;
-        if (flags & FRCNN_CONV_ADD_RES) {
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
-            float a[8], b[8];
-            unpack8(v, a);
-            unpack8(rv, b);
+        bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+        constexpr int C8 = BN / 8;
+        constexpr int ST_IT = (BM * C8 + T - 1) / T;
+        if (!(flags & FRCNN_CONV_ADD_RES)) {
+            // store instructions this wave certainly issues below (iterations in which all its 64 lanes are in range)
+            const int rows_valid = min(BM, p.M - m0);
+            const bool cols_full = n0 + BN <= p.Cout;
+            int full = 0;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += b[e];
-            v = pack8(a);
-        }
-        *reinterpret_cast<u32x4*>(y + off) = v;
-    }
-
-    if (flags & FRCNN_CONV_STATS) {
-        constexpr int PARTS = T / BN;
-        constexpr int RPART = BM / PARTS;
-        const int col = tid % BN, part = tid / BN;
-        if (n0 + col < p.Cout) {
-            float s = 0.f, ss = 0.f;
-            const int rbeg = part * RPART;
-            const int rend = min(rbeg + RPART, p.M - m0);
-            for (int r = rbeg; r < rend; ++r) {
-                const float v = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(stage + r * ROWB + col * 2));
-                s += v;
-                ss += v * v;
+            for (int it = 0; it < ST_IT; ++it) {
+                const int r_last = (it * T + wave * 64 + 63) / C8;
+                full += (cols_full && r_last < rows_valid) ? 1 : 0;
             }
-            // 64 accumulation slots (pre-zeroed by the caller) keep the finalize pass short; a slot sees
-            // tiles/64 float atomics per address, each wave instruction adding 256 contiguous bytes
-            float* dst = p.stats + ((long long)((tile_m * PARTS + part) & (FRCNN_STAT_SLOTS - 1)) * 2) * p.Cout + n0 + col;
-            atomicAdd(dst, s);
-            atomicAdd(dst + p.Cout, ss);
+            ep_hist[0] = full;
+            ep_sum = ep_hist[0] + ep_hist[1] + ep_hist[2];
+        }
+        for (int idx = tid; idx < BM * C8; idx += T) {
+            const int r = idx / C8, c8 = idx - r * C8;
+            const int m = m0 + r, c = n0 + c8 * 8;
+            if (m >= p.M || c >= p.Cout) continue;
+            u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + c8 * 16);
+            const long long off = out_row_of(p, m) * p.Cout + c;
+            if (flags & FRCNN_CONV_ADD_RES) {
+                const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
+                float a[8], b[8];
+                unpack8(v, a);
+                unpack8(rv, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += b[e];
+                v = pack8(a);
+            }
+            *reinterpret_cast<u32x4*>(y + off) = v;
+        }
+        // the next item's epilogue writes `stage` again only after >= 1 slice barrier of the main loop
+    }
+    if (bf16_path && (flags & FRCNN_CONV_STATS)) {
+        // flush the block's BN partial sums: one float atomic per channel and statistic, spread over 64 pre-zeroed slots
+        if (stats_n0 >= 0) flush_stats();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        float* slot = p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2) * p.Cout;
+        for (int c = tid; c < 2 * p.Cout; c += T) {
+            const float v = stat_s[c];
+            if (v != 0.f) atomicAdd(slot + c, v);
         }
     }
+#endif
 }
 
-struct TileCfg { int bm, bn, bk; };
+struct TileCfg { int bm, bn, bk, stages, waves; };
+
+int num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
 
 TileCfg pick_tile(const frcnn_conv_desc* d) {
     TileCfg t;
     t.bk = (d->cin % 64 == 0) ? 64 : 32;
     t.bn = d->cout >= 128 ? 128 : 64;
     const long long M = (long long)d->n * d->ho * d->wo;
-    const long long blocks128 = ((M + 127) / 128) * ((d->cout + t.bn - 1) / t.bn) * (d->split_k > 1 ? d->split_k : 1);
-    t.bm = blocks128 >= 512 ? 128 : 64;
+    const int split = d->split_k > 1 ? d->split_k : 1;
+    const long long items128 = ((M + 127) / 128) * ((d->cout + t.bn - 1) / t.bn) * split;
+    t.bm = items128 >= 256 ? 128 : 64;
+    // ring depth: as deep as 160 KiB allows next to the epilogue staging tile
+    t.stages = (t.bm == 128 && t.bn == 128 && t.bk == 64) ? 3 : 4;
+    t.waves = 8;
     return t;
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
-int launch(const ConvParams& p, int split, hipStream_t s) {
-    constexpr int loop_bytes = 2 * (BM + BN) * BK * 2;
-    constexpr int stage_bytes = BM * (BN * 2 + 16);
-    constexpr int smem = loop_bytes > stage_bytes ? loop_bytes : stage_bytes;
-    dim3 grid(p.tiles_m * p.tiles_n, 1, split);
-    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, BK, WM, WN>), smem) != 0) { frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem); return FRCNN_EINVAL; }
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(WM * WN * 64), smem, s, p);
+template <int BM, int BN, int BK, int S, int NW>
+int launch(const ConvParams& p, hipStream_t s) {
+    constexpr int base = S * (BM + BN) * BK * 2 + BM * (BN * 2 + 16);
+    static_assert(base <= 163840 - 3 * 1024 * 4, "LDS budget (ring + staging + bias/stat arrays of <= 1024 channels)");
+    int smem = base;
+    if (!(p.flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC))) {
+        if (p.flags & FRCNN_CONV_BIAS) smem += p.Cout * 4;
+        if (p.flags & FRCNN_CONV_STATS) smem += 2 * p.Cout * 4;
+    }
+    if (smem > 163840) {
+        frcnn_set_error("frcnn_conv2d_fprop: cout=%d too large for the LDS bias/statistics arrays", p.Cout);
+        return FRCNN_EINVAL;
+    }
+    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, BK, S, NW>), smem) != 0) {
+        frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
+        return FRCNN_EINVAL;
+    }
+    const int per_cu = 163840 / smem >= 2 ? 2 : 1;
+    int grid = num_cus() * per_cu;
+    if (grid > p.items) grid = p.items;
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, S, NW>), dim3(grid), dim3(NW * 64), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
     return FRCNN_OK;
 }
-
-int stats_parts(const TileCfg& t) { return 256 / t.bn; }
 
 }  // namespace
 
@@ -366,22 +609,38 @@ extern "C" int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x,
     FRCNN_CHECK_ARG(p.Ktot % t.bk == 0, "conv2d_fprop: K=%d not a multiple of %d", p.Ktot, t.bk);
     p.k_tiles = p.Ktot / t.bk;
     p.k_tiles_per_split = (p.k_tiles + split - 1) / split;
+    p.split = (p.k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;     // no empty K-splits
     p.tiles_m = (int)((M + t.bm - 1) / t.bm);
     p.tiles_n = (d->cout + t.bn - 1) / t.bn;
+    const long long items = (long long)p.tiles_m * p.tiles_n * p.split;
+    FRCNN_CHECK_ARG(items < (1ll << 30), "conv2d_fprop: too many tiles");
+    p.items = (int)items;
+    p.taps = d->kh * d->kw;
+    p.linear_a = (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->ho == d->hi && d->wo == d->wi) ? 1 : 0;
     p.in_row_stride = (long long)d->wi * d->in_pix_stride;
     p.in_img_stride = (long long)d->hi * p.in_row_stride;
+    {
+        // 32-bit buffer addressing: voffset (pixel) + soffset (tap) must stay below 2^32 - 16
+        const long long halo = (long long)d->pad_h * p.in_row_stride + (long long)d->pad_w * d->in_pix_stride;
+        const long long x_elems = (long long)d->n * p.in_img_stride + (long long)d->kw * d->in_pix_stride + 64;   // slack: stem tap reads
+        const long long xb = (x_elems + halo) * 2, wb = (long long)d->cout * p.Ktot * 2;
+        FRCNN_CHECK_ARG(xb < 0xFFFF0000ll && wb < 0xFFFF0000ll, "conv2d_fprop: operand larger than 4 GiB (32-bit buffer offsets)");
+        p.x_bytes = (unsigned)xb;
+        p.w_bytes = (unsigned)wb;
+        p.in_row_stride32 = (int)p.in_row_stride;
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
-#define FRCNN_DISPATCH(BM_, BN_, BK_, WM_, WN_) \
-    if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch<BM_, BN_, BK_, WM_, WN_>(p, split, s);
-    FRCNN_DISPATCH(128, 128, 64, 2, 2)
-    FRCNN_DISPATCH(128, 64, 64, 2, 2)
-    FRCNN_DISPATCH(64, 128, 64, 2, 2)
-    FRCNN_DISPATCH(64, 64, 64, 2, 2)
-    FRCNN_DISPATCH(128, 128, 32, 2, 2)
-    FRCNN_DISPATCH(128, 64, 32, 2, 2)
-    FRCNN_DISPATCH(64, 128, 32, 2, 2)
-    FRCNN_DISPATCH(64, 64, 32, 2, 2)
+#define FRCNN_DISPATCH(BM_, BN_, BK_, S_) \
+    if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && t.stages == S_) return launch<BM_, BN_, BK_, S_, 8>(p, s);
+    FRCNN_DISPATCH(128, 128, 64, 3)
+    FRCNN_DISPATCH(128, 64, 64, 4)
+    FRCNN_DISPATCH(64, 128, 64, 4)
+    FRCNN_DISPATCH(64, 64, 64, 4)
+    FRCNN_DISPATCH(128, 128, 32, 4)
+    FRCNN_DISPATCH(128, 64, 32, 4)
+    FRCNN_DISPATCH(64, 128, 32, 4)
+    FRCNN_DISPATCH(64, 64, 32, 4)
 #undef FRCNN_DISPATCH
     frcnn_set_error("conv2d_fprop: no tile configuration for bm=%d bn=%d bk=%d", t.bm, t.bn, t.bk);
     return FRCNN_EINVAL;

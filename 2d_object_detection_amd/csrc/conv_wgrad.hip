@@ -234,7 +234,8 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
     p.tiles_ci = (d->cin + bn - 1) / bn;
     p.p_tiles = (int)((M + BKP - 1) / BKP);
     const int blocks_mn = p.tiles_co * p.taps * p.tiles_ci;
-    int split = (1024 + blocks_mn - 1) / blocks_mn;
+    // every split adds one fp32 tile of float atomics (chip-wide ~1.3 TB/s): aim for ~1.5 workgroups per CU, no more
+    int split = (384 + blocks_mn - 1) / blocks_mn;
     if (split > p.p_tiles) split = p.p_tiles;
     if (split < 1) split = 1;
     p.p_tiles_per_split = (p.p_tiles + split - 1) / split;

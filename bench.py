@@ -79,6 +79,28 @@ def profile_conv_kernels(model, built, steps=3):
                     events.append((name, fl, e0, e1))
     torch.cuda.synchronize()
     model._restore(state, built["optimizer"])
+    if os.environ.get("FRCNN_LAYER_TABLE"):
+        # per-launch table (median over steps) for kernel work: shape, us, TFLOP/s, GB/s of compulsory traffic
+        per = {}
+        order = []
+        i = 0
+        for it in range(steps):
+            for fn, args, kwargs, name, fl in records:
+                if name is None:
+                    continue
+                ev = events[i]
+                i += 1
+                key = len(order) if it == 0 else None
+                if it == 0:
+                    order.append((name, args[0], fl))
+                per.setdefault(i - 1 - it * (len(events) // steps), []).append(ev[2].elapsed_time(ev[3]) * 1e3)
+        with open(os.environ["FRCNN_LAYER_TABLE"], "w") as fh:
+            for j, (name, d, fl) in enumerate(order):
+                us = sorted(per[j])[len(per[j]) // 2]
+                m = d.n * d.ho * d.wo
+                byts = 2.0 * (m * d.kh * d.kw * 0 + m * d.cin + m * d.cout + d.cout * d.kh * d.kw * d.cin)
+                fh.write("%-26s M=%7d cin=%5d cout=%5d k=%dx%d s=%d  %8.1f us %7.1f TF/s %7.0f GB/s(min traffic)\n" % (
+                    name, m, d.cin, d.cout, d.kh, d.kw, d.stride, us, fl / us / 1e6, byts / us / 1e3))
     for name, fl, e0, e1 in events:
         f = fam.setdefault(name, {"launches": 0, "seconds": 0.0, "flops": 0.0})
         f["launches"] += 1
