@@ -120,17 +120,17 @@ __global__ void bn_apply_kernel(const bf16_t* __restrict__ z, const float* __res
 // ---------------------------------------------------------------- BN backward
 // Block = 256 threads arranged as (C8 lanes over channel vectors) x (256/C8 row lanes) when C8 <= 256.
 // Generic layout: thread handles channel-vector cv = tid % C8L and rows rl, rl+RL, ... of its block slab.
-constexpr int kBwdRowsPerBlock = 256;   // rows per reduce block
+// rows per reduce block are chosen per launch so that even the small-M conv4 layers start ~1000 workgroups
 template <bool MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ act,
                                                             const bf16_t* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ part,
-                                                            int64_t M, int C) {
-    // one block reduces kBwdRowsPerBlock rows for all channels; channel vectors are looped when C8 > 256
+                                                            int64_t M, int C, int rows_per_block) {
+    // one block reduces rows_per_block rows for all channels; channel vectors are looped when C8 > 256
     extern __shared__ float red[];      // [256][16] floats
     const int C8 = C / 8;
-    const int64_t row_begin = (int64_t)blockIdx.x * kBwdRowsPerBlock;
-    const int64_t row_end = min(M, row_begin + kBwdRowsPerBlock);
+    const int64_t row_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
     const int lanes_c = C8 < 256 ? C8 : 256;
     const int RL = 256 / lanes_c;       // row lanes
     for (int cv0 = 0; cv0 < C8; cv0 += lanes_c) {
@@ -444,14 +444,19 @@ extern "C" int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act
     FRCNN_CHECK_ARG(gout && z && mean && invstd && partial && c % 8 == 0, "bn_bwd_reduce: bad arguments");
     const int c8 = c / 8;
     FRCNN_CHECK_ARG(c8 >= 256 ? (c8 % 256 == 0) : (256 % c8 == 0), "bn_bwd_reduce: c/8=%d must divide or be a multiple of 256", c8);
-    const int blocks = (int)((m + kBwdRowsPerBlock - 1) / kBwdRowsPerBlock);   // row blocks; they fold into FRCNN_STAT_SLOTS slots
+    // row blocks (they fold into FRCNN_STAT_SLOTS slots): ~1024 workgroups, at least one row per row lane
+    const int row_lanes = c8 < 256 ? 256 / c8 : 1;
+    int rows_per_block = (int)((m + 1023) / 1024);
+    if (rows_per_block < row_lanes) rows_per_block = row_lanes;
+    if (rows_per_block < 8) rows_per_block = 8;
+    const int blocks = (int)((m + rows_per_block - 1) / rows_per_block);
     const size_t smem = 256 * 16 * sizeof(float);
     if (act)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), smem, S_(stream), CBF(gout), CBF(act), CBF(z), mean,
-                           invstd, partial, m, c);
+                           invstd, partial, m, c, rows_per_block);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), smem, S_(stream), CBF(gout), CBF(act), CBF(z), mean,
-                           invstd, partial, m, c);
+                           invstd, partial, m, c, rows_per_block);
     FRCNN_CHECK_LAUNCH("bn_bwd_reduce");
     return FRCNN_OK;
 }
