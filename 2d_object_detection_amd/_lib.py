@@ -29,6 +29,7 @@ _SIGNATURES = {
     "frcnn_conv2d_fprop": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "frcnn_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
     "frcnn_weights_transpose_flip": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "frcnn_weights_transpose_flip_batched": (c_int, [P, c_int, c_int64, P]),
     "frcnn_cast_f32_bf16": (c_int, [P, P, c_int64, P]),
     "frcnn_stem_pack_weights": (c_int, [P, P, c_int, P]),
     "frcnn_stem_unpack_grad": (c_int, [P, P, c_int, P]),

@@ -120,6 +120,9 @@ class FastRCNNDetector:
     def refresh_weights(self, plan):
         plan.add(ops.weights_transpose_flip, self.store.weight("fast_rcnn_heads/kernel"), self.w_t, HEAD_LD, 1, 1, self.flat)
 
+    def flip_entries(self):
+        return [(self.store.weight("fast_rcnn_heads/kernel"), self.w_t, HEAD_LD, 1, 1, self.flat)]
+
     def forward_plan(self, plan, feature_maps, rois):
         st = self.store
         plan.add(ops.roi_crop_pool_fwd, feature_maps, rois, self.batch, self.p, self.hf, self.wf, self.cf, self.ps, self.ks, self.pooled,

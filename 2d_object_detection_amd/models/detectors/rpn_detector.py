@@ -132,6 +132,11 @@ class RPNDetector:
         plan.add(ops.weights_transpose_flip, st.weight("rpn_intermediate_layer/kernel"), self.w_inter_t, 256, self.ws, self.ws, self.cf)
         plan.add(ops.weights_transpose_flip, st.weight("rpn_heads/kernel"), self.w_heads_t, HEAD_LD, 1, 1, 256)
 
+    def flip_entries(self):
+        st = self.store
+        return [(st.weight("rpn_intermediate_layer/kernel"), self.w_inter_t, 256, self.ws, self.ws, self.cf),
+                (st.weight("rpn_heads/kernel"), self.w_heads_t, HEAD_LD, 1, 1, 256)]
+
     def forward_plan(self, plan, feature_maps, training):
         st = self.store
         plan.add(ops.conv2d_fprop, self.d_inter, feature_maps, st.weight_bf16("rpn_intermediate_layer/kernel"), self.f,

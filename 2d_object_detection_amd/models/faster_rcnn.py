@@ -184,9 +184,11 @@ class FasterRCNN:
             mods.fe.backward_plan(plan, g_feat)
             plan.cut("update")
             optimizer.apply_plan(plan)
-            mods.fe.refresh_weights(plan)
-            mods.rpn.refresh_weights(plan)
-            mods.rcnn.refresh_weights(plan)
+            # derived weights: all tap-flipped transposes (backbone, RPN, heads) in ONE launch + the packed stem filter
+            table, total = ops.make_transpose_flip_table(mods.fe.flip_entries() + mods.rpn.flip_entries() + mods.rcnn.flip_entries(), dev)
+            plan.hold(table)
+            plan.add(ops.weights_transpose_flip_batched, table, total)
+            mods.fe.stem.refresh_weights(plan)
             plan.add(ops.step_increment, optimizer.iterations)
         nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
         preds = {"rpn_boxes": nms_rpn["pred_boxes"], "rpn_scores": nms_rpn["pred_scores"], "rcnn_boxes": nms_rcnn["pred_boxes"],

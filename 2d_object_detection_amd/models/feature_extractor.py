@@ -44,7 +44,7 @@ class _ConvBN:
         self.is_stem = (k == 7)
 
     # -- buffers for a fixed input geometry
-    def setup(self, n, hi, wi, device, training):
+    def setup(self, n, hi, wi, device, training, acc=None):
         s, p, k = self.stride, self.pad, self.k
         self.n, self.hi, self.wi = n, hi, wi
         if self.is_stem:
@@ -66,10 +66,12 @@ class _ConvBN:
         self.scale, self.shift = torch.empty(c, **f32), torch.empty(c, **f32)
         if training:
             self.tiles = ops.conv_stat_tiles(self.desc)
-            self.stats = torch.zeros(self.tiles, 2, c, **f32)          # atomically accumulated: zeroed every step
+            # atomically accumulated buffers: carved from ONE flat tensor that is zeroed by a single fill per step
+            self.stats = acc(self.tiles * 2 * c).view(self.tiles, 2, c) if acc else torch.zeros(self.tiles, 2, c, **f32)
             self.mean, self.invstd = torch.empty(c, **f32), torch.empty(c, **f32)
             self.bwd_blocks = ops.bn_bwd_blocks(self.m)
-            self.bwd_partial = torch.zeros(self.bwd_blocks, 2, c, **f32)
+            self.bwd_partial = (acc(self.bwd_blocks * 2 * c).view(self.bwd_blocks, 2, c) if acc
+                                else torch.zeros(self.bwd_blocks, 2, c, **f32))
             self.c1, self.c2 = torch.empty(c, **f32), torch.empty(c, **f32)
             self.dz = torch.empty(self.m, c, dtype=BF16, device=device)
 
@@ -225,6 +227,11 @@ class FeatureExtractor:
         for u in self.conv_units():
             u.refresh_weights(plan)
 
+    def flip_entries(self):
+        """(fp32 master, data-gradient weight buffer, cout, kh, kw, cin) of every conv except the stem (batched refresh)."""
+        st = self.store
+        return [(st.weight(u.name + "_conv/kernel"), u.w_t, u.cout, u.k, u.k, u.cin) for u in self.conv_units() if not u.is_stem]
+
     # ------------------------------------------------------------------ plans
     def setup(self, batch, training):
         """Allocate activations for a batch size; returns the static input buffer [B,H,W,3] uint8."""
@@ -233,7 +240,18 @@ class FeatureExtractor:
         self.batch = batch
         self.images = torch.zeros(batch, h, w, 3, dtype=torch.uint8, device=dev)
         st = self.stem
-        st.setup(batch, h, w, dev, training)
+        acc = None
+        if training:
+            slots = 64                                          # FRCNN_STAT_SLOTS
+            total = sum(2 * slots * 2 * u.cout for u in self.conv_units())
+            self.acc_flat = torch.zeros(total, dtype=torch.float32, device=dev)
+            cursor = [0]
+
+            def acc(nfloats):
+                v = self.acc_flat[cursor[0]:cursor[0] + nfloats]
+                cursor[0] += nfloats
+                return v
+        st.setup(batch, h, w, dev, training, acc)
         npad = batch * st.hp * st.wp * 4
         self.xpad_flat = torch.zeros(npad + 256, dtype=BF16, device=dev)        # slack for the 8-wide tap reads
         self.xpad = self.xpad_flat[:npad].view(batch, st.hp, st.wp, 4)
@@ -246,11 +264,11 @@ class FeatureExtractor:
         for (n, ci, f, s, first) in self.specs:
             u = self.units[n]
             if first:
-                u[0].setup(batch, hi, wi, dev, training)
-            u[1].setup(batch, hi, wi, dev, training)
+                u[0].setup(batch, hi, wi, dev, training, acc)
+            u[1].setup(batch, hi, wi, dev, training, acc)
             ho, wo = u[1].ho, u[1].wo
-            u[2].setup(batch, ho, wo, dev, training)
-            u[3].setup(batch, ho, wo, dev, training)
+            u[2].setup(batch, ho, wo, dev, training, acc)
+            u[3].setup(batch, ho, wo, dev, training, acc)
             m = batch * ho * wo
             a = {"a1": torch.empty(m, f, dtype=BF16, device=dev), "a2": torch.empty(m, f, dtype=BF16, device=dev),
                  "out": torch.empty(m, 4 * f, dtype=BF16, device=dev)}
@@ -272,9 +290,7 @@ class FeatureExtractor:
         st = self.stem
         if training:
             # BN statistics / backward partial sums are accumulated with atomics: one multi-tensor zero per step
-            acc = [t for u in self.conv_units() for t in (u.stats, u.bwd_partial)]
-            plan.hold(acc)
-            plan.add(torch._foreach_zero_, acc)
+            plan.add(self.acc_flat.zero_)
         plan.add(ops.preprocess, self.images, self.xpad, 3)
         st.forward(plan, self.xpad_flat, training)
         st.apply(plan, self.a_stem, relu=True)

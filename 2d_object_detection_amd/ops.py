@@ -56,6 +56,19 @@ def weights_transpose_flip(w, w_t, cout, kh, kw, cin):
     call("frcnn_weights_transpose_flip", _p(w), _p(w_t), cout, kh, kw, cin, _stream())
 
 
+def make_transpose_flip_table(entries, device):
+    """entries: list of (w fp32 master view, w_t bf16 buffer, cout, kh, kw, cin) -> (int64 table on device, total)."""
+    rows, begin = [], 0
+    for (w, w_t, cout, kh, kw, cin) in entries:
+        rows.append([w.data_ptr(), w_t.data_ptr(), cout, kh, kw, cin, begin, 0])
+        begin += cout * kh * kw * cin
+    return torch.tensor(rows, dtype=torch.int64, device=device), begin
+
+
+def weights_transpose_flip_batched(table, total):
+    call("frcnn_weights_transpose_flip_batched", _p(table), table.shape[0], total, _stream())
+
+
 def cast_f32_bf16(src, dst, n=None):
     call("frcnn_cast_f32_bf16", _p(src), _p(dst), src.numel() if n is None else n, _stream())
 

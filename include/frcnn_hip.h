@@ -79,6 +79,9 @@ int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcn
 /* w_t[ci][KH-1-kh][KW-1-kw][co] (bf16) = w[co][kh][kw][ci] (fp32 master) : data-gradient weights. */
 int frcnn_weights_transpose_flip(const float* w, frcnn_bf16* w_t, int cout, int kh, int kw, int cin,
                                  frcnn_stream_t stream);
+/* the same for n layers in ONE launch: table (device, int64[n][8]) rows = {w ptr, w_t ptr, cout, kh, kw, cin,
+ * first flat output index (prefix sum of the layer sizes), 0}; total = sum of the layer sizes. */
+int frcnn_weights_transpose_flip_batched(const int64_t* table, int n, int64_t total, frcnn_stream_t stream);
 /* plain fp32 -> bf16 cast of n elements */
 int frcnn_cast_f32_bf16(const float* src, frcnn_bf16* dst, int64_t n, frcnn_stream_t stream);
 /* stem weights: master [64][7][7][3] fp32 <-> padded GEMM form [64][7][8][4]
