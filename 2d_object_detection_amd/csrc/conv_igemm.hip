@@ -23,6 +23,7 @@
 // 16-lane butterflies, stages the tile in a dedicated LDS region and writes 16-byte/lane coalesced
 // rows, optionally adding a residual and scattering with stride 2 (data gradient of strided 1x1).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -37,13 +38,16 @@ struct ConvParams {
     int Ho, Wo, Cout, out_h, out_w, out_scatter, flags;
     int M, Ktot, k_tiles, k_tiles_per_split, split, taps, linear_a;
     int in_row_stride32;                    // in_row_stride (elements); the whole tensor stays below 2 GiB
-    unsigned x_bytes, w_bytes;              // buffer descriptor sizes (x incl. the leading halo shift)
+    unsigned x_bytes, w_bytes, y_bytes;     // buffer descriptor sizes (x incl. the leading halo shift)
+    int tap_mask;                           // taps <= 32: per-row tap validity bit masks
+    int direct_out;                         // bf16 output row == GEMM row and the tensor stays below 4 GiB: buffer-store epilogue
     int tiles_m, tiles_n, items;            // items = tiles_m * tiles_n * split
     long long in_row_stride, in_img_stride;
 };
 
 template <int BK>
 __device__ __forceinline__ int swz(int chunk, int row) {
+    if (BK == 128) return chunk ^ (row & 15);
     if (BK == 64) return chunk ^ (row & 7);
     return chunk ^ ((4 - ((row >> 2) & 3)) & 3);
 }
@@ -65,16 +69,10 @@ __device__ __forceinline__ long long out_row_of(const ConvParams& p, int m) {
 // dispatch over the possible values (an under-estimate only waits longer, never too little).
 #define FRCNN_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
 __device__ __forceinline__ void wait_vmcnt_at_most(int n) {
-    switch (n < 48 ? n : 48) {
+    switch (n < 8 ? n : 8) {
         FRCNN_VMCNT_CASE(0) FRCNN_VMCNT_CASE(1) FRCNN_VMCNT_CASE(2) FRCNN_VMCNT_CASE(3) FRCNN_VMCNT_CASE(4) FRCNN_VMCNT_CASE(5)
-        FRCNN_VMCNT_CASE(6) FRCNN_VMCNT_CASE(7) FRCNN_VMCNT_CASE(8) FRCNN_VMCNT_CASE(9) FRCNN_VMCNT_CASE(10) FRCNN_VMCNT_CASE(11)
-        FRCNN_VMCNT_CASE(12) FRCNN_VMCNT_CASE(13) FRCNN_VMCNT_CASE(14) FRCNN_VMCNT_CASE(15) FRCNN_VMCNT_CASE(16) FRCNN_VMCNT_CASE(17)
-        FRCNN_VMCNT_CASE(18) FRCNN_VMCNT_CASE(19) FRCNN_VMCNT_CASE(20) FRCNN_VMCNT_CASE(21) FRCNN_VMCNT_CASE(22) FRCNN_VMCNT_CASE(23)
-        FRCNN_VMCNT_CASE(24) FRCNN_VMCNT_CASE(25) FRCNN_VMCNT_CASE(26) FRCNN_VMCNT_CASE(27) FRCNN_VMCNT_CASE(28) FRCNN_VMCNT_CASE(29)
-        FRCNN_VMCNT_CASE(30) FRCNN_VMCNT_CASE(31) FRCNN_VMCNT_CASE(32) FRCNN_VMCNT_CASE(33) FRCNN_VMCNT_CASE(34) FRCNN_VMCNT_CASE(35)
-        FRCNN_VMCNT_CASE(36) FRCNN_VMCNT_CASE(37) FRCNN_VMCNT_CASE(38) FRCNN_VMCNT_CASE(39) FRCNN_VMCNT_CASE(40) FRCNN_VMCNT_CASE(41)
-        FRCNN_VMCNT_CASE(42) FRCNN_VMCNT_CASE(43) FRCNN_VMCNT_CASE(44) FRCNN_VMCNT_CASE(45) FRCNN_VMCNT_CASE(46) FRCNN_VMCNT_CASE(47)
-        default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+        FRCNN_VMCNT_CASE(6) FRCNN_VMCNT_CASE(7)
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
     }
 }
 #undef FRCNN_VMCNT_CASE
@@ -148,13 +146,16 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
     constexpr int MI = WTM / 16, NI = WTN / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int ROWB = BN * 2 + 16;            // epilogue staging row pitch (bytes)
+    constexpr int C8 = BN / 8;                   // 16-byte chunks per output tile row
+    constexpr int ST_IT = (BM * C8) / T;         // store passes (one 16-byte store per lane each) per tile
+    static_assert((BM * C8) % T == 0, "store loop covers the tile in whole passes");
     static_assert(MI >= 1 && NI >= 1 && S >= 2 && S <= 4, "unsupported tile");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* ring = smem;                              // [S][A tile | B tile]
+    unsigned char* ring = smem;                              // [S A tiles][S B tiles]: slot strides stay inside the ds_read offset field
     unsigned char* stage = smem + S * STAGE_BYTES;           // [BM][ROWB] epilogue staging
     float* bias_s = reinterpret_cast<float*>(stage + BM * ROWB);                      // [Cout]    (BIAS, bf16 path)
-    float* stat_s = bias_s + ((p.flags & FRCNN_CONV_BIAS) ? p.Cout : 0);             // [2][Cout] (STATS)
+    float* stat_s = bias_s + ((p.flags & FRCNN_CONV_BIAS) ? p.tiles_n * BN : 0);     // [2][Cout] (STATS); bias is padded to the tile grid
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
         // bias and the per-block BN partial sums live in LDS: no ordinary global load in the loop (the compiler would
         // drain the DMA ring with vmcnt(0) for it) and ONE global atomic flush per block instead of one per tile
         if (flags & FRCNN_CONV_BIAS)
-            for (int c = tid; c < p.Cout; c += T) bias_s[c] = p.bias[c];
+            for (int c = tid; c < p.tiles_n * BN; c += T) bias_s[c] = c < p.Cout ? p.bias[c] : 0.f;
         if (flags & FRCNN_CONV_STATS)
             for (int c = tid; c < 2 * p.Cout; c += T) stat_s[c] = 0.f;
         __syncthreads();
@@ -182,6 +183,8 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
     const long long halo = (long long)p.pad_h * p.in_row_stride + (long long)p.pad_w * p.in_pix_stride;
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - halo), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.y_bytes, 0x00020000);
     ItemWalk ld_items;
     ld_items.init(p.items, p.tiles_n, p.split, blockIdx.x, gridDim.x);
     ItemWalk cp_items = ld_items;
@@ -189,7 +192,10 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
     int ld_c0 = 0, ld_kh = 0, ld_kw = 0;         // filter tap / channel offset of the next slice
     unsigned ld_soff_a = 0, ld_soff_b = 0;       // scalar byte offsets of the next slice
     unsigned a_voff[A_IT], b_voff[B_IT];
-    int a_iy0[A_IT], a_ix0[A_IT];
+    int a_iy0[A_IT] = {}, a_ix0[A_IT] = {};
+    unsigned a_mask[A_IT] = {};                  // bit t: filter tap t of this row lies inside the image (taps <= 32)
+    int ld_tap = 0;                              // kh * KW + kw of the next slice
+    int ld_seq = 0, cp_seq = 0;                  // item sequence numbers of loader / consumer
     const int lrow = lane / CPR, lslot = lane % CPR;
     const int hw = p.Ho * p.Wo;
     const int Lw = [&]() {                       // DMA instructions THIS wave issues per slice (vmcnt units)
@@ -203,8 +209,9 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
         const int m0 = ld_items.tm * BM, n0 = ld_items.tn * BN;
         const int kt = ld_items.ks * p.k_tiles_per_split;
         ld_left = min(p.k_tiles, kt + p.k_tiles_per_split) - kt;
+        ++ld_seq;
         if (p.taps == 1) {
-            ld_kh = ld_kw = 0;
+            ld_kh = ld_kw = ld_tap = 0;
             ld_c0 = kt * BK;
         } else {
             const int k0 = kt * BK;
@@ -212,29 +219,45 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
             ld_c0 = k0 - tap * p.Cin;
             ld_kh = tap / p.KW;
             ld_kw = tap - ld_kh * p.KW;
+            ld_tap = tap;
         }
         ld_soff_a = (unsigned)((ld_kh * p.in_row_stride32 + ld_kw * p.in_pix_stride + ld_c0) * 2);
         ld_soff_b = (unsigned)(kt * BK * 2);
+        // straight-line selects with compile-time indices only: a branchy per-row form makes hipcc keep these small
+        // arrays in scratch memory, whose reloads drain the DMA ring (s_waitcnt vmcnt(0)) at every slice
+        if (p.linear_a) {                                    // 1x1 stride-1: output pixel m reads input pixel m
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int r = (wave + NW * i) * RPI + lrow;
-            const int m = m0 + r;
-            const unsigned chunk_b = (unsigned)swz<BK>(lslot, r) * 16u;     // LDS slot lslot of row r must hold this chunk
-            const bool ok = m < p.M && r < BM;
-            if (p.linear_a) {                                // 1x1 stride-1: output pixel m reads input pixel m
-                a_voff[i] = ok ? (unsigned)m * (unsigned)(p.in_pix_stride * 2) + chunk_b : kOob;
-                a_iy0[i] = a_ix0[i] = 0;
-            } else if (ok) {
-                const int n = m / hw;
+            for (int i = 0; i < A_IT; ++i) {
+                const int r = (wave + NW * i) * RPI + lrow;
+                const int m = m0 + r;
+                const unsigned chunk_b = (unsigned)swz<BK>(lslot, r) * 16u; // LDS slot lslot of row r must hold this chunk
+                a_voff[i] = (m < p.M && r < BM) ? (unsigned)m * (unsigned)(p.in_pix_stride * 2) + chunk_b : kOob;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int r = (wave + NW * i) * RPI + lrow;
+                const int m = m0 + r;
+                const unsigned chunk_b = (unsigned)swz<BK>(lslot, r) * 16u;
+                const int n = m / hw;                        // rows beyond M compute harmless garbage, masked below
                 const int rem = m - n * hw;
                 const int oy = rem / p.Wo;
                 const int ox = rem - oy * p.Wo;
                 a_iy0[i] = oy * p.stride - p.pad_h;
                 a_ix0[i] = ox * p.stride - p.pad_w;
-                a_voff[i] = (unsigned)(((n * p.Hi + oy * p.stride) * p.Wi + ox * p.stride) * p.in_pix_stride * 2) + chunk_b;
-            } else {
-                a_voff[i] = kOob;
-                a_iy0[i] = a_ix0[i] = 0;
+                const unsigned vo = (unsigned)(((n * p.Hi + oy * p.stride) * p.Wi + ox * p.stride) * p.in_pix_stride * 2) + chunk_b;
+                a_voff[i] = (m < p.M && r < BM) ? vo : kOob;
+            }
+            if (p.tap_mask) {                                // per-tap validity as one bit each: 3 VALU per DMA piece and slice
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) a_mask[i] = 0u;
+                int t = 0;
+                for (int kh = 0; kh * p.KW < p.taps; ++kh)
+                    for (int kw = 0; kw < p.KW; ++kw, ++t) {
+#pragma unroll
+                        for (int i = 0; i < A_IT; ++i)       // innermost and fully unrolled: the arrays stay in registers
+                            a_mask[i] |= ((unsigned)(a_iy0[i] + kh) < (unsigned)p.Hi && (unsigned)(a_ix0[i] + kw) < (unsigned)p.Wi) ? (1u << t) : 0u;
+                    }
             }
         }
 #pragma unroll
@@ -248,15 +271,19 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     auto issue_slice = [&](const int slot) {     // DMA one K-slice of the loader's item into ring slot
-        unsigned char* sa = ring + slot * STAGE_BYTES;
-        unsigned char* sb = sa + A_BYTES;
+        unsigned char* sa = ring + slot * A_BYTES;
+        unsigned char* sb = ring + S * A_BYTES + slot * B_BYTES;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             if (wave + NW * i < A_INSTR) {       // wave-uniform
                 unsigned vo = a_voff[i];
                 if (!p.linear_a) {
-                    const int iy = a_iy0[i] + ld_kh, ix = a_ix0[i] + ld_kw;
-                    vo = ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) ? vo : kOob;
+                    if (p.tap_mask) {
+                        vo = ((a_mask[i] >> ld_tap) & 1u) ? vo : kOob;
+                    } else {
+                        const int iy = a_iy0[i] + ld_kh, ix = a_ix0[i] + ld_kw;
+                        vo = ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) ? vo : kOob;
+                    }
                 }
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(sa + (wave + NW * i) * 1024), 16, vo, ld_soff_a, 0, 0);
             }
@@ -272,6 +299,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
         ld_c0 += BK;
         if (ld_c0 == p.Cin) {                    // next filter tap
             ld_c0 = 0;
+            ++ld_tap;
             if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
             ld_soff_a = (unsigned)((ld_kh * p.in_row_stride32 + ld_kw * p.in_pix_stride) * 2);
         }
@@ -320,6 +348,33 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
             }
     };
 
+    // fragment read offsets inside a tile, per 32-wide K step: the swizzle term only depends on the lane (every
+    // fragment starts on a multiple of 16 rows), so slot / fragment-row offsets are immediates of the ds_read
+    constexpr int KK = BK / 32;
+    unsigned a_foff[KK], b_foff[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        a_foff[kk] = (unsigned)((wm * WTM + frow) * (BK * 2) + swz<BK>(kk * 4 + fchunk, frow) * 16);
+        b_foff[kk] = (unsigned)((wn * WTN + frow) * (BK * 2) + swz<BK>(kk * 4 + fchunk, frow) * 16);
+    }
+    auto mfma_slice = [&](const int slot) {      // acc += A(slot) * B(slot)^T for this wave's WTM x WTN sub-tile
+        const unsigned char* cA = ring + slot * A_BYTES;
+        const unsigned char* cB = ring + S * A_BYTES + slot * B_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(cA + i * 16 * (BK * 2) + a_foff[kk]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(cB + j * 16 * (BK * 2) + b_foff[kk]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
     int issued = 0, consumed = 0, ld_slot = 0, cp_slot = 0;
     int ep_sum = 0, ep_hist[3] = {0, 0, 0};      // epilogue vector-memory ops of this wave in the last 3 iterations
     // prologue: fill S-1 ring slots
@@ -340,6 +395,7 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
             const int kb = cp_ks * p.k_tiles_per_split;
             cp_left = min(p.k_tiles, kb + p.k_tiles_per_split) - kb;
             cp_items.advance(p.tiles_n, p.split);
+            ++cp_seq;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -349,14 +405,46 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
                 stats_n0 = cp_n0;
             }
         }
+#define FRCNN_WAIT_IMM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+        // ---- steady state of a long-K item: the loader is still inside the consumer's item with >= S slices to go, the
+        // ring is full and no epilogue store is in flight.  S slices per trip with compile-time ring slots: per slice one
+        // counted wait, one barrier, the DMA of slice +S-1 and the MFMA block -- no item / epilogue bookkeeping.
+        if (UNIFORM_L && cp_slot == 0 && ep_sum == 0 && ld_seq == cp_seq && ld_left >= S && issued - consumed == S - 1) {
+            int trips = ld_left / S;
+            issued += trips * S;
+            consumed += trips * S;
+            cp_left -= trips * S;
+            do {
+#pragma unroll
+                for (int c = 0; c < S; ++c) {
+                    FRCNN_WAIT_IMM((S - 2) * LC);
+                    __builtin_amdgcn_s_barrier();
+                    issue_slice((c + S - 1) % S);
+                    mfma_slice(c);
+                }
+            } while (--trips != 0);
+            continue;                            // cp_left >= S - 1 slices of this item remain for the general path
+        }
         // slice `consumed` must have landed.  Ops this wave issued AFTER that slice's DMA: the DMA of the younger
         // slices and the epilogue stores of the last S-1 iterations (ep_sum; under-estimates are safe).
         const int younger = issued - consumed - 1;
-        if (UNIFORM_L && younger == S - 2 && ep_sum == 0) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LC) : "memory");       // steady state: one immediate, no dispatch
+        // the immediate must be a compile-time constant: a short chain over the values that occur in steady state
+        // (ring full, 0..S-1 epilogues in the window); everything else (pipeline drain) rounds down, i.e. waits longer
+        if (UNIFORM_L) {
+            if (younger == S - 2) {
+                if (ep_sum == 0) FRCNN_WAIT_IMM((S - 2) * LC);
+                else if (ep_sum == ST_IT) FRCNN_WAIT_IMM((S - 2) * LC + ST_IT);
+                else if (ep_sum == 2 * ST_IT) FRCNN_WAIT_IMM((S - 2) * LC + 2 * ST_IT);
+                else FRCNN_WAIT_IMM((S - 2) * LC + (S > 3 ? 3 : 2) * ST_IT);
+            } else if (S > 3 && younger == S - 3) {
+                FRCNN_WAIT_IMM((S > 3 ? S - 3 : 0) * LC);
+            } else {
+                FRCNN_WAIT_IMM(0);
+            }
         } else {
-            wait_vmcnt_at_most(younger * Lw + ep_sum);
+            wait_vmcnt_at_most(younger * Lw);    // few values (Lw <= 2 on the non-uniform tiles)
         }
+#undef FRCNN_WAIT_IMM
         __builtin_amdgcn_s_barrier();            // everyone's DMA of this slice landed; everyone finished reading the previous slot
         // age the epilogue history: the slice consumed next was issued one iteration later than this one
         if (ep_sum != 0) {
@@ -371,28 +459,8 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
             ld_slot = ld_slot + 1 == S ? 0 : ld_slot + 1;
             ++issued;
         }
-        const unsigned char* cA = ring + cp_slot * STAGE_BYTES;
-        const unsigned char* cB = cA + A_BYTES;
+        mfma_slice(cp_slot);
         cp_slot = cp_slot + 1 == S ? 0 : cp_slot + 1;
-#pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8 af[MI], bfr[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int r = wm * WTM + i * 16 + frow;
-                af[i] = *reinterpret_cast<const bf16x8*>(cA + r * (BK * 2) + swz<BK>(kk * 4 + fchunk, r) * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int r = wn * WTN + j * 16 + frow;
-                bfr[j] = *reinterpret_cast<const bf16x8*>(cB + r * (BK * 2) + swz<BK>(kk * 4 + fchunk, r) * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
         ++consumed;
         if (--cp_left != 0) continue;
 
@@ -426,68 +494,109 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
             continue;
         }
 
+        // Specialised on (STATS, M-tail tile) through wave-uniform branches taken once per tile: the per-element work is
+        // bias add, clamp, one packed bf16 convert per pair and three flops of statistics -- no LDS round trips, no branches.
+        const bool tail = m0 + BM > p.M;
+        float bv[NI][4];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int r = wm * WTM + i * 16 + frow;
-            const bool row_ok = m0 + r < p.M;
+        for (int j = 0; j < NI; ++j) {
+            f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (flags & FRCNN_CONV_BIAS) b = *reinterpret_cast<const f32x4*>(bias_s + n0 + wn * WTN + j * 16 + fchunk * 4);   // zero padded to the tile grid
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int cl = wn * WTN + j * 16 + fchunk * 4;
-                unsigned short hb[4];
+            for (int e = 0; e < 4; ++e) bv[j][e] = b[e];
+        }
+        const float lo = (flags & FRCNN_CONV_RELU) ? 0.f : -__builtin_inff();
+        auto convert_tile = [&](auto stats_c, auto tail_c) {
+            constexpr bool ST = decltype(stats_c)::value, TL = decltype(tail_c)::value;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[i][j][e];
-                    if (flags & FRCNN_CONV_BIAS) v += (n0 + cl + e < p.Cout) ? bias_s[n0 + cl + e] : 0.f;
-                    if (flags & FRCNN_CONV_RELU) v = fmaxf(v, 0.f);
-                    hb[e] = f32_to_bf16_bits(v);
-                    if (flags & FRCNN_CONV_STATS) {
-                        const float q = row_ok ? bf16_bits_to_f32(hb[e]) : 0.f;
-                        ssum[j][e] += q;
-                        ssq[j][e] += q * q;
+            for (int i = 0; i < MI; ++i) {
+                const int r = wm * WTM + i * 16 + frow;
+                const bool row_ok = !TL || m0 + r < p.M;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int cl = wn * WTN + j * 16 + fchunk * 4;
+                    u32x2 pk;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x2 v;
+                        v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] + bv[j][2 * h], lo, __builtin_inff());
+                        v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
+                        const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
+                        pk[h] = bits;
+                        if (ST) {
+                            float q0 = __uint_as_float(bits << 16), q1 = __uint_as_float(bits & 0xFFFF0000u);
+                            if (TL) { q0 = row_ok ? q0 : 0.f; q1 = row_ok ? q1 : 0.f; }
+                            ssum[j][2 * h] += q0;
+                            ssq[j][2 * h] += q0 * q0;
+                            ssum[j][2 * h + 1] += q1;
+                            ssq[j][2 * h + 1] += q1 * q1;
+                        }
                     }
+                    lds_write_b64(stage_a + r * ROWB + cl * 2, pk);
                 }
-                u32x2 pk;
-                pk[0] = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
-                pk[1] = (unsigned)hb[2] | ((unsigned)hb[3] << 16);
-                lds_write_b64(stage_a + r * ROWB + cl * 2, pk);
             }
+        };
+        if (flags & FRCNN_CONV_STATS) {
+            if (tail) convert_tile(std::true_type{}, std::true_type{});
+            else convert_tile(std::true_type{}, std::false_type{});
+        } else {
+            convert_tile(std::false_type{}, std::false_type{});
         }
         // staging tile complete: LDS writes are tracked by lgkmcnt; a raw barrier does NOT drain the DMA ring
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
-        bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
-        constexpr int C8 = BN / 8;
-        constexpr int ST_IT = (BM * C8 + T - 1) / T;
-        if (!(flags & FRCNN_CONV_ADD_RES)) {
-            // store instructions this wave certainly issues below (iterations in which all its 64 lanes are in range)
-            const int rows_valid = min(BM, p.M - m0);
-            const bool cols_full = n0 + BN <= p.Cout;
-            int full = 0;
+        if (p.direct_out) {
+            // output row == GEMM row: buffer stores with a per-lane offset that is fixed for the whole kernel (row-in-pass,
+            // 16-byte column chunk) and a scalar offset per pass; lanes outside the tensor carry an out-of-range offset
+            const int lrow_o = tid / C8, lc8 = tid - lrow_o * C8;
+            const bool col_ok = n0 + lc8 * 8 < p.Cout;
+            const unsigned vo_lane = (unsigned)(lrow_o * p.Cout * 2 + lc8 * 16);
+            unsigned soff = (unsigned)((m0 * p.Cout + n0) * 2);
+            const unsigned pass_pitch = (unsigned)((T / C8) * p.Cout * 2);
+            ep_hist[0] = ST_IT;
+            ep_sum = ep_hist[0] + ep_hist[1] + ep_hist[2];
 #pragma unroll
             for (int it = 0; it < ST_IT; ++it) {
-                const int r_last = (it * T + wave * 64 + 63) / C8;
-                full += (cols_full && r_last < rows_valid) ? 1 : 0;
-            }
-            ep_hist[0] = full;
-            ep_sum = ep_hist[0] + ep_hist[1] + ep_hist[2];
-        }
-        for (int idx = tid; idx < BM * C8; idx += T) {
-            const int r = idx / C8, c8 = idx - r * C8;
-            const int m = m0 + r, c = n0 + c8 * 8;
-            if (m >= p.M || c >= p.Cout) continue;
-            u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + c8 * 16);
-            const long long off = out_row_of(p, m) * p.Cout + c;
-            if (flags & FRCNN_CONV_ADD_RES) {
-                const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
-                float a[8], b[8];
-                unpack8(v, a);
-                unpack8(rv, b);
+                const int r = lrow_o + it * (T / C8);
+                // the pass offset travels in the VGPR offset, not in soffset: with an SGPR soffset hipcc omits the wait state
+                // between a 16-byte buffer store and a VALU overwrite of its data registers, and gfx950 does need it
+                const unsigned vo = (col_ok && (!tail || m0 + r < p.M)) ? vo_lane + soff : kOob;
+                u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + lc8 * 16);
+                if (flags & FRCNN_CONV_ADD_RES) {
+                    const u32x4 rv = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, vo, 0, 0);
+                    float a[8], b[8];
+                    unpack8(v, a);
+                    unpack8(rv, b);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] += b[e];
-                v = pack8(a);
+                    for (int e = 0; e < 8; ++e) a[e] += b[e];
+                    v = pack8(a);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo, 0, 0);
+                soff += pass_pitch;
             }
-            *reinterpret_cast<u32x4*>(y + off) = v;
+        } else {
+            // strided scatter (data gradient of a stride-2 1x1 convolution): per-row address computation
+            bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+            ep_hist[0] = 0;                      // not counted: the next waits only become more conservative
+            ep_sum = ep_hist[1] + ep_hist[2];
+            for (int idx = tid; idx < BM * C8; idx += T) {
+                const int r = idx / C8, c8 = idx - r * C8;
+                const int m = m0 + r, c = n0 + c8 * 8;
+                if (m >= p.M || c >= p.Cout) continue;
+                u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + c8 * 16);
+                const long long off = out_row_of(p, m) * p.Cout + c;
+                if (flags & FRCNN_CONV_ADD_RES) {
+                    const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
+                    float a[8], b[8];
+                    unpack8(v, a);
+                    unpack8(rv, b);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] += b[e];
+                    v = pack8(a);
+                }
+                *reinterpret_cast<u32x4*>(y + off) = v;
+            }
         }
         // the next item's epilogue writes `stage` again only after >= 1 slice barrier of the main loop
     }
@@ -529,6 +638,10 @@ TileCfg pick_tile(const frcnn_conv_desc* d) {
     // ring depth: as deep as 160 KiB allows next to the epilogue staging tile
     t.stages = (t.bm == 128 && t.bn == 128 && t.bk == 64) ? 3 : 4;
     t.waves = 8;
+    if (const char* e = getenv("FRCNN_IGEMM_TILE")) {          // kernel development aid: "bm,bn,stages"
+        int bm = 0, bn = 0, st = 0, bk = t.bk, nw = t.waves;
+        if (sscanf(e, "%d,%d,%d,%d,%d", &bm, &bn, &st, &bk, &nw) >= 3) { t.bm = bm; t.bn = bn; t.stages = st; t.bk = bk; t.waves = nw; }
+    }
     return t;
 }
 
@@ -538,7 +651,7 @@ int launch(const ConvParams& p, hipStream_t s) {
     static_assert(base <= 163840 - 3 * 1024 * 4, "LDS budget (ring + staging + bias/stat arrays of <= 1024 channels)");
     int smem = base;
     if (!(p.flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC))) {
-        if (p.flags & FRCNN_CONV_BIAS) smem += p.Cout * 4;
+        if (p.flags & FRCNN_CONV_BIAS) smem += p.tiles_n * BN * 4;
         if (p.flags & FRCNN_CONV_STATS) smem += 2 * p.Cout * 4;
     }
     if (smem > 163840) {
@@ -616,6 +729,7 @@ extern "C" int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x,
     FRCNN_CHECK_ARG(items < (1ll << 30), "conv2d_fprop: too many tiles");
     p.items = (int)items;
     p.taps = d->kh * d->kw;
+    p.tap_mask = p.taps <= 32 ? 1 : 0;
     p.linear_a = (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->ho == d->hi && d->wo == d->wi) ? 1 : 0;
     p.in_row_stride = (long long)d->wi * d->in_pix_stride;
     p.in_img_stride = (long long)d->hi * p.in_row_stride;
@@ -628,20 +742,35 @@ extern "C" int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x,
         p.x_bytes = (unsigned)xb;
         p.w_bytes = (unsigned)wb;
         p.in_row_stride32 = (int)p.in_row_stride;
+        const long long yb = M * d->cout * 2;
+        p.direct_out = (d->out_scatter == 1 && d->out_h == d->ho && d->out_w == d->wo && yb < 0xFFFF0000ll) ? 1 : 0;
+        p.y_bytes = p.direct_out ? (unsigned)yb : 0u;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
-#define FRCNN_DISPATCH(BM_, BN_, BK_, S_) \
-    if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && t.stages == S_) return launch<BM_, BN_, BK_, S_, 8>(p, s);
+#define FRCNN_DISPATCH(BM_, BN_, BK_, S_) FRCNN_DISPATCH_W(BM_, BN_, BK_, S_, 8)
+#define FRCNN_DISPATCH_W(BM_, BN_, BK_, S_, W_) \
+    if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && t.stages == S_ && t.waves == W_) return launch<BM_, BN_, BK_, S_, W_>(p, s);
     FRCNN_DISPATCH(128, 128, 64, 3)
     FRCNN_DISPATCH(128, 64, 64, 4)
     FRCNN_DISPATCH(64, 128, 64, 4)
     FRCNN_DISPATCH(64, 64, 64, 4)
+    FRCNN_DISPATCH(64, 64, 64, 3)
+    FRCNN_DISPATCH(64, 64, 64, 2)
+    FRCNN_DISPATCH(128, 64, 64, 3)
+    FRCNN_DISPATCH(128, 64, 64, 2)
+    FRCNN_DISPATCH_W(128, 128, 64, 3, 4)
+    FRCNN_DISPATCH_W(128, 64, 128, 2, 4)
+    FRCNN_DISPATCH_W(128, 64, 128, 2, 8)
+    FRCNN_DISPATCH_W(64, 128, 128, 2, 4)
+    FRCNN_DISPATCH_W(128, 64, 64, 4, 4)
+    FRCNN_DISPATCH_W(64, 64, 128, 3, 4)
     FRCNN_DISPATCH(128, 128, 32, 4)
     FRCNN_DISPATCH(128, 64, 32, 4)
     FRCNN_DISPATCH(64, 128, 32, 4)
     FRCNN_DISPATCH(64, 64, 32, 4)
 #undef FRCNN_DISPATCH
+#undef FRCNN_DISPATCH_W
     frcnn_set_error("conv2d_fprop: no tile configuration for bm=%d bn=%d bk=%d", t.bm, t.bn, t.bk);
     return FRCNN_EINVAL;
 }
