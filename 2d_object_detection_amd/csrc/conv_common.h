@@ -1,0 +1,72 @@
+// Shared by the implicit-GEMM convolution kernels (conv_igemm.hip: persistent split-K / fp32-output kernel,
+// conv_tile.hip: one-tile-per-workgroup bf16 kernel): launch parameters, LDS swizzle, LDS helpers.
+#pragma once
+#include "common.h"
+
+#define FRCNN_ENOTSUP (-100)      /* internal: no instantiation of the one-tile kernel fits, use the general one */
+
+namespace {
+
+struct ConvParams {
+    const bf16_t* x;
+    const bf16_t* w;
+    const float* bias;
+    const bf16_t* res;
+    void* y;
+    float* stats;
+    int Hi, Wi, in_pix_stride, Cin, KW, stride, pad_h, pad_w;
+    int Ho, Wo, Cout, out_h, out_w, out_scatter, flags;
+    int M, Ktot, k_tiles, k_tiles_per_split, split, taps, linear_a;
+    int in_row_stride32;                    // in_row_stride (elements); the whole tensor stays below 2 GiB
+    unsigned x_bytes, w_bytes, y_bytes;     // buffer descriptor sizes (x incl. the leading halo shift)
+    int tap_mask;                           // taps <= 32: per-row tap validity bit masks
+    int direct_out;                         // bf16 output row == GEMM row and the tensor stays below 4 GiB: buffer-store epilogue
+    int tiles_m, tiles_n, items;            // items = tiles_m * tiles_n * split
+    long long in_row_stride, in_img_stride;
+};
+
+template <int BK>
+__device__ __forceinline__ int swz(int chunk, int row) {
+    if (BK == 128) return chunk ^ (row & 15);
+    if (BK == 64) return chunk ^ (row & 7);
+    return chunk ^ ((4 - ((row >> 2) & 3)) & 3);
+}
+
+__device__ __forceinline__ long long out_row_of(const ConvParams& p, int m) {
+    if (p.out_scatter == 1 && p.out_h == p.Ho && p.out_w == p.Wo) return m;
+    const int hw = p.Ho * p.Wo;
+    const int n = m / hw;
+    const int rem = m - n * hw;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    return ((long long)n * p.out_h + (long long)oy * p.out_scatter) * p.out_w + (long long)ox * p.out_scatter;
+}
+
+// Epilogue LDS writes go through inline asm: hipcc orders every DS *write/atomic* it emits behind ALL pending
+// LDS-DMA (s_waitcnt vmcnt(0)), although staging tile / statistics array and DMA ring never overlap; that would
+// drain the prefetch ring once per tile.  The asm forms are invisible to that pass; their completion is awaited
+// explicitly (s_waitcnt lgkmcnt(0)) before the barrier that publishes them.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void lds_write_b64(unsigned addr, u32x2 v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_add_f32(unsigned addr, float v) {
+    asm volatile("ds_add_f32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+constexpr unsigned kOob = 0xFFFFFFF0u;       // voffset beyond every buffer: the hardware range check returns zeros
+
+inline int num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+}  // namespace

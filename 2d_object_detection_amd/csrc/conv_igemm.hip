@@ -22,45 +22,10 @@
 // reduces the BatchNorm statistics (sum, sum of squares of the ROUNDED outputs) in registers with
 // 16-lane butterflies, stages the tile in a dedicated LDS region and writes 16-byte/lane coalesced
 // rows, optionally adding a residual and scattering with stride 2 (data gradient of strided 1x1).
-#include "common.h"
+#include "conv_common.h"
 #include <stdlib.h>
 
 namespace {
-
-struct ConvParams {
-    const bf16_t* x;
-    const bf16_t* w;
-    const float* bias;
-    const bf16_t* res;
-    void* y;
-    float* stats;
-    int Hi, Wi, in_pix_stride, Cin, KW, stride, pad_h, pad_w;
-    int Ho, Wo, Cout, out_h, out_w, out_scatter, flags;
-    int M, Ktot, k_tiles, k_tiles_per_split, split, taps, linear_a;
-    int in_row_stride32;                    // in_row_stride (elements); the whole tensor stays below 2 GiB
-    unsigned x_bytes, w_bytes, y_bytes;     // buffer descriptor sizes (x incl. the leading halo shift)
-    int tap_mask;                           // taps <= 32: per-row tap validity bit masks
-    int direct_out;                         // bf16 output row == GEMM row and the tensor stays below 4 GiB: buffer-store epilogue
-    int tiles_m, tiles_n, items;            // items = tiles_m * tiles_n * split
-    long long in_row_stride, in_img_stride;
-};
-
-template <int BK>
-__device__ __forceinline__ int swz(int chunk, int row) {
-    if (BK == 128) return chunk ^ (row & 15);
-    if (BK == 64) return chunk ^ (row & 7);
-    return chunk ^ ((4 - ((row >> 2) & 3)) & 3);
-}
-
-__device__ __forceinline__ long long out_row_of(const ConvParams& p, int m) {
-    if (p.out_scatter == 1 && p.out_h == p.Ho && p.out_w == p.Wo) return m;
-    const int hw = p.Ho * p.Wo;
-    const int n = m / hw;
-    const int rem = m - n * hw;
-    const int oy = rem / p.Wo;
-    const int ox = rem - oy * p.Wo;
-    return ((long long)n * p.out_h + (long long)oy * p.out_scatter) * p.out_w + (long long)ox * p.out_scatter;
-}
 
 // gfx950 retires loads, LDS-DMA, stores and atomics through ONE in-order vmcnt: "slice q landed" is
 // "at most n younger vector-memory ops are still outstanding", where n must count the DMA of the
@@ -76,20 +41,6 @@ __device__ __forceinline__ void wait_vmcnt_at_most(int n) {
     }
 }
 #undef FRCNN_VMCNT_CASE
-
-// Epilogue LDS writes go through inline asm: hipcc orders every DS *write/atomic* it emits behind ALL pending
-// LDS-DMA (s_waitcnt vmcnt(0)), although staging tile / statistics array and DMA ring never overlap; that would
-// drain the prefetch ring once per tile.  The asm forms are invisible to that pass; their completion is awaited
-// explicitly (s_waitcnt lgkmcnt(0)) before the barrier that publishes them.
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
-}
-__device__ __forceinline__ void lds_write_b64(unsigned addr, u32x2 v) {
-    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ void lds_add_f32(unsigned addr, float v) {
-    asm volatile("ds_add_f32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
 
 // Block -> work-item schedule.  Blocks b, b+8, ... share an XCD (its L2): every XCD owns a contiguous chunk
 // of the item list (item = tile * split + k-split, tile = tile_m * tiles_n + tile_n) and its blocks interleave
@@ -130,7 +81,6 @@ struct ItemWalk {
     }
 };
 
-constexpr unsigned kOob = 0xFFFFFFF0u;       // voffset beyond every buffer: the hardware range check returns zeros
 
 template <int BM, int BN, int BK, int S, int NW>
 __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
@@ -616,17 +566,6 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
 
 struct TileCfg { int bm, bn, bk, stages, waves; };
 
-int num_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
 TileCfg pick_tile(const frcnn_conv_desc* d) {
     TileCfg t;
     t.bk = (d->cin % 64 == 0) ? 64 : 32;
@@ -671,6 +610,8 @@ int launch(const ConvParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipStream_t s);     // conv_tile.hip
 
 extern "C" int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d) {
     if (!d) return FRCNN_EINVAL;
@@ -747,6 +688,14 @@ extern "C" int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x,
         p.y_bytes = p.direct_out ? (unsigned)yb : 0u;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!(flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC))) {
+        // bf16 output: one tile per workgroup (conv_tile.hip) unless no instantiation fits
+        static const bool use_tile = !(getenv("FRCNN_TILE_KERNEL") && getenv("FRCNN_TILE_KERNEL")[0] == '0');
+        if (use_tile) {
+            const int rc = frcnn_conv_tile_dispatch(&p, d, s);
+            if (rc != FRCNN_ENOTSUP) return rc;
+        }
+    }
 
 #define FRCNN_DISPATCH(BM_, BN_, BK_, S_) FRCNN_DISPATCH_W(BM_, BN_, BK_, S_, 8)
 #define FRCNN_DISPATCH_W(BM_, BN_, BK_, S_, W_) \

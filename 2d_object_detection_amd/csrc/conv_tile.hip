@@ -1,0 +1,423 @@
+// Implicit-GEMM convolution, bf16 output: ONE output tile per workgroup, several workgroups per CU.
+//
+// Same GEMM view, LDS image and MFMA operand order as conv_igemm.hip (C[M pixels][Cout] = A[M][K] * W[Cout][K]^T,
+// K walked in BK-wide slices that never straddle a filter tap, operands DMA'd global -> LDS with the XOR swizzle
+// applied on the source side).  What differs is the schedule: a workgroup owns one BM x BN tile, streams its K slices
+// through a short ring (S = 2 or 3 slots), runs the epilogue and exits.  Latency is hidden by OCCUPANCY instead of
+// cross-tile prefetch: the epilogue staging tile aliases the ring (no DMA is in flight any more), so the LDS footprint
+// is max(ring, staging) and two or three workgroups share a CU -- one tile's prologue / epilogue overlaps its
+// neighbours' MFMA loops.  Everything the inner loop could branch on is a template parameter (LIN: 1x1 stride-1
+// addressing, STATS: BatchNorm partial sums) or folded into per-lane registers computed once (tap validity bit masks,
+// fragment read offsets), which keeps the per-slice instruction stream short: the loop is issue-bound long before it is
+// MFMA- or LDS-bound (measured: 83 SALU + 60 VALU per slice and wave in the general persistent kernel).
+#include "conv_common.h"
+#include <stdlib.h>
+
+namespace {
+
+template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC>
+__global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = 8, T = 512, WM = 2, WN = 4;
+    constexpr int CPR = BK / 8;                  // 16-byte chunks per tile row
+    constexpr int RPI = 64 / CPR;                // rows written by one DMA wave instruction (1 KiB)
+    constexpr int A_INSTR = BM / RPI, B_INSTR = BN / RPI;
+    constexpr int A_IT = (A_INSTR + NW - 1) / NW, B_IT = (B_INSTR + NW - 1) / NW;
+    constexpr bool A_UNI = A_INSTR % NW == 0, B_UNI = B_INSTR % NW == 0;
+    constexpr int LC = A_INSTR / NW + B_INSTR / NW;
+    static_assert(S == 2 || (S == 3 && A_UNI && B_UNI), "counted waits need a uniform DMA split");
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, KK = BK / 32;
+    static_assert(MI >= 1 && NI >= 1, "tile too small for 8 waves");
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int ROWB = BN * 2 + 16;            // staging row pitch (bytes)
+    constexpr int C8 = BN / 8, ST_IT = (BM * C8) / T;
+    static_assert((BM * C8) % T == 0, "store loop covers the tile in whole passes");
+    constexpr int RING = S * (A_BYTES + B_BYTES), STG = BM * ROWB;
+    constexpr int BIG = RING > STG ? RING : STG;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;                  // [S A tiles][S B tiles]
+    unsigned char* stage = smem;                 // [BM][ROWB], aliases the ring once the K loop has drained
+    float* stat_t = reinterpret_cast<float*>(smem + BIG);   // [2][BN] partial sums of this tile (STATS)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int flags = p.flags;
+
+    // workgroup -> tile.  Workgroups b, b+8, ... run on one XCD: each XCD takes a contiguous chunk of the tile list
+    // (n fastest), so the workgroups that share an L2 read neighbouring pixel rows and the same weight panels.
+    int tm, tn;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, local = bid >> 3;
+        const int q = nb >> 3, r = nb & 7;
+        const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        tm = tile / p.tiles_n;
+        tn = tile - tm * p.tiles_n;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    if (STATS) {
+        if (tid < 2 * BN) stat_t[tid] = 0.f;     // published by the K loop's barriers
+    }
+    // bias of this tile's channels (lane: 4 consecutive channels per 16-wide fragment column), issued before the K loop
+    float bv[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int c = n0 + wn * WTN + j * 16 + fchunk * 4;
+        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+        if ((flags & FRCNN_CONV_BIAS) && c < p.Cout) b = *reinterpret_cast<const f32x4*>(p.bias + c);   // Cout % 8 == 0
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[j][e] = b[e];
+    }
+
+    // ------------------------------------------------------------------ loader (LDS-DMA) state
+    const long long halo = (long long)p.pad_h * p.in_row_stride + (long long)p.pad_w * p.in_pix_stride;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - halo), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    unsigned a_voff[A_IT], a_mask[A_IT], b_voff[B_IT];
+    const int lrow = lane / CPR, lslot = lane % CPR;
+    if (LIN) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int r = (wave + NW * i) * RPI + lrow;
+            const int m = m0 + r;
+            a_voff[i] = (m < p.M && r < BM) ? (unsigned)m * (unsigned)(p.in_pix_stride * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
+            a_mask[i] = 1u;
+        }
+    } else {
+        const int hw = p.Ho * p.Wo;
+        int iy0[A_IT], ix0[A_IT];
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int r = (wave + NW * i) * RPI + lrow;
+            const int m = m0 + r;
+            const int n = m / hw;                // rows beyond M compute harmless garbage, masked below
+            const int rem = m - n * hw;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            iy0[i] = oy * p.stride - p.pad_h;
+            ix0[i] = ox * p.stride - p.pad_w;
+            const unsigned vo = (unsigned)(((n * p.Hi + oy * p.stride) * p.Wi + ox * p.stride) * p.in_pix_stride * 2) + (unsigned)swz<BK>(lslot, r) * 16u;
+            a_voff[i] = (m < p.M && r < BM) ? vo : kOob;
+            a_mask[i] = 0u;
+        }
+        int t = 0;                               // bit t of a_mask: filter tap t of this row lies inside the image
+        for (int kh = 0; kh * p.KW < p.taps; ++kh)
+            for (int kw = 0; kw < p.KW; ++kw, ++t) {
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i)
+                    a_mask[i] |= ((unsigned)(iy0[i] + kh) < (unsigned)p.Hi && (unsigned)(ix0[i] + kw) < (unsigned)p.Wi) ? (1u << t) : 0u;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int r = (wave + NW * i) * RPI + lrow;
+        const int n = n0 + r;
+        b_voff[i] = (n < p.Cout && r < BN) ? (unsigned)n * (unsigned)(p.Ktot * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
+    }
+    int ld_c0 = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0;
+    unsigned ld_soff_a = 0, ld_soff_b = 0;
+
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto issue_slice = [&](const int slot) {     // DMA the next K slice into ring slot
+        unsigned char* sa = ring + slot * A_BYTES;
+        unsigned char* sb = ring + S * A_BYTES + slot * B_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            if (A_UNI || wave + NW * i < A_INSTR) {
+                const unsigned vo = LIN ? a_voff[i] : (((a_mask[i] >> ld_tap) & 1u) ? a_voff[i] : kOob);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(sa + (wave + NW * i) * 1024), 16, vo, ld_soff_a, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            if (B_UNI || wave + NW * i < B_INSTR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (wave + NW * i) * 1024), 16, b_voff[i], ld_soff_b, 0, 0);
+        }
+        ld_soff_b += BK * 2;
+        ld_soff_a += BK * 2;
+        if (!LIN) {
+            ld_c0 += BK;
+            if (ld_c0 == p.Cin) {                // next filter tap
+                ld_c0 = 0;
+                ++ld_tap;
+                if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
+                ld_soff_a = (unsigned)((ld_kh * p.in_row_stride32 + ld_kw * p.in_pix_stride) * 2);
+            }
+        }
+    };
+
+    // ------------------------------------------------------------------ consumer (MFMA) state
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment read offsets per 32-wide K step: the swizzle term only depends on the lane (fragments start on multiples
+    // of 16 rows), so slot and fragment-row offsets are immediates of the ds_read
+    unsigned a_foff[KK], b_foff[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        a_foff[kk] = (unsigned)((wm * WTM + frow) * (BK * 2) + swz<BK>(kk * 4 + fchunk, frow) * 16);
+        b_foff[kk] = (unsigned)((wn * WTN + frow) * (BK * 2) + swz<BK>(kk * 4 + fchunk, frow) * 16);
+    }
+    auto mfma_slice = [&](const int slot) {      // acc += A(slot) * B(slot)^T, fragments of step kk+1 fetched under the MFMAs of kk
+        const unsigned char* cA = ring + slot * A_BYTES;
+        const unsigned char* cB = ring + S * A_BYTES + slot * B_BYTES;
+        bf16x8 af[2][MI], bfr[2][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(cA + i * 16 * (BK * 2) + a_foff[0]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(cB + j * 16 * (BK * 2) + b_foff[0]);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < KK) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[nxt][i] = *reinterpret_cast<const bf16x8*>(cA + i * 16 * (BK * 2) + a_foff[kk + 1]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bfr[nxt][j] = *reinterpret_cast<const bf16x8*>(cB + j * 16 * (BK * 2) + b_foff[kk + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ------------------------------------------------------------------ K loop
+#define FRCNN_WAIT_IMM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    const int nk = p.k_tiles;
+    {
+        const int pre = nk < S - 1 ? nk : S - 1;
+        for (int s = 0; s < pre; ++s) issue_slice(s);
+    }
+    int left = nk;                               // slices to consume
+    int to_issue = nk - (nk < S - 1 ? nk : S - 1);
+    while (to_issue >= S) {                      // whole trips around the ring: compile-time slots, ring stays full
+#pragma unroll
+        for (int c = 0; c < S; ++c) {
+            FRCNN_WAIT_IMM((S - 2) * LC);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's fragment reads of the slot refilled next have completed
+            __builtin_amdgcn_s_barrier();        // slice landed for everyone; everyone finished reading the slot refilled next
+            issue_slice((c + S - 1) % S);
+            mfma_slice(c);
+        }
+        to_issue -= S;
+        left -= S;
+    }
+    int slot = 0;                                // the consumer is back at slot 0 after whole trips
+    while (left > 0) {                           // < S slices left to issue, then the drain
+        if (to_issue > 0) FRCNN_WAIT_IMM((S - 2) * LC);
+        else FRCNN_WAIT_IMM(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (to_issue > 0) {
+            issue_slice(slot == 0 ? S - 1 : slot - 1);
+            --to_issue;
+        }
+        mfma_slice(slot);
+        slot = slot + 1 == S ? 0 : slot + 1;
+        --left;
+    }
+#undef FRCNN_WAIT_IMM
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // every wave is done with the ring: the staging tile may overwrite it
+
+    // ------------------------------------------------------------------ epilogue
+    // lane holds, for fragment (i,j): pixel = wm*WTM + i*16 + (lane&15); couts = wn*WTN + j*16 + (lane>>4)*4 + 0..3
+    const bool tail = m0 + BM > p.M;
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.y_bytes, 0x00020000);
+    const int lrow_o = tid / C8, lc8 = tid - lrow_o * C8;
+    const bool col_ok = n0 + lc8 * 8 < p.Cout;
+    const unsigned vo_lane = (unsigned)(lrow_o * p.Cout * 2 + lc8 * 16);
+    const unsigned pass_pitch = (unsigned)((T / C8) * p.Cout * 2);
+    const unsigned tile_off = (unsigned)((m0 * p.Cout + n0) * 2);
+    u32x4 resv[ST_IT];
+    if (p.direct_out && (flags & FRCNN_CONV_ADD_RES)) {      // residual rows of this tile: in flight under the convert phase
+#pragma unroll
+        for (int it = 0; it < ST_IT; ++it) {
+            const int r = lrow_o + it * (T / C8);
+            const unsigned vo = (col_ok && (!tail || m0 + r < p.M)) ? vo_lane + tile_off + it * pass_pitch : kOob;
+            resv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, vo, 0, 0);
+        }
+    }
+
+    float ssum[NI][4], ssq[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssum[j][e] = ssq[j][e] = 0.f;
+    const float lo = (flags & FRCNN_CONV_RELU) ? 0.f : -__builtin_inff();
+    auto convert_tile = [&](auto tail_c) {
+        constexpr bool TL = decltype(tail_c)::value;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = wm * WTM + i * 16 + frow;
+            const bool row_ok = !TL || m0 + r < p.M;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int cl = wn * WTN + j * 16 + fchunk * 4;
+                u32x2 pk;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x2 v;
+                    v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] + bv[j][2 * h], lo, __builtin_inff());
+                    v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
+                    const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
+                    pk[h] = bits;
+                    if (STATS) {                 // sums of the ROUNDED outputs (what the next layer reads)
+                        float q0 = __uint_as_float(bits << 16), q1 = __uint_as_float(bits & 0xFFFF0000u);
+                        if (TL) { q0 = row_ok ? q0 : 0.f; q1 = row_ok ? q1 : 0.f; }
+                        ssum[j][2 * h] += q0;
+                        ssq[j][2 * h] += q0 * q0;
+                        ssum[j][2 * h + 1] += q1;
+                        ssq[j][2 * h + 1] += q1 * q1;
+                    }
+                }
+                *reinterpret_cast<u32x2*>(stage + r * ROWB + cl * 2) = pk;
+            }
+        }
+    };
+    if (STATS && tail) convert_tile(std::true_type{});
+    else convert_tile(std::false_type{});
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = ssum[j][e], b = ssq[j][e];
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) {
+                    a += __shfl_xor(a, sh);
+                    b += __shfl_xor(b, sh);
+                }
+                if (frow == 0) {
+                    const int cl = wn * WTN + j * 16 + fchunk * 4 + e;
+                    atomicAdd(stat_t + cl, a);           // LDS atomics: the two row halves (wm) of the tile meet here
+                    atomicAdd(stat_t + BN + cl, b);
+                }
+            }
+    }
+    __syncthreads();
+
+    if (STATS && tid < 2 * BN) {
+        // one float atomic per channel and statistic, spread over FRCNN_STAT_SLOTS pre-zeroed slots; consecutive lanes
+        // add consecutive channels
+        const int st = tid / BN, cl = tid - st * BN;
+        if (n0 + cl < p.Cout)
+            atomicAdd(p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + n0 + cl, stat_t[tid]);
+    }
+    if (p.direct_out) {
+#pragma unroll
+        for (int it = 0; it < ST_IT; ++it) {
+            const int r = lrow_o + it * (T / C8);
+            // the offset travels in the VGPR, not in soffset: with an SGPR soffset hipcc omits the wait state between a
+            // 16-byte buffer store and a VALU overwrite of its data registers, and gfx950 does need it
+            const unsigned vo = (col_ok && (!tail || m0 + r < p.M)) ? vo_lane + tile_off + it * pass_pitch : kOob;
+            u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + lc8 * 16);
+            if (flags & FRCNN_CONV_ADD_RES) {
+                float a[8], b[8];
+                unpack8(v, a);
+                unpack8(resv[it], b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += b[e];
+                v = pack8(a);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo, 0, 0);
+        }
+    } else {
+        // strided scatter (data gradient of a stride-2 1x1 convolution): per-row address computation
+        bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+        for (int idx = tid; idx < BM * C8; idx += T) {
+            const int r = idx / C8, c8 = idx - r * C8;
+            const int m = m0 + r, c = n0 + c8 * 8;
+            if (m >= p.M || c >= p.Cout) continue;
+            u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + c8 * 16);
+            const long long off = out_row_of(p, m) * p.Cout + c;
+            if (flags & FRCNN_CONV_ADD_RES) {
+                const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
+                float a[8], b[8];
+                unpack8(v, a);
+                unpack8(rv, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += b[e];
+                v = pack8(a);
+            }
+            *reinterpret_cast<u32x4*>(y + off) = v;
+        }
+    }
+#endif
+}
+
+template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC>
+int launch_tile(const ConvParams& p, hipStream_t s) {
+    constexpr int ring = S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16);
+    constexpr int smem = (ring > stg ? ring : stg) + 2 * BN * 4;
+    static_assert(smem <= 163840, "LDS budget");
+    static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
+    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC>), smem) != 0) {
+        frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
+        return FRCNN_EINVAL;
+    }
+    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p);
+    FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
+    return FRCNN_OK;
+}
+
+template <int BM, int BN, int BK, int S, int OCC>
+int launch_tile_flags(const ConvParams& p, hipStream_t s) {
+    const bool stats = (p.flags & FRCNN_CONV_STATS) != 0;
+    if (p.linear_a) return stats ? launch_tile<BM, BN, BK, S, true, true, OCC>(p, s) : launch_tile<BM, BN, BK, S, true, false, OCC>(p, s);
+    return stats ? launch_tile<BM, BN, BK, S, false, true, OCC>(p, s) : launch_tile<BM, BN, BK, S, false, false, OCC>(p, s);
+}
+
+}  // namespace
+
+// Tile choice + launch for the bf16-output path (called by frcnn_conv2d_fprop in conv_igemm.hip).  p arrives with the
+// geometry fields filled in; tiles_m / tiles_n / k_tiles are set here.  Returns FRCNN_ENOTSUP when no instantiation fits
+// (the caller then uses the general persistent kernel).
+int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipStream_t s) {
+    ConvParams p = *reinterpret_cast<const ConvParams*>(params);      // private copy: the caller falls back on ENOTSUP
+    if (p.taps > 32 || d->split_k > 1) return FRCNN_ENOTSUP;
+    int bk = (d->cin % 128 == 0 && p.Ktot >= 512) ? 128 : (d->cin % 64 == 0 ? 64 : 32);
+    int bn = d->cout >= 128 ? 128 : 64;
+    const long long M = p.M;
+    const long long tiles128 = ((M + 127) / 128) * ((d->cout + bn - 1) / bn);
+    int bm = tiles128 >= 2 * num_cus() ? 128 : 64;
+    int stages = 2;
+    if (const char* e = getenv("FRCNN_TILE")) {                 // kernel development aid: "bm,bn,bk,stages"
+        int a = 0, b = 0, c = 0, st = 0;
+        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &st) == 4) { bm = a; bn = b; bk = c; stages = st; }
+    }
+    if (d->cin % bk != 0) return FRCNN_ENOTSUP;
+    p.k_tiles = p.Ktot / bk;
+    p.k_tiles_per_split = p.k_tiles;
+    p.split = 1;
+    p.tiles_m = (int)((M + bm - 1) / bm);
+    p.tiles_n = (d->cout + bn - 1) / bn;
+    p.items = p.tiles_m * p.tiles_n;
+#define FRCNN_TILE(BM_, BN_, BK_, S_, OCC_) \
+    if (bm == BM_ && bn == BN_ && bk == BK_ && stages == S_) return launch_tile_flags<BM_, BN_, BK_, S_, OCC_>(p, s);
+    FRCNN_TILE(128, 128, 64, 2, 2)
+    FRCNN_TILE(128, 64, 64, 2, 2)
+    FRCNN_TILE(64, 128, 64, 2, 2)
+    FRCNN_TILE(64, 64, 64, 2, 3)
+    FRCNN_TILE(128, 128, 128, 2, 1)
+    FRCNN_TILE(128, 64, 128, 2, 1)
+    FRCNN_TILE(64, 128, 128, 2, 1)
+    FRCNN_TILE(64, 64, 128, 2, 2)
+    FRCNN_TILE(128, 64, 32, 2, 2)
+    FRCNN_TILE(128, 128, 64, 3, 1)
+    FRCNN_TILE(128, 64, 64, 3, 2)
+    FRCNN_TILE(64, 128, 64, 3, 2)
+    FRCNN_TILE(64, 64, 64, 3, 2)
+#undef FRCNN_TILE
+    return FRCNN_ENOTSUP;
+}
