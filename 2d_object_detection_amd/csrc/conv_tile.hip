@@ -386,12 +386,15 @@ int launch_tile_flags(const ConvParams& p, hipStream_t s) {
 int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipStream_t s) {
     ConvParams p = *reinterpret_cast<const ConvParams*>(params);      // private copy: the caller falls back on ENOTSUP
     if (p.taps > 32 || d->split_k > 1) return FRCNN_ENOTSUP;
-    int bk = (d->cin % 128 == 0 && p.Ktot >= 512) ? 128 : (d->cin % 64 == 0 ? 64 : 32);
-    int bn = d->cout >= 128 ? 128 : 64;
+    // measured on the R50-C4 layer shapes (tools/tile_sweep.py): 128-row tiles and BK = 64 win almost everywhere (two
+    // workgroups per CU); 128 output channels per tile once that still leaves >= ~200 tiles, else 64; a third ring slot
+    // only pays on very long K with the narrow tile
+    int bk = d->cin % 64 == 0 ? 64 : 32;
     const long long M = p.M;
-    const long long tiles128 = ((M + 127) / 128) * ((d->cout + bn - 1) / bn);
-    int bm = tiles128 >= 2 * num_cus() ? 128 : 64;
-    int stages = 2;
+    int bm = 128;
+    const long long tiles_m128 = (M + 127) / 128;
+    int bn = (d->cout >= 128 && tiles_m128 * ((d->cout + 127) / 128) >= 200) ? 128 : 64;
+    int stages = (bn == 64 && bk == 64 && p.Ktot / bk >= 64) ? 3 : 2;
     if (const char* e = getenv("FRCNN_TILE")) {                 // kernel development aid: "bm,bn,bk,stages"
         int a = 0, b = 0, c = 0, st = 0;
         if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &st) == 4) { bm = a; bn = b; bk = c; stages = st; }

@@ -1,0 +1,63 @@
+"""Sweep the tile configurations of the one-tile conv kernel over the layer shapes of the R50-C4 step
+(kernel development aid).  usage: python tools/tile_sweep.py [iters]"""
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ops = importlib.import_module("2d_object_detection_amd.ops")
+BF = torch.bfloat16
+
+SHAPES = [  # n, h, w, cin, cout, k, stride, pad
+    (4, 188, 621, 32, 64, 0, 0, 0),       # placeholder for the stem (skipped: packed row-gather geometry)
+    (4, 94, 311, 64, 256, 1, 1, 0), (4, 94, 311, 64, 64, 1, 1, 0), (4, 94, 311, 64, 64, 3, 1, 1), (4, 94, 311, 256, 64, 1, 1, 0),
+    (4, 94, 311, 256, 512, 1, 2, 0), (4, 94, 311, 256, 128, 1, 2, 0),
+    (4, 47, 156, 128, 128, 3, 1, 1), (4, 47, 156, 128, 512, 1, 1, 0), (4, 47, 156, 512, 128, 1, 1, 0), (4, 47, 156, 128, 256, 1, 1, 0),
+    (4, 47, 156, 512, 256, 1, 1, 0), (4, 47, 156, 512, 1024, 1, 2, 0), (4, 47, 156, 512, 256, 1, 2, 0),
+    (4, 24, 78, 256, 256, 3, 1, 1), (4, 24, 78, 256, 1024, 1, 1, 0), (4, 24, 78, 1024, 256, 1, 1, 0), (4, 24, 78, 1024, 256, 3, 1, 1),
+    (4, 24, 78, 256, 1024, 3, 1, 1), (4, 24, 78, 256, 512, 1, 1, 0), (4, 24, 78, 1024, 512, 1, 1, 0), (4, 24, 78, 256, 128, 1, 1, 0),
+    (4, 24, 78, 128, 256, 1, 1, 0), (1, 16, 16, 64, 50176, 1, 1, 0),
+]
+CONFIGS = [(bm, bn, bk, s) for bk in (64, 128) for bm in (128, 64) for bn in (128, 64) for s in (2, 3) if not (bk == 128 and s == 3)]
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for (n, h, w, cin, cout, k, s, p) in SHAPES[1:]:
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        m = n * ho * wo
+        x = torch.randn(n, h, w, cin, device="cuda", generator=g).to(BF)
+        wt = (torch.randn(cout, k, k, cin, device="cuda", generator=g) / (cin * k * k) ** 0.5).to(BF)
+        bias = torch.zeros(cout, device="cuda")
+        y = torch.empty(m, cout, dtype=BF, device="cuda")
+        stats = torch.zeros(64, 2, cout, device="cuda")
+        d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout, flags=ops.CONV_BIAS | ops.CONV_STATS)
+        res = []
+        for cfg in CONFIGS:
+            if cin % cfg[2] != 0 or (cfg[1] == 128 and cout < 128):
+                continue
+            os.environ["FRCNN_TILE"] = "%d,%d,%d,%d" % cfg
+            try:
+                for _ in range(2):
+                    ops.conv2d_fprop(d, x, wt, y, bias=bias, stats=stats)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    ops.conv2d_fprop(d, x, wt, y, bias=bias, stats=stats)
+                e1.record()
+                torch.cuda.synchronize()
+                res.append((e0.elapsed_time(e1) * 1e3 / iters, cfg))
+            except Exception as ex:  # noqa: BLE001
+                res.append((1e9, cfg))
+        res.sort()
+        fl = 2.0 * m * cout * k * k * cin
+        print("M=%6d cin=%5d cout=%5d k=%d s=%d : " % (m, cin, cout, k, s) + "  ".join("%s %.1fus(%.0fTF)" % (",".join(map(str, c)), t, fl / t / 1e6) for t, c in res[:5]), flush=True)
+    os.environ.pop("FRCNN_TILE", None)
+
+
+if __name__ == "__main__":
+    main()
