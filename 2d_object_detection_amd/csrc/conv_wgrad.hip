@@ -12,7 +12,8 @@
 // One workgroup owns one (co tile, tap, ci tile) output tile for a contiguous pixel range (gridDim.z
 // ranges); the partial tile is staged through LDS and added to the fp32 gradient with whole-row
 // (256-byte contiguous) float atomics.
-#include "common.h"
+#include "conv_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,8 +29,6 @@ struct WgradParams {
     int in_row_stride32;
     unsigned x_bytes, dz_bytes;
 };
-
-constexpr unsigned kOob = 0xFFFFFFF0u;
 
 // 32-byte-chunk XOR swizzle of a pixel-major tile of W channels: the 4x16 blocks fetched by one
 // ds_read_b64_tr_b16 half-wave (pixel rows {0-3, 8-11} or {4-7, 12-15}) land on distinct banks.
@@ -57,28 +56,31 @@ __device__ __forceinline__ bf16x8 load_frag_tr(const unsigned char* tile, int kp
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_imm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+enum { X_LINEAR = 0, X_ROWIDX = 1, X_GENERAL = 2 };   // how the x operand's pixel rows are addressed
 
-template <int BM /*co*/, int BN /*ci*/, int S>
-__global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
+// Lanes whose channel chunk lies outside the tensor start here: the per-slice pixel advance keeps them inside
+// [2 GiB, 4 GiB), beyond every descriptor (operands are checked to stay below 2 GiB), so the range check zero-fills.
+constexpr unsigned kColOob = 0x80000000u;
+
+template <int BM /*co*/, int BN /*ci*/, int S, int MODE, int OCC>
+__global__ __launch_bounds__(512, 2 * OCC) void wgrad_kernel(const WgradParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NW = 8, T = 512, BKP = 64;
+    constexpr int NW = 8, T = 512, BKP = 64, KK = BKP / 32;
     constexpr int WM = 2, WN = 4;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = (WTM + 15) / 16, NI = (WTN + 15) / 16;
     constexpr bool N_SPLIT = WTN >= 16;                       // BN = 32: only waves with wn < 2 own columns
-    constexpr int Z_BYTES = BKP * BM * 2, X_BYTES = BKP * BN * 2, STAGE_BYTES = Z_BYTES + X_BYTES;
+    constexpr int Z_BYTES = BKP * BM * 2, X_BYTES = BKP * BN * 2;
     constexpr int Z_RPI = 1024 / (BM * 2), X_RPI = 1024 / (BN * 2);          // pixel rows per 1-KiB DMA instruction
     constexpr int Z_INSTR = BKP / Z_RPI, X_INSTR = BKP / X_RPI;
     constexpr int Z_IT = (Z_INSTR + NW - 1) / NW, X_IT = (X_INSTR + NW - 1) / NW;
-    static_assert(Z_INSTR % NW == 0 || Z_INSTR < NW, "tile");
+    constexpr bool Z_UNI = Z_INSTR % NW == 0, X_UNI = X_INSTR % NW == 0;
+    constexpr int LC = Z_INSTR / NW + X_INSTR / NW;
+    static_assert(S == 2 || (S == 3 && Z_UNI && X_UNI), "counted waits need a uniform DMA split");
     constexpr int SROW = BN * 4 + 16;                        // staging pitch (bytes)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* ring = smem;                // [S][Z tile | X tile]; the epilogue staging re-uses it after the loop
+    unsigned char* ring = smem;                // [S Z tiles][S X tiles]; the epilogue staging re-uses it after the loop
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
     const int pt_begin = blockIdx.z * p.p_tiles_per_split;
     const int pt_end = min(p.p_tiles, pt_begin + p.p_tiles_per_split);
     const int n_slices = pt_end - pt_begin;
+    const int pix0 = pt_begin * BKP;
 
     // descriptors: x shifted back by the halo so that the per-lane pixel offset and the scalar tap offset are >= 0
     const long long halo = (long long)p.pad_h * p.in_row_stride32 + (long long)p.pad_w * p.in_pix_stride;
@@ -103,18 +106,18 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
     const unsigned soff_x = (unsigned)((kh * p.in_row_stride32 + kw * p.in_pix_stride + ci0) * 2);
     const unsigned soff_z = (unsigned)(co0 * 2);
 
-    // per-lane DMA state: this lane's pixel row inside a slice and its swizzled source column
-    int z_row[Z_IT], x_row[X_IT];
-    unsigned z_col[Z_IT], x_col[X_IT];        // byte offset of the 16-byte source chunk inside the channel row, or kOob
-    int x_n[X_IT], x_oy[X_IT], x_ox[X_IT];    // im2col walk of the lane's pixel (advanced by BKP per slice)
+    // per-lane DMA state.  dz (and x when its rows are linear in the pixel index): a byte offset that advances by a
+    // constant per slice; pixel rows beyond M fall outside the descriptor and read zeros.
+    unsigned z_vo[Z_IT], x_vo[X_IT], x_col[X_IT];
+    int x_row[X_IT], x_n[X_IT], x_oy[X_IT], x_ox[X_IT];    // im2col walk of the lane's pixel (X_GENERAL)
+    const unsigned z_step = (unsigned)(BKP * p.dz_stride * 2), x_step = (unsigned)(BKP * p.in_pix_stride * 2);
 #pragma unroll
     for (int i = 0; i < Z_IT; ++i) {
         const int ins = wave + NW * i;
         const int lanes_per_row = (BM * 2) / 16;
         const int r = ins * Z_RPI + lane / lanes_per_row, s16 = lane % lanes_per_row;
         const int col = (((s16 >> 1) ^ fsw<BM>(r)) << 4) + (s16 & 1) * 8;          // element column that LDS slot s16 of row r must hold
-        z_row[i] = r;
-        z_col[i] = (ins < Z_INSTR && co0 + col < p.Cout) ? (unsigned)(col * 2) : kOob;
+        z_vo[i] = (ins < Z_INSTR && co0 + col < p.Cout) ? (unsigned)(pix0 + r) * (unsigned)(p.dz_stride * 2) + (unsigned)(col * 2) : kColOob;
     }
     const int hw = p.Ho * p.Wo;
 #pragma unroll
@@ -123,56 +126,50 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
         const int lanes_per_row = (BN * 2) / 16;
         const int r = ins * X_RPI + lane / lanes_per_row, s16 = lane % lanes_per_row;
         const int col = (((s16 >> 1) ^ fsw<BN>(r)) << 4) + (s16 & 1) * 8;
+        const bool col_ok = ins < X_INSTR && ci0 + col < p.Cin;
         x_row[i] = r;
-        x_col[i] = (ins < X_INSTR && ci0 + col < p.Cin) ? (unsigned)(col * 2) : kOob;
-        const int m = pt_begin * BKP + r;
-        x_n[i] = m / hw;
-        const int rem = m - x_n[i] * hw;
-        x_oy[i] = rem / p.Wo;
-        x_ox[i] = rem - x_oy[i] * p.Wo;
+        x_col[i] = col_ok ? (unsigned)(col * 2) : kColOob;
+        x_vo[i] = col_ok ? (unsigned)(pix0 + r) * (unsigned)(p.in_pix_stride * 2) + (unsigned)(col * 2) : kColOob;
+        if (MODE == X_GENERAL) {
+            const int m = pix0 + r;
+            x_n[i] = m / hw;
+            const int rem = m - x_n[i] * hw;
+            x_oy[i] = rem / p.Wo;
+            x_ox[i] = rem - x_oy[i] * p.Wo;
+        }
     }
-    const int Lw = [&]() {
-        int l = 0;
-        for (int i = 0; i < Z_IT; ++i) l += (wave + NW * i < Z_INSTR) ? 1 : 0;
-        for (int i = 0; i < X_IT; ++i) l += (wave + NW * i < X_INSTR) ? 1 : 0;
-        return l;
-    }();
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    int ld_pix0 = pt_begin * BKP;
+    int ld_pix0 = pix0;
     auto issue_slice = [&](const int slot) {
-        unsigned char* sz = ring + slot * STAGE_BYTES;
-        unsigned char* sx = sz + Z_BYTES;
+        unsigned char* sz = ring + slot * Z_BYTES;
+        unsigned char* sx = ring + S * Z_BYTES + slot * X_BYTES;
 #pragma unroll
         for (int i = 0; i < Z_IT; ++i) {
-            if (wave + NW * i < Z_INSTR) {
-                const int m = ld_pix0 + z_row[i];
-                const unsigned vo = (m < p.M && z_col[i] != kOob) ? (unsigned)m * (unsigned)(p.dz_stride * 2) + z_col[i] : kOob;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (lds_ptr_t)(sz + (wave + NW * i) * 1024), 16, vo, soff_z, 0, 0);
+            if (Z_UNI || wave + NW * i < Z_INSTR) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (lds_ptr_t)(sz + (wave + NW * i) * 1024), 16, z_vo[i], soff_z, 0, 0);
+                z_vo[i] += z_step;
             }
         }
 #pragma unroll
         for (int i = 0; i < X_IT; ++i) {
-            if (wave + NW * i < X_INSTR) {
-                const int m = ld_pix0 + x_row[i];
-                unsigned vo = kOob;
-                if (m < p.M && x_col[i] != kOob) {
-                    if (p.row_index) {
-                        vo = (unsigned)p.row_index[m] * (unsigned)(p.in_pix_stride * 2) + x_col[i];
-                    } else if (p.linear_x) {
-                        vo = (unsigned)m * (unsigned)(p.in_pix_stride * 2) + x_col[i];
-                    } else {
-                        const int iy = x_oy[i] * p.stride - p.pad_h + kh, ix = x_ox[i] * p.stride - p.pad_w + kw;
-                        if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-                            vo = (unsigned)(((x_n[i] * p.Hi + x_oy[i] * p.stride) * p.Wi + x_ox[i] * p.stride) * p.in_pix_stride * 2) + x_col[i];
-                    }
-                }
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(sx + (wave + NW * i) * 1024), 16, vo, soff_x, 0, 0);
-                if (!p.linear_x && !p.row_index) {           // advance this lane's pixel by BKP (division-free)
-                    x_ox[i] += BKP;
+            if (X_UNI || wave + NW * i < X_INSTR) {
+                unsigned vo;
+                if (MODE == X_LINEAR) {
+                    vo = x_vo[i];
+                    x_vo[i] += x_step;
+                } else if (MODE == X_ROWIDX) {
+                    const int m = ld_pix0 + x_row[i];
+                    vo = (m < p.M && x_col[i] != kColOob) ? (unsigned)p.row_index[m] * (unsigned)(p.in_pix_stride * 2) + x_col[i] : kOob;
+                } else {
+                    const int iy = x_oy[i] * p.stride - p.pad_h + kh, ix = x_ox[i] * p.stride - p.pad_w + kw;
+                    const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && x_n[i] * hw < p.M && x_col[i] != kColOob;
+                    vo = ok ? (unsigned)(((x_n[i] * p.Hi + x_oy[i] * p.stride) * p.Wi + x_ox[i] * p.stride) * p.in_pix_stride * 2) + x_col[i] : kOob;
+                    x_ox[i] += BKP;                          // advance this lane's pixel by BKP (division-free)
                     while (x_ox[i] >= p.Wo) { x_ox[i] -= p.Wo; ++x_oy[i]; }
                     while (x_oy[i] >= p.Ho) { x_oy[i] -= p.Ho; ++x_n[i]; }
                 }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(sx + (wave + NW * i) * 1024), 16, vo, soff_x, 0, 0);
             }
         }
         ld_pix0 += BKP;
@@ -184,45 +181,117 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int issued = 0, ld_slot = 0, cp_slot = 0;
-    for (int s = 0; s < S - 1; ++s) {
-        if (issued < n_slices) {
-            issue_slice(ld_slot);
-            ld_slot = ld_slot + 1 == S ? 0 : ld_slot + 1;
-            ++issued;
-        }
-    }
+    // transposing fragment reads: the swizzle term of a lane is the same for every 32-pixel step and for both 4-row
+    // halves, so one byte offset per channel fragment is computed once; slot / step / half are ds_read immediates
     const bool owns_cols = N_SPLIT || wn * 16 < BN;
-    for (int q = 0; q < n_slices; ++q) {
-        const int younger = issued - q - 1;
-        if (younger >= 2) { if (Lw == 4) wait_vmcnt_imm<8>(); else if (Lw == 3) wait_vmcnt_imm<6>(); else if (Lw == 2) wait_vmcnt_imm<4>(); else wait_vmcnt_imm<2>(); }
-        else if (younger == 1) { if (Lw == 4) wait_vmcnt_imm<4>(); else if (Lw == 3) wait_vmcnt_imm<3>(); else if (Lw == 2) wait_vmcnt_imm<2>(); else wait_vmcnt_imm<1>(); }
-        else wait_vmcnt_imm<0>();
-        __builtin_amdgcn_s_barrier();
-        if (issued < n_slices) {
-            issue_slice(ld_slot);
-            ld_slot = ld_slot + 1 == S ? 0 : ld_slot + 1;
-            ++issued;
-        }
-        const unsigned char* cZ = ring + cp_slot * STAGE_BYTES;
-        const unsigned char* cX = cZ + Z_BYTES;
-        cp_slot = cp_slot + 1 == S ? 0 : cp_slot + 1;
-        if (owns_cols) {
+    unsigned z_foff[MI], x_foff[NI];
+    {
+        const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+        const int r1 = 8 * g + q;
 #pragma unroll
-            for (int kk = 0; kk < BKP / 32; ++kk) {
-                bf16x8 zf[MI], xf[NI];
+        for (int i = 0; i < MI; ++i) z_foff[i] = (unsigned)tile_off<BM>(r1, wm * WTM + i * 16 + 4 * pp);
 #pragma unroll
-                for (int i = 0; i < MI; ++i) zf[i] = load_frag_tr<BM>(cZ, kk * 32, wm * WTM + i * 16, lane);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) xf[j] = load_frag_tr<BN>(cX, kk * 32, (N_SPLIT ? wn * WTN : wn * 16) + j * 16, lane);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], zf[i], acc[i][j], 0, 0, 0);
-            }
-        }
+        for (int j = 0; j < NI; ++j) x_foff[j] = (unsigned)tile_off<BN>(r1, (N_SPLIT ? wn * WTN : wn * 16) + j * 16 + 4 * pp);
     }
+    // The transposing reads go through inline asm: hipcc orders every ds_read_b64_tr_b16 it emits itself behind ALL pending
+    // LDS-DMA (s_waitcnt vmcnt(0) right after the DMA issue -- no prefetch left).  The asm forms are invisible to that pass;
+    // their completion is awaited by a counted s_waitcnt lgkmcnt followed by empty asm statements that take the destination
+    // registers as in/out operands, so no consumer (not even a register copy) can be scheduled before the data has landed.
+    const unsigned lds_base = lds_addr(ring);
+    unsigned z_addr[MI], x_addr[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) z_addr[i] = lds_base + z_foff[i];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) x_addr[j] = lds_base + S * Z_BYTES + x_foff[j];
+    constexpr int NR = 2 * (MI + NI);            // reads per 32-pixel step
+    static_assert(NR <= 15, "lgkmcnt is a 4-bit counter");
+    auto read_step = [&](auto slot_c, auto kk_c, u32x2 (&zl)[MI], u32x2 (&zh)[MI], u32x2 (&xl)[NI], u32x2 (&xh)[NI]) {
+        constexpr int slot = decltype(slot_c)::value, kk = decltype(kk_c)::value;
+        constexpr int zo = slot * Z_BYTES + kk * 32 * (BM * 2), xo = slot * X_BYTES + kk * 32 * (BN * 2);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const unsigned za = z_addr[i];       // (asm operands cannot name a captured variable of a generic lambda directly)
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(zl[i]) : "v"(za), "n"(zo) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(zh[i]) : "v"(za), "n"(zo + 4 * (BM * 2)) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const unsigned xa = x_addr[j];
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xl[j]) : "v"(xa), "n"(xo) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xh[j]) : "v"(xa), "n"(xo + 4 * (BN * 2)) : "memory");
+        }
+    };
+    auto frag = [](const u32x2 lo, const u32x2 hi) -> bf16x8 {
+        const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    // wait until at most `pending` younger LDS reads are outstanding (LDS returns in order) and pin the step's registers
+    auto wait_step = [&](auto pending_c, u32x2 (&zl)[MI], u32x2 (&zh)[MI], u32x2 (&xl)[NI], u32x2 (&xh)[NI]) {
+        constexpr int pending = decltype(pending_c)::value;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(pending) : "memory");
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(zl[i]), "+v"(zh[i]));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(xl[j]), "+v"(xh[j]));
+    };
+    auto mfma_slice = [&](auto slot_c) {
+        if (!owns_cols) return;
+        u32x2 zl[2][MI], zh[2][MI], xl[2][NI], xh[2][NI];
+        read_step(slot_c, std::integral_constant<int, 0>{}, zl[0], zh[0], xl[0], xh[0]);
+        static_assert(KK == 2, "two 32-pixel steps per 64-pixel slice");
+        read_step(slot_c, std::integral_constant<int, 1>{}, zl[1], zh[1], xl[1], xh[1]);
+        wait_step(std::integral_constant<int, NR>{}, zl[0], zh[0], xl[0], xh[0]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(xl[0][j], xh[0][j]), frag(zl[0][i], zh[0][i]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);       // keep the first step's MFMAs ahead of the wait for the second step's reads
+        wait_step(std::integral_constant<int, 0>{}, zl[1], zh[1], xl[1], xh[1]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(xl[1][j], xh[1][j]), frag(zl[1][i], zh[1][i]), acc[i][j], 0, 0, 0);
+    };
+
+#define FRCNN_WAIT_IMM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    {
+        const int pre = n_slices < S - 1 ? n_slices : S - 1;
+        for (int s = 0; s < pre; ++s) issue_slice(s);
+    }
+    int left = n_slices;
+    int to_issue = n_slices - (n_slices < S - 1 ? n_slices : S - 1);
+    auto step = [&](auto c_c) {                  // one slice with compile-time ring slots
+        constexpr int c = decltype(c_c)::value;
+        FRCNN_WAIT_IMM((S - 2) * LC);
+        __builtin_amdgcn_s_barrier();            // slice landed for everyone; everyone's reads of the slot refilled next are done (lgkmcnt(0) in mfma_slice)
+        issue_slice((c + S - 1) % S);
+        mfma_slice(c_c);
+    };
+    while (to_issue >= S) {                      // whole trips around the ring: the ring stays full
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        if (S == 3) step(std::integral_constant<int, S - 1>{});
+        to_issue -= S;
+        left -= S;
+    }
+    int slot = 0;
+    while (left > 0) {
+        if (to_issue > 0) FRCNN_WAIT_IMM((S - 2) * LC);
+        else FRCNN_WAIT_IMM(0);
+        __builtin_amdgcn_s_barrier();
+        if (to_issue > 0) {
+            issue_slice(slot == 0 ? S - 1 : slot - 1);
+            --to_issue;
+        }
+        if (slot == 0) mfma_slice(std::integral_constant<int, 0>{});
+        else if (slot == 1) mfma_slice(std::integral_constant<int, 1>{});
+        else mfma_slice(std::integral_constant<int, S - 1>{});
+        slot = slot + 1 == S ? 0 : slot + 1;
+        --left;
+    }
+#undef FRCNN_WAIT_IMM
 
     // D rows = ci (4 consecutive per lane), cols = co (lane & 15): stage [co][ci] fp32 in the (now idle) ring, then
     // whole-row float atomics (64 lanes x 4 B = 256 contiguous bytes per wave instruction)
@@ -251,31 +320,27 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradParams p) {
 #endif
 }
 
-int num_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
-template <int BM, int BN, int S>
-int launch(const WgradParams& p, int split, hipStream_t s) {
+template <int BM, int BN, int S, int MODE, int OCC>
+int launch_mode(const WgradParams& p, int split, hipStream_t s) {
     constexpr int ring_bytes = S * 64 * (BM + BN) * 2;
     constexpr int stage_bytes = BM * (BN * 4 + 16);
     constexpr int smem = ring_bytes > stage_bytes ? ring_bytes : stage_bytes;
-    static_assert(smem <= 163840, "LDS budget");
-    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_kernel<BM, BN, S>), smem) != 0) {
+    static_assert(smem * OCC <= 163840, "LDS budget");
+    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_kernel<BM, BN, S, MODE, OCC>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_wgrad: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
     dim3 grid(p.tiles_co * p.taps * p.tiles_ci, 1, split);
-    hipLaunchKernelGGL((wgrad_kernel<BM, BN, S>), grid, dim3(512), smem, s, p);
+    hipLaunchKernelGGL((wgrad_kernel<BM, BN, S, MODE, OCC>), grid, dim3(512), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad");
     return FRCNN_OK;
+}
+
+template <int BM, int BN, int S, int OCC>
+int launch(const WgradParams& p, int split, hipStream_t s) {
+    if (p.row_index) return launch_mode<BM, BN, S, X_ROWIDX, OCC>(p, split, s);
+    if (p.linear_x) return launch_mode<BM, BN, S, X_LINEAR, OCC>(p, split, s);
+    return launch_mode<BM, BN, S, X_GENERAL, OCC>(p, split, s);
 }
 
 }  // namespace
@@ -309,34 +374,48 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
         const long long halo = (long long)d->pad_h * in_row_stride + (long long)d->pad_w * d->in_pix_stride;
         // with row_index the x extent is unknown here: the caller's rows are trusted (checked upstream), use the 4 GiB cap
         const long long x_elems = row_index ? 0x7FFF0000ll : (long long)d->n * d->hi * in_row_stride + (long long)d->kw * d->in_pix_stride + 64;
-        const long long xb = (x_elems + halo) * 2, zb = M * dz_stride * 2;
-        FRCNN_CHECK_ARG(xb < 0xFFFF0000ll && zb < 0xFFFF0000ll, "conv2d_wgrad: operand larger than 4 GiB (32-bit buffer offsets)");
+        // linear rows: the descriptor ends exactly at pixel M, so the pixel tail of the last slice reads zeros
+        const long long xb = p.linear_x ? M * d->in_pix_stride * 2 : (x_elems + halo) * 2, zb = M * dz_stride * 2;
+        FRCNN_CHECK_ARG(xb < 0xFFFF0000ll && zb < 0x7FFF0000ll && (!p.linear_x || xb < 0x7FFF0000ll),
+                        "conv2d_wgrad: operand too large for 32-bit buffer offsets");
         p.x_bytes = (unsigned)xb;
         p.dz_bytes = (unsigned)zb;
     }
 
-    const int bm = d->cout >= 128 ? 128 : 64;
-    const int bn = d->cin >= 128 ? 128 : (d->cin >= 64 ? 64 : 32);
+    // measured on the R50-C4 layer shapes (tools/wgrad_sweep.py): 64 x 64 tiles with a 3-slot ring (three workgroups per
+    // CU) win nearly everywhere -- small tiles need few pixel splits to fill the chip, and every split costs one fp32 tile
+    // of float atomics
+    int bm = 64;
+    int bn = d->cin >= 64 ? 64 : 32;
+    int stages = bn == 32 ? 2 : 3, want_split = 0;
+    if (const char* e = getenv("FRCNN_WGRAD")) {                // kernel development aid: "bm,bn,stages,split"
+        int a = 0, b = 0, c = 0, sp = 0;
+        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &sp) == 4) { bm = a; bn = b; stages = c; want_split = sp; }
+    }
     constexpr int BKP = 64;
     p.tiles_co = (d->cout + bm - 1) / bm;
     p.tiles_ci = (d->cin + bn - 1) / bn;
     p.p_tiles = (int)((M + BKP - 1) / BKP);
     const int blocks_mn = p.tiles_co * p.taps * p.tiles_ci;
-    // every split adds one fp32 tile of float atomics (chip-wide ~1.3 TB/s): aim for ~1.5 workgroups per CU, no more
-    int split = (num_cus() * 3 / 2 + blocks_mn - 1) / blocks_mn;
+    // ~one workgroup per CU for 1x1 filters, two for multi-tap filters (their tile count is already large)
+    int split = want_split > 0 ? want_split : (num_cus() * (p.taps > 1 ? 2 : 1) + blocks_mn - 1) / blocks_mn;
     if (split > p.p_tiles) split = p.p_tiles;
     if (split < 1) split = 1;
     p.p_tiles_per_split = (p.p_tiles + split - 1) / split;
     split = (p.p_tiles + p.p_tiles_per_split - 1) / p.p_tiles_per_split;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define FRCNN_DISPATCH(BM_, BN_, S_) \
-    if (bm == BM_ && bn == BN_) return launch<BM_, BN_, S_>(p, split, s);
-    FRCNN_DISPATCH(128, 128, 3)
-    FRCNN_DISPATCH(128, 64, 4)
-    FRCNN_DISPATCH(128, 32, 4)
-    FRCNN_DISPATCH(64, 128, 4)
-    FRCNN_DISPATCH(64, 64, 4)
-    FRCNN_DISPATCH(64, 32, 4)
+#define FRCNN_DISPATCH(BM_, BN_, S_, OCC_) \
+    if (bm == BM_ && bn == BN_ && stages == S_) return launch<BM_, BN_, S_, OCC_>(p, split, s);
+    FRCNN_DISPATCH(128, 128, 2, 2)
+    FRCNN_DISPATCH(128, 64, 2, 3)
+    FRCNN_DISPATCH(128, 32, 2, 3)
+    FRCNN_DISPATCH(64, 128, 2, 3)
+    FRCNN_DISPATCH(64, 64, 2, 3)
+    FRCNN_DISPATCH(64, 32, 2, 3)
+    FRCNN_DISPATCH(128, 128, 3, 1)
+    FRCNN_DISPATCH(128, 64, 3, 2)
+    FRCNN_DISPATCH(64, 128, 3, 2)
+    FRCNN_DISPATCH(64, 64, 3, 3)
 #undef FRCNN_DISPATCH
     frcnn_set_error("conv2d_wgrad: no tile configuration");
     return FRCNN_EINVAL;
