@@ -209,6 +209,156 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int block
     c2[c] = (float)(sx * inv_m);
 }
 
+// ---------------------------------------------------------------- fused BN finalize + apply (training)
+// grid = (64-channel strips, row chunks), 256 threads.  Every workgroup first reduces the conv kernel's partial sums of
+// ITS 64 channels (slots x 2 x 64 floats, L2 resident) to scale / shift -- no separate finalize launch -- and keeps each
+// thread's 8 channels in registers for all its rows, so the streaming loop issues one 16-byte load per stream and one
+// 16-byte store, no parameter loads.  The row-chunk-0 workgroups also publish mean / invstd (for the backward pass) and
+// update the moving statistics.
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __restrict__ z, const float* __restrict__ part, int slots,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
+                                                             float inv_count, float unbias, const bf16_t* __restrict__ res, int relu,
+                                                             bf16_t* __restrict__ out, float* __restrict__ mean_o,
+                                                             float* __restrict__ invstd_o, int64_t M, int C, int rows_per_block) {
+    __shared__ double red[2][4][64];
+    __shared__ float s_scale[64], s_shift[64];
+    const int c0 = blockIdx.x * 64;
+    {
+        const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        const int c = c0 + cl;
+        double s = 0.0, ss = 0.0;
+        if (c < C)
+            for (int t = sl; t < slots; t += 4) {
+                s += (double)part[((int64_t)t * 2) * C + c];
+                ss += (double)part[((int64_t)t * 2 + 1) * C + c];
+            }
+        red[0][sl][cl] = s;
+        red[1][sl][cl] = ss;
+        __syncthreads();
+        if (sl == 0 && c < C) {
+            s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+            ss = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+            const double mean = s * inv_count;
+            double var = ss * inv_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = gamma[c] * invstd;
+            s_scale[cl] = sc;
+            s_shift[cl] = beta[c] - (float)mean * sc;
+            if (blockIdx.y == 0) {
+                mean_o[c] = (float)mean;
+                invstd_o[c] = invstd;
+                mm[c] = mm[c] * momentum + (float)mean * (1.f - momentum);
+                mv[c] = mv[c] * momentum + (float)(var * unbias) * (1.f - momentum);
+            }
+        }
+        __syncthreads();
+    }
+    const int v = threadIdx.x & 7, rl = threadIdx.x >> 3;        // 8 channel vectors x 32 row lanes
+    const int C8 = C / 8, cv = c0 / 8 + v;
+    if (cv >= C8) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = s_scale[v * 8 + e]; sh[e] = s_shift[v * 8 + e]; }
+    const int64_t row_begin = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
+#pragma unroll 4
+    for (int64_t r = row_begin + rl; r < row_end; r += 32) {
+        const int64_t i = r * C8 + cv;
+        float x[8];
+        unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = x[e] * sc[e] + sh[e];
+        if (res) {
+            float q[8];
+            unpack8(*reinterpret_cast<const u32x4*>(res + i * 8), q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += q[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+        }
+        *reinterpret_cast<u32x4*>(out + i * 8) = pack8(x);
+    }
+}
+
+// fused BN backward finalize + apply: c1 = sum(g)/m, c2 = sum(g*xhat)/m of the workgroup's 64 channels from the reduce
+// kernel's slot partials; the row-chunk-0 workgroups publish dgamma / dbeta.
+template <bool MASK>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ act,
+                                                                 const bf16_t* __restrict__ z, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ part, int slots, float inv_m,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 bf16_t* __restrict__ dz, bf16_t* __restrict__ gpre, int64_t M, int C,
+                                                                 int rows_per_block) {
+    __shared__ double red[2][4][64];
+    __shared__ float s_par[4][64];                // gamma*invstd, mean, invstd (xhat), c1, c2 folded: a, mu, is, k1, k2
+    __shared__ float s_c2[64];
+    const int c0 = blockIdx.x * 64;
+    {
+        const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        const int c = c0 + cl;
+        double s = 0.0, sx = 0.0;
+        if (c < C)
+            for (int t = sl; t < slots; t += 4) {
+                s += (double)part[((int64_t)t * 2) * C + c];
+                sx += (double)part[((int64_t)t * 2 + 1) * C + c];
+            }
+        red[0][sl][cl] = s;
+        red[1][sl][cl] = sx;
+        __syncthreads();
+        if (sl == 0 && c < C) {
+            s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+            sx = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+            const float is = invstd[c];
+            s_par[0][cl] = gamma[c] * is;
+            s_par[1][cl] = mean[c];
+            s_par[2][cl] = is;
+            s_par[3][cl] = (float)(s * inv_m);
+            s_c2[cl] = (float)(sx * inv_m);
+            if (blockIdx.y == 0) {
+                dbeta[c] = (float)s;
+                dgamma[c] = (float)sx;
+            }
+        }
+        __syncthreads();
+    }
+    const int v = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int C8 = C / 8, cv = c0 / 8 + v;
+    if (cv >= C8) return;
+    float ga[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ga[e] = s_par[0][v * 8 + e]; mu[e] = s_par[1][v * 8 + e]; is[e] = s_par[2][v * 8 + e];
+        k1[e] = s_par[3][v * 8 + e]; k2[e] = s_c2[v * 8 + e];
+    }
+    const int64_t row_begin = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
+#pragma unroll 2
+    for (int64_t r = row_begin + rl; r < row_end; r += 32) {
+        const int64_t i = r * C8 + cv;
+        float g[8], zz[8], o[8];
+        unpack8(*reinterpret_cast<const u32x4*>(gout + i * 8), g);
+        unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), zz);
+        if (MASK) {
+            float a[8];
+            unpack8(*reinterpret_cast<const u32x4*>(act + i * 8), a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = (zz[e] - mu[e]) * is[e];
+            o[e] = ga[e] * (g[e] - k1[e] - xh * k2[e]);
+        }
+        *reinterpret_cast<u32x4*>(dz + i * 8) = pack8(o);
+        if (gpre) *reinterpret_cast<u32x4*>(gpre + i * 8) = pack8(g);
+    }
+}
+
 template <bool MASK>
 __global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ act, const bf16_t* __restrict__ z,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -463,6 +613,51 @@ extern "C" int frcnn_bn_apply(const frcnn_bf16* z, const float* scale, const flo
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(nvec, 256)), dim3(256), 0, S_(stream), CBF(z), scale, shift, CBF(res), relu,
                        BF(out), nvec, c / 8);
     FRCNN_CHECK_LAUNCH("bn_apply");
+    return FRCNN_OK;
+}
+
+// rows per workgroup of the strip kernels: ~1024 workgroups, at least 64 rows (the per-workgroup statistics prologue
+// must stay small next to the streamed rows)
+static int strip_rows_per_block(int64_t m, int c) {
+    const int strips = (c + 63) / 64;
+    int64_t chunks = 1024 / strips;
+    if (chunks < 1) chunks = 1;
+    int64_t rows = (m + chunks - 1) / chunks;
+    if (rows < 64) rows = 64;
+    return (int)rows;
+}
+
+extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const float* stats_partial, int slots, int64_t count, const float* gamma,
+                                    const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
+                                    const frcnn_bf16* res, int relu, frcnn_bf16* out, float* mean, float* invstd, int64_t m, int c,
+                                    frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(z && stats_partial && gamma && beta && moving_mean && moving_var && out && mean && invstd && count > 0 &&
+                        slots > 0 && c % 8 == 0,
+                    "bn_train_apply: bad arguments");
+    const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
+    const int rows = strip_rows_per_block(m, c);
+    const dim3 grid((c + 63) / 64, (unsigned)((m + rows - 1) / rows));
+    hipLaunchKernelGGL(bn_train_apply_kernel, grid, dim3(256), 0, S_(stream), CBF(z), stats_partial, slots, gamma, beta, moving_mean,
+                       moving_var, momentum, eps, (float)(1.0 / (double)count), unbias, CBF(res), relu, BF(out), mean, invstd, m, c, rows);
+    FRCNN_CHECK_LAUNCH("bn_train_apply");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const frcnn_bf16* z, const float* mean,
+                                        const float* invstd, const float* gamma, const float* partial, int slots, float* dgamma,
+                                        float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(gout && z && mean && invstd && gamma && partial && dgamma && dbeta && dz && m > 0 && slots > 0 && c % 8 == 0,
+                    "bn_bwd_apply_fused: bad arguments");
+    const int rows = strip_rows_per_block(m, c);
+    const dim3 grid((c + 63) / 64, (unsigned)((m + rows - 1) / rows));
+    const float inv_m = (float)(1.0 / (double)m);
+    if (act)
+        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<true>, grid, dim3(256), 0, S_(stream), CBF(gout), CBF(act), CBF(z), mean, invstd,
+                           gamma, partial, slots, inv_m, dgamma, dbeta, BF(dz), BF(gpre), m, c, rows);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<false>, grid, dim3(256), 0, S_(stream), CBF(gout), CBF(act), CBF(z), mean, invstd,
+                           gamma, partial, slots, inv_m, dgamma, dbeta, BF(dz), BF(gpre), m, c, rows);
+    FRCNN_CHECK_LAUNCH("bn_bwd_apply_fused");
     return FRCNN_OK;
 }
 

@@ -91,24 +91,28 @@ class _ConvBN:
         st = self.store
         plan.add(ops.conv2d_fprop, self.desc, x, self.w_fwd(), self.z, bias=st.weight(self.name + "_conv/bias"),
                  stats=self.stats if training else None)
-        g, b = st.weight(self.name + "_bn/gamma"), st.weight(self.name + "_bn/beta")
-        if training:
-            plan.add(ops.bn_finalize_train, self.stats, self.tiles, self.cout, self.m, g, b, self.mm, self.mv, BN_MOMENTUM, BN_EPS,
-                     self.scale, self.shift, self.mean, self.invstd)
-        else:
+        self._training = training
+        if not training:
+            g, b = st.weight(self.name + "_bn/gamma"), st.weight(self.name + "_bn/beta")
             plan.add(ops.bn_finalize_eval, self.cout, g, b, self.mm, self.mv, BN_EPS, self.scale, self.shift)
 
     def apply(self, plan, out, res=None, relu=True):
-        plan.add(ops.bn_apply, self.z, self.scale, self.shift, out, self.m, self.cout, res=res, relu=relu)
+        if self._training:
+            # batch statistics -> scale/shift inside the apply kernel (every workgroup reduces its own 64 channels)
+            st = self.store
+            plan.add(ops.bn_train_apply, self.z, self.stats, self.tiles, self.m, st.weight(self.name + "_bn/gamma"),
+                     st.weight(self.name + "_bn/beta"), self.mm, self.mv, BN_MOMENTUM, BN_EPS, out, self.mean, self.invstd, self.m,
+                     self.cout, res=res, relu=relu)
+        else:
+            plan.add(ops.bn_apply, self.z, self.scale, self.shift, out, self.m, self.cout, res=res, relu=relu)
 
     # -- backward: gout (grad of the BN[+res][+relu] output), act = that output (None when no ReLU)
     def backward_bn(self, plan, gout, act, gpre=None):
         st = self.store
         plan.add(ops.bn_bwd_reduce, gout, act, self.z, self.mean, self.invstd, self.bwd_partial, self.m, self.cout)
-        plan.add(ops.bn_bwd_finalize, self.bwd_partial, self.bwd_blocks, self.cout, self.m, st.grad(self.name + "_bn/gamma"),
-                 st.grad(self.name + "_bn/beta"), self.c1, self.c2)
-        plan.add(ops.bn_bwd_apply, gout, act, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"), self.c1, self.c2,
-                 self.dz, gpre, self.m, self.cout)
+        plan.add(ops.bn_bwd_apply_fused, gout, act, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"),
+                 self.bwd_partial, self.bwd_blocks, st.grad(self.name + "_bn/gamma"), st.grad(self.name + "_bn/beta"), self.dz, gpre,
+                 self.m, self.cout)
         # the conv bias feeds a training-mode BN: its gradient is identically zero (flat grad buffer is pre-zeroed)
 
     def backward_weights(self, plan, x):

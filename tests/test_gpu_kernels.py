@@ -75,6 +75,19 @@ def test_bn_forward_backward(ops):
     _close(dbeta, bt.grad, 1e-3, 1e-2, "dbeta")
     _close(dz, zz.grad, 2 ** -6, 2e-3, "dz")
     _close(gpre, gout * (out_ref.detach() > 0), 0, 0, "gpre")
+    # fused forms (one launch each): same arithmetic, every workgroup reduces the partial sums of its own 64 channels
+    mm2, mv2 = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    mean2, invstd2 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    out2 = torch.empty(m, c, dtype=BF, device=dev)
+    ops.bn_train_apply(zd, parts, 4, m, gamma.to(dev), beta.to(dev), mm2, mv2, 0.99, 1.001e-5, out2, mean2, invstd2, m, c,
+                       res=res.to(BF).to(dev), relu=True)
+    dgamma2, dbeta2 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    dz2, gpre2 = torch.empty(m, c, dtype=BF, device=dev), torch.empty(m, c, dtype=BF, device=dev)
+    ops.bn_bwd_apply_fused(gd, act, zd, mean, invstd, gamma.to(dev), partial, nb, dgamma2, dbeta2, dz2, gpre2, m, c)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out) and torch.equal(mean2, mean) and torch.equal(invstd2, invstd), "fused train apply"
+    assert torch.equal(mm2, mm) and torch.equal(mv2, mv), "fused moving statistics"
+    assert torch.equal(dz2, dz) and torch.equal(gpre2, gpre) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta), "fused bwd apply"
 
 
 def test_bn_wide_channels_and_eval(ops):
