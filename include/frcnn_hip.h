@@ -54,7 +54,7 @@ const char* frcnn_last_error(void);
 #define FRCNN_CONV_ADD_RES    8   /* y = conv + res (res bf16, same addressing as y; may alias y) */
 #define FRCNN_CONV_STATS      16  /* accumulate (float atomics) the column sum / sum-of-squares of the bf16-rounded
                                      output into stats_partial [FRCNN_STAT_SLOTS][2][cout], which must be pre-zeroed */
-#define FRCNN_STAT_SLOTS      64
+#define FRCNN_STAT_SLOTS      16
 #define FRCNN_CONV_SPLITK_ATOMIC 32 /* y (fp32, pre-zeroed) accumulated with atomics over split_k K-slices */
 typedef struct {
     int n, hi, wi, in_pix_stride, cin;
