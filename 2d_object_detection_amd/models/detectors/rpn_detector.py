@@ -150,6 +150,12 @@ class RPNDetector:
     def backward_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, feature_maps, g_feat):
         """Per-sample loss gradients -> parameter gradients; ADDS the feature-map gradient into
         g_feat (bf16 [M, C], already holding the RoI-branch gradient)."""
+        self.backward_params_plan(plan, dlogits_s, ddeltas_s, indices, num_samples, feature_maps)
+        self.backward_data_plan(plan, g_feat)
+
+    def backward_params_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, feature_maps):
+        """Everything of the RPN backward pass that does not need the RoI-branch gradient (a side-stream branch of the
+        training step runs it next to the Fast-RCNN backward pass)."""
         st = self.store
         plan.add(self.dhead32.zero_)
         plan.add(ops.rpn_head_grad, dlogits_s, ddeltas_s, indices, self._keep, self.batch, num_samples, self.num_anchors, self.apl,
@@ -161,6 +167,8 @@ class RPNDetector:
         plan.add(ops.relu_bwd, self.g_f, self.f, self.dz_f)
         plan.add(ops.colsum_bf16, self.dz_f, self.m, 256, 256, st.grad("rpn_intermediate_layer/bias"))
         plan.add(ops.conv2d_wgrad, self.d_inter, feature_maps, self.dz_f, st.grad("rpn_intermediate_layer/kernel"))
+
+    def backward_data_plan(self, plan, g_feat):
         plan.add(ops.conv2d_fprop, self.d_inter_bwd, self.dz_f, self.w_inter_t, g_feat, res=g_feat)
 
     # ------------------------------------------------------------------ reference call surface

@@ -137,13 +137,16 @@ class FasterRCNN:
 
         if training:
             plan.add(self.store.g.zero_)
+            # derived weights for the backward pass: all tap-flipped transposes (backbone, RPN, heads) in ONE launch, on a
+            # side stream under the forward pass (first needed by the head backward passes)
+            table, total = ops.make_transpose_flip_table(mods.fe.flip_entries() + mods.rpn.flip_entries() + mods.rcnn.flip_entries(), dev)
+            plan.hold(table)
+            with plan.branch("weight_flips"):
+                plan.add(ops.weights_transpose_flip_batched, table, total)
         feat = mods.fe.forward_plan(plan, training)
         feat2d = feat.view(batch * gh * gw, cf)
         rpn_out = mods.rpn.forward_plan(plan, feat2d, training)
         n = rpn_out["pred_scores"].shape[1]
-        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"])
-        rois = nms_rpn["pred_boxes"]
-        rcnn_out = mods.rcnn.forward_plan(plan, feat, rois)
 
         # ---- targets, sampling, losses (+ per-sample gradients)
         f32 = dict(dtype=torch.float32, device=dev)
@@ -161,36 +164,56 @@ class FasterRCNN:
         # data-parallel: classification losses are means over the GLOBAL batch (scale 1/world before the SUM
         # all-reduce); regression losses are sums over rows (utils/losses.py:40) -> scale 1
         cls_scale = 1.0 / self.world_size
-        plan.add(ops.assign_targets, rpn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
-                 rs["foreground_iou_interval"], rs["background_iou_interval"], t["rpn_tl"], t["rpn_tb"])
-        plan.add(ops.sample_indices, t["rpn_tl"], batch, n, 2, S_rpn, rs["foreground_proportion"], self.sampling_seed, step, 0,
-                 t["rpn_idx"], t["rpn_ws"], self.status)
-        plan.add(ops.losses, rpn_out["pred_scores"], rpn_out["pred_boxes"], t["rpn_tl"], t["rpn_tb"], t["rpn_idx"], batch, n, 2, S_rpn,
-                 cls_scale, 1.0, losses[0:2], t.get("rpn_dl"), t.get("rpn_dd"))
-        plan.add(ops.assign_targets, rcnn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, P, G, nc1, False, W, H,
-                 cs["foreground_iou_interval"], cs["background_iou_interval"], t["rcnn_tl"], t["rcnn_tb"])
-        plan.add(ops.sample_indices, t["rcnn_tl"], batch, P, nc1, S_rcnn, cs["foreground_proportion"], self.sampling_seed, step, 2,
-                 t["rcnn_idx"], t["rcnn_ws"], self.status)
-        plan.add(ops.losses, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"], batch, P, nc1,
-                 S_rcnn, cls_scale, 1.0, losses[2:4], t.get("rcnn_dl"), t.get("rcnn_dd"))
+        # The RPN target / loss chain only needs the RPN outputs: it runs on a side stream next to proposal NMS, RoI pooling
+        # and the Fast-RCNN heads, and continues with the part of the RPN backward pass that does not need the RoI-branch
+        # gradient.  The detection NMS of the step's predictions is a second branch under the head backward passes.
+        def rpn_targets_and_losses():
+            plan.add(ops.assign_targets, rpn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
+                     rs["foreground_iou_interval"], rs["background_iou_interval"], t["rpn_tl"], t["rpn_tb"])
+            plan.add(ops.sample_indices, t["rpn_tl"], batch, n, 2, S_rpn, rs["foreground_proportion"], self.sampling_seed, step, 0,
+                     t["rpn_idx"], t["rpn_ws"], self.status)
+            plan.add(ops.losses, rpn_out["pred_scores"], rpn_out["pred_boxes"], t["rpn_tl"], t["rpn_tb"], t["rpn_idx"], batch, n, 2, S_rpn,
+                     cls_scale, 1.0, losses[0:2], t.get("rpn_dl"), t.get("rpn_dd"))
+
+        def rcnn_targets_and_losses():
+            plan.add(ops.assign_targets, rcnn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, P, G, nc1, False, W, H,
+                     cs["foreground_iou_interval"], cs["background_iou_interval"], t["rcnn_tl"], t["rcnn_tb"])
+            plan.add(ops.sample_indices, t["rcnn_tl"], batch, P, nc1, S_rcnn, cs["foreground_proportion"], self.sampling_seed, step, 2,
+                     t["rcnn_idx"], t["rcnn_ws"], self.status)
+            plan.add(ops.losses, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"], batch, P, nc1,
+                     S_rcnn, cls_scale, 1.0, losses[2:4], t.get("rcnn_dl"), t.get("rcnn_dd"))
 
         if training:
             g_feat = torch.empty(batch * gh * gw, cf, dtype=BF16, device=dev)
             plan.hold(g_feat)
             t["g_feat"] = g_feat
+            plan.join("weight_flips")
+            with plan.branch("rpn_side"):
+                rpn_targets_and_losses()
+                mods.rpn.backward_params_plan(plan, t["rpn_dl"], t["rpn_dd"], t["rpn_idx"], S_rpn, feat2d)
+        else:
+            rpn_targets_and_losses()
+        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"])
+        rois = nms_rpn["pred_boxes"]
+        rcnn_out = mods.rcnn.forward_plan(plan, feat, rois)
+        if training:
+            with plan.branch("detections"):
+                nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
+        rcnn_targets_and_losses()
+
+        if training:
             mods.rcnn.backward_plan(plan, t["rcnn_dl"], t["rcnn_dd"], t["rcnn_idx"], S_rcnn, rois, g_feat)
-            mods.rpn.backward_plan(plan, t["rpn_dl"], t["rpn_dd"], t["rpn_idx"], S_rpn, feat2d, g_feat)
+            plan.join("rpn_side")
+            mods.rpn.backward_data_plan(plan, g_feat)
+            plan.join("detections")
             plan.cut("bwd_conv4")
             mods.fe.backward_plan(plan, g_feat)
             plan.cut("update")
             optimizer.apply_plan(plan)
-            # derived weights: all tap-flipped transposes (backbone, RPN, heads) in ONE launch + the packed stem filter
-            table, total = ops.make_transpose_flip_table(mods.fe.flip_entries() + mods.rpn.flip_entries() + mods.rcnn.flip_entries(), dev)
-            plan.hold(table)
-            plan.add(ops.weights_transpose_flip_batched, table, total)
             mods.fe.stem.refresh_weights(plan)
             plan.add(ops.step_increment, optimizer.iterations)
-        nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
+        else:
+            nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
         preds = {"rpn_boxes": nms_rpn["pred_boxes"], "rpn_scores": nms_rpn["pred_scores"], "rcnn_boxes": nms_rcnn["pred_boxes"],
                  "rcnn_scores": nms_rcnn["pred_scores"], "rcnn_classes": nms_rcnn["pred_classes"]}
         aux = {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn, "nms_rcnn": nms_rcnn, "targets": t, "feature_maps": feat}

@@ -7,24 +7,57 @@ captured into hipGraphs (training: no per-kernel host cost, no host sync anywher
 Plans are cut into *segments* so that a data-parallel driver can interleave RCCL all-reduces of
 finished gradient buckets with the remaining backward segments.
 """
+import os
+
 import numpy as np
 import torch
 
 
+_SERIAL = bool(os.environ.get("FRCNN_SERIAL_PLAN"))      # debugging aid: run branch launches on the main stream
+
+
+class _Branch:
+    def __init__(self, plan, name):
+        self.plan, self.name = plan, name
+
+    def __enter__(self):
+        assert self.plan._branch is None, "plan branches do not nest"
+        self.plan._branch = self.name
+        return self
+
+    def __exit__(self, *exc):
+        self.plan._branch = None
+        return False
+
+
 class Plan:
+    """Ordered launches, cut into segments.  Launches added inside `with plan.branch(name):` run on a side stream that
+    forks from the main stream at the branch's first launch and is joined back by `plan.join(name)` (or at the end of
+    the segment): small latency-bound kernels (NMS, target assignment, weight re-layouts) overlap the convolutions of
+    the main stream instead of serialising with them.  Under graph capture the fork / join events become graph edges."""
+
     def __init__(self, name="plan"):
         self.name = name
         self.segments = [[]]
         self.segment_names = ["main"]
         self.keep = []            # buffers owned by the plan
         self._graphs = None
+        self._branch = None
+        self._streams = {}
 
     # -- construction
     def add(self, fn, *args, **kwargs):
-        self.segments[-1].append((fn, args, kwargs))
+        self.segments[-1].append((fn, args, kwargs, None if _SERIAL else self._branch))
+
+    def branch(self, name):
+        return _Branch(self, name)
+
+    def join(self, name):
+        self.segments[-1].append((None, (name,), {}, None))
 
     def cut(self, name):
         """Start a new segment (a gradient bucket of the previous segment is complete here)."""
+        assert self._branch is None
         if self.segments[-1]:
             self.segments.append([])
             self.segment_names.append(name)
@@ -37,12 +70,37 @@ class Plan:
 
     @property
     def num_launches(self):
-        return sum(len(s) for s in self.segments)
+        return sum(1 for s in self.segments for e in s if e[0] is not None)
 
     # -- execution
+    def _join(self, main, side, name):
+        ev = torch.cuda.Event()
+        ev.record(side.pop(name))
+        main.wait_event(ev)
+
     def run_segment(self, i):
-        for fn, args, kwargs in self.segments[i]:
-            fn(*args, **kwargs)
+        main = None                                # (no CUDA call for plans without branches: host-logic tests run on CPU)
+        side = {}
+        for fn, args, kwargs, br in self.segments[i]:
+            if fn is None:
+                if args[0] in side:
+                    self._join(main, side, args[0])
+            elif br is None:
+                fn(*args, **kwargs)
+            else:
+                if main is None:
+                    main = torch.cuda.current_stream()
+                if br not in side:
+                    if br not in self._streams:
+                        self._streams[br] = torch.cuda.Stream()
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    self._streams[br].wait_event(ev)
+                    side[br] = self._streams[br]
+                with torch.cuda.stream(side[br]):
+                    fn(*args, **kwargs)
+        for name in list(side):
+            self._join(main, side, name)
 
     def run(self):
         for i in range(len(self.segments)):

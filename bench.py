@@ -56,7 +56,9 @@ def profile_conv_kernels(model, built, steps=3):
         return cin, cout
 
     for seg in plan.segments:
-        for fn, args, kwargs in seg:
+        for fn, args, kwargs, _branch in seg:
+            if fn is None:                       # join marker of a side-stream branch (the profile pass runs serially)
+                continue
             if fn is ops.conv2d_fprop or fn is ops.conv2d_wgrad:
                 d = args[0]
                 cin, cout = true_dims(d, fn)

@@ -53,6 +53,20 @@ def test_plan_segments():
     assert log == ["b", "c", "a", "b", "c", "d"] and not p.captured
 
 
+def test_plan_branches_are_recorded():
+    p = RT.Plan("b")
+    log = []
+    p.add(log.append, "m0")
+    with p.branch("side"):
+        p.add(log.append, "s0")
+        p.add(log.append, "s1")
+    p.add(log.append, "m1")
+    p.join("side")
+    p.add(log.append, "m2")
+    assert [e[3] for e in p.segments[0]] == [None, "side", "side", None, None, None] and p.num_launches == 5
+    assert p.segments[0][4][0] is None and p.segments[0][4][1] == ("side",)
+
+
 def test_piecewise_constant_decay_matches_reference_schedule():
     # train_faster_rcnn.py:62-68,109-112: 1e-3 until step 40000, 1e-4 until 80000, then 1e-5
     s = OPT.PiecewiseConstantDecay([40000, 80000], [1e-3, 1e-4, 1e-5])
