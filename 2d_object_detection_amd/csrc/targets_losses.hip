@@ -46,14 +46,17 @@ __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams
     float* tb = p.tb + (int64_t)b * p.R * (p.C1 - 1) * 4;
     const int C = p.C1 - 1;
 
-    // ---- compact the non-padding ground truth in order (training.py:43-45), absolute coords (:48)
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int g = 0; g < p.G; ++g) {
+    // ---- compact the non-padding ground truth in order (training.py:43-45), absolute coords (:48): one thread per gt row,
+    // order-preserving slots from wave ballots (G <= 128: two waves)
+    __shared__ int wave_cnt[2];
+    bool keep = false;
+    int obj = -1;
+    unsigned long long keep_mask = 0ull;
+    if (threadIdx.x < kMaxGt) {
+        const int g = threadIdx.x;
+        if (g < p.G) {
             float s = 0.f;
             for (int c = 0; c < p.C1g; ++c) s += gl[g * p.C1g + c];
-            bool keep;
-            int obj = -1;
             if (p.objectness) {                       // rpn_detector.py:141: one_hot(int(sum), 2)
                 const int k = (int)s;
                 obj = (k == 0 || k == 1) ? k : -1;
@@ -61,17 +64,21 @@ __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams
             } else {
                 keep = s != 0.0f;
             }
-            if (keep && n < kMaxGt) {
-                f32x4 bx = {gbx[g * 4] * p.W, gbx[g * 4 + 1] * p.H, gbx[g * 4 + 2] * p.W, gbx[g * 4 + 3] * p.H};
-                gbox[n] = bx;
-                garea[n] = (bx[2] - bx[0]) * (bx[3] - bx[1]);
-                gsrc[n] = g;
-                gobj[n] = obj;
-                ++n;
-            }
         }
-        nvalid = n;
+        keep_mask = __ballot(keep);
+        if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(keep_mask);
     }
+    __syncthreads();
+    if (keep) {
+        const int g = threadIdx.x;
+        const int n = ((threadIdx.x >> 6) ? wave_cnt[0] : 0) + __popcll(keep_mask & ((1ull << (threadIdx.x & 63)) - 1ull));
+        f32x4 bx = {gbx[g * 4] * p.W, gbx[g * 4 + 1] * p.H, gbx[g * 4 + 2] * p.W, gbx[g * 4 + 3] * p.H};
+        gbox[n] = bx;
+        garea[n] = (bx[2] - bx[0]) * (bx[3] - bx[1]);
+        gsrc[n] = g;
+        gobj[n] = obj;
+    }
+    if (threadIdx.x == 0) nvalid = wave_cnt[0] + wave_cnt[1];
     __syncthreads();
     const int ng = nvalid;
 
