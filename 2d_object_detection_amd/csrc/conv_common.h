@@ -13,7 +13,7 @@ struct ConvParams {
     const float* bias;
     const bf16_t* res;
     void* y;
-    float* stats;
+    double* stats;                         // [FRCNN_STAT_SLOTS][2][Cout] f64: cross-workgroup sums are order-independent to ~1e-16
     int Hi, Wi, in_pix_stride, Cin, KW, stride, pad_h, pad_w;
     int Ho, Wo, Cout, out_h, out_w, out_scatter, flags;
     int M, Ktot, k_tiles, k_tiles_per_split, split, taps, linear_a;
@@ -22,6 +22,7 @@ struct ConvParams {
     int tap_mask;                           // taps <= 32: per-row tap validity bit masks
     int direct_out;                         // bf16 output row == GEMM row and the tensor stays below 4 GiB: buffer-store epilogue
     int tiles_m, tiles_n, items;            // items = tiles_m * tiles_n * split
+    int tiles_per_block;                    // conv_tile.hip: consecutive m-tiles per workgroup
     long long in_row_stride, in_img_stride;
 };
 

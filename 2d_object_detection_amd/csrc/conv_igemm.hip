@@ -555,10 +555,10 @@ __global__ __launch_bounds__(NW * 64) void igemm_kernel(const ConvParams p) {
         if (stats_n0 >= 0) flush_stats();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        float* slot = p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2) * p.Cout;
+        double* slot = p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2) * p.Cout;
         for (int c = tid; c < 2 * p.Cout; c += T) {
             const float v = stat_s[c];
-            if (v != 0.f) atomicAdd(slot + c, v);
+            if (v != 0.f) atomicAdd(slot + c, (double)v);
         }
     }
 #endif
@@ -619,7 +619,7 @@ extern "C" int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d) {
 }
 
 extern "C" int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
-                                  const frcnn_bf16* res, void* y, float* stats_partial, frcnn_stream_t stream) {
+                                  const frcnn_bf16* res, void* y, double* stats_partial, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(d && x && w && y, "conv2d_fprop: null pointer");
     FRCNN_CHECK_ARG(d->cin > 0 && d->cin % 32 == 0, "conv2d_fprop: cin=%d must be a multiple of 32", d->cin);
     FRCNN_CHECK_ARG(d->cout > 0 && d->cout % 8 == 0, "conv2d_fprop: cout=%d must be a multiple of 8", d->cout);

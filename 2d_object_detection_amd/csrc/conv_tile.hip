@@ -15,7 +15,7 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC>
+template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI>
 __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = 8, T = 512, WM = 2, WN = 4;
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     constexpr bool A_UNI = A_INSTR % NW == 0, B_UNI = B_INSTR % NW == 0;
     constexpr int LC = A_INSTR / NW + B_INSTR / NW;
     static_assert(S == 2 || (S == 3 && A_UNI && B_UNI), "counted waits need a uniform DMA split");
+    static_assert(!MULTI || (S == 2 && A_UNI && B_UNI), "tile runs use the two-slot ring with a uniform DMA split");
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, KK = BK / 32;
     static_assert(MI >= 1 && NI >= 1, "tile too small for 8 waves");
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -33,12 +34,15 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     constexpr int C8 = BN / 8, ST_IT = (BM * C8) / T;
     static_assert((BM * C8) % T == 0, "store loop covers the tile in whole passes");
     constexpr int RING = S * (A_BYTES + B_BYTES), STG = BM * ROWB;
-    constexpr int BIG = RING > STG ? RING : STG;
+    // one tile per workgroup: the staging tile aliases the drained ring.  Tile runs (MULTI): the ring keeps prefetching the
+    // next tile while the epilogue runs, so the staging tile has its own LDS.
+    constexpr int STAGE_OFF = MULTI ? RING : 0;
+    constexpr int BIG = MULTI ? RING + STG : (RING > STG ? RING : STG);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;                  // [S A tiles][S B tiles]
-    unsigned char* stage = smem;                 // [BM][ROWB], aliases the ring once the K loop has drained
-    float* stat_t = reinterpret_cast<float*>(smem + BIG);   // [2][BN] partial sums of this tile (STATS)
+    unsigned char* stage = smem + STAGE_OFF;     // [BM][ROWB]
+    float* stat_t = reinterpret_cast<float*>(smem + BIG);   // [2][BN] partial sums of this workgroup (STATS)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -47,18 +51,21 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     const int frow = lane & 15, fchunk = lane >> 4;
     const int flags = p.flags;
 
-    // workgroup -> tile.  Workgroups b, b+8, ... run on one XCD: each XCD takes a contiguous chunk of the tile list
-    // (n fastest), so the workgroups that share an L2 read neighbouring pixel rows and the same weight panels.
-    int tm, tn;
+    // workgroup -> run of tiles_per_block consecutive m-tiles of one n-tile (one tile unless MULTI).  Workgroups b, b+8, ...
+    // run on one XCD: each XCD takes a contiguous chunk of the unit list (n fastest), so the workgroups that share an L2
+    // read neighbouring pixel rows and the same weight panels.
+    int tm_begin, tn, tile_count;
     {
         const int nb = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, local = bid >> 3;
         const int q = nb >> 3, r = nb & 7;
-        const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-        tm = tile / p.tiles_n;
-        tn = tile - tm * p.tiles_n;
+        const int unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        const int run = unit / p.tiles_n;
+        tn = unit - run * p.tiles_n;
+        tm_begin = MULTI ? run * p.tiles_per_block : run;
+        tile_count = MULTI ? min(p.tiles_per_block, p.tiles_m - tm_begin) : 1;
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int n0 = tn * BN;
 
     if (STATS) {
         if (tid < 2 * BN) stat_t[tid] = 0.f;     // published by the K loop's barriers
@@ -80,50 +87,55 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     unsigned a_voff[A_IT], a_mask[A_IT], b_voff[B_IT];
     const int lrow = lane / CPR, lslot = lane % CPR;
-    if (LIN) {
+    auto setup_tile = [&](const int m0) {        // per-lane source offsets (and tap validity masks) of the A rows of tile m0
+        if (LIN) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int r = (wave + NW * i) * RPI + lrow;
-            const int m = m0 + r;
-            a_voff[i] = (m < p.M && r < BM) ? (unsigned)m * (unsigned)(p.in_pix_stride * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
-            a_mask[i] = 1u;
-        }
-    } else {
-        const int hw = p.Ho * p.Wo;
-        int iy0[A_IT], ix0[A_IT];
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int r = (wave + NW * i) * RPI + lrow;
-            const int m = m0 + r;
-            const int n = m / hw;                // rows beyond M compute harmless garbage, masked below
-            const int rem = m - n * hw;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            iy0[i] = oy * p.stride - p.pad_h;
-            ix0[i] = ox * p.stride - p.pad_w;
-            const unsigned vo = (unsigned)(((n * p.Hi + oy * p.stride) * p.Wi + ox * p.stride) * p.in_pix_stride * 2) + (unsigned)swz<BK>(lslot, r) * 16u;
-            a_voff[i] = (m < p.M && r < BM) ? vo : kOob;
-            a_mask[i] = 0u;
-        }
-        int t = 0;                               // bit t of a_mask: filter tap t of this row lies inside the image
-        for (int kh = 0; kh * p.KW < p.taps; ++kh)
-            for (int kw = 0; kw < p.KW; ++kw, ++t) {
-#pragma unroll
-                for (int i = 0; i < A_IT; ++i)
-                    a_mask[i] |= ((unsigned)(iy0[i] + kh) < (unsigned)p.Hi && (unsigned)(ix0[i] + kw) < (unsigned)p.Wi) ? (1u << t) : 0u;
+            for (int i = 0; i < A_IT; ++i) {
+                const int r = (wave + NW * i) * RPI + lrow;
+                const int m = m0 + r;
+                a_voff[i] = (m < p.M && r < BM) ? (unsigned)m * (unsigned)(p.in_pix_stride * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
+                a_mask[i] = 1u;
             }
-    }
+        } else {
+            const int hw = p.Ho * p.Wo;
+            int iy0[A_IT], ix0[A_IT];
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int r = (wave + NW * i) * RPI + lrow;
+                const int m = m0 + r;
+                const int n = m / hw;            // rows beyond M compute harmless garbage, masked below
+                const int rem = m - n * hw;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                iy0[i] = oy * p.stride - p.pad_h;
+                ix0[i] = ox * p.stride - p.pad_w;
+                const unsigned vo = (unsigned)(((n * p.Hi + oy * p.stride) * p.Wi + ox * p.stride) * p.in_pix_stride * 2) + (unsigned)swz<BK>(lslot, r) * 16u;
+                a_voff[i] = (m < p.M && r < BM) ? vo : kOob;
+                a_mask[i] = 0u;
+            }
+            int t = 0;                           // bit t of a_mask: filter tap t of this row lies inside the image
+            for (int kh = 0; kh * p.KW < p.taps; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw, ++t) {
+#pragma unroll
+                    for (int i = 0; i < A_IT; ++i)
+                        a_mask[i] |= ((unsigned)(iy0[i] + kh) < (unsigned)p.Hi && (unsigned)(ix0[i] + kw) < (unsigned)p.Wi) ? (1u << t) : 0u;
+                }
+        }
+    };
+    setup_tile(tm_begin * BM);
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int r = (wave + NW * i) * RPI + lrow;
         const int n = n0 + r;
         b_voff[i] = (n < p.Cout && r < BN) ? (unsigned)n * (unsigned)(p.Ktot * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
     }
+    const int nk = p.k_tiles;
     int ld_c0 = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0;
+    int ld_k = 0, ld_m0 = tm_begin * BM;         // loader position: K slice inside its tile, first row of its tile
     unsigned ld_soff_a = 0, ld_soff_b = 0;
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    auto issue_slice = [&](const int slot) {     // DMA the next K slice into ring slot
+    auto issue_slice = [&](const int slot) {     // DMA the loader's next K slice into ring slot
         unsigned char* sa = ring + slot * A_BYTES;
         unsigned char* sb = ring + S * A_BYTES + slot * B_BYTES;
 #pragma unroll
@@ -149,14 +161,17 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
                 ld_soff_a = (unsigned)((ld_kh * p.in_row_stride32 + ld_kw * p.in_pix_stride) * 2);
             }
         }
+        if (MULTI && ++ld_k == nk) {             // the loader moves on to the next tile of the run
+            ld_k = 0;
+            ld_m0 += BM;
+            ld_c0 = ld_tap = ld_kh = ld_kw = 0;
+            ld_soff_a = ld_soff_b = 0;
+            setup_tile(ld_m0);                   // (beyond the run's last tile nothing is issued any more)
+        }
     };
 
     // ------------------------------------------------------------------ consumer (MFMA) state
     f32x4 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // fragment read offsets per 32-wide K step: the swizzle term only depends on the lane (fragments start on multiples
     // of 16 rows), so slot and fragment-row offsets are immediates of the ds_read
     unsigned a_foff[KK], b_foff[KK];
@@ -190,104 +205,172 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
         }
     };
 
-    // ------------------------------------------------------------------ K loop
-#define FRCNN_WAIT_IMM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-    const int nk = p.k_tiles;
-    {
-        const int pre = nk < S - 1 ? nk : S - 1;
-        for (int s = 0; s < pre; ++s) issue_slice(s);
-    }
-    int left = nk;                               // slices to consume
-    int to_issue = nk - (nk < S - 1 ? nk : S - 1);
-    while (to_issue >= S) {                      // whole trips around the ring: compile-time slots, ring stays full
-#pragma unroll
-        for (int c = 0; c < S; ++c) {
-            FRCNN_WAIT_IMM((S - 2) * LC);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's fragment reads of the slot refilled next have completed
-            __builtin_amdgcn_s_barrier();        // slice landed for everyone; everyone finished reading the slot refilled next
-            issue_slice((c + S - 1) % S);
-            mfma_slice(c);
-        }
-        to_issue -= S;
-        left -= S;
-    }
-    int slot = 0;                                // the consumer is back at slot 0 after whole trips
-    while (left > 0) {                           // < S slices left to issue, then the drain
-        if (to_issue > 0) FRCNN_WAIT_IMM((S - 2) * LC);
-        else FRCNN_WAIT_IMM(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (to_issue > 0) {
-            issue_slice(slot == 0 ? S - 1 : slot - 1);
-            --to_issue;
-        }
-        mfma_slice(slot);
-        slot = slot + 1 == S ? 0 : slot + 1;
-        --left;
-    }
-#undef FRCNN_WAIT_IMM
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                // every wave is done with the ring: the staging tile may overwrite it
-
-    // ------------------------------------------------------------------ epilogue
-    // lane holds, for fragment (i,j): pixel = wm*WTM + i*16 + (lane&15); couts = wn*WTN + j*16 + (lane>>4)*4 + 0..3
-    const bool tail = m0 + BM > p.M;
+    // epilogue state that does not depend on the tile
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_res = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.y_bytes, 0x00020000);
     const int lrow_o = tid / C8, lc8 = tid - lrow_o * C8;
     const bool col_ok = n0 + lc8 * 8 < p.Cout;
     const unsigned vo_lane = (unsigned)(lrow_o * p.Cout * 2 + lc8 * 16);
     const unsigned pass_pitch = (unsigned)((T / C8) * p.Cout * 2);
-    const unsigned tile_off = (unsigned)((m0 * p.Cout + n0) * 2);
-    u32x4 resv[ST_IT];
-    if (p.direct_out && (flags & FRCNN_CONV_ADD_RES)) {      // residual rows of this tile: in flight under the convert phase
-#pragma unroll
-        for (int it = 0; it < ST_IT; ++it) {
-            const int r = lrow_o + it * (T / C8);
-            const unsigned vo = (col_ok && (!tail || m0 + r < p.M)) ? vo_lane + tile_off + it * pass_pitch : kOob;
-            resv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, vo, 0, 0);
-        }
-    }
-
-    float ssum[NI][4], ssq[NI][4];
+    const unsigned stage_a = lds_addr(stage);
+    float ssum[NI][4], ssq[NI][4];               // BatchNorm partial sums of this workgroup's tiles (one n-tile)
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) ssum[j][e] = ssq[j][e] = 0.f;
     const float lo = (flags & FRCNN_CONV_RELU) ? 0.f : -__builtin_inff();
-    auto convert_tile = [&](auto tail_c) {
-        constexpr bool TL = decltype(tail_c)::value;
+
+    // ------------------------------------------------------------------ K loops of the run's tiles
+#define FRCNN_WAIT_IMM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    const int total_slices = tile_count * nk;
+    {
+        const int pre = total_slices < S - 1 ? total_slices : S - 1;
+        for (int s = 0; s < pre; ++s) issue_slice(s);
+    }
+    int to_issue = total_slices - (total_slices < S - 1 ? total_slices : S - 1);
+    int slot = 0;
+    for (int t = 0; t < tile_count; ++t) {
+        const int m0 = (tm_begin + t) * BM;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int r = wm * WTM + i * 16 + frow;
-            const bool row_ok = !TL || m0 + r < p.M;
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int cl = wn * WTN + j * 16 + fchunk * 4;
-                u32x2 pk;
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int left = nk;                           // slices of this tile still to consume
+        // a tile's first slice was issued BEFORE the previous tile's epilogue stores: those ST_IT stores may stay in flight
+        bool after_epilogue = MULTI && t > 0 && p.direct_out;
+        while (left > 0) {
+            if (slot == 0 && !after_epilogue && left >= S && to_issue >= S) {
+                // whole trips around the ring: compile-time slots, ring stays full
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    f32x2 v;
-                    v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] + bv[j][2 * h], lo, __builtin_inff());
-                    v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
-                    const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
-                    pk[h] = bits;
-                    if (STATS) {                 // sums of the ROUNDED outputs (what the next layer reads)
-                        float q0 = __uint_as_float(bits << 16), q1 = __uint_as_float(bits & 0xFFFF0000u);
-                        if (TL) { q0 = row_ok ? q0 : 0.f; q1 = row_ok ? q1 : 0.f; }
-                        ssum[j][2 * h] += q0;
-                        ssq[j][2 * h] += q0 * q0;
-                        ssum[j][2 * h + 1] += q1;
-                        ssq[j][2 * h + 1] += q1 * q1;
-                    }
+                for (int c = 0; c < S; ++c) {
+                    FRCNN_WAIT_IMM((S - 2) * LC);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's fragment reads of the slot refilled next have completed
+                    __builtin_amdgcn_s_barrier();        // slice landed for everyone; everyone finished reading the slot refilled next
+                    issue_slice((c + S - 1) % S);
+                    mfma_slice(c);
                 }
-                *reinterpret_cast<u32x2*>(stage + r * ROWB + cl * 2) = pk;
+                to_issue -= S;
+                left -= S;
+                continue;
+            }
+            if (after_epilogue) FRCNN_WAIT_IMM(ST_IT);                     // (MULTI: S == 2)
+            else if (to_issue > 0) FRCNN_WAIT_IMM((S - 2) * LC);
+            else FRCNN_WAIT_IMM(0);
+            after_epilogue = false;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (to_issue > 0) {
+                issue_slice(slot == 0 ? S - 1 : slot - 1);
+                --to_issue;
+            }
+            mfma_slice(slot);
+            slot = slot + 1 == S ? 0 : slot + 1;
+            --left;
+        }
+        if (!MULTI) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();        // every wave is done with the ring: the staging tile may overwrite it
+        }
+
+        // -------------------------------------------------------------- epilogue of tile t
+        // lane holds, for fragment (i,j): pixel = wm*WTM + i*16 + (lane&15); couts = wn*WTN + j*16 + (lane>>4)*4 + 0..3
+        const bool tail = m0 + BM > p.M;
+        const unsigned tile_off = (unsigned)((m0 * p.Cout + n0) * 2);
+        u32x4 resv[ST_IT];
+        if (p.direct_out && (flags & FRCNN_CONV_ADD_RES)) {  // residual rows of this tile: in flight under the convert phase
+#pragma unroll
+            for (int it = 0; it < ST_IT; ++it) {
+                const int r = lrow_o + it * (T / C8);
+                const unsigned vo = (col_ok && (!tail || m0 + r < p.M)) ? vo_lane + tile_off + it * pass_pitch : kOob;
+                resv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, vo, 0, 0);
             }
         }
-    };
-    if (STATS && tail) convert_tile(std::true_type{});
-    else convert_tile(std::false_type{});
+        auto convert_tile = [&](auto tail_c) {
+            constexpr bool TL = decltype(tail_c)::value;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int r = wm * WTM + i * 16 + frow;
+                const bool row_ok = !TL || m0 + r < p.M;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int cl = wn * WTN + j * 16 + fchunk * 4;
+                    u32x2 pk;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x2 v;
+                        v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] + bv[j][2 * h], lo, __builtin_inff());
+                        v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
+                        const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
+                        pk[h] = bits;
+                        if (STATS) {             // sums of the ROUNDED outputs (what the next layer reads)
+                            float q0 = __uint_as_float(bits << 16), q1 = __uint_as_float(bits & 0xFFFF0000u);
+                            if (TL) { q0 = row_ok ? q0 : 0.f; q1 = row_ok ? q1 : 0.f; }
+                            ssum[j][2 * h] += q0;
+                            ssq[j][2 * h] += q0 * q0;
+                            ssum[j][2 * h + 1] += q1;
+                            ssq[j][2 * h + 1] += q1 * q1;
+                        }
+                    }
+                    // MULTI: the next tile's DMA is in flight and hipcc would order a DS write it emits itself behind ALL
+                    // pending LDS-DMA (vmcnt(0)); the asm form is invisible to that pass
+                    if (MULTI) lds_write_b64(stage_a + r * ROWB + cl * 2, pk);
+                    else *reinterpret_cast<u32x2*>(stage + r * ROWB + cl * 2) = pk;
+                }
+            }
+        };
+        if (STATS && tail) convert_tile(std::true_type{});
+        else convert_tile(std::false_type{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // staging tile complete (a raw barrier does not drain the DMA ring)
+
+        if (p.direct_out) {
+#pragma unroll
+            for (int it = 0; it < ST_IT; ++it) {
+                const int r = lrow_o + it * (T / C8);
+                // the offset travels in the VGPR, not in soffset: with an SGPR soffset hipcc omits the wait state between a
+                // 16-byte buffer store and a VALU overwrite of its data registers, and gfx950 does need it
+                const unsigned vo = (col_ok && (!tail || m0 + r < p.M)) ? vo_lane + tile_off + it * pass_pitch : kOob;
+                u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + lc8 * 16);
+                if (flags & FRCNN_CONV_ADD_RES) {
+                    float a[8], b[8];
+                    unpack8(v, a);
+                    unpack8(resv[it], b);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] += b[e];
+                    v = pack8(a);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo, 0, 0);
+            }
+        } else {
+            // strided scatter (data gradient of a stride-2 1x1 convolution): per-row address computation
+            bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+            for (int idx = tid; idx < BM * C8; idx += T) {
+                const int r = idx / C8, c8 = idx - r * C8;
+                const int m = m0 + r, c = n0 + c8 * 8;
+                if (m >= p.M || c >= p.Cout) continue;
+                u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + c8 * 16);
+                const long long off = out_row_of(p, m) * p.Cout + c;
+                if (flags & FRCNN_CONV_ADD_RES) {
+                    const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
+                    float a[8], b[8];
+                    unpack8(v, a);
+                    unpack8(rv, b);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] += b[e];
+                    v = pack8(a);
+                }
+                *reinterpret_cast<u32x4*>(y + off) = v;
+            }
+        }
+        // (MULTI) the next tile's convert phase writes the staging tile only after >= 1 barrier of its K loop
+    }
+#undef FRCNN_WAIT_IMM
+
     if (STATS) {
+        // the run's tiles share one n-tile: 16-lane butterflies, the two row halves (wm) meet in LDS, then one float atomic
+        // per channel and statistic into one of FRCNN_STAT_SLOTS pre-zeroed slots (consecutive lanes: consecutive channels).
+        // The workgroup's own partial is an fp32 sum in a fixed order; the cross-workgroup sum is accumulated in f64, whose
+        // rounding (1e-16) makes the arrival order of the atomics invisible in the fp32 statistics derived from it
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -300,82 +383,40 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
                 }
                 if (frow == 0) {
                     const int cl = wn * WTN + j * 16 + fchunk * 4 + e;
-                    atomicAdd(stat_t + cl, a);           // LDS atomics: the two row halves (wm) of the tile meet here
+                    atomicAdd(stat_t + cl, a);
                     atomicAdd(stat_t + BN + cl, b);
                 }
             }
-    }
-    __syncthreads();
-
-    if (STATS && tid < 2 * BN) {
-        // one float atomic per channel and statistic, spread over FRCNN_STAT_SLOTS pre-zeroed slots; consecutive lanes
-        // add consecutive channels
-        const int st = tid / BN, cl = tid - st * BN;
-        if (n0 + cl < p.Cout)
-            atomicAdd(p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + n0 + cl, stat_t[tid]);
-    }
-    if (p.direct_out) {
-#pragma unroll
-        for (int it = 0; it < ST_IT; ++it) {
-            const int r = lrow_o + it * (T / C8);
-            // the offset travels in the VGPR, not in soffset: with an SGPR soffset hipcc omits the wait state between a
-            // 16-byte buffer store and a VALU overwrite of its data registers, and gfx950 does need it
-            const unsigned vo = (col_ok && (!tail || m0 + r < p.M)) ? vo_lane + tile_off + it * pass_pitch : kOob;
-            u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + lc8 * 16);
-            if (flags & FRCNN_CONV_ADD_RES) {
-                float a[8], b[8];
-                unpack8(v, a);
-                unpack8(resv[it], b);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] += b[e];
-                v = pack8(a);
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo, 0, 0);
-        }
-    } else {
-        // strided scatter (data gradient of a stride-2 1x1 convolution): per-row address computation
-        bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
-        for (int idx = tid; idx < BM * C8; idx += T) {
-            const int r = idx / C8, c8 = idx - r * C8;
-            const int m = m0 + r, c = n0 + c8 * 8;
-            if (m >= p.M || c >= p.Cout) continue;
-            u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + c8 * 16);
-            const long long off = out_row_of(p, m) * p.Cout + c;
-            if (flags & FRCNN_CONV_ADD_RES) {
-                const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
-                float a[8], b[8];
-                unpack8(v, a);
-                unpack8(rv, b);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] += b[e];
-                v = pack8(a);
-            }
-            *reinterpret_cast<u32x4*>(y + off) = v;
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int st = tid / BN, cl = tid - st * BN;
+            if (n0 + cl < p.Cout)
+                atomicAdd(p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + n0 + cl, (double)stat_t[tid]);
         }
     }
 #endif
 }
 
-template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC>
+template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI>
 int launch_tile(const ConvParams& p, hipStream_t s) {
     constexpr int ring = S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16);
-    constexpr int smem = (ring > stg ? ring : stg) + 2 * BN * 4;
+    constexpr int smem = (MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4;
     static_assert(smem <= 163840, "LDS budget");
     static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
-    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC>), smem) != 0) {
+    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
-    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p);
+    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI>), dim3(p.items), dim3(512), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
     return FRCNN_OK;
 }
 
-template <int BM, int BN, int BK, int S, int OCC>
+template <int BM, int BN, int BK, int S, int OCC, bool MULTI>
 int launch_tile_flags(const ConvParams& p, hipStream_t s) {
     const bool stats = (p.flags & FRCNN_CONV_STATS) != 0;
-    if (p.linear_a) return stats ? launch_tile<BM, BN, BK, S, true, true, OCC>(p, s) : launch_tile<BM, BN, BK, S, true, false, OCC>(p, s);
-    return stats ? launch_tile<BM, BN, BK, S, false, true, OCC>(p, s) : launch_tile<BM, BN, BK, S, false, false, OCC>(p, s);
+    if (p.linear_a) return stats ? launch_tile<BM, BN, BK, S, true, true, OCC, MULTI>(p, s) : launch_tile<BM, BN, BK, S, true, false, OCC, MULTI>(p, s);
+    return stats ? launch_tile<BM, BN, BK, S, false, true, OCC, MULTI>(p, s) : launch_tile<BM, BN, BK, S, false, false, OCC, MULTI>(p, s);
 }
 
 }  // namespace
@@ -395,9 +436,19 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
     const long long tiles_m128 = (M + 127) / 128;
     int bn = (d->cout >= 128 && tiles_m128 * ((d->cout + 127) / 128) >= 200) ? 128 : 64;
     int stages = (bn == 64 && bk == 64 && p.Ktot / bk >= 64) ? 3 : 2;
-    if (const char* e = getenv("FRCNN_TILE")) {                 // kernel development aid: "bm,bn,bk,stages"
-        int a = 0, b = 0, c = 0, st = 0;
-        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &st) == 4) { bm = a; bn = b; bk = c; stages = st; }
+    // short K (<= 4 slices): runs of consecutive m-tiles per workgroup -- the ring prefetches the next tile under the
+    // epilogue, bias / statistics / addressing are set up once per run; narrow tiles keep two workgroups per CU
+    int tpb = 1;                                                // tiles per workgroup (1: one-tile kernel)
+    if (bk == 64) {
+        const int kt = p.Ktot / 64;
+        tpb = kt == 1 ? 8 : kt == 2 ? 4 : kt <= 4 ? 2 : 1;
+        const int tn64 = (d->cout + 63) / 64;
+        while (tpb > 1 && ((tiles_m128 + tpb - 1) / tpb) * tn64 < 512) tpb >>= 1;
+        if (tpb > 1) { bn = 64; stages = 2; }
+    }
+    if (const char* e = getenv("FRCNN_TILE")) {                 // kernel development aid: "bm,bn,bk,stages[,tiles_per_block]"
+        int a = 0, b = 0, c = 0, st = 0, tp = 1;
+        if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &st, &tp) >= 4) { bm = a; bn = b; bk = c; stages = st; tpb = tp; }
     }
     if (d->cin % bk != 0) return FRCNN_ENOTSUP;
     p.k_tiles = p.Ktot / bk;
@@ -405,9 +456,15 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
     p.split = 1;
     p.tiles_m = (int)((M + bm - 1) / bm);
     p.tiles_n = (d->cout + bn - 1) / bn;
-    p.items = p.tiles_m * p.tiles_n;
+    p.tiles_per_block = tpb;
+    p.items = ((p.tiles_m + tpb - 1) / tpb) * p.tiles_n;
 #define FRCNN_TILE(BM_, BN_, BK_, S_, OCC_) \
-    if (bm == BM_ && bn == BN_ && bk == BK_ && stages == S_) return launch_tile_flags<BM_, BN_, BK_, S_, OCC_>(p, s);
+    if (tpb == 1 && bm == BM_ && bn == BN_ && bk == BK_ && stages == S_) return launch_tile_flags<BM_, BN_, BK_, S_, OCC_, false>(p, s);
+#define FRCNN_RUN(BM_, BN_, BK_, OCC_) \
+    if (tpb > 1 && bm == BM_ && bn == BN_ && bk == BK_ && stages == 2) return launch_tile_flags<BM_, BN_, BK_, 2, OCC_, true>(p, s);
+    FRCNN_RUN(128, 64, 64, 2)
+    FRCNN_RUN(128, 128, 64, 1)
+    FRCNN_RUN(64, 64, 64, 3)
     FRCNN_TILE(128, 128, 64, 2, 2)
     FRCNN_TILE(128, 64, 64, 2, 2)
     FRCNN_TILE(64, 128, 64, 2, 2)
@@ -422,5 +479,6 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
     FRCNN_TILE(64, 128, 64, 3, 2)
     FRCNN_TILE(64, 64, 64, 3, 2)
 #undef FRCNN_TILE
+#undef FRCNN_RUN
     return FRCNN_ENOTSUP;
 }

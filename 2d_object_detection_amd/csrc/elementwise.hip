@@ -47,7 +47,7 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ img, bf16_t* __res
 }
 
 // ---------------------------------------------------------------- BN finalize
-__global__ void bn_finalize_train_kernel(const float* __restrict__ part, int tiles, int C, float inv_count, float unbias,
+__global__ void bn_finalize_train_kernel(const double* __restrict__ part, int tiles, int C, float inv_count, float unbias,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
                                          float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
@@ -59,8 +59,8 @@ __global__ void bn_finalize_train_kernel(const float* __restrict__ part, int til
     double s = 0.0, ss = 0.0;
     if (c < C)
         for (int t = sl; t < tiles; t += 4) {
-            s += (double)part[((int64_t)t * 2) * C + c];
-            ss += (double)part[((int64_t)t * 2 + 1) * C + c];
+            s += part[((int64_t)t * 2) * C + c];
+            ss += part[((int64_t)t * 2 + 1) * C + c];
         }
     red[0][sl][cl] = s;
     red[1][sl][cl] = ss;
@@ -215,7 +215,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int block
 // thread's 8 channels in registers for all its rows, so the streaming loop issues one 16-byte load per stream and one
 // 16-byte store, no parameter loads.  The row-chunk-0 workgroups also publish mean / invstd (for the backward pass) and
 // update the moving statistics.
-__global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __restrict__ z, const float* __restrict__ part, int slots,
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __restrict__ z, const double* __restrict__ part, int slots,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
                                                              float inv_count, float unbias, const bf16_t* __restrict__ res, int relu,
@@ -584,7 +584,7 @@ extern "C" int frcnn_preprocess_u8_bgr_mean(const uint8_t* images, frcnn_bf16* o
     return FRCNN_OK;
 }
 
-extern "C" int frcnn_bn_finalize_train(const float* stats_partial, int tiles, int c, int64_t count, const float* gamma,
+extern "C" int frcnn_bn_finalize_train(const double* stats_partial, int tiles, int c, int64_t count, const float* gamma,
                                        const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
                                        float* scale, float* shift, float* mean, float* invstd, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(stats_partial && gamma && beta && moving_mean && moving_var && scale && shift && mean && invstd && count > 0,
@@ -627,7 +627,7 @@ static int strip_rows_per_block(int64_t m, int c) {
     return (int)rows;
 }
 
-extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const float* stats_partial, int slots, int64_t count, const float* gamma,
+extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_partial, int slots, int64_t count, const float* gamma,
                                     const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
                                     const frcnn_bf16* res, int relu, frcnn_bf16* out, float* mean, float* invstd, int64_t m, int c,
                                     frcnn_stream_t stream) {

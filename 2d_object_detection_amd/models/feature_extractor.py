@@ -67,7 +67,9 @@ class _ConvBN:
         if training:
             self.tiles = ops.conv_stat_tiles(self.desc)
             # atomically accumulated buffers: carved from ONE flat tensor that is zeroed by a single fill per step
-            self.stats = acc(self.tiles * 2 * c).view(self.tiles, 2, c) if acc else torch.zeros(self.tiles, 2, c, **f32)
+            # f64 partial sums: the arrival order of the conv kernels' atomics does not show in the statistics
+            self.stats = (acc(self.tiles * 2 * c * 2).view(torch.float64).view(self.tiles, 2, c) if acc
+                          else torch.zeros(self.tiles, 2, c, dtype=torch.float64, device=device))
             self.mean, self.invstd = torch.empty(c, **f32), torch.empty(c, **f32)
             self.bwd_blocks = ops.bn_bwd_blocks(self.m)
             self.bwd_partial = (acc(self.bwd_blocks * 2 * c).view(self.bwd_blocks, 2, c) if acc
@@ -246,8 +248,9 @@ class FeatureExtractor:
         st = self.stem
         acc = None
         if training:
-            slots = 64                                          # FRCNN_STAT_SLOTS
-            total = sum(2 * slots * 2 * u.cout for u in self.conv_units())
+            slots = ops.STAT_SLOTS                              # FRCNN_STAT_SLOTS
+            # per BN layer: forward statistics [slots][2][c] in f64 (two floats each) + backward partial sums [slots][2][c] fp32
+            total = sum(3 * slots * 2 * u.cout for u in self.conv_units())
             self.acc_flat = torch.zeros(total, dtype=torch.float32, device=dev)
             cursor = [0]
 

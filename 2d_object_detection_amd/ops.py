@@ -40,6 +40,9 @@ def conv_desc(n, hi, wi, cin, kh, kw, stride, pad_h, pad_w, ho, wo, cout, in_pix
                     ho if out_h is None else out_h, wo if out_w is None else out_w, out_scatter, flags, split_k)
 
 
+STAT_SLOTS = 16          # FRCNN_STAT_SLOTS of include/frcnn_hip.h (checked against the library in tests/test_abi.py)
+
+
 def conv_stat_tiles(d):
     return _lib.load().frcnn_conv2d_stat_tiles(byref(d))
 

@@ -53,7 +53,8 @@ const char* frcnn_last_error(void);
 #define FRCNN_CONV_OUT_F32    4   /* y is fp32 instead of bf16 */
 #define FRCNN_CONV_ADD_RES    8   /* y = conv + res (res bf16, same addressing as y; may alias y) */
 #define FRCNN_CONV_STATS      16  /* accumulate (float atomics) the column sum / sum-of-squares of the bf16-rounded
-                                     output into stats_partial [FRCNN_STAT_SLOTS][2][cout], which must be pre-zeroed */
+                                     output into stats_partial, f64 [FRCNN_STAT_SLOTS][2][cout], which must be pre-zeroed
+                                     (f64: the arrival order of the atomics does not show in the statistics) */
 #define FRCNN_STAT_SLOTS      16
 #define FRCNN_CONV_SPLITK_ATOMIC 32 /* y (fp32, pre-zeroed) accumulated with atomics over split_k K-slices */
 typedef struct {
@@ -66,7 +67,7 @@ typedef struct {
 /* rows of the stats_partial buffer [rows][2][cout] (== FRCNN_STAT_SLOTS) */
 int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d);
 int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
-                       const frcnn_bf16* res, void* y, float* stats_partial, frcnn_stream_t stream);
+                       const frcnn_bf16* res, void* y, double* stats_partial, frcnn_stream_t stream);
 
 /* Weight gradient: dw[co,kh,kw,ci] (fp32, accumulated with atomics into a pre-zeroed buffer) =
  * sum_pixels dz[(n,oy,ox), co] * x[n, oy*stride-pad_h+kh, ox*stride-pad_w+kw, ci].
@@ -99,7 +100,7 @@ int frcnn_preprocess_u8_bgr_mean(const uint8_t* images, frcnn_bf16* out, int b, 
  * finalize_train: reduce conv stats partials [tiles][2][c] -> mean/invstd, fused scale/shift
  * (scale = gamma*invstd, shift = beta - mean*scale), and update the moving averages
  * (moving = moving*momentum + batch*(1-momentum), variance unbiased as FusedBatchNormV3). */
-int frcnn_bn_finalize_train(const float* stats_partial, int tiles, int c, int64_t count, const float* gamma,
+int frcnn_bn_finalize_train(const double* stats_partial, int tiles, int c, int64_t count, const float* gamma,
                             const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
                             float* scale, float* shift, float* mean, float* invstd, frcnn_stream_t stream);
 int frcnn_bn_finalize_eval(int c, const float* gamma, const float* beta, const float* moving_mean,
@@ -125,7 +126,7 @@ int frcnn_bn_bwd_apply(const frcnn_bf16* gout, const frcnn_bf16* act, const frcn
  * each: every workgroup reduces the partial sums of its own 64 channels).
  * train_apply    : out = [relu](z*scale + shift [+ res]); writes mean / invstd, updates the moving statistics
  * bwd_apply_fused: dz = gamma*invstd*(g - c1 - xhat*c2), gpre (optional) = g; writes dgamma / dbeta */
-int frcnn_bn_train_apply(const frcnn_bf16* z, const float* stats_partial, int slots, int64_t count, const float* gamma,
+int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_partial, int slots, int64_t count, const float* gamma,
                          const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
                          const frcnn_bf16* res, int relu, frcnn_bf16* out, float* mean, float* invstd, int64_t m, int c,
                          frcnn_stream_t stream);

@@ -53,7 +53,7 @@ def test_conv_fprop(ops, case):
     xd, wd, bd = x.to(BF).cuda(), _ohwi(wt).to(BF).cuda(), bias.cuda()
     y = torch.full((n, ho, wo, cout), float("nan"), dtype=BF, device="cuda")
     tiles = ops.conv_stat_tiles(d)
-    stats = torch.zeros(tiles, 2, cout, device="cuda")
+    stats = torch.zeros(tiles, 2, cout, dtype=torch.float64, device="cuda")
     ops.conv2d_fprop(d, xd, wd, y, bias=bd, stats=stats if case["stats"] else None)
     torch.cuda.synchronize()
     _close(y, ref, 2 ** -7, 2e-2, "conv output")

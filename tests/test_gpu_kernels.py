@@ -46,7 +46,7 @@ def test_bn_forward_backward(ops):
     dev = "cuda"
     zd = z.to(BF).to(dev)
     # stats partials as the conv epilogue would write them: 4 row blocks
-    parts = torch.zeros(4, 2, c, device=dev)
+    parts = torch.zeros(4, 2, c, dtype=torch.float64, device=dev)
     for i, blk in enumerate(z.chunk(4)):
         parts[i, 0] = blk.sum(0).to(dev)
         parts[i, 1] = (blk * blk).sum(0).to(dev)

@@ -168,11 +168,12 @@ def test_train_step_gradients_and_update(setup):
     vel = {}
     ol, _, grads, _ = O.train_step(p, vel, cfg, images, gl, gb, lr=0.01, seed=11, rpn_sample_indices=t["rpn_idx"].cpu(),
                                    rcnn_sample_indices=t["rcnn_idx"].cpu(), quant=oresnet.bf16_storage)
-    # Loss gate.  Calibration of the RCNN losses: the BatchNorm partial sums are accumulated with float atomics, so their
-    # fp32 summation order -- and with it the last bits of the feature maps (equal to 6e-6 relative) -- changes from run to
-    # run; repeated runs of the SAME binary on this batch give rcnn_cls = 3.2139 or 3.1008 (oracle 3.3349): last-bit changes
-    # of the scores reorder proposals around the NMS / IoU thresholds, so the RoI set itself moves.  10 % covers that; the
-    # RPN losses (fixed anchors) stay at 3 %.  Loss arithmetic itself is gated to 1e-4 in test_forward_pipeline.
+    # Loss gate.  Calibration of the RCNN losses: the HIP forward pass is reproducible (BatchNorm partial sums are
+    # accumulated in f64), but it sums in a different ORDER than the oracle, and last-bit changes of the feature maps
+    # (6e-6 relative) reorder proposals around the NMS / IoU thresholds, so the RoI set itself moves: three builds of this
+    # library whose conv outputs were bit-identical on 391 shapes and that differed only in the fp32 summation order of the
+    # BN statistics gave rcnn_cls = 3.2712, 3.2173 and 3.1008 on this batch (oracle 3.3349).  10 % covers that; the RPN
+    # losses (fixed anchors) stay at 3 %.  Loss arithmetic itself is gated to 1e-4 in test_forward_pipeline.
     for k in ol:
         tol = 0.10 if k.startswith("rcnn") else 0.03
         assert abs(float(losses[k]) - float(ol[k])) < tol * max(1.0, abs(float(ol[k]))), (k, float(losses[k]), float(ol[k]))
@@ -235,7 +236,8 @@ def test_graph_replay_matches_eager(setup):
         res.append((l1, w1, l2))
     (l1e, w1e, l2e), (l1g, w1g, l2g) = res
     for k in l1e:
-        # step 1: identical weights and inputs -> only float-atomic ordering differs
+        # step 1: identical weights and inputs -> only float-atomic ordering differs (the BN statistics are accumulated in
+        # f64, so the forward pass -- and with it the discrete NMS / sampling decisions -- is reproducible)
         assert abs(l1e[k] - l1g[k]) <= 1e-5 * max(1.0, abs(l1e[k])), (k, l1e[k], l1g[k])
         # step 2: a 1e-7 difference can flip a near-tied NMS order / IoU threshold (one sampled row = 1/32 of the mean)
         assert abs(l2e[k] - l2g[k]) <= 0.15 * max(1.0, abs(l2e[k])), (k, l2e[k], l2g[k])

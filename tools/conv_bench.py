@@ -25,7 +25,7 @@ def main():
     if mode == "fprop":
         d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout, flags=ops.CONV_BIAS | ops.CONV_STATS)
         y = torch.empty(m, cout, dtype=BF, device="cuda")
-        stats = torch.zeros(64, 2, cout, device="cuda")
+        stats = torch.zeros(16, 2, cout, dtype=torch.float64, device="cuda")
         fn = lambda: ops.conv2d_fprop(d, x, wt, y, bias=bias, stats=stats)
     else:
         d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout)

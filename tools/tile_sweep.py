@@ -20,7 +20,8 @@ SHAPES = [  # n, h, w, cin, cout, k, stride, pad
     (4, 24, 78, 256, 1024, 3, 1, 1), (4, 24, 78, 256, 512, 1, 1, 0), (4, 24, 78, 1024, 512, 1, 1, 0), (4, 24, 78, 256, 128, 1, 1, 0),
     (4, 24, 78, 128, 256, 1, 1, 0), (1, 16, 16, 64, 50176, 1, 1, 0),
 ]
-CONFIGS = [(bm, bn, bk, s) for bk in (64, 128) for bm in (128, 64) for bn in (128, 64) for s in (2, 3) if not (bk == 128 and s == 3)]
+CONFIGS = [(bm, bn, bk, s, 1) for bk in (64, 128) for bm in (128, 64) for bn in (128, 64) for s in (2, 3) if not (bk == 128 and s == 3)]
+CONFIGS += [(bm, bn, 64, 2, t) for (bm, bn) in ((128, 64), (128, 128), (64, 64)) for t in (2, 4, 8)]      # tile runs
 
 
 def main():
@@ -33,13 +34,13 @@ def main():
         wt = (torch.randn(cout, k, k, cin, device="cuda", generator=g) / (cin * k * k) ** 0.5).to(BF)
         bias = torch.zeros(cout, device="cuda")
         y = torch.empty(m, cout, dtype=BF, device="cuda")
-        stats = torch.zeros(64, 2, cout, device="cuda")
+        stats = torch.zeros(16, 2, cout, dtype=torch.float64, device="cuda")
         d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout, flags=ops.CONV_BIAS | ops.CONV_STATS)
         res = []
         for cfg in CONFIGS:
             if cin % cfg[2] != 0 or (cfg[1] == 128 and cout < 128):
                 continue
-            os.environ["FRCNN_TILE"] = "%d,%d,%d,%d" % cfg
+            os.environ["FRCNN_TILE"] = "%d,%d,%d,%d,%d" % cfg
             try:
                 for _ in range(2):
                     ops.conv2d_fprop(d, x, wt, y, bias=bias, stats=stats)
