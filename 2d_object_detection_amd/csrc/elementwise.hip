@@ -118,71 +118,64 @@ __global__ void bn_apply_kernel(const bf16_t* __restrict__ z, const float* __res
 }
 
 // ---------------------------------------------------------------- BN backward
-// Block = 256 threads arranged as (C8 lanes over channel vectors) x (256/C8 row lanes) when C8 <= 256.
-// Generic layout: thread handles channel-vector cv = tid % C8L and rows rl, rl+RL, ... of its block slab.
-// rows per reduce block are chosen per launch so that even the small-M conv4 layers start ~1000 workgroups
+// reduce: grid = (64-channel strips, row chunks), 256 threads = 8 channel vectors x 32 row lanes.  A thread keeps mean /
+// invstd of its 8 channels in registers and streams its rows with independent 16-byte loads (unrolled: 12 loads in flight per
+// thread); the 32 row lanes meet in an LDS tree and the workgroup adds its 2 x 64 partial sums to one of
+// FRCNN_STAT_SLOTS pre-zeroed slots with coalesced float atomics (consecutive lanes: consecutive channels).
 template <bool MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ act,
                                                             const bf16_t* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ part,
                                                             int64_t M, int C, int rows_per_block) {
-    // one block reduces rows_per_block rows for all channels; channel vectors are looped when C8 > 256
-    extern __shared__ float red[];      // [256][16] floats
-    const int C8 = C / 8;
-    const int64_t row_begin = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
-    const int lanes_c = C8 < 256 ? C8 : 256;
-    const int RL = 256 / lanes_c;       // row lanes
-    for (int cv0 = 0; cv0 < C8; cv0 += lanes_c) {
-        const int cl = threadIdx.x % lanes_c, rl = threadIdx.x / lanes_c;
-        const int cv = cv0 + cl;
-        float sg[8], sgx[8];
+    __shared__ float red[32][8][17];             // [row lane][vector][16 sums + pad]
+    const int c0 = blockIdx.x * 64;
+    const int v = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int C8 = C / 8, cv = c0 / 8 + v;
+    float sg[8], sgx[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sg[e] = sgx[e] = 0.f;
-        if (cv < C8 && rl < RL) {
-            float mu[8], is[8];
+    for (int e = 0; e < 8; ++e) sg[e] = sgx[e] = 0.f;
+    if (cv < C8) {
+        float mu[8], is[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { mu[e] = mean[cv * 8 + e]; is[e] = invstd[cv * 8 + e]; }
-            for (int64_t r = row_begin + rl; r < row_end; r += RL) {
-                float g[8], zz[8];
-                unpack8(*reinterpret_cast<const u32x4*>(gout + (r * C8 + cv) * 8), g);
-                unpack8(*reinterpret_cast<const u32x4*>(z + (r * C8 + cv) * 8), zz);
-                if (MASK) {
-                    float a[8];
-                    unpack8(*reinterpret_cast<const u32x4*>(act + (r * C8 + cv) * 8), a);
+        for (int e = 0; e < 8; ++e) { mu[e] = mean[cv * 8 + e]; is[e] = invstd[cv * 8 + e]; }
+        const int64_t row_begin = (int64_t)blockIdx.y * rows_per_block;
+        const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
+#pragma unroll 4
+        for (int64_t r = row_begin + rl; r < row_end; r += 32) {
+            const int64_t i = r * C8 + cv;
+            float g[8], zz[8];
+            unpack8(*reinterpret_cast<const u32x4*>(gout + i * 8), g);
+            unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), zz);
+            if (MASK) {
+                float a[8];
+                unpack8(*reinterpret_cast<const u32x4*>(act + i * 8), a);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
-                }
+                for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+            }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    sg[e] += g[e];
-                    sgx[e] += g[e] * ((zz[e] - mu[e]) * is[e]);
-                }
+            for (int e = 0; e < 8; ++e) {
+                sg[e] += g[e];
+                sgx[e] += g[e] * ((zz[e] - mu[e]) * is[e]);
             }
         }
-        // reduce over row lanes through LDS
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = sg[e]; red[threadIdx.x * 16 + 8 + e] = sgx[e]; }
-        __syncthreads();
-        // tree over the RL row lanes (RL is a power of two): all 256 threads take part, no serial tail for narrow C
-        for (int s = RL >> 1; s > 0; s >>= 1) {
-            if (rl < s) {
+    for (int e = 0; e < 8; ++e) { red[rl][v][e] = sg[e]; red[rl][v][8 + e] = sgx[e]; }
+    __syncthreads();
+    for (int s = 16; s > 0; s >>= 1) {
+        if (rl < s) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) red[threadIdx.x * 16 + e] += red[(threadIdx.x + s * lanes_c) * 16 + e];
-            }
-            __syncthreads();
-        }
-        // accumulate into one of FRCNN_STAT_SLOTS pre-zeroed slots.  Shape the float atomics: consecutive lanes add
-        // consecutive channels (256 contiguous bytes per wave instruction); a lane-per-row pattern is ~17x slower.
-        {
-            float* slot = part + ((int64_t)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2) * C + cv0 * 8;
-            const int nch = min(lanes_c, C8 - cv0) * 8;           // channels of this pass
-            for (int idx = threadIdx.x; idx < 2 * nch; idx += 256) {
-                const int stat = idx >= nch ? 1 : 0, c = idx - stat * nch;
-                atomicAdd(slot + stat * C + c, red[(c >> 3) * 16 + stat * 8 + (c & 7)]);
-            }
+            for (int e = 0; e < 16; ++e) red[rl][v][e] += red[rl + s][v][e];
         }
         __syncthreads();
+    }
+    if (threadIdx.x < 128) {
+        const int stat = threadIdx.x >> 6, cl = threadIdx.x & 63;
+        const int c = c0 + cl;
+        if (c < C) {
+            const int slot = (int)((blockIdx.y * gridDim.x + blockIdx.x) & (FRCNN_STAT_SLOTS - 1));
+            atomicAdd(part + ((int64_t)slot * 2 + stat) * C + c, red[0][cl >> 3][stat * 8 + (cl & 7)]);
+        }
     }
 }
 
@@ -665,25 +658,15 @@ extern "C" int frcnn_bn_bwd_blocks(int64_t m) { (void)m; return FRCNN_STAT_SLOTS
 
 extern "C" int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act, const frcnn_bf16* z, const float* mean,
                                    const float* invstd, float* partial, int64_t m, int c, frcnn_stream_t stream) {
-    FRCNN_CHECK_ARG(gout && z && mean && invstd && partial && c % 8 == 0, "bn_bwd_reduce: bad arguments");
-    const int c8 = c / 8;
-    FRCNN_CHECK_ARG(c8 >= 256 ? (c8 % 256 == 0) : (256 % c8 == 0), "bn_bwd_reduce: c/8=%d must divide or be a multiple of 256", c8);
-    // row blocks (they fold into FRCNN_STAT_SLOTS slots): ~1024 workgroups, at least one row per row lane
-    const int row_lanes = c8 < 256 ? 256 / c8 : 1;
-    int64_t target_blocks = m / 64;                              // each block ends with 2*C float atomics: keep them few
-    if (target_blocks < 256) target_blocks = 256;
-    if (target_blocks > 1024) target_blocks = 1024;
-    int rows_per_block = (int)((m + target_blocks - 1) / target_blocks);
-    if (rows_per_block < row_lanes) rows_per_block = row_lanes;
-    if (rows_per_block < 8) rows_per_block = 8;
-    const int blocks = (int)((m + rows_per_block - 1) / rows_per_block);
-    const size_t smem = 256 * 16 * sizeof(float);
+    FRCNN_CHECK_ARG(gout && z && mean && invstd && partial && c % 8 == 0 && m > 0, "bn_bwd_reduce: bad arguments");
+    const int rows = strip_rows_per_block(m, c);
+    const dim3 grid((c + 63) / 64, (unsigned)((m + rows - 1) / rows));
     if (act)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), smem, S_(stream), CBF(gout), CBF(act), CBF(z), mean,
-                           invstd, partial, m, c, rows_per_block);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, S_(stream), CBF(gout), CBF(act), CBF(z), mean, invstd,
+                           partial, m, c, rows);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), smem, S_(stream), CBF(gout), CBF(act), CBF(z), mean,
-                           invstd, partial, m, c, rows_per_block);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, S_(stream), CBF(gout), CBF(act), CBF(z), mean, invstd,
+                           partial, m, c, rows);
     FRCNN_CHECK_LAUNCH("bn_bwd_reduce");
     return FRCNN_OK;
 }
