@@ -25,7 +25,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     constexpr int A_IT = (A_INSTR + NW - 1) / NW, B_IT = (B_INSTR + NW - 1) / NW;
     constexpr bool A_UNI = A_INSTR % NW == 0, B_UNI = B_INSTR % NW == 0;
     constexpr int LC = A_INSTR / NW + B_INSTR / NW;
-    static_assert(S == 2 || (S == 3 && A_UNI && B_UNI), "counted waits need a uniform DMA split");
+    static_assert(S == 2 || (S >= 3 && S <= 6 && A_UNI && B_UNI), "counted waits need a uniform DMA split");
     static_assert(!MULTI || (S == 2 && A_UNI && B_UNI), "tile runs use the two-slot ring with a uniform DMA split");
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, KK = BK / 32;
     static_assert(MI >= 1 && NI >= 1, "tile too small for 8 waves");
@@ -435,7 +435,7 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
     int bm = 128;
     const long long tiles_m128 = (M + 127) / 128;
     int bn = (d->cout >= 128 && tiles_m128 * ((d->cout + 127) / 128) >= 200) ? 128 : 64;
-    int stages = (bn == 64 && bk == 64 && p.Ktot / bk >= 64) ? 3 : 2;
+    int stages = (bn == 64 && bk == 64 && p.Ktot / bk >= 8) ? 3 : 2;     // (cold-cache sweep: the third slot pays from 8 slices on)
     // short K (<= 4 slices): runs of consecutive m-tiles per workgroup -- the ring prefetches the next tile under the
     // epilogue, bias / statistics / addressing are set up once per run; narrow tiles keep two workgroups per CU
     int tpb = 1;                                                // tiles per workgroup (1: one-tile kernel)
@@ -478,6 +478,10 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
     FRCNN_TILE(128, 64, 64, 3, 2)
     FRCNN_TILE(64, 128, 64, 3, 2)
     FRCNN_TILE(64, 64, 64, 3, 2)
+    FRCNN_TILE(128, 64, 64, 4, 1)
+    FRCNN_TILE(128, 64, 64, 6, 1)
+    FRCNN_TILE(128, 128, 64, 4, 1)
+    FRCNN_TILE(64, 64, 64, 6, 1)
 #undef FRCNN_TILE
 #undef FRCNN_RUN
     return FRCNN_ENOTSUP;

@@ -151,6 +151,7 @@ def main():
 
     rank, world, local_rank = D.init_from_env()
     assert world == args.gpus, "launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    local_rank = int(os.environ.get("FRCNN_BENCH_DEVICE", local_rank))      # (rehearsals: several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cfg = C.default_config()                                   # 375 x 1242, 7 classes, reference hyper-parameters

@@ -21,13 +21,24 @@ SHAPES = [  # n, h, w, cin, cout, k, stride, pad
     (4, 24, 78, 128, 256, 1, 1, 0), (1, 16, 16, 64, 50176, 1, 1, 0),
 ]
 CONFIGS = [(bm, bn, bk, s, 1) for bk in (64, 128) for bm in (128, 64) for bn in (128, 64) for s in (2, 3) if not (bk == 128 and s == 3)]
-CONFIGS += [(bm, bn, 64, 2, t) for (bm, bn) in ((128, 64), (128, 128), (64, 64)) for t in (2, 4, 8)]      # tile runs
+CONFIGS += [(128, 64, 64, 4, 1), (128, 64, 64, 6, 1), (128, 128, 64, 4, 1), (64, 64, 64, 6, 1)]               # deep rings
+CONFIGS += [(bm, bn, 64, 2, t) for (bm, bn) in ((128, 64), (128, 128), (64, 64)) for t in (2, 4, 8, 16)]      # tile runs
+
+
+COLD = "--cold" in sys.argv
+FLUSH = None
 
 
 def main():
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    global FLUSH
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
+    if COLD:
+        FLUSH = torch.zeros(160 * 1024 * 1024, device="cuda")
     g = torch.Generator(device="cuda").manual_seed(0)
+    only = [a for a in sys.argv[1:] if a.startswith("--m=")]
     for (n, h, w, cin, cout, k, s, p) in SHAPES[1:]:
+        if only and str(n * ((h + 2 * p - k) // s + 1) * ((w + 2 * p - k) // s + 1)) != only[0][4:]:
+            continue
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         m = n * ho * wo
         x = torch.randn(n, h, w, cin, device="cuda", generator=g).to(BF)
@@ -45,6 +56,20 @@ def main():
                 for _ in range(2):
                     ops.conv2d_fprop(d, x, wt, y, bias=bias, stats=stats)
                 torch.cuda.synchronize()
+                if COLD:
+                    # one call at a time behind a 640 MB write that evicts L2 and the Infinity Cache: in the training step
+                    # every layer finds its operands in HBM, not in the caches a back-to-back loop keeps warm
+                    tot = 0.0
+                    for _ in range(iters):
+                        FLUSH.add_(1.0)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        ops.conv2d_fprop(d, x, wt, y, bias=bias, stats=stats)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        tot += e0.elapsed_time(e1) * 1e3
+                    res.append((tot / iters, cfg))
+                    continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(iters):
