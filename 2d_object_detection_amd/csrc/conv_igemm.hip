@@ -688,8 +688,8 @@ extern "C" int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x,
         p.y_bytes = p.direct_out ? (unsigned)yb : 0u;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (!(flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC))) {
-        // bf16 output: one tile per workgroup (conv_tile.hip) unless no instantiation fits
+    {
+        // one tile (or a run of tiles) per workgroup (conv_tile.hip) unless no instantiation fits
         const char* sel = getenv("FRCNN_TILE_KERNEL");              // "0": force the general kernel (A/B testing aid)
         const bool use_tile = !(sel && sel[0] == '0');
         if (use_tile) {

@@ -15,7 +15,7 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI>
+template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI, bool F32>
 __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = 8, T = 512, WM = 2, WN = 4;
@@ -27,6 +27,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     constexpr int LC = A_INSTR / NW + B_INSTR / NW;
     static_assert(S == 2 || (S >= 3 && S <= 6 && A_UNI && B_UNI), "counted waits need a uniform DMA split");
     static_assert(!MULTI || (S == 2 && A_UNI && B_UNI), "tile runs use the two-slot ring with a uniform DMA split");
+    static_assert(!F32 || (!MULTI && !STATS), "fp32 / split-K output: one tile per workgroup, no statistics");
+    constexpr int STG32 = BM * (BN * 4 + 16);   // fp32 staging tile (F32)
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, KK = BK / 32;
     static_assert(MI >= 1 && NI >= 1, "tile too small for 8 waves");
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     // one tile per workgroup: the staging tile aliases the drained ring.  Tile runs (MULTI): the ring keeps prefetching the
     // next tile while the epilogue runs, so the staging tile has its own LDS.
     constexpr int STAGE_OFF = MULTI ? RING : 0;
-    constexpr int BIG = MULTI ? RING + STG : (RING > STG ? RING : STG);
+    constexpr int BIG = F32 ? (RING > STG32 ? RING : STG32) : MULTI ? RING + STG : (RING > STG ? RING : STG);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;                  // [S A tiles][S B tiles]
@@ -129,10 +131,12 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
         const int n = n0 + r;
         b_voff[i] = (n < p.Cout && r < BN) ? (unsigned)n * (unsigned)(p.Ktot * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
     }
-    const int nk = p.k_tiles;
-    int ld_c0 = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0;
+    // F32: blockIdx.y selects a K range of k_tiles_per_split slices (split-K, 1x1 filters only)
+    const int kt0 = F32 ? blockIdx.y * p.k_tiles_per_split : 0;
+    const int nk = F32 ? min(p.k_tiles, kt0 + p.k_tiles_per_split) - kt0 : p.k_tiles;
+    int ld_c0 = kt0 * BK, ld_tap = 0, ld_kh = 0, ld_kw = 0;
     int ld_k = 0, ld_m0 = tm_begin * BM;         // loader position: K slice inside its tile, first row of its tile
-    unsigned ld_soff_a = 0, ld_soff_b = 0;
+    unsigned ld_soff_a = (unsigned)(kt0 * BK * 2), ld_soff_b = (unsigned)(kt0 * BK * 2);
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     auto issue_slice = [&](const int slot) {     // DMA the loader's next K slice into ring slot
@@ -274,6 +278,41 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
 
         // -------------------------------------------------------------- epilogue of tile t
         // lane holds, for fragment (i,j): pixel = wm*WTM + i*16 + (lane&15); couts = wn*WTN + j*16 + (lane>>4)*4 + 0..3
+        if (F32) {
+            // fp32 output (RPN heads) / split-K partial sums (Dense heads): the tile is staged in the drained ring and leaves
+            // with whole rows -- 64 lanes x 4 B = 256 contiguous bytes per store / float-atomic wave instruction
+            constexpr int ROW32 = BN * 4 + 16;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int r = wm * WTM + i * 16 + frow;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int cl = wn * WTN + j * 16 + fchunk * 4;
+                    f32x4 v = acc[i][j];
+                    if (blockIdx.y == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bv[j][e];
+                    }
+                    if (flags & FRCNN_CONV_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *reinterpret_cast<f32x4*>(smem + r * ROW32 + cl * 4) = v;
+                }
+            }
+            __syncthreads();
+            float* y = reinterpret_cast<float*>(p.y);
+            for (int idx = tid; idx < BM * BN; idx += T) {
+                const int r = idx / BN, c = idx - r * BN;
+                const int m = m0 + r;
+                if (m < p.M && n0 + c < p.Cout) {
+                    const float v = *reinterpret_cast<const float*>(smem + r * ROW32 + c * 4);
+                    if (flags & FRCNN_CONV_SPLITK_ATOMIC) atomicAdd(y + (long long)m * p.Cout + n0 + c, v);
+                    else y[(long long)m * p.Cout + n0 + c] = v;
+                }
+            }
+            continue;
+        }
         const bool tail = m0 + BM > p.M;
         const unsigned tile_off = (unsigned)((m0 * p.Cout + n0) * 2);
         u32x4 resv[ST_IT];
@@ -397,17 +436,17 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
 #endif
 }
 
-template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI>
+template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI, bool F32 = false>
 int launch_tile(const ConvParams& p, hipStream_t s) {
-    constexpr int ring = S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16);
-    constexpr int smem = (MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4;
+    constexpr int ring = S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
+    constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4;
     static_assert(smem <= 163840, "LDS budget");
     static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
-    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI>), smem) != 0) {
+    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI, F32>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
-    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI>), dim3(p.items), dim3(512), smem, s, p);
+    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI, F32>), dim3(p.items, F32 ? p.split : 1), dim3(512), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
     return FRCNN_OK;
 }
@@ -426,7 +465,21 @@ int launch_tile_flags(const ConvParams& p, hipStream_t s) {
 // (the caller then uses the general persistent kernel).
 int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipStream_t s) {
     ConvParams p = *reinterpret_cast<const ConvParams*>(params);      // private copy: the caller falls back on ENOTSUP
-    if (p.taps > 32 || d->split_k > 1) return FRCNN_ENOTSUP;
+    if (p.taps > 32) return FRCNN_ENOTSUP;
+    if (p.flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC)) {
+        // fp32 output / split-K partial sums: 1x1 filters whose output rows are the GEMM rows, K a multiple of 64
+        if (p.taps != 1 || !p.linear_a || d->cin % 64 != 0 || (p.flags & (FRCNN_CONV_STATS | FRCNN_CONV_ADD_RES))) return FRCNN_ENOTSUP;
+        p.k_tiles = p.Ktot / 64;
+        int split = d->split_k > 1 ? d->split_k : 1;
+        p.k_tiles_per_split = (p.k_tiles + split - 1) / split;
+        p.split = (p.k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
+        p.tiles_m = (p.M + 127) / 128;
+        p.tiles_n = (d->cout + 63) / 64;
+        p.tiles_per_block = 1;
+        p.items = p.tiles_m * p.tiles_n;
+        return launch_tile<128, 64, 64, 3, true, false, 2, false, true>(p, s);
+    }
+    if (d->split_k > 1) return FRCNN_ENOTSUP;
     // measured on the R50-C4 layer shapes (tools/tile_sweep.py): 128-row tiles and BK = 64 win almost everywhere (two
     // workgroups per CU); 128 output channels per tile once that still leaves >= ~200 tiles, else 64; a third ring slot
     // only pays on very long K with the narrow tile

@@ -259,6 +259,9 @@ class FasterRCNN:
         self._feed(built, images, gt_labels, gt_boxes)
         plan = built["plan"]
         nseg = len(plan.segments)
+        if sync_fn is None and plan.captured:
+            plan.replay()                        # nothing to interleave between segments: the whole step is one graph
+            return self._losses_dict(built), built["preds"]
         for i in range(nseg):
             if plan.captured:
                 plan.replay_segment(i)

@@ -42,6 +42,7 @@ class Plan:
         self.segment_names = ["main"]
         self.keep = []            # buffers owned by the plan
         self._graphs = None
+        self._whole = None
         self._branch = None
         self._streams = {}
 
@@ -117,14 +118,18 @@ class Plan:
             pool = g.pool()
             graphs.append(g)
         self._graphs = graphs
+        # the whole step as ONE graph for callers that do not interleave anything between segments (single GPU)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool):
+            self.run()
+        self._whole = g
         return graphs
 
     def replay_segment(self, i):
         self._graphs[i].replay()
 
     def replay(self):
-        for g in self._graphs:
-            g.replay()
+        self._whole.replay()
 
     @property
     def captured(self):

@@ -62,13 +62,17 @@ def profile_conv_kernels(model, built, steps=3):
             if fn is ops.conv2d_fprop or fn is ops.conv2d_wgrad:
                 d = args[0]
                 cin, cout = true_dims(d, fn)
-                name = "igemm_kernel(fprop/dgrad)" if fn is ops.conv2d_fprop else "wgrad_kernel"
+                name = "conv fprop/dgrad (conv_tile_kernel, igemm_kernel)" if fn is ops.conv2d_fprop else "conv wgrad (wgrad_kernel)"
                 records.append((fn, args, kwargs, name, conv_flops(d, cin, cout)))
             else:
                 records.append((fn, args, kwargs, None, 0.0))
     state = model._snapshot(built["optimizer"])
     events = []
     for it in range(steps + 1):
+        # Let the host run ahead: a ~30 ms device-side spin is enqueued first, so every event record and launch of the step
+        # is already queued when the GPU reaches it.  Otherwise each event pair would also time the 5-10 us the stream
+        # idles between an eager launch and the start of its kernel (a graph replay has no such gaps).
+        torch.cuda._sleep(60_000_000)
         for fn, args, kwargs, name, fl in records:
             if name is None:
                 fn(*args, **kwargs)
