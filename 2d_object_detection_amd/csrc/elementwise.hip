@@ -122,8 +122,8 @@ __global__ void bn_apply_kernel(const bf16_t* __restrict__ z, const float* __res
 // invstd of its 8 channels in registers and streams its rows with independent 16-byte loads (unrolled: 12 loads in flight per
 // thread); the 32 row lanes meet in an LDS tree and the workgroup adds its 2 x 64 partial sums to one of
 // FRCNN_STAT_SLOTS pre-zeroed slots with coalesced float atomics (consecutive lanes: consecutive channels).
-template <bool MASK>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ act,
+template <int MASK>    // 0: no ReLU, 1: mask from the activation tensor, 2: mask from the forward pass's bit mask
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gout, const void* __restrict__ act,
                                                             const bf16_t* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ part,
                                                             int64_t M, int C, int rows_per_block) {
@@ -146,11 +146,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
             float g[8], zz[8];
             unpack8(*reinterpret_cast<const u32x4*>(gout + i * 8), g);
             unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), zz);
-            if (MASK) {
+            if (MASK == 1) {
                 float a[8];
-                unpack8(*reinterpret_cast<const u32x4*>(act + i * 8), a);
+                unpack8(*reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(act) + i * 8), a);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+            } else if (MASK == 2) {
+                const unsigned m = reinterpret_cast<const uint8_t*>(act)[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -212,8 +216,9 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
                                                              float inv_count, float unbias, const bf16_t* __restrict__ res, int relu,
-                                                             bf16_t* __restrict__ out, float* __restrict__ mean_o,
-                                                             float* __restrict__ invstd_o, int64_t M, int C, int rows_per_block) {
+                                                             bf16_t* __restrict__ out, uint8_t* __restrict__ relu_mask,
+                                                             float* __restrict__ mean_o, float* __restrict__ invstd_o, int64_t M, int C,
+                                                             int rows_per_block) {
     __shared__ double red[2][4][64];
     __shared__ float s_scale[64], s_shift[64];
     const int c0 = blockIdx.x * 64;
@@ -273,14 +278,26 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
         }
-        *reinterpret_cast<u32x4*>(out + i * 8) = pack8(x);
+        const u32x4 pk = pack8(x);
+        *reinterpret_cast<u32x4*>(out + i * 8) = pk;
+        if (relu_mask) {
+            // one bit per element: (stored bf16 activation > 0), i.e. exactly what the backward pass would derive from the
+            // activation itself -- it reads this byte instead of the 16-byte activation vector (twice)
+            unsigned m = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                m |= ((pk[q] & 0x7FFFu) != 0u && !(pk[q] & 0x8000u)) ? (1u << (2 * q)) : 0u;
+                m |= ((pk[q] & 0x7FFF0000u) != 0u && !(pk[q] & 0x80000000u)) ? (1u << (2 * q + 1)) : 0u;
+            }
+            relu_mask[i] = (uint8_t)m;
+        }
     }
 }
 
 // fused BN backward finalize + apply: c1 = sum(g)/m, c2 = sum(g*xhat)/m of the workgroup's 64 channels from the reduce
 // kernel's slot partials; the row-chunk-0 workgroups publish dgamma / dbeta.
-template <bool MASK>
-__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ act,
+template <int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* __restrict__ gout, const void* __restrict__ act,
                                                                  const bf16_t* __restrict__ z, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                  const float* __restrict__ part, int slots, float inv_m,
@@ -336,11 +353,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
         float g[8], zz[8], o[8];
         unpack8(*reinterpret_cast<const u32x4*>(gout + i * 8), g);
         unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), zz);
-        if (MASK) {
+        if (MASK == 1) {
             float a[8];
-            unpack8(*reinterpret_cast<const u32x4*>(act + i * 8), a);
+            unpack8(*reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(act) + i * 8), a);
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+        } else if (MASK == 2) {
+            const unsigned m = reinterpret_cast<const uint8_t*>(act)[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -622,8 +643,8 @@ static int strip_rows_per_block(int64_t m, int c) {
 
 extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_partial, int slots, int64_t count, const float* gamma,
                                     const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
-                                    const frcnn_bf16* res, int relu, frcnn_bf16* out, float* mean, float* invstd, int64_t m, int c,
-                                    frcnn_stream_t stream) {
+                                    const frcnn_bf16* res, int relu, frcnn_bf16* out, uint8_t* relu_mask, float* mean, float* invstd,
+                                    int64_t m, int c, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(z && stats_partial && gamma && beta && moving_mean && moving_var && out && mean && invstd && count > 0 &&
                         slots > 0 && c % 8 == 0,
                     "bn_train_apply: bad arguments");
@@ -631,42 +652,47 @@ extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_par
     const int rows = strip_rows_per_block(m, c);
     const dim3 grid((c + 63) / 64, (unsigned)((m + rows - 1) / rows));
     hipLaunchKernelGGL(bn_train_apply_kernel, grid, dim3(256), 0, S_(stream), CBF(z), stats_partial, slots, gamma, beta, moving_mean,
-                       moving_var, momentum, eps, (float)(1.0 / (double)count), unbias, CBF(res), relu, BF(out), mean, invstd, m, c, rows);
+                       moving_var, momentum, eps, (float)(1.0 / (double)count), unbias, CBF(res), relu, BF(out), relu_mask, mean, invstd,
+                       m, c, rows);
     FRCNN_CHECK_LAUNCH("bn_train_apply");
     return FRCNN_OK;
 }
 
-extern "C" int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const frcnn_bf16* z, const float* mean,
-                                        const float* invstd, const float* gamma, const float* partial, int slots, float* dgamma,
-                                        float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, frcnn_stream_t stream) {
-    FRCNN_CHECK_ARG(gout && z && mean && invstd && gamma && partial && dgamma && dbeta && dz && m > 0 && slots > 0 && c % 8 == 0,
+extern "C" int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z,
+                                        const float* mean, const float* invstd, const float* gamma, const float* partial, int slots,
+                                        float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c,
+                                        frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(gout && z && mean && invstd && gamma && partial && dgamma && dbeta && dz && m > 0 && slots > 0 && c % 8 == 0 &&
+                        !(act && relu_mask),
                     "bn_bwd_apply_fused: bad arguments");
     const int rows = strip_rows_per_block(m, c);
     const dim3 grid((c + 63) / 64, (unsigned)((m + rows - 1) / rows));
     const float inv_m = (float)(1.0 / (double)m);
-    if (act)
-        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<true>, grid, dim3(256), 0, S_(stream), CBF(gout), CBF(act), CBF(z), mean, invstd,
-                           gamma, partial, slots, inv_m, dgamma, dbeta, BF(dz), BF(gpre), m, c, rows);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<false>, grid, dim3(256), 0, S_(stream), CBF(gout), CBF(act), CBF(z), mean, invstd,
-                           gamma, partial, slots, inv_m, dgamma, dbeta, BF(dz), BF(gpre), m, c, rows);
+#define FRCNN_LAUNCH(MODE, PTR)                                                                                                      \
+    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<MODE>, grid, dim3(256), 0, S_(stream), CBF(gout), (const void*)(PTR), CBF(z), mean, \
+                       invstd, gamma, partial, slots, inv_m, dgamma, dbeta, BF(dz), BF(gpre), m, c, rows)
+    if (relu_mask) FRCNN_LAUNCH(2, relu_mask);
+    else if (act) FRCNN_LAUNCH(1, act);
+    else FRCNN_LAUNCH(0, nullptr);
+#undef FRCNN_LAUNCH
     FRCNN_CHECK_LAUNCH("bn_bwd_apply_fused");
     return FRCNN_OK;
 }
 
 extern "C" int frcnn_bn_bwd_blocks(int64_t m) { (void)m; return FRCNN_STAT_SLOTS; }
 
-extern "C" int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act, const frcnn_bf16* z, const float* mean,
-                                   const float* invstd, float* partial, int64_t m, int c, frcnn_stream_t stream) {
-    FRCNN_CHECK_ARG(gout && z && mean && invstd && partial && c % 8 == 0 && m > 0, "bn_bwd_reduce: bad arguments");
+extern "C" int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z,
+                                   const float* mean, const float* invstd, float* partial, int64_t m, int c, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(gout && z && mean && invstd && partial && c % 8 == 0 && m > 0 && !(act && relu_mask), "bn_bwd_reduce: bad arguments");
     const int rows = strip_rows_per_block(m, c);
     const dim3 grid((c + 63) / 64, (unsigned)((m + rows - 1) / rows));
-    if (act)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, S_(stream), CBF(gout), CBF(act), CBF(z), mean, invstd,
-                           partial, m, c, rows);
-    else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, S_(stream), CBF(gout), CBF(act), CBF(z), mean, invstd,
-                           partial, m, c, rows);
+#define FRCNN_LAUNCH(MODE, PTR)                                                                                                    \
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<MODE>, grid, dim3(256), 0, S_(stream), CBF(gout), (const void*)(PTR), CBF(z), mean, invstd, \
+                       partial, m, c, rows)
+    if (relu_mask) FRCNN_LAUNCH(2, relu_mask);
+    else if (act) FRCNN_LAUNCH(1, act);
+    else FRCNN_LAUNCH(0, nullptr);
+#undef FRCNN_LAUNCH
     FRCNN_CHECK_LAUNCH("bn_bwd_reduce");
     return FRCNN_OK;
 }

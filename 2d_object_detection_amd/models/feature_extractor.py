@@ -76,6 +76,8 @@ class _ConvBN:
                                 else torch.zeros(self.bwd_blocks, 2, c, **f32))
             self.c1, self.c2 = torch.empty(c, **f32), torch.empty(c, **f32)
             self.dz = torch.empty(self.m, c, dtype=BF16, device=device)
+            # ReLU bit mask written by the forward BN kernel: the backward kernels read 1 bit instead of 16 per element
+            self.relu_mask = torch.empty(self.m, c // 8, dtype=torch.uint8, device=device)
 
     def refresh_weights(self, plan):
         """(re)build the derived bf16 weight forms from the fp32 masters."""
@@ -104,17 +106,18 @@ class _ConvBN:
             st = self.store
             plan.add(ops.bn_train_apply, self.z, self.stats, self.tiles, self.m, st.weight(self.name + "_bn/gamma"),
                      st.weight(self.name + "_bn/beta"), self.mm, self.mv, BN_MOMENTUM, BN_EPS, out, self.mean, self.invstd, self.m,
-                     self.cout, res=res, relu=relu)
+                     self.cout, res=res, relu=relu, relu_mask=self.relu_mask if relu else None)
         else:
             plan.add(ops.bn_apply, self.z, self.scale, self.shift, out, self.m, self.cout, res=res, relu=relu)
 
     # -- backward: gout (grad of the BN[+res][+relu] output), act = that output (None when no ReLU)
     def backward_bn(self, plan, gout, act, gpre=None):
         st = self.store
-        plan.add(ops.bn_bwd_reduce, gout, act, self.z, self.mean, self.invstd, self.bwd_partial, self.m, self.cout)
-        plan.add(ops.bn_bwd_apply_fused, gout, act, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"),
+        mask = self.relu_mask if act is not None else None       # (act only says whether the layer ends in a ReLU)
+        plan.add(ops.bn_bwd_reduce, gout, None, self.z, self.mean, self.invstd, self.bwd_partial, self.m, self.cout, relu_mask=mask)
+        plan.add(ops.bn_bwd_apply_fused, gout, None, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"),
                  self.bwd_partial, self.bwd_blocks, st.grad(self.name + "_bn/gamma"), st.grad(self.name + "_bn/beta"), self.dz, gpre,
-                 self.m, self.cout)
+                 self.m, self.cout, relu_mask=mask)
         # the conv bias feeds a training-mode BN: its gradient is identically zero (flat grad buffer is pre-zeroed)
 
     def backward_weights(self, plan, x):

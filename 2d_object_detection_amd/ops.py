@@ -104,22 +104,23 @@ def bn_apply(z, scale, shift, out, m, c, res=None, relu=True):
     call("frcnn_bn_apply", _p(z), _p(scale), _p(shift), _p(res), 1 if relu else 0, _p(out), m, c, _stream())
 
 
-def bn_train_apply(z, stats, slots, count, gamma, beta, mm, mv, momentum, eps, out, mean, invstd, m, c, res=None, relu=True):
+def bn_train_apply(z, stats, slots, count, gamma, beta, mm, mv, momentum, eps, out, mean, invstd, m, c, res=None, relu=True,
+                   relu_mask=None):
     call("frcnn_bn_train_apply", _p(z), _p(stats), slots, count, _p(gamma), _p(beta), _p(mm), _p(mv), momentum, eps, _p(res),
-         1 if relu else 0, _p(out), _p(mean), _p(invstd), m, c, _stream())
+         1 if relu else 0, _p(out), _p(relu_mask), _p(mean), _p(invstd), m, c, _stream())
 
 
-def bn_bwd_apply_fused(gout, act, z, mean, invstd, gamma, partial, slots, dgamma, dbeta, dz, gpre, m, c):
-    call("frcnn_bn_bwd_apply_fused", _p(gout), _p(act), _p(z), _p(mean), _p(invstd), _p(gamma), _p(partial), slots, _p(dgamma),
-         _p(dbeta), _p(dz), _p(gpre), m, c, _stream())
+def bn_bwd_apply_fused(gout, act, z, mean, invstd, gamma, partial, slots, dgamma, dbeta, dz, gpre, m, c, relu_mask=None):
+    call("frcnn_bn_bwd_apply_fused", _p(gout), _p(act), _p(relu_mask), _p(z), _p(mean), _p(invstd), _p(gamma), _p(partial), slots,
+         _p(dgamma), _p(dbeta), _p(dz), _p(gpre), m, c, _stream())
 
 
 def bn_bwd_blocks(m):
     return _lib.load().frcnn_bn_bwd_blocks(m)
 
 
-def bn_bwd_reduce(gout, act, z, mean, invstd, partial, m, c):
-    call("frcnn_bn_bwd_reduce", _p(gout), _p(act), _p(z), _p(mean), _p(invstd), _p(partial), m, c, _stream())
+def bn_bwd_reduce(gout, act, z, mean, invstd, partial, m, c, relu_mask=None):
+    call("frcnn_bn_bwd_reduce", _p(gout), _p(act), _p(relu_mask), _p(z), _p(mean), _p(invstd), _p(partial), m, c, _stream())
 
 
 def bn_bwd_finalize(partial, blocks, c, m, dgamma, dbeta, c1, c2):

@@ -114,7 +114,7 @@ int frcnn_bn_apply(const frcnn_bf16* z, const float* scale, const float* shift, 
  * finalize: dgamma = sum g*xhat, dbeta = sum g, c1 = dbeta/m, c2 = dgamma/m
  * apply   : dz = gamma*invstd*(g - c1 - xhat*c2);  gpre (optional) = g */
 int frcnn_bn_bwd_blocks(int64_t m);
-int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act, const frcnn_bf16* z, const float* mean,
+int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z, const float* mean,
                         const float* invstd, float* partial, int64_t m, int c, frcnn_stream_t stream);
 int frcnn_bn_bwd_finalize(const float* partial, int blocks, int c, int64_t m, float* dgamma, float* dbeta,
                           float* c1, float* c2, frcnn_stream_t stream);
@@ -124,15 +124,18 @@ int frcnn_bn_bwd_apply(const frcnn_bf16* gout, const frcnn_bf16* act, const frcn
 /* Fused forms used by the training step (reference: keras BatchNormalization(training=True) inside
  * models/feature_extractor.py's ResNet50; same arithmetic as finalize_train + apply / bwd_finalize + bwd_apply, one launch
  * each: every workgroup reduces the partial sums of its own 64 channels).
- * train_apply    : out = [relu](z*scale + shift [+ res]); writes mean / invstd, updates the moving statistics
+ * train_apply    : out = [relu](z*scale + shift [+ res]); writes mean / invstd, updates the moving statistics; optionally
+ *                  writes relu_mask [m][c/8]: bit e of byte (row, c/8) = (out[row][8*(c/8)+e] > 0).  The backward kernels take
+ *                  EITHER the activation tensor (act) OR that bit mask (relu_mask) as the ReLU mask, or neither (no ReLU)
  * bwd_apply_fused: dz = gamma*invstd*(g - c1 - xhat*c2), gpre (optional) = g; writes dgamma / dbeta */
 int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_partial, int slots, int64_t count, const float* gamma,
                          const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
-                         const frcnn_bf16* res, int relu, frcnn_bf16* out, float* mean, float* invstd, int64_t m, int c,
-                         frcnn_stream_t stream);
-int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const frcnn_bf16* z, const float* mean,
-                             const float* invstd, const float* gamma, const float* partial, int slots, float* dgamma,
-                             float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, frcnn_stream_t stream);
+                         const frcnn_bf16* res, int relu, frcnn_bf16* out, uint8_t* relu_mask, float* mean, float* invstd,
+                         int64_t m, int c, frcnn_stream_t stream);
+int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z,
+                             const float* mean, const float* invstd, const float* gamma, const float* partial, int slots,
+                             float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c,
+                             frcnn_stream_t stream);
 /* g_out = g * (act > 0): ReLU backward without BN (RPN intermediate layer) */
 int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, int64_t n, frcnn_stream_t stream);
 /* per-channel column sum of a bf16 [m,c] matrix ADDED (float atomics) to fp32 out[c] (bias gradients;

@@ -88,6 +88,23 @@ def test_bn_forward_backward(ops):
     assert torch.equal(out2, out) and torch.equal(mean2, mean) and torch.equal(invstd2, invstd), "fused train apply"
     assert torch.equal(mm2, mm) and torch.equal(mv2, mv), "fused moving statistics"
     assert torch.equal(dz2, dz) and torch.equal(gpre2, gpre) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta), "fused bwd apply"
+    # ReLU bit mask: written by the forward kernel, read by the backward kernels instead of the activation tensor
+    rmask = torch.zeros(m, c // 8, dtype=torch.uint8, device=dev)
+    out3 = torch.empty(m, c, dtype=BF, device=dev)
+    ops.bn_train_apply(zd, parts, 4, m, gamma.to(dev), beta.to(dev), mm2.clone(), mv2.clone(), 0.99, 1.001e-5, out3, mean2, invstd2, m, c,
+                       res=res.to(BF).to(dev), relu=True, relu_mask=rmask)
+    torch.cuda.synchronize()
+    bits = ((rmask.cpu()[:, :, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(m, c).bool()
+    assert torch.equal(out3, out2) and torch.equal(bits, out3.float().cpu() > 0), "relu bit mask"
+    pa, pb = torch.zeros(nb, 2, c, device=dev), torch.zeros(nb, 2, c, device=dev)
+    ops.bn_bwd_reduce(gd, out3, zd, mean, invstd, pa, m, c)
+    ops.bn_bwd_reduce(gd, None, zd, mean, invstd, pb, m, c, relu_mask=rmask)
+    res_a = [torch.empty(c, device=dev), torch.empty(c, device=dev), torch.empty(m, c, dtype=BF, device=dev), torch.empty(m, c, dtype=BF, device=dev)]
+    res_b = [torch.empty(c, device=dev), torch.empty(c, device=dev), torch.empty(m, c, dtype=BF, device=dev), torch.empty(m, c, dtype=BF, device=dev)]
+    ops.bn_bwd_apply_fused(gd, out3, zd, mean, invstd, gamma.to(dev), pa, nb, res_a[0], res_a[1], res_a[2], res_a[3], m, c)
+    ops.bn_bwd_apply_fused(gd, None, zd, mean, invstd, gamma.to(dev), pb, nb, res_b[0], res_b[1], res_b[2], res_b[3], m, c, relu_mask=rmask)
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and all(torch.equal(x, y) for x, y in zip(res_a, res_b)), "bit mask == activation mask"
 
 
 def test_bn_wide_channels_and_eval(ops):
