@@ -543,26 +543,40 @@ __global__ void transpose_flip_kernel(const float* __restrict__ w, bf16_t* __res
     }
 }
 
-// batched form: table[i] = {w ptr, wt ptr, cout, kh, kw, cin, first flat output index, unused}; one launch for all layers
-__global__ void transpose_flip_batched_kernel(const long long* __restrict__ table, int n, long long total) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = n - 1;                       // last segment whose first index <= i
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (table[mid * 8 + 6] <= i) lo = mid; else hi = mid - 1;
-        }
-        const long long* d = table + lo * 8;
-        const float* w = reinterpret_cast<const float*>(d[0]);
-        bf16_t* wt = reinterpret_cast<bf16_t*>(d[1]);
-        const int Cout = (int)d[2], KH = (int)d[3], KW = (int)d[4], Cin = (int)d[5];
-        long long j = i - d[6];                       // output index [ci][kh'][kw'][co]
-        const int co = (int)(j % Cout);
-        long long t = j / Cout;
-        const int kwp = (int)(t % KW);
-        t /= KW;
-        const int khp = (int)(t % KH);
-        const int ci = (int)(t / KH);
-        wt[j] = (bf16_t)w[(((long long)co * KH + (KH - 1 - khp)) * KW + (KW - 1 - kwp)) * Cin + ci];
+// batched form: table[i] = {w ptr, wt ptr, cout, kh, kw, cin, first tile index, unused}; one launch for all layers.
+// One workgroup per 32 x 32 (co, ci) tile of one filter tap, transposed through LDS: both the fp32 reads (ci contiguous)
+// and the bf16 writes (co contiguous) are coalesced; the layer is found by a per-workgroup (scalar) binary search.
+__global__ __launch_bounds__(256) void transpose_flip_batched_kernel(const long long* __restrict__ table, int n, long long total_tiles) {
+    __shared__ float tile[32][33];
+    const long long tidx = blockIdx.x;
+    int lo = 0, hi = n - 1;                           // last layer whose first tile <= tidx
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 6] <= tidx) lo = mid; else hi = mid - 1;
+    }
+    const long long* d = table + lo * 8;
+    const float* w = reinterpret_cast<const float*>(d[0]);
+    bf16_t* wt = reinterpret_cast<bf16_t*>(d[1]);
+    const int Cout = (int)d[2], KH = (int)d[3], KW = (int)d[4], Cin = (int)d[5];
+    const int tci = (Cin + 31) >> 5, tco = (Cout + 31) >> 5;
+    int t = (int)(tidx - d[6]);                       // ((tap * tco) + co_tile) * tci + ci_tile
+    const int ci0 = (t % tci) * 32;
+    t /= tci;
+    const int co0 = (t % tco) * 32;
+    const int tap = t / tco;                          // source tap kh*KW + kw; destination tap is the flipped one
+    const int taps = KH * KW;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+        tile[ty + 8 * k][tx] = (co < Cout && ci < Cin) ? w[((long long)co * taps + tap) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    const int tap_dst = taps - 1 - tap;               // (KH-1-kh)*KW + (KW-1-kw)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ci = ci0 + ty + 8 * k, co = co0 + tx;
+        if (ci < Cin && co < Cout) wt[((long long)ci * taps + tap_dst) * Cout + co] = (bf16_t)tile[tx][ty + 8 * k];
     }
 }
 
@@ -789,7 +803,8 @@ extern "C" int frcnn_weights_transpose_flip(const float* w, frcnn_bf16* w_t, int
 
 extern "C" int frcnn_weights_transpose_flip_batched(const int64_t* table, int n, int64_t total, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(table && n > 0 && total > 0, "weights_transpose_flip_batched: bad arguments");
-    hipLaunchKernelGGL(transpose_flip_batched_kernel, dim3(grid_for(total, 256)), dim3(256), 0, S_(stream),
+    FRCNN_CHECK_ARG(total < (1ll << 31), "weights_transpose_flip_batched: too many tiles");
+    hipLaunchKernelGGL(transpose_flip_batched_kernel, dim3((unsigned)total), dim3(256), 0, S_(stream),
                        reinterpret_cast<const long long*>(table), n, (long long)total);
     FRCNN_CHECK_LAUNCH("weights_transpose_flip_batched");
     return FRCNN_OK;

@@ -60,11 +60,12 @@ def weights_transpose_flip(w, w_t, cout, kh, kw, cin):
 
 
 def make_transpose_flip_table(entries, device):
-    """entries: list of (w fp32 master view, w_t bf16 buffer, cout, kh, kw, cin) -> (int64 table on device, total)."""
+    """entries: list of (w fp32 master view, w_t bf16 buffer, cout, kh, kw, cin) -> (int64 table on device, total tiles).
+    The kernel runs one workgroup per 32 x 32 (cout, cin) tile of one filter tap."""
     rows, begin = [], 0
     for (w, w_t, cout, kh, kw, cin) in entries:
         rows.append([w.data_ptr(), w_t.data_ptr(), cout, kh, kw, cin, begin, 0])
-        begin += cout * kh * kw * cin
+        begin += kh * kw * ((cout + 31) // 32) * ((cin + 31) // 32)
     return torch.tensor(rows, dtype=torch.int64, device=device), begin
 
 

@@ -214,8 +214,15 @@ def main():
             dom = max(fam, key=lambda k: fam[k]["seconds"])
             f = fam[dom]
             achieved = f["flops"] / f["seconds"] / 1e12
+            # HBM bytes per launch of the same family from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+            # command (gfx950 correction applied: profiles/hbm_traffic.py); measured offline, so read from the committed file
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 5),
+                               "traffic": None if traffic is None else round(traffic), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)",
                                "launches_per_step": f["launches"], "avg_launch_us": round(f["seconds"] / f["launches"] * 1e6, 2),
                                "algorithmic_gflop_per_launch": round(f["flops"] / f["launches"] / 1e9, 4),
                                "families": {k: {"launches_per_step": v["launches"], "ms_per_step": round(v["seconds"] * 1e3, 4),
