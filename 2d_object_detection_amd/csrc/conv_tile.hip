@@ -15,10 +15,12 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI, bool F32>
-__global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParams p) {
+template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI, bool F32, int NW, bool PIPE>
+__global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NW = 8, T = 512, WM = 2, WN = 4;
+    // NW = 8: 2 x 4 waves; NW = 4: 2 x 2 waves with four times the MFMA work per wave and slice -- the loop is
+    // issue-bound, and the per-wave overhead (waits, DMA issue, fragment reads shared by fewer waves) is per wave
+    constexpr int T = NW * 64, WM = 2, WN = NW / 2;
     constexpr int CPR = BK / 8;                  // 16-byte chunks per tile row
     constexpr int RPI = 64 / CPR;                // rows written by one DMA wave instruction (1 KiB)
     constexpr int A_INSTR = BM / RPI, B_INSTR = BN / RPI;
@@ -30,7 +32,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     static_assert(!F32 || (!MULTI && !STATS), "fp32 / split-K output: one tile per workgroup, no statistics");
     constexpr int STG32 = BM * (BN * 4 + 16);   // fp32 staging tile (F32)
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, KK = BK / 32;
-    static_assert(MI >= 1 && NI >= 1, "tile too small for 8 waves");
+    static_assert(MI >= 1 && NI >= 1, "tile too small for the wave grid");
+    static_assert(2 * BN <= T, "statistics flush: one thread per (statistic, channel)");
+    static_assert(!PIPE || (S >= 3 && !MULTI && KK == 2 && MI + NI <= 15), "pipelined K loop: >= 3 slots, one tile, BK = 64");
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int ROWB = BN * 2 + 16;            // staging row pitch (bytes)
     constexpr int C8 = BN / 8, ST_IT = (BM * C8) / T;
@@ -240,6 +244,85 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         int left = nk;                           // slices of this tile still to consume
+        if (PIPE) {
+            // Software-pipelined K loop.  The barrier of iteration s certifies slice s+1 (slice s was certified one iteration
+            // earlier), so the fragments of the NEXT 32-wide step -- the first step of slice s+1 included -- are always in flight
+            // while the MFMAs of the current step run: the LDS latency, exposed once per step in the plain loop (which made every
+            // tile shape land on the same time), never reaches the matrix pipe.  The reads are inline asm: counted lgkmcnt
+            // waits that hipcc cannot merge or move, destination registers pinned by in/out operands of the wait.
+            constexpr int NR = MI + NI;          // ds_read_b128 per step
+            const unsigned lbase = lds_addr(ring);
+            u32x4 fa[2][MI], fb[2][NI];
+            auto rd = [&](u32x4& dst, const unsigned addr, auto off_c) {
+                constexpr int off = decltype(off_c)::value;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
+            };
+            auto read_frags = [&](u32x4 (&a)[MI], u32x4 (&b)[NI], const int slot_, const int kk) {
+                const unsigned aa = lbase + slot_ * A_BYTES + a_foff[kk];
+                const unsigned ba = lbase + S * A_BYTES + slot_ * B_BYTES + b_foff[kk];
+                rd(a[0], aa, std::integral_constant<int, 0>{});
+                if (MI > 1) rd(a[MI > 1 ? 1 : 0], aa, std::integral_constant<int, 1 * 16 * BK * 2>{});
+                if (MI > 2) rd(a[MI > 2 ? 2 : 0], aa, std::integral_constant<int, 2 * 16 * BK * 2>{});
+                if (MI > 3) rd(a[MI > 3 ? 3 : 0], aa, std::integral_constant<int, 3 * 16 * BK * 2>{});
+                rd(b[0], ba, std::integral_constant<int, 0>{});
+                if (NI > 1) rd(b[NI > 1 ? 1 : 0], ba, std::integral_constant<int, 1 * 16 * BK * 2>{});
+                if (NI > 2) rd(b[NI > 2 ? 2 : 0], ba, std::integral_constant<int, 2 * 16 * BK * 2>{});
+                if (NI > 3) rd(b[NI > 3 ? 3 : 0], ba, std::integral_constant<int, 3 * 16 * BK * 2>{});
+            };
+            auto wait_frags = [&](auto pending_c, u32x4 (&a)[MI], u32x4 (&b)[NI]) {
+                constexpr int pending = decltype(pending_c)::value;
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(pending) : "memory");
+#pragma unroll
+                for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(a[i]));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(b[j]));
+            };
+            auto mfma_step = [&](u32x4 (&a)[MI], u32x4 (&b)[NI]) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]), acc[i][j], 0, 0, 0);
+            };
+            // slice 0 certified by hand, its first fragments requested
+            {
+                // (the prologue issued min(S-1, nk) slices: wait until only the younger ones are outstanding)
+                const int pre = nk < S - 1 ? nk : S - 1;
+                if (pre == S - 1) FRCNN_WAIT_IMM((S - 2) * LC);
+                else FRCNN_WAIT_IMM(0);
+            }
+            __builtin_amdgcn_s_barrier();
+            int cslot = 0, islot = S - 1;        // consumer slot, slot the next DMA goes to
+            read_frags(fa[0], fb[0], 0, 0);
+            for (int sl = 0; sl < nk; ++sl) {
+                const int nslot = cslot + 1 == S ? 0 : cslot + 1;
+                if (sl + 1 < nk) {
+                    // certify slice sl+1: DMA issued after it = slices sl+2 .. sl+S-2 (when they exist)
+                    if (sl + S - 2 < nk) FRCNN_WAIT_IMM((S - 3) * LC);
+                    else FRCNN_WAIT_IMM(0);
+                    __builtin_amdgcn_s_barrier();        // slice sl+1 visible to all; everyone is done reading slice sl-1
+                }
+                if (to_issue > 0) {
+                    issue_slice(islot);                  // slot of slice sl-1
+                    islot = islot + 1 == S ? 0 : islot + 1;
+                    --to_issue;
+                }
+                read_frags(fa[1], fb[1], cslot, 1);
+                wait_frags(std::integral_constant<int, NR>{}, fa[0], fb[0]);
+                mfma_step(fa[0], fb[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sl + 1 < nk) {
+                    read_frags(fa[0], fb[0], nslot, 0);
+                    wait_frags(std::integral_constant<int, NR>{}, fa[1], fb[1]);
+                } else {
+                    wait_frags(std::integral_constant<int, 0>{}, fa[1], fb[1]);
+                }
+                mfma_step(fa[1], fb[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                cslot = nslot;
+            }
+            left = 0;
+        }
         // a tile's first slice was issued BEFORE the previous tile's epilogue stores: those ST_IT stores may stay in flight
         bool after_epilogue = MULTI && t > 0 && p.direct_out;
         while (left > 0) {
@@ -436,26 +519,29 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
 #endif
 }
 
-template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI, bool F32 = false>
+template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI, bool F32 = false, int NW = 8, bool PIPE = false>
 int launch_tile(const ConvParams& p, hipStream_t s) {
     constexpr int ring = S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
     constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4;
     static_assert(smem <= 163840, "LDS budget");
     static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
-    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI, F32>), smem) != 0) {
+    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI, F32, NW, PIPE>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
-    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI, F32>), dim3(p.items, F32 ? p.split : 1), dim3(512), smem, s, p);
+    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI, F32, NW, PIPE>), dim3(p.items, F32 ? p.split : 1), dim3(NW * 64), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
     return FRCNN_OK;
 }
 
-template <int BM, int BN, int BK, int S, int OCC, bool MULTI>
+template <int BM, int BN, int BK, int S, int OCC, bool MULTI, int NW = 8, bool PIPE = false>
 int launch_tile_flags(const ConvParams& p, hipStream_t s) {
     const bool stats = (p.flags & FRCNN_CONV_STATS) != 0;
-    if (p.linear_a) return stats ? launch_tile<BM, BN, BK, S, true, true, OCC, MULTI>(p, s) : launch_tile<BM, BN, BK, S, true, false, OCC, MULTI>(p, s);
-    return stats ? launch_tile<BM, BN, BK, S, false, true, OCC, MULTI>(p, s) : launch_tile<BM, BN, BK, S, false, false, OCC, MULTI>(p, s);
+    if (p.linear_a)
+        return stats ? launch_tile<BM, BN, BK, S, true, true, OCC, MULTI, false, NW, PIPE>(p, s)
+                     : launch_tile<BM, BN, BK, S, true, false, OCC, MULTI, false, NW, PIPE>(p, s);
+    return stats ? launch_tile<BM, BN, BK, S, false, true, OCC, MULTI, false, NW, PIPE>(p, s)
+                 : launch_tile<BM, BN, BK, S, false, false, OCC, MULTI, false, NW, PIPE>(p, s);
 }
 
 }  // namespace
@@ -492,6 +578,7 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
     // short K (<= 4 slices): runs of consecutive m-tiles per workgroup -- the ring prefetches the next tile under the
     // epilogue, bias / statistics / addressing are set up once per run; narrow tiles keep two workgroups per CU
     int tpb = 1;                                                // tiles per workgroup (1: one-tile kernel)
+    int waves = 8, pipe = 0;
     if (bk == 64) {
         const int kt = p.Ktot / 64;
         tpb = kt == 1 ? 8 : kt == 2 ? 4 : kt <= 4 ? 2 : 1;
@@ -500,8 +587,8 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
         if (tpb > 1) { bn = 64; stages = 2; }
     }
     if (const char* e = getenv("FRCNN_TILE")) {                 // kernel development aid: "bm,bn,bk,stages[,tiles_per_block]"
-        int a = 0, b = 0, c = 0, st = 0, tp = 1;
-        if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &st, &tp) >= 4) { bm = a; bn = b; bk = c; stages = st; tpb = tp; }
+        int a = 0, b = 0, c = 0, st = 0, tp = 1, nw = 8, pp = 0;
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &a, &b, &c, &st, &tp, &nw, &pp) >= 4) { bm = a; bn = b; bk = c; stages = st; tpb = tp; waves = nw; pipe = pp; }
     }
     if (d->cin % bk != 0) return FRCNN_ENOTSUP;
     p.k_tiles = p.Ktot / bk;
@@ -511,10 +598,30 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
     p.tiles_n = (d->cout + bn - 1) / bn;
     p.tiles_per_block = tpb;
     p.items = ((p.tiles_m + tpb - 1) / tpb) * p.tiles_n;
+#define FRCNN_PIPE(BM_, BN_, S_, OCC_, W_) \
+    if (tpb == 1 && pipe && waves == W_ && bm == BM_ && bn == BN_ && bk == 64 && stages == S_) return launch_tile_flags<BM_, BN_, 64, S_, OCC_, false, W_, true>(p, s);
+    FRCNN_PIPE(128, 64, 3, 2, 8)
+    FRCNN_PIPE(128, 64, 4, 1, 8)
+    FRCNN_PIPE(64, 128, 4, 1, 8)
+    FRCNN_PIPE(128, 128, 3, 1, 8)
+    FRCNN_PIPE(128, 128, 4, 1, 8)
+    FRCNN_PIPE(64, 64, 4, 2, 8)
+    FRCNN_PIPE(128, 128, 4, 1, 4)
+    FRCNN_PIPE(64, 128, 4, 1, 4)
+    FRCNN_PIPE(128, 64, 4, 1, 4)
+#undef FRCNN_PIPE
+    if (pipe) return FRCNN_ENOTSUP;
 #define FRCNN_TILE(BM_, BN_, BK_, S_, OCC_) \
-    if (tpb == 1 && bm == BM_ && bn == BN_ && bk == BK_ && stages == S_) return launch_tile_flags<BM_, BN_, BK_, S_, OCC_, false>(p, s);
+    if (tpb == 1 && waves == 8 && bm == BM_ && bn == BN_ && bk == BK_ && stages == S_) return launch_tile_flags<BM_, BN_, BK_, S_, OCC_, false>(p, s);
+#define FRCNN_TILE4(BM_, BN_, BK_, S_, OCC_) \
+    if (tpb == 1 && waves == 4 && bm == BM_ && bn == BN_ && bk == BK_ && stages == S_) return launch_tile_flags<BM_, BN_, BK_, S_, OCC_, false, 4>(p, s);
 #define FRCNN_RUN(BM_, BN_, BK_, OCC_) \
-    if (tpb > 1 && bm == BM_ && bn == BN_ && bk == BK_ && stages == 2) return launch_tile_flags<BM_, BN_, BK_, 2, OCC_, true>(p, s);
+    if (tpb > 1 && waves == 8 && bm == BM_ && bn == BN_ && bk == BK_ && stages == 2) return launch_tile_flags<BM_, BN_, BK_, 2, OCC_, true>(p, s);
+    FRCNN_TILE4(128, 128, 64, 2, 2)
+    FRCNN_TILE4(128, 128, 64, 3, 1)
+    FRCNN_TILE4(64, 128, 64, 3, 2)
+    FRCNN_TILE4(128, 64, 64, 3, 2)
+    FRCNN_TILE4(64, 64, 64, 3, 3)
     FRCNN_RUN(128, 64, 64, 2)
     FRCNN_RUN(128, 128, 64, 1)
     FRCNN_RUN(64, 64, 64, 3)
@@ -536,6 +643,7 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
     FRCNN_TILE(128, 128, 64, 4, 1)
     FRCNN_TILE(64, 64, 64, 6, 1)
 #undef FRCNN_TILE
+#undef FRCNN_TILE4
 #undef FRCNN_RUN
     return FRCNN_ENOTSUP;
 }

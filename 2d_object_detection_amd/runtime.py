@@ -17,12 +17,12 @@ _SERIAL = bool(os.environ.get("FRCNN_SERIAL_PLAN"))      # debugging aid: run br
 
 
 class _Branch:
-    def __init__(self, plan, name):
-        self.plan, self.name = plan, name
+    def __init__(self, plan, name, follow):
+        self.plan, self.name, self.follow = plan, name, follow
 
     def __enter__(self):
         assert self.plan._branch is None, "plan branches do not nest"
-        self.plan._branch = self.name
+        self.plan._branch = (self.name, self.follow)
         return self
 
     def __exit__(self, *exc):
@@ -50,8 +50,11 @@ class Plan:
     def add(self, fn, *args, **kwargs):
         self.segments[-1].append((fn, args, kwargs, None if _SERIAL else self._branch))
 
-    def branch(self, name):
-        return _Branch(self, name)
+    def branch(self, name, follow=False):
+        """follow=True: the block's first launch additionally waits for everything enqueued on the main stream so far, even
+        if the branch already exists (a side stream that trails the main chain: every weight-gradient kernel depends on the
+        BN backward kernel just before it, nothing on the main chain depends on the weight gradients)."""
+        return _Branch(self, name, follow)
 
     def join(self, name):
         self.segments[-1].append((None, (name,), {}, None))
@@ -82,6 +85,7 @@ class Plan:
     def run_segment(self, i):
         main = None                                # (no CUDA call for plans without branches: host-logic tests run on CPU)
         side = {}
+        prev_branch = None
         for fn, args, kwargs, br in self.segments[i]:
             if fn is None:
                 if args[0] in side:
@@ -89,17 +93,20 @@ class Plan:
             elif br is None:
                 fn(*args, **kwargs)
             else:
+                name, follow = br
                 if main is None:
                     main = torch.cuda.current_stream()
-                if br not in side:
-                    if br not in self._streams:
-                        self._streams[br] = torch.cuda.Stream()
+                first_of_block = prev_branch != br
+                if name not in side or (follow and first_of_block):
+                    if name not in self._streams:
+                        self._streams[name] = torch.cuda.Stream()
                     ev = torch.cuda.Event()
                     ev.record(main)
-                    self._streams[br].wait_event(ev)
-                    side[br] = self._streams[br]
-                with torch.cuda.stream(side[br]):
+                    self._streams[name].wait_event(ev)
+                    side[name] = self._streams[name]
+                with torch.cuda.stream(side[name]):
                     fn(*args, **kwargs)
+            prev_branch = br if fn is not None else prev_branch
         for name in list(side):
             self._join(main, side, name)
 

@@ -63,7 +63,7 @@ def test_plan_branches_are_recorded():
     p.add(log.append, "m1")
     p.join("side")
     p.add(log.append, "m2")
-    assert [e[3] for e in p.segments[0]] == [None, "side", "side", None, None, None] and p.num_launches == 5
+    assert [e[3] for e in p.segments[0]] == [None, ("side", False), ("side", False), None, None, None] and p.num_launches == 5
     assert p.segments[0][4][0] is None and p.segments[0][4][1] == ("side",)
 
 

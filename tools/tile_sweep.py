@@ -22,6 +22,9 @@ SHAPES = [  # n, h, w, cin, cout, k, stride, pad
 ]
 CONFIGS = [(bm, bn, bk, s, 1) for bk in (64, 128) for bm in (128, 64) for bn in (128, 64) for s in (2, 3) if not (bk == 128 and s == 3)]
 CONFIGS += [(128, 64, 64, 4, 1), (128, 64, 64, 6, 1), (128, 128, 64, 4, 1), (64, 64, 64, 6, 1)]               # deep rings
+CONFIGS += [(128, 64, 64, 3, 1, 8, 1), (128, 64, 64, 4, 1, 8, 1), (64, 128, 64, 4, 1, 8, 1), (128, 128, 64, 3, 1, 8, 1), (128, 128, 64, 4, 1, 8, 1), (64, 64, 64, 4, 1, 8, 1),
+            (128, 128, 64, 4, 1, 4, 1), (64, 128, 64, 4, 1, 4, 1), (128, 64, 64, 4, 1, 4, 1)]       # software-pipelined K loop
+CONFIGS += [(128, 128, 64, 2, 1, 4), (128, 128, 64, 3, 1, 4), (64, 128, 64, 3, 1, 4), (128, 64, 64, 3, 1, 4), (64, 64, 64, 3, 1, 4)]   # 4 waves
 CONFIGS += [(bm, bn, 64, 2, t) for (bm, bn) in ((128, 64), (128, 128), (64, 64)) for t in (2, 4, 8, 16)]      # tile runs
 
 
@@ -51,7 +54,7 @@ def main():
         for cfg in CONFIGS:
             if cin % cfg[2] != 0 or (cfg[1] == 128 and cout < 128):
                 continue
-            os.environ["FRCNN_TILE"] = "%d,%d,%d,%d,%d" % cfg
+            os.environ["FRCNN_TILE"] = ",".join(str(v) for v in cfg)
             try:
                 for _ in range(2):
                     ops.conv2d_fprop(d, x, wt, y, bias=bias, stats=stats)
