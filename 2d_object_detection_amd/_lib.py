@@ -18,6 +18,11 @@ class ConvDesc(Structure):
         "ho", "wo", "cout", "out_h", "out_w", "out_scatter", "flags", "split_k")]
 
 
+class BnReduce(Structure):
+    """frcnn_bn_reduce"""
+    _fields_ = [("z", c_void_p), ("relu_mask", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("partial", c_void_p)]
+
+
 CONV_BIAS, CONV_RELU, CONV_OUT_F32, CONV_ADD_RES, CONV_STATS, CONV_SPLITK_ATOMIC = 1, 2, 4, 8, 16, 32
 
 P = c_void_p
@@ -27,6 +32,7 @@ _SIGNATURES = {
     "frcnn_last_error": (c_char_p, []),
     "frcnn_conv2d_stat_tiles": (c_int, [POINTER(ConvDesc)]),
     "frcnn_conv2d_fprop": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
+    "frcnn_conv2d_dgrad_bnreduce": (c_int, [POINTER(ConvDesc), P, P, P, P, POINTER(BnReduce), P]),
     "frcnn_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
     "frcnn_weights_transpose_flip": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "frcnn_weights_transpose_flip_batched": (c_int, [P, c_int, c_int64, P]),

@@ -23,6 +23,13 @@ struct ConvParams {
     int direct_out;                         // bf16 output row == GEMM row and the tensor stays below 4 GiB: buffer-store epilogue
     int tiles_m, tiles_n, items;            // items = tiles_m * tiles_n * split
     int tiles_per_block;                    // conv_tile.hip: consecutive m-tiles per workgroup
+    // fused BatchNorm-backward reduce of the layer that CONSUMES this data gradient (conv_tile.hip, SMODE 2): its raw conv
+    // output z, its ReLU bit mask (or NULL), batch mean / invstd, and its [FRCNN_STAT_SLOTS][2][Cout] fp32 partial sums
+    const bf16_t* red_z;
+    const unsigned char* red_mask;
+    const float* red_mean;
+    const float* red_invstd;
+    float* red_part;
     long long in_row_stride, in_img_stride;
 };
 

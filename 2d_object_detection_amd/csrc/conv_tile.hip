@@ -15,9 +15,11 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI, bool F32, int NW, bool PIPE>
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, int NW, bool PIPE>
 __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // SMODE 0: plain, 1: BatchNorm statistics of the output (forward), 2: BatchNorm-backward reduce of the consumer layer
+    constexpr bool STATS = SMODE == 1, RED = SMODE == 2;
     // NW = 8: 2 x 4 waves; NW = 4: 2 x 2 waves with four times the MFMA work per wave and slice -- the loop is
     // issue-bound, and the per-wave overhead (waits, DMA issue, fragment reads shared by fewer waves) is per wave
     constexpr int T = NW * 64, WM = 2, WN = NW / 2;
@@ -29,7 +31,8 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
     constexpr int LC = A_INSTR / NW + B_INSTR / NW;
     static_assert(S == 2 || (S >= 3 && S <= 6 && A_UNI && B_UNI), "counted waits need a uniform DMA split");
     static_assert(!MULTI || (S == 2 && A_UNI && B_UNI), "tile runs use the two-slot ring with a uniform DMA split");
-    static_assert(!F32 || (!MULTI && !STATS), "fp32 / split-K output: one tile per workgroup, no statistics");
+    static_assert(!F32 || (!MULTI && SMODE == 0), "fp32 / split-K output: one tile per workgroup, no statistics");
+    static_assert(SMODE != 2 || (MULTI ? S * (BM + BN) * BK * 2 + BM * (BN * 2 + 16) : S * (BM + BN) * BK * 2) >= NW * 64 * 64, "reduce tree needs 64 B of LDS per thread");
     constexpr int STG32 = BM * (BN * 4 + 16);   // fp32 staging tile (F32)
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, KK = BK / 32;
     static_assert(MI >= 1 && NI >= 1, "tile too small for the wave grid");
@@ -227,6 +230,14 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) ssum[j][e] = ssq[j][e] = 0.f;
     const float lo = (flags & FRCNN_CONV_RELU) ? 0.f : -__builtin_inff();
+    // RED: this kernel's output is the gradient g arriving at a BatchNorm layer; accumulate that layer's backward sums
+    // sum(g*m) and sum(g*m*z) (m = its ReLU mask) for this thread's 8 channels over the rows it stores -- the separate reduce
+    // pass (one more read of g, z and the mask, one more launch per layer) disappears.  mean / invstd enter at the flush:
+    // sum(g*m*xhat) = invstd * (sum(g*m*z) - mean * sum(g*m)).
+    const __amdgpu_buffer_rsrc_t rsrc_rz = __builtin_amdgcn_make_buffer_rsrc((void*)p.red_z, 0, p.y_bytes, 0x00020000);
+    float rsg[8], rsgz[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rsg[e] = rsgz[e] = 0.f;
 
     // ------------------------------------------------------------------ K loops of the run's tiles
 #define FRCNN_WAIT_IMM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
@@ -407,6 +418,18 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
                 resv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, vo, 0, 0);
             }
         }
+        u32x4 redz[ST_IT];
+        unsigned redm[ST_IT];
+        if (RED && p.direct_out) {               // consumer layer's z rows and mask bytes: also in flight under the convert phase
+#pragma unroll
+            for (int it = 0; it < ST_IT; ++it) {
+                const int r = lrow_o + it * (T / C8);
+                const bool ok = col_ok && (!tail || m0 + r < p.M);
+                const unsigned vo = ok ? vo_lane + tile_off + it * pass_pitch : kOob;
+                redz[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rz, vo, 0, 0);
+                redm[it] = (p.red_mask && ok) ? p.red_mask[vo >> 4] : 0xFFu;      // byte index = (row * Cout + c) / 8
+            }
+        }
         auto convert_tile = [&](auto tail_c) {
             constexpr bool TL = decltype(tail_c)::value;
 #pragma unroll
@@ -462,6 +485,18 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
                     v = pack8(a);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo, 0, 0);
+                if (RED) {                       // rows / columns outside the tensor: z loads returned zeros -> g*z = 0; mask g too
+                    float g[8], zz[8];
+                    unpack8(v, g);
+                    unpack8(redz[it], zz);
+                    const bool ok = vo != kOob;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gm = (ok && ((redm[it] >> e) & 1u)) ? g[e] : 0.f;
+                        rsg[e] += gm;
+                        rsgz[e] += gm * zz[e];
+                    }
+                }
             }
         } else {
             // strided scatter (data gradient of a stride-2 1x1 convolution): per-row address computation
@@ -482,12 +517,53 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
                     v = pack8(a);
                 }
                 *reinterpret_cast<u32x4*>(y + off) = v;
+                if (RED) {
+                    float g[8], zz[8];
+                    unpack8(v, g);
+                    unpack8(*reinterpret_cast<const u32x4*>(p.red_z + off), zz);
+                    const unsigned mk = p.red_mask ? p.red_mask[off >> 3] : 0xFFu;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gm = ((mk >> e) & 1u) ? g[e] : 0.f;
+                        rsg[e] += gm;
+                        rsgz[e] += gm * zz[e];
+                    }
+                }
             }
         }
         // (MULTI) the next tile's convert phase writes the staging tile only after >= 1 barrier of its K loop
     }
 #undef FRCNN_WAIT_IMM
 
+    if (RED) {
+        // the T / C8 row lanes that share a channel vector meet in an LDS tree (the ring / staging region is idle now), then
+        // 2 x BN coalesced float atomics into the consumer layer's slot partial sums
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);             // [T / C8][C8][16]
+        constexpr int RL = T / C8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(lrow_o * C8 + lc8) * 16 + e] = rsg[e];
+            red[(lrow_o * C8 + lc8) * 16 + 8 + e] = rsgz[e];
+        }
+        __syncthreads();
+        for (int st = RL >> 1; st > 0; st >>= 1) {
+            if (lrow_o < st) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[(lrow_o * C8 + lc8) * 16 + e] += red[((lrow_o + st) * C8 + lc8) * 16 + e];
+            }
+            __syncthreads();
+        }
+        if (tid < 2 * BN) {
+            const int st = tid / BN, cl = tid - st * BN;
+            const int c = n0 + cl;
+            if (c < p.Cout) {
+                const float sg = red[(cl >> 3) * 16 + (cl & 7)], sgz = red[(cl >> 3) * 16 + 8 + (cl & 7)];
+                const float v = st == 0 ? sg : p.red_invstd[c] * (sgz - p.red_mean[c] * sg);
+                atomicAdd(p.red_part + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + c, v);
+            }
+        }
+    }
     if (STATS) {
         // the run's tiles share one n-tile: 16-lane butterflies, the two row halves (wm) meet in LDS, then one float atomic
         // per channel and statistic into one of FRCNN_STAT_SLOTS pre-zeroed slots (consecutive lanes: consecutive channels).
@@ -519,29 +595,40 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
 #endif
 }
 
-template <int BM, int BN, int BK, int S, bool LIN, bool STATS, int OCC, bool MULTI, bool F32 = false, int NW = 8, bool PIPE = false>
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, int NW = 8, bool PIPE = false>
 int launch_tile(const ConvParams& p, hipStream_t s) {
     constexpr int ring = S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
     constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4;
     static_assert(smem <= 163840, "LDS budget");
     static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
-    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI, F32, NW, PIPE>), smem) != 0) {
+    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, NW, PIPE>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
-    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, STATS, OCC, MULTI, F32, NW, PIPE>), dim3(p.items, F32 ? p.split : 1), dim3(NW * 64), smem, s, p);
+    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, NW, PIPE>), dim3(p.items, F32 ? p.split : 1), dim3(NW * 64), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
     return FRCNN_OK;
 }
 
 template <int BM, int BN, int BK, int S, int OCC, bool MULTI, int NW = 8, bool PIPE = false>
 int launch_tile_flags(const ConvParams& p, hipStream_t s) {
-    const bool stats = (p.flags & FRCNN_CONV_STATS) != 0;
-    if (p.linear_a)
-        return stats ? launch_tile<BM, BN, BK, S, true, true, OCC, MULTI, false, NW, PIPE>(p, s)
-                     : launch_tile<BM, BN, BK, S, true, false, OCC, MULTI, false, NW, PIPE>(p, s);
-    return stats ? launch_tile<BM, BN, BK, S, false, true, OCC, MULTI, false, NW, PIPE>(p, s)
-                 : launch_tile<BM, BN, BK, S, false, false, OCC, MULTI, false, NW, PIPE>(p, s);
+    const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
+    // the fused reduce needs 64 B of (idle) LDS per thread for its tree
+    constexpr bool red_ok = (MULTI ? S * (BM + BN) * BK * 2 + BM * (BN * 2 + 16) : S * (BM + BN) * BK * 2) >= NW * 64 * 64;
+    if (smode == 2) {
+        if constexpr (red_ok) {
+            return p.linear_a ? launch_tile<BM, BN, BK, S, true, 2, OCC, MULTI, false, NW, PIPE>(p, s)
+                              : launch_tile<BM, BN, BK, S, false, 2, OCC, MULTI, false, NW, PIPE>(p, s);
+        } else {
+            return FRCNN_ENOTSUP;
+        }
+    }
+    if (p.linear_a) {
+        if (smode == 1) return launch_tile<BM, BN, BK, S, true, 1, OCC, MULTI, false, NW, PIPE>(p, s);
+        return launch_tile<BM, BN, BK, S, true, 0, OCC, MULTI, false, NW, PIPE>(p, s);
+    }
+    if (smode == 1) return launch_tile<BM, BN, BK, S, false, 1, OCC, MULTI, false, NW, PIPE>(p, s);
+    return launch_tile<BM, BN, BK, S, false, 0, OCC, MULTI, false, NW, PIPE>(p, s);
 }
 
 }  // namespace
@@ -563,7 +650,7 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
         p.tiles_n = (d->cout + 63) / 64;
         p.tiles_per_block = 1;
         p.items = p.tiles_m * p.tiles_n;
-        return launch_tile<128, 64, 64, 3, true, false, 2, false, true>(p, s);
+        return launch_tile<128, 64, 64, 3, true, 0, 2, false, true>(p, s);
     }
     if (d->split_k > 1) return FRCNN_ENOTSUP;
     // measured on the R50-C4 layer shapes (tools/tile_sweep.py): 128-row tiles and BK = 64 win almost everywhere (two

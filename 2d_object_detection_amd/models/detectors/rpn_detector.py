@@ -168,8 +168,15 @@ class RPNDetector:
         plan.add(ops.colsum_bf16, self.dz_f, self.m, 256, 256, st.grad("rpn_intermediate_layer/bias"))
         plan.add(ops.conv2d_wgrad, self.d_inter, feature_maps, self.dz_f, st.grad("rpn_intermediate_layer/kernel"))
 
-    def backward_data_plan(self, plan, g_feat):
-        plan.add(ops.conv2d_fprop, self.d_inter_bwd, self.dz_f, self.w_inter_t, g_feat, res=g_feat)
+    def backward_data_plan(self, plan, g_feat, consumer=None):
+        """consumer: the backbone's last conv unit -- g_feat is complete after this kernel, so it also runs that unit's
+        BatchNorm-backward reduce."""
+        if consumer is not None:
+            red = consumer.reduce_args(relu=True)
+            plan.hold(red)
+            plan.add(ops.conv2d_dgrad_bnreduce, self.d_inter_bwd, self.dz_f, self.w_inter_t, g_feat, red, res=g_feat)
+        else:
+            plan.add(ops.conv2d_fprop, self.d_inter_bwd, self.dz_f, self.w_inter_t, g_feat, res=g_feat)
 
     # ------------------------------------------------------------------ reference call surface
     def __call__(self, feature_maps, training=False):

@@ -204,10 +204,10 @@ class FasterRCNN:
         if training:
             mods.rcnn.backward_plan(plan, t["rcnn_dl"], t["rcnn_dd"], t["rcnn_idx"], S_rcnn, rois, g_feat)
             plan.join("rpn_side")
-            mods.rpn.backward_data_plan(plan, g_feat)
+            mods.rpn.backward_data_plan(plan, g_feat, consumer=mods.fe.last_unit())
             plan.join("detections")
             plan.cut("bwd_conv4")
-            mods.fe.backward_plan(plan, g_feat)
+            mods.fe.backward_plan(plan, g_feat, g_feat_reduced=True)
             plan.cut("update")
             optimizer.apply_plan(plan)
             mods.fe.stem.refresh_weights(plan)

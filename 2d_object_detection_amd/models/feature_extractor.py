@@ -111,10 +111,18 @@ class _ConvBN:
             plan.add(ops.bn_apply, self.z, self.scale, self.shift, out, self.m, self.cout, res=res, relu=relu)
 
     # -- backward: gout (grad of the BN[+res][+relu] output), act = that output (None when no ReLU)
-    def backward_bn(self, plan, gout, act, gpre=None):
+    def reduce_args(self, relu=True):
+        """frcnn_bn_reduce of this layer's BatchNorm for the data-gradient kernel that produces its incoming gradient."""
+        if getattr(self, "_red", None) is None or self._red[0] != relu:
+            self._red = (relu, ops.bn_reduce_args(self.z, self.relu_mask if relu else None, self.mean, self.invstd, self.bwd_partial))
+        return self._red[1]
+
+    def backward_bn(self, plan, gout, act, gpre=None, reduced=False):
+        """reduced: the kernel that produced gout already accumulated this layer's backward sums (conv2d_dgrad_bnreduce)."""
         st = self.store
         mask = self.relu_mask if act is not None else None       # (act only says whether the layer ends in a ReLU)
-        plan.add(ops.bn_bwd_reduce, gout, None, self.z, self.mean, self.invstd, self.bwd_partial, self.m, self.cout, relu_mask=mask)
+        if not reduced:
+            plan.add(ops.bn_bwd_reduce, gout, None, self.z, self.mean, self.invstd, self.bwd_partial, self.m, self.cout, relu_mask=mask)
         plan.add(ops.bn_bwd_apply_fused, gout, None, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"),
                  self.bwd_partial, self.bwd_blocks, st.grad(self.name + "_bn/gamma"), st.grad(self.name + "_bn/beta"), self.dz, gpre,
                  self.m, self.cout, relu_mask=mask)
@@ -129,8 +137,9 @@ class _ConvBN:
         else:
             plan.add(ops.conv2d_wgrad, self.desc, x, self.dz, st.grad(self.name + "_conv/kernel"))
 
-    def backward_data(self, plan, gx, res=None):
-        """gx[n,hi,wi,cin] = conv_transpose(dz) (+ res); stride-2 1x1 scatters into a pre-zeroed gx."""
+    def backward_data(self, plan, gx, res=None, consumer=None):
+        """gx[n,hi,wi,cin] = conv_transpose(dz) (+ res); stride-2 1x1 scatters into a pre-zeroed gx.  consumer: the conv unit
+        whose BatchNorm(+ReLU) output gradient gx is -- its backward reduce is fused into this kernel."""
         k, s = self.k, self.stride
         if s == 1:
             d = ops.conv_desc(self.n, self.ho, self.wo, self.cout, k, k, 1, self.pad, self.pad, self.hi, self.wi, self.cin,
@@ -140,7 +149,12 @@ class _ConvBN:
             d = ops.conv_desc(self.n, self.ho, self.wo, self.cout, 1, 1, 1, 0, 0, self.ho, self.wo, self.cin, out_h=self.hi,
                               out_w=self.wi, out_scatter=s, flags=ops.CONV_ADD_RES if res is not None else 0)
         plan.hold(d)
-        plan.add(ops.conv2d_fprop, d, self.dz, self.w_t, gx, res=res)
+        if consumer is not None:
+            red = consumer.reduce_args(relu=True)
+            plan.hold(red)
+            plan.add(ops.conv2d_dgrad_bnreduce, d, self.dz, self.w_t, gx, red, res=res)
+        else:
+            plan.add(ops.conv2d_fprop, d, self.dz, self.w_t, gx, res=res)
 
 
 class FeatureExtractor:
@@ -323,9 +337,18 @@ class FeatureExtractor:
             x = a["out"]
         return self.feature_maps
 
-    def backward_plan(self, plan, g_feat):
-        """g_feat: bf16 gradient w.r.t. feature_maps [B*gh*gw, C].  Cuts the plan after each stage."""
+    def last_unit(self):
+        """The conv unit whose BatchNorm+ReLU produces feature_maps (consumer of the feature-map gradient)."""
+        return self.units[self.specs[-1][0]][3]
+
+    def backward_plan(self, plan, g_feat, g_feat_reduced=False):
+        """g_feat: bf16 gradient w.r.t. feature_maps [B*gh*gw, C].  Cuts the plan after each stage.
+        g_feat_reduced: the kernel that wrote g_feat already ran the BN-backward reduce of last_unit()."""
         gout = g_feat
+        gout_reduced = g_feat_reduced
+        prev_of = {}
+        for i, spec in enumerate(self.specs):
+            prev_of[spec[0]] = self.units[self.specs[i - 1][0]][3] if i > 0 else None
         prev_stage = None
         xs = {}
         x = self.pool
@@ -338,24 +361,27 @@ class FeatureExtractor:
                 plan.cut("bwd_conv%d" % stage)
             prev_stage = stage
             u, a, xin = self.units[n], self.acts[n], xs[n]
-            u[3].backward_bn(plan, gout, a["out"], gpre=a["gpre"])
+            # every data-gradient kernel also runs the BN-backward reduce of the layer that consumes its output
+            u[3].backward_bn(plan, gout, a["out"], gpre=a["gpre"], reduced=gout_reduced)
             u[3].backward_weights(plan, a["a2"])
-            u[3].backward_data(plan, a["g2"])
-            u[2].backward_bn(plan, a["g2"], a["a2"])
+            u[3].backward_data(plan, a["g2"], consumer=u[2])
+            u[2].backward_bn(plan, a["g2"], a["a2"], reduced=True)
             u[2].backward_weights(plan, a["a1"])
-            u[2].backward_data(plan, a["g1"])
-            u[1].backward_bn(plan, a["g1"], a["a1"])
+            u[2].backward_data(plan, a["g1"], consumer=u[1])
+            u[1].backward_bn(plan, a["g1"], a["a1"], reduced=True)
             u[1].backward_weights(plan, xin)
+            prev = prev_of[n]                     # block whose output this block's input gradient is (None: max-pool output)
             if first:
                 u[0].backward_bn(plan, a["gpre"], None)
                 u[0].backward_weights(plan, xin)
                 if s != 1:
                     plan.add(a["gin"].zero_)
                 u[1].backward_data(plan, a["gin"])
-                u[0].backward_data(plan, a["gin"], res=a["gin"])
+                u[0].backward_data(plan, a["gin"], res=a["gin"], consumer=prev)   # gin is complete here (untouched pixels are zero)
             else:
-                u[1].backward_data(plan, a["gin"], res=a["gpre"])
+                u[1].backward_data(plan, a["gin"], res=a["gpre"], consumer=prev)
             gout = a["gin"]
+            gout_reduced = prev is not None
         st = self.stem
         plan.add(ops.maxpool_bwd, gout, self.pool_arg, self.g_stem, self.batch, st.ho, st.wo, 64, self.hp1, self.wp1)
         st.backward_bn(plan, self.g_stem, self.a_stem)

@@ -10,7 +10,7 @@ from ctypes import byref, c_float, c_void_p
 import torch
 
 from . import _lib
-from ._lib import (CONV_ADD_RES, CONV_BIAS, CONV_OUT_F32, CONV_RELU, CONV_SPLITK_ATOMIC, CONV_STATS, ConvDesc, call)
+from ._lib import (CONV_ADD_RES, CONV_BIAS, CONV_OUT_F32, CONV_RELU, CONV_SPLITK_ATOMIC, CONV_STATS, BnReduce, ConvDesc, call)
 
 BF16 = torch.bfloat16
 
@@ -49,6 +49,17 @@ def conv_stat_tiles(d):
 
 def conv2d_fprop(d, x, w, y, bias=None, res=None, stats=None):
     call("frcnn_conv2d_fprop", byref(d), _p(x), _p(w), _p(bias), _p(res), _p(y), _p(stats), _stream())
+
+
+def bn_reduce_args(z, relu_mask, mean, invstd, partial):
+    """frcnn_bn_reduce for conv2d_dgrad_bnreduce (keep the returned struct alive as long as a plan refers to it)."""
+    return BnReduce(z.data_ptr(), relu_mask.data_ptr() if relu_mask is not None else None, mean.data_ptr(), invstd.data_ptr(),
+                    partial.data_ptr())
+
+
+def conv2d_dgrad_bnreduce(d, dz, w_t, gx, red, res=None):
+    """gx = conv(dz, w_t) [+ res], fused with the BatchNorm-backward reduce of the layer that consumes gx."""
+    call("frcnn_conv2d_dgrad_bnreduce", byref(d), _p(dz), _p(w_t), _p(res), _p(gx), byref(red), _stream())
 
 
 def conv2d_wgrad(d, x, dz, dw, dz_stride=None, row_index=None):

@@ -210,3 +210,64 @@ def test_conv_wgrad_stem_and_rowindex(ops):
     ops.conv2d_wgrad(d2, pooled.to(BF).cuda(), dl.to(BF).cuda(), dw2, dz_stride=64, row_index=rows.cuda())
     torch.cuda.synchronize()
     _close(dw2, ref2, 2e-4, 1e-2, "head wgrad (row_index)")
+
+
+@pytest.mark.parametrize("case", [
+    dict(n=2, h=12, w=39, cin=256, cout=64, k=1, res=True, mask=True),       # short K: tile run
+    dict(n=4, h=24, w=78, cin=64, cout=256, k=1, res=True, mask=True),
+    dict(n=2, h=13, w=17, cin=128, cout=128, k=3, res=False, mask=True),
+    dict(n=1, h=24, w=78, cin=1024, cout=256, k=1, res=False, mask=False),
+])
+def test_conv_dgrad_with_fused_bn_reduce(ops, case):
+    """conv2d_dgrad_bnreduce == conv2d_fprop followed by bn_bwd_reduce on its output (same gx bits; partial sums equal up to
+    fp32 summation order and the sum(g*z) - mean*sum(g) form of sum(g*xhat))."""
+    g = torch.Generator(device="cuda").manual_seed(7)
+    n, h, w, cin, cout, k = (case[x] for x in ("n", "h", "w", "cin", "cout", "k"))
+    m = n * h * w
+    dz = torch.randn(m, cin, device="cuda", generator=g).to(BF)
+    wt = (torch.randn(cout, k, k, cin, device="cuda", generator=g) / (cin * k * k) ** 0.5).to(BF)
+    res = torch.randn(m, cout, device="cuda", generator=g).to(BF) if case["res"] else None
+    z = (torch.randn(m, cout, device="cuda", generator=g) * 2 + 0.5).to(BF)
+    mask = torch.randint(0, 256, (m, cout // 8), device="cuda", generator=g, dtype=torch.uint8) if case["mask"] else None
+    mean = z.float().mean(0).contiguous()
+    invstd = (1.0 / (z.float().var(0, unbiased=False) + 1e-5).sqrt()).contiguous()
+    d = ops.conv_desc(n, h, w, cin, k, k, 1, k // 2, k // 2, h, w, cout, flags=ops.CONV_ADD_RES if res is not None else 0)
+    slots = ops.STAT_SLOTS
+    gx_a, gx_b = torch.empty(m, cout, dtype=BF, device="cuda"), torch.empty(m, cout, dtype=BF, device="cuda")
+    pa, pb = torch.zeros(slots, 2, cout, device="cuda"), torch.zeros(slots, 2, cout, device="cuda")
+    ops.conv2d_fprop(d, dz, wt, gx_a, res=res)
+    ops.bn_bwd_reduce(gx_a, None, z, mean, invstd, pa, m, cout, relu_mask=mask)
+    red = ops.bn_reduce_args(z, mask, mean, invstd, pb)
+    ops.conv2d_dgrad_bnreduce(d, dz, wt, gx_b, red, res=res)
+    torch.cuda.synchronize()
+    assert torch.equal(gx_a, gx_b), "fused kernel changes the data gradient"
+    sa, sb = pa.sum(0).double(), pb.sum(0).double()
+    scale = sa.abs().max(dim=1, keepdim=True).values + 1e-6
+    assert float(((sa - sb).abs() / scale).max()) < 2e-4, float(((sa - sb).abs() / scale).max())
+
+
+def test_conv_dgrad_scatter_with_fused_bn_reduce(ops):
+    g = torch.Generator(device="cuda").manual_seed(8)
+    n, ho, wo, cin, cout = 2, 12, 39, 512, 256
+    hi, wi = 2 * ho, 2 * wo
+    dz = torch.randn(n * ho * wo, cin, device="cuda", generator=g).to(BF)
+    wt = (torch.randn(cout, 1, 1, cin, device="cuda", generator=g) / cin ** 0.5).to(BF)
+    mo = n * hi * wi
+    z = torch.randn(mo, cout, device="cuda", generator=g).to(BF)
+    mask = torch.randint(0, 256, (mo, cout // 8), device="cuda", generator=g, dtype=torch.uint8)
+    mean, invstd = z.float().mean(0).contiguous(), (1.0 / (z.float().var(0, unbiased=False) + 1e-5).sqrt()).contiguous()
+    base = torch.randn(mo, cout, device="cuda", generator=g).to(BF)
+    d = ops.conv_desc(n, ho, wo, cin, 1, 1, 1, 0, 0, ho, wo, cout, out_h=hi, out_w=wi, out_scatter=2, flags=ops.CONV_ADD_RES)
+    slots = ops.STAT_SLOTS
+    ya, yb = base.clone(), base.clone()
+    pa, pb = torch.zeros(slots, 2, cout, device="cuda"), torch.zeros(slots, 2, cout, device="cuda")
+    ops.conv2d_fprop(d, dz, wt, ya, res=ya)
+    # reference partial sums over the rows the scatter touches only (the fused kernel sees exactly those)
+    rows = (torch.arange(n)[:, None, None] * hi * wi + torch.arange(ho)[None, :, None] * 2 * wi + torch.arange(wo)[None, None, :] * 2).reshape(-1).cuda()
+    ops.bn_bwd_reduce(ya[rows].contiguous(), None, z[rows].contiguous(), mean, invstd, pa, rows.numel(), cout, relu_mask=mask[rows].contiguous())
+    ops.conv2d_dgrad_bnreduce(d, dz, wt, yb, ops.bn_reduce_args(z, mask, mean, invstd, pb), res=yb)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    sa, sb = pa.sum(0).double(), pb.sum(0).double()
+    scale = sa.abs().max(dim=1, keepdim=True).values + 1e-6
+    assert float(((sa - sb).abs() / scale).max()) < 2e-4
