@@ -289,7 +289,16 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
                 m |= ((pk[q] & 0x7FFFu) != 0u && !(pk[q] & 0x8000u)) ? (1u << (2 * q)) : 0u;
                 m |= ((pk[q] & 0x7FFF0000u) != 0u && !(pk[q] & 0x80000000u)) ? (1u << (2 * q + 1)) : 0u;
             }
-            relu_mask[i] = (uint8_t)m;
+            // the 8 channel-vector lanes of a row (consecutive lanes) pool their bytes: one 8-byte store per row and strip
+            unsigned x = m << (8 * (v & 3));
+            x |= __shfl_xor(x, 1);
+            x |= __shfl_xor(x, 2);
+            const unsigned y = __shfl_xor(x, 4);
+            if (C8 % 8 == 0) {
+                if (v == 0) *reinterpret_cast<u32x2*>(relu_mask + i) = u32x2{x, y};      // i = r*C8 + cv, cv % 8 == 0 here
+            } else {
+                relu_mask[i] = (uint8_t)m;
+            }
         }
     }
 }
