@@ -32,7 +32,7 @@ _SIGNATURES = {
     "frcnn_last_error": (c_char_p, []),
     "frcnn_conv2d_stat_tiles": (c_int, [POINTER(ConvDesc)]),
     "frcnn_conv2d_fprop": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
-    "frcnn_conv2d_dgrad_bnreduce": (c_int, [POINTER(ConvDesc), P, P, P, P, POINTER(BnReduce), P]),
+    "frcnn_conv2d_dgrad_bnreduce": (c_int, [POINTER(ConvDesc), P, P, P, P, P, POINTER(BnReduce), P]),
     "frcnn_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
     "frcnn_weights_transpose_flip": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "frcnn_weights_transpose_flip_batched": (c_int, [P, c_int, c_int64, P]),

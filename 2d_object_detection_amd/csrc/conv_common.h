@@ -30,6 +30,8 @@ struct ConvParams {
     const float* red_mean;
     const float* red_invstd;
     float* red_part;
+    const unsigned char* res_mask;          // ADD_RES: bit mask applied to the residual (the ReLU mask of the block output whose
+                                            // gradient the residual is) or NULL
     long long in_row_stride, in_img_stride;
 };
 

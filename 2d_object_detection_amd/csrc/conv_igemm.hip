@@ -619,23 +619,26 @@ extern "C" int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d) {
 }
 
 static int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
-                             const frcnn_bf16* res, void* y, double* stats_partial, const frcnn_bn_reduce* red, frcnn_stream_t stream);
+                             const frcnn_bf16* res, const uint8_t* res_mask, void* y, double* stats_partial, const frcnn_bn_reduce* red,
+                             frcnn_stream_t stream);
 
 extern "C" int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
                                   const frcnn_bf16* res, void* y, double* stats_partial, frcnn_stream_t stream) {
-    return conv2d_fprop_impl(d, x, w, bias, res, y, stats_partial, nullptr, stream);
+    return conv2d_fprop_impl(d, x, w, bias, res, nullptr, y, stats_partial, nullptr, stream);
 }
 
 extern "C" int frcnn_conv2d_dgrad_bnreduce(const frcnn_conv_desc* d, const frcnn_bf16* dz, const frcnn_bf16* w_t, const frcnn_bf16* res,
-                                           frcnn_bf16* gx, const frcnn_bn_reduce* red, frcnn_stream_t stream) {
+                                           const uint8_t* res_mask, frcnn_bf16* gx, const frcnn_bn_reduce* red, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(!res_mask || (res && d && (d->flags & FRCNN_CONV_ADD_RES)), "conv2d_dgrad_bnreduce: res_mask without ADD_RES residual");
     FRCNN_CHECK_ARG(red && red->z && red->mean && red->invstd && red->partial, "conv2d_dgrad_bnreduce: incomplete reduce arguments");
     FRCNN_CHECK_ARG(d && !(d->flags & (FRCNN_CONV_STATS | FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC | FRCNN_CONV_BIAS | FRCNN_CONV_RELU)),
                     "conv2d_dgrad_bnreduce: only ADD_RES may be set");
-    return conv2d_fprop_impl(d, dz, w_t, nullptr, res, gx, nullptr, red, stream);
+    return conv2d_fprop_impl(d, dz, w_t, nullptr, res, res_mask, gx, nullptr, red, stream);
 }
 
 static int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
-                             const frcnn_bf16* res, void* y, double* stats_partial, const frcnn_bn_reduce* red, frcnn_stream_t stream) {
+                             const frcnn_bf16* res, const uint8_t* res_mask, void* y, double* stats_partial, const frcnn_bn_reduce* red,
+                             frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(d && x && w && y, "conv2d_fprop: null pointer");
     FRCNN_CHECK_ARG(d->cin > 0 && d->cin % 32 == 0, "conv2d_fprop: cin=%d must be a multiple of 32", d->cin);
     FRCNN_CHECK_ARG(d->cout > 0 && d->cout % 8 == 0, "conv2d_fprop: cout=%d must be a multiple of 8", d->cout);
@@ -673,6 +676,7 @@ static int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, cons
     p.red_mean = red ? red->mean : nullptr;
     p.red_invstd = red ? red->invstd : nullptr;
     p.red_part = red ? red->partial : nullptr;
+    p.res_mask = res_mask;
     p.Hi = d->hi; p.Wi = d->wi; p.in_pix_stride = d->in_pix_stride; p.Cin = d->cin; p.KW = d->kw;
     p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
     p.Ho = d->ho; p.Wo = d->wo; p.Cout = d->cout; p.out_h = d->out_h; p.out_w = d->out_w; p.out_scatter = d->out_scatter;

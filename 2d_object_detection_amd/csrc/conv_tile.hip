@@ -416,6 +416,12 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
                 const int r = lrow_o + it * (T / C8);
                 const unsigned vo = (col_ok && (!tail || m0 + r < p.M)) ? vo_lane + tile_off + it * pass_pitch : kOob;
                 resv[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_res, vo, 0, 0);
+                if (p.res_mask) {                // masked residual: zero the elements whose mask bit is clear (no gpre tensor)
+                    const unsigned mk = vo != kOob ? p.res_mask[vo >> 4] : 0u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        resv[it][q] &= (((mk >> (2 * q)) & 1u) ? 0x0000FFFFu : 0u) | (((mk >> (2 * q + 1)) & 1u) ? 0xFFFF0000u : 0u);
+                }
             }
         }
         u32x4 redz[ST_IT];
@@ -508,7 +514,13 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
                 u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + c8 * 16);
                 const long long off = out_row_of(p, m) * p.Cout + c;
                 if (flags & FRCNN_CONV_ADD_RES) {
-                    const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
+                    u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
+                    if (p.res_mask) {
+                        const unsigned mk = p.res_mask[off >> 3];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            rv[q] &= (((mk >> (2 * q)) & 1u) ? 0x0000FFFFu : 0u) | (((mk >> (2 * q + 1)) & 1u) ? 0xFFFF0000u : 0u);
+                    }
                     float a[8], b[8];
                     unpack8(v, a);
                     unpack8(rv, b);

@@ -117,10 +117,13 @@ class _ConvBN:
             self._red = (relu, ops.bn_reduce_args(self.z, self.relu_mask if relu else None, self.mean, self.invstd, self.bwd_partial))
         return self._red[1]
 
-    def backward_bn(self, plan, gout, act, gpre=None, reduced=False):
-        """reduced: the kernel that produced gout already accumulated this layer's backward sums (conv2d_dgrad_bnreduce)."""
+    def backward_bn(self, plan, gout, act, gpre=None, reduced=False, mask=None):
+        """reduced: the kernel that produced gout already accumulated this layer's backward sums (conv2d_dgrad_bnreduce).
+        mask: ReLU bit mask to apply to gout instead of this layer's own (the shortcut BN of a block receives the block-output
+        gradient masked by the block's final ReLU)."""
         st = self.store
-        mask = self.relu_mask if act is not None else None       # (act only says whether the layer ends in a ReLU)
+        if mask is None:
+            mask = self.relu_mask if act is not None else None   # (act only says whether the layer ends in a ReLU)
         if not reduced:
             plan.add(ops.bn_bwd_reduce, gout, None, self.z, self.mean, self.invstd, self.bwd_partial, self.m, self.cout, relu_mask=mask)
         plan.add(ops.bn_bwd_apply_fused, gout, None, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"),
@@ -137,7 +140,7 @@ class _ConvBN:
         else:
             plan.add(ops.conv2d_wgrad, self.desc, x, self.dz, st.grad(self.name + "_conv/kernel"))
 
-    def backward_data(self, plan, gx, res=None, consumer=None):
+    def backward_data(self, plan, gx, res=None, consumer=None, res_mask=None):
         """gx[n,hi,wi,cin] = conv_transpose(dz) (+ res); stride-2 1x1 scatters into a pre-zeroed gx.  consumer: the conv unit
         whose BatchNorm(+ReLU) output gradient gx is -- its backward reduce is fused into this kernel."""
         k, s = self.k, self.stride
@@ -152,8 +155,9 @@ class _ConvBN:
         if consumer is not None:
             red = consumer.reduce_args(relu=True)
             plan.hold(red)
-            plan.add(ops.conv2d_dgrad_bnreduce, d, self.dz, self.w_t, gx, red, res=res)
+            plan.add(ops.conv2d_dgrad_bnreduce, d, self.dz, self.w_t, gx, red, res=res, res_mask=res_mask)
         else:
+            assert res_mask is None
             plan.add(ops.conv2d_fprop, d, self.dz, self.w_t, gx, res=res)
 
 
@@ -301,7 +305,6 @@ class FeatureExtractor:
             if training:
                 a["g1"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a1
                 a["g2"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a2
-                a["gpre"] = torch.empty(m, 4 * f, dtype=BF16, device=dev)
                 a["gin"] = torch.empty(batch * hi * wi, ci, dtype=BF16, device=dev)   # grad wrt the block input
             self.acts[n] = a
             hi, wi = ho, wo
@@ -362,7 +365,10 @@ class FeatureExtractor:
             prev_stage = stage
             u, a, xin = self.units[n], self.acts[n], xs[n]
             # every data-gradient kernel also runs the BN-backward reduce of the layer that consumes its output
-            u[3].backward_bn(plan, gout, a["out"], gpre=a["gpre"], reduced=gout_reduced)
+            # the block-output gradient after the final ReLU (g * mask) is never materialised: its two consumers -- the
+            # shortcut branch and the residual add of the block-input gradient -- read gout and the block's ReLU bit mask
+            gblock, mblock = gout, u[3].relu_mask
+            u[3].backward_bn(plan, gout, a["out"], reduced=gout_reduced)
             u[3].backward_weights(plan, a["a2"])
             u[3].backward_data(plan, a["g2"], consumer=u[2])
             u[2].backward_bn(plan, a["g2"], a["a2"], reduced=True)
@@ -372,14 +378,14 @@ class FeatureExtractor:
             u[1].backward_weights(plan, xin)
             prev = prev_of[n]                     # block whose output this block's input gradient is (None: max-pool output)
             if first:
-                u[0].backward_bn(plan, a["gpre"], None)
+                u[0].backward_bn(plan, gblock, None, mask=mblock)
                 u[0].backward_weights(plan, xin)
                 if s != 1:
                     plan.add(a["gin"].zero_)
                 u[1].backward_data(plan, a["gin"])
                 u[0].backward_data(plan, a["gin"], res=a["gin"], consumer=prev)   # gin is complete here (untouched pixels are zero)
             else:
-                u[1].backward_data(plan, a["gin"], res=a["gpre"], consumer=prev)
+                u[1].backward_data(plan, a["gin"], res=gblock, consumer=prev, res_mask=mblock)
             gout = a["gin"]
             gout_reduced = prev is not None
         st = self.stem

@@ -57,9 +57,9 @@ def bn_reduce_args(z, relu_mask, mean, invstd, partial):
                     partial.data_ptr())
 
 
-def conv2d_dgrad_bnreduce(d, dz, w_t, gx, red, res=None):
-    """gx = conv(dz, w_t) [+ res], fused with the BatchNorm-backward reduce of the layer that consumes gx."""
-    call("frcnn_conv2d_dgrad_bnreduce", byref(d), _p(dz), _p(w_t), _p(res), _p(gx), byref(red), _stream())
+def conv2d_dgrad_bnreduce(d, dz, w_t, gx, red, res=None, res_mask=None):
+    """gx = conv(dz, w_t) [+ res (* res_mask bits)], fused with the BatchNorm-backward reduce of the layer that consumes gx."""
+    call("frcnn_conv2d_dgrad_bnreduce", byref(d), _p(dz), _p(w_t), _p(res), _p(res_mask), _p(gx), byref(red), _stream())
 
 
 def conv2d_wgrad(d, x, dz, dw, dz_stride=None, row_index=None):

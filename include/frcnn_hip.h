@@ -68,7 +68,9 @@ typedef struct {
  * gradient g arriving at a BatchNorm layer whose raw input was z; while storing gx the kernel accumulates that layer's
  * partial[slot][0][c] += sum g*m and partial[slot][1][c] += sum g*m*xhat (m = relu_mask bit or 1, xhat = (z-mean)*invstd),
  * i.e. exactly what frcnn_bn_bwd_reduce(gout = gx, ...) would add -- one launch and one read of gx, z and the mask less per
- * layer (reference: the tf.GradientTape backward of keras BatchNormalization + Conv2D, models/faster_rcnn.py:95-107). */
+ * layer (reference: the tf.GradientTape backward of keras BatchNormalization + Conv2D, models/faster_rcnn.py:95-107).
+ * res_mask (optional, with FRCNN_CONV_ADD_RES): bit mask [M][C/8] applied to the residual before the add -- the residual
+ * branch of a ResNet block passes the block-output gradient and the block's ReLU mask instead of a materialised product. */
 typedef struct frcnn_bn_reduce {
     const frcnn_bf16* z;          /* [M][Cout of this conv = channels of the BN layer] */
     const uint8_t* relu_mask;     /* [M][C/8] or NULL (no ReLU) */
@@ -77,7 +79,7 @@ typedef struct frcnn_bn_reduce {
     float* partial;               /* [FRCNN_STAT_SLOTS][2][C], pre-zeroed, accumulated with float atomics */
 } frcnn_bn_reduce;
 int frcnn_conv2d_dgrad_bnreduce(const frcnn_conv_desc* d, const frcnn_bf16* dz, const frcnn_bf16* w_t, const frcnn_bf16* res,
-                                frcnn_bf16* gx, const frcnn_bn_reduce* red, frcnn_stream_t stream);
+                                const uint8_t* res_mask, frcnn_bf16* gx, const frcnn_bn_reduce* red, frcnn_stream_t stream);
 /* rows of the stats_partial buffer [rows][2][cout] (== FRCNN_STAT_SLOTS) */
 int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d);
 int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,

@@ -172,7 +172,12 @@ def test_backbone_backward_teacher_forced():
         res = nchw(a["sc"], ho, wo) if first else xin
         gx, gw, gg, gbt, gres = _unit_backward(params, n + "_3", nchw(a["a2"], ho, wo), 1, 0, g_up, res=res)
         cmp(n + " g2", nchw(a["g2"], ho, wo), gx, 0.015)
-        cmp(n + " gpre", nchw(a["gpre"], ho, wo), gres, 0.015)
+        # the masked block-output gradient is not materialised any more (its consumers read gout and the ReLU bit mask):
+        # rebuild it from the bit mask the forward kernel wrote, which must equal (block output > 0)
+        bits = ((u[3].relu_mask[:, :, None] >> torch.arange(8, dtype=torch.uint8, device=gout.device)) & 1).reshape(gout.shape).bool()
+        assert torch.equal(bits, a["out"] > 0), n + " relu bit mask"
+        gpre_t = torch.where(bits, gout, torch.zeros_like(gout))
+        cmp(n + " gpre", nchw(gpre_t, ho, wo), gres, 0.015)
         check_params(n + "_3", gw, gg, gbt)
         gx, gw, gg, gbt, _ = _unit_backward(params, n + "_2", nchw(a["a1"], ho, wo), 1, 1, nchw(a["g2"], ho, wo))
         cmp(n + " g1", nchw(a["g1"], ho, wo), gx, 0.015)
@@ -180,11 +185,11 @@ def test_backbone_backward_teacher_forced():
         c1, gw, gg, gbt, _ = _unit_backward(params, n + "_1", xin, s, 0, nchw(a["g1"], ho, wo))
         check_params(n + "_1", gw, gg, gbt)
         if first:
-            c0, gw, gg, gbt, _ = _unit_backward(params, n + "_0", xin, s, 0, nchw(a["gpre"], ho, wo), relu=False)
+            c0, gw, gg, gbt, _ = _unit_backward(params, n + "_0", xin, s, 0, nchw(gpre_t, ho, wo), relu=False)
             check_params(n + "_0", gw, gg, gbt)
             exp_gin = c1 + c0
         else:
-            exp_gin = c1 + nchw(a["gpre"], ho, wo)
+            exp_gin = c1 + nchw(gpre_t, ho, wo)
         cmp(n + " gin", nchw(a["gin"], hi, wi), exp_gin, 0.015)
         gout = a["gin"]
     # max-pool backward + stem

@@ -271,3 +271,24 @@ def test_conv_dgrad_scatter_with_fused_bn_reduce(ops):
     sa, sb = pa.sum(0).double(), pb.sum(0).double()
     scale = sa.abs().max(dim=1, keepdim=True).values + 1e-6
     assert float(((sa - sb).abs() / scale).max()) < 2e-4
+
+
+def test_conv_dgrad_masked_residual(ops):
+    """res_mask: the residual enters the add through a bit mask == adding the pre-masked tensor."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    n, h, w, cin, cout = 2, 24, 39, 256, 1024
+    m = n * h * w
+    dz = torch.randn(m, cin, device="cuda", generator=g).to(BF)
+    wt = (torch.randn(cout, 1, 1, cin, device="cuda", generator=g) / cin ** 0.5).to(BF)
+    res = torch.randn(m, cout, device="cuda", generator=g).to(BF)
+    mask = torch.randint(0, 256, (m, cout // 8), device="cuda", generator=g, dtype=torch.uint8)
+    bits = ((mask[:, :, None] >> torch.arange(8, dtype=torch.uint8, device="cuda")) & 1).reshape(m, cout).bool()
+    z = torch.randn(m, cout, device="cuda", generator=g).to(BF)
+    mean, invstd = z.float().mean(0).contiguous(), torch.ones(cout, device="cuda")
+    d = ops.conv_desc(n, h, w, cin, 1, 1, 1, 0, 0, h, w, cout, flags=ops.CONV_ADD_RES)
+    ya, yb = torch.empty(m, cout, dtype=BF, device="cuda"), torch.empty(m, cout, dtype=BF, device="cuda")
+    ops.conv2d_fprop(d, dz, wt, ya, res=torch.where(bits, res, torch.zeros_like(res)))
+    part = torch.zeros(ops.STAT_SLOTS, 2, cout, device="cuda")
+    ops.conv2d_dgrad_bnreduce(d, dz, wt, yb, ops.bn_reduce_args(z, None, mean, invstd, part), res=res, res_mask=mask)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
