@@ -59,10 +59,10 @@ def profile_conv_kernels(model, built, steps=3):
         for fn, args, kwargs, _branch in seg:
             if fn is None:                       # join marker of a side-stream branch (the profile pass runs serially)
                 continue
-            if fn is ops.conv2d_fprop or fn is ops.conv2d_wgrad:
+            if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce or fn is ops.conv2d_wgrad:
                 d = args[0]
                 cin, cout = true_dims(d, fn)
-                name = "conv fprop/dgrad (conv_tile_kernel, igemm_kernel)" if fn is ops.conv2d_fprop else "conv wgrad (wgrad_kernel)"
+                name = "conv wgrad (wgrad_kernel)" if fn is ops.conv2d_wgrad else "conv fprop/dgrad (conv_tile_kernel, igemm_kernel)"
                 records.append((fn, args, kwargs, name, conv_flops(d, cin, cout)))
             else:
                 records.append((fn, args, kwargs, None, 0.0))
