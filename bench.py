@@ -67,6 +67,16 @@ def profile_conv_kernels(model, built, steps=3):
             else:
                 records.append((fn, args, kwargs, None, 0.0))
     state = model._snapshot(built["optimizer"])
+    # cost of an event pair itself (two marker packets back to back, nothing between): subtracted from every measurement
+    torch.cuda._sleep(20_000_000)
+    cal = []
+    for _ in range(200):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        cal.append((e0, e1))
+    torch.cuda.synchronize()
+    pair_overhead_s = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2] * 1e-3
     events = []
     for it in range(steps + 1):
         # Let the host run ahead: a ~30 ms device-side spin is enqueued first, so every event record and launch of the step
@@ -110,11 +120,12 @@ def profile_conv_kernels(model, built, steps=3):
     for name, fl, e0, e1 in events:
         f = fam.setdefault(name, {"launches": 0, "seconds": 0.0, "flops": 0.0})
         f["launches"] += 1
-        f["seconds"] += e0.elapsed_time(e1) * 1e-3
+        f["seconds"] += max(e0.elapsed_time(e1) * 1e-3 - pair_overhead_s, 0.0)
         f["flops"] += fl
     for f in fam.values():
         for k in f:
             f[k] /= steps
+        f["event_pair_overhead_us"] = pair_overhead_s * 1e6
     return fam
 
 
@@ -225,6 +236,7 @@ def main():
                                "traffic": None if traffic is None else round(traffic), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)",
                                "launches_per_step": f["launches"], "avg_launch_us": round(f["seconds"] / f["launches"] * 1e6, 2),
                                "algorithmic_gflop_per_launch": round(f["flops"] / f["launches"] / 1e9, 4),
+                               "event_pair_overhead_us": round(f["event_pair_overhead_us"], 2),
                                "families": {k: {"launches_per_step": v["launches"], "ms_per_step": round(v["seconds"] * 1e3, 4),
                                                 "tflops": round(v["flops"] / v["seconds"] / 1e12, 2)} for k, v in fam.items()}}
         if not args.no_cpu_baseline:
