@@ -160,7 +160,7 @@ __device__ void bitonic_desc(unsigned long long* keys, int n_pad) {
 // network (measured: 367 us of the 439 us RPN-proposal NMS were the bitonic sort of 16384 keys).  rocPRIM's block radix sort
 // does the digit ranking; its scratch aliases the key array (the keys live in registers during the sort).
 template <int IPT>
-__device__ void radix_sort_desc(unsigned long long* keys) {
+__device__ void radix_sort_desc(unsigned long long* keys, void* scratch) {
     using Sort = hipcub::BlockRadixSort<unsigned int, NMS_T, IPT, unsigned int>;
     unsigned int k[IPT], v[IPT];
 #pragma unroll
@@ -170,7 +170,7 @@ __device__ void radix_sort_desc(unsigned long long* keys) {
         v[e] = (unsigned int)x;
     }
     __syncthreads();
-    Sort(*reinterpret_cast<typename Sort::TempStorage*>(keys)).SortDescending(k, v);
+    Sort(*reinterpret_cast<typename Sort::TempStorage*>(scratch)).SortDescending(k, v);
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < IPT; ++e) keys[threadIdx.x * IPT + e] = ((unsigned long long)k[e] << 32) | v[e];
@@ -181,23 +181,37 @@ constexpr size_t NMS_RADIX_SCRATCH = sizeof(hipcub::BlockRadixSort<unsigned int,
                                          ? sizeof(hipcub::BlockRadixSort<unsigned int, NMS_T, 16, unsigned int>::TempStorage)
                                          : sizeof(hipcub::BlockRadixSort<unsigned int, NMS_T, 4, unsigned int>::TempStorage);
 
-__device__ void sort_keys_desc(unsigned long long* keys, int n_pad, bool in_lds) {
-    if (in_lds && n_pad == 16 * NMS_T) radix_sort_desc<16>(keys);
-    else if (in_lds && n_pad == 8 * NMS_T) radix_sort_desc<8>(keys);
-    else if (in_lds && n_pad == 4 * NMS_T) radix_sort_desc<4>(keys);
+// keys: LDS or global; scratch: LDS (may alias keys -- they live in registers during the radix sort)
+__device__ void sort_keys_desc(unsigned long long* keys, void* scratch, int n_pad) {
+    if (n_pad == 16 * NMS_T) radix_sort_desc<16>(keys, scratch);
+    else if (n_pad == 8 * NMS_T) radix_sort_desc<8>(keys, scratch);
+    else if (n_pad == 4 * NMS_T) radix_sort_desc<4>(keys, scratch);
     else bitonic_desc(keys, n_pad);
+}
+
+// Where the candidate keys of one (image, class) live: in LDS when they fit next to the kept list, else in a global slab
+// (the radix sort still runs in LDS scratch for n_pad <= NMS_LDS_KEYS).  Returns the dynamic LDS size of nms_class_kernel.
+static size_t nms_class_lds(int n_pad, int max_per_class, bool* keys_global) {
+    constexpr size_t kLdsMax = 160 * 1024;
+    const size_t fixed = (size_t)max_per_class * 20 + 256 /*NMS_CH*/ * (16 + 32 + 4 + 4 + 4) + 16 + 8;
+    const bool radix = n_pad >= 4 * NMS_T && n_pad <= NMS_LDS_KEYS;
+    const size_t lds_keys = ((size_t)n_pad * 8 > NMS_RADIX_SCRATCH || !radix) ? (size_t)n_pad * 8 : NMS_RADIX_SCRATCH;
+    if (n_pad <= NMS_LDS_KEYS && fixed + lds_keys <= kLdsMax) { *keys_global = false; return fixed + lds_keys; }
+    *keys_global = true;
+    return fixed + (radix ? NMS_RADIX_SCRATCH : 0);
 }
 
 struct NmsParams {
     const float* boxes; const float* scores;
-    int N, q, C, score_stride, score_offset, max_per_class, n_pad;
+    int N, q, C, score_stride, score_offset, max_per_class, n_pad, keys_global;
     float iou_thr, score_thr;
-    unsigned long long* gkeys;       // global scratch [B*C][n_pad] (only when n_pad > NMS_LDS_KEYS)
+    unsigned long long* gkeys;       // global scratch [B*C][n_pad] (only when keys_global)
     unsigned long long* kept_keys;   // [B][C*max_per_class]: (score key << 32 | ~(class*max_per_class + slot)) or 0
     int* kept_idx;                   // [B][C*max_per_class] box index
 };
 
-constexpr int NMS_CH = 256;                  // candidates resolved per iteration of the greedy loop
+constexpr int NMS_CH = 256;                  // candidates resolved per iteration of the greedy loop (nms_class_lds assumes 256)
+static_assert(NMS_CH == 256, "nms_class_lds sizes the chunk arrays for 256 candidates");
 
 // One workgroup per (image, class): sort the candidates by score, then greedy suppression in chunks of NMS_CH candidates:
 //   1. every candidate of the chunk is tested against the boxes kept so far (4 threads per candidate);
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     const int b = blockIdx.x / p.C, c = blockIdx.x % p.C;
     const int bc = (p.q == 1) ? 0 : c;
     const float* boxes = p.boxes + (int64_t)b * p.N * p.q * 4;
-    unsigned long long* keys = (p.n_pad <= NMS_LDS_KEYS) ? lkeys : p.gkeys + (int64_t)blockIdx.x * p.n_pad;
+    unsigned long long* keys = p.keys_global ? p.gkeys + (int64_t)blockIdx.x * p.n_pad : lkeys;
 
     for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) {
         unsigned long long k = 0ull;
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     }
     if (threadIdx.x == 0) { misc[0] = 0; }
     __syncthreads();
-    sort_keys_desc(keys, p.n_pad, p.n_pad <= NMS_LDS_KEYS);
+    sort_keys_desc(keys, lkeys, p.n_pad);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int kept = 0;
@@ -455,7 +469,9 @@ extern "C" size_t frcnn_nms_workspace_bytes(int b, int n, int c, int max_per_cla
     (void)max_total;
     const int n_pad = next_pow2(n);
     size_t bytes = (size_t)b * c * max_per_class * (sizeof(unsigned long long) + sizeof(int));
-    if (n_pad > NMS_LDS_KEYS) bytes += (size_t)b * c * n_pad * sizeof(unsigned long long);
+    bool keys_global;
+    nms_class_lds(n_pad, max_per_class, &keys_global);
+    if (keys_global) bytes += (size_t)b * c * n_pad * sizeof(unsigned long long) + 8;
     return (bytes + 255) & ~(size_t)255;
 }
 
@@ -481,8 +497,9 @@ extern "C" int frcnn_nms_combined(const float* boxes, const float* scores, int b
     p.gkeys = reinterpret_cast<unsigned long long*>(ws + (size_t)b * c * max_per_class * (sizeof(unsigned long long) + sizeof(int)));
     // keep the u64 scratch 8-byte aligned
     if (((size_t)b * c * max_per_class * sizeof(int)) % 8) p.gkeys = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(p.gkeys) + 4);
-    size_t smem = (size_t)max_per_class * 20 + NMS_CH * (16 + 32 + 4 + 4 + 4) + 16 + 8;
-    if (n_pad <= NMS_LDS_KEYS) smem += ((size_t)n_pad * 8 > NMS_RADIX_SCRATCH || n_pad < 4 * NMS_T) ? (size_t)n_pad * 8 : NMS_RADIX_SCRATCH;
+    bool keys_global;
+    const size_t smem = nms_class_lds(n_pad, max_per_class, &keys_global);
+    p.keys_global = keys_global ? 1 : 0;
     FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(nms_class_kernel), smem) == 0, "nms_combined: cannot reserve %zu B of LDS", smem);
     hipLaunchKernelGGL(nms_class_kernel, dim3(b * c), dim3(NMS_T), smem, S_(stream), p);
     FRCNN_CHECK_LAUNCH("nms_combined(class)");

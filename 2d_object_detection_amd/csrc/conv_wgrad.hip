@@ -86,7 +86,18 @@ __global__ __launch_bounds__(512, 2 * OCC) void wgrad_kernel(const WgradParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
 
+    // Workgroups are dealt round-robin to the 8 XCDs.  Give every XCD a contiguous chunk of the (pixel split, tile) list,
+    // tile fastest: all tiles of one pixel range then run on the same XCD at about the same time, and both operands
+    // of that range come out of HBM once instead of once per XCD.
     int bid = blockIdx.x;
+    {
+        const int total = gridDim.x, q = total >> 3, r = total & 7;
+        const int xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int tiles_all = p.tiles_co * p.taps * p.tiles_ci;
+    const int split_idx = bid / tiles_all;
+    bid -= split_idx * tiles_all;
     const int tile_ci = bid % p.tiles_ci;
     bid /= p.tiles_ci;
     const int tap = bid % p.taps;
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void wgrad_kernel(const WgradParams p
     const int co0 = tile_co * BM, ci0 = tile_ci * BN;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
 
-    const int pt_begin = blockIdx.z * p.p_tiles_per_split;
+    const int pt_begin = split_idx * p.p_tiles_per_split;
     const int pt_end = min(p.p_tiles, pt_begin + p.p_tiles_per_split);
     const int n_slices = pt_end - pt_begin;
     const int pix0 = pt_begin * BKP;
@@ -330,7 +341,7 @@ int launch_mode(const WgradParams& p, int split, hipStream_t s) {
         frcnn_set_error("frcnn_conv2d_wgrad: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
-    dim3 grid(p.tiles_co * p.taps * p.tiles_ci, 1, split);
+    dim3 grid(p.tiles_co * p.taps * p.tiles_ci * split, 1, 1);
     hipLaunchKernelGGL((wgrad_kernel<BM, BN, S, MODE, OCC>), grid, dim3(512), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad");
     return FRCNN_OK;

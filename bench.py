@@ -112,11 +112,13 @@ def profile_conv_kernels(model, built, steps=3):
                 per.setdefault(i - 1 - it * (len(events) // steps), []).append(ev[2].elapsed_time(ev[3]) * 1e3)
         with open(os.environ["FRCNN_LAYER_TABLE"], "w") as fh:
             for j, (name, d, fl) in enumerate(order):
-                us = sorted(per[j])[len(per[j]) // 2]
+                us = max(sorted(per[j])[len(per[j]) // 2] - pair_overhead_s * 1e6, 0.1)
                 m = d.n * d.ho * d.wo
                 byts = 2.0 * (m * d.kh * d.kw * 0 + m * d.cin + m * d.cout + d.cout * d.kh * d.kw * d.cin)
-                fh.write("%-26s M=%7d cin=%5d cout=%5d k=%dx%d s=%d  %8.1f us %7.1f TF/s %7.0f GB/s(min traffic)\n" % (
-                    name, m, d.cin, d.cout, d.kh, d.kw, d.stride, us, fl / us / 1e6, byts / us / 1e3))
+                roof = max(fl / 2.5e15, byts / 8e12) * 1e6
+                fh.write("%-26s M=%7d cin=%5d cout=%5d k=%dx%d s=%d  %8.1f us %7.1f TF/s %7.0f GB/s(min traffic)  roof %6.1f us (%s) frac %.2f\n" % (
+                    name, m, d.cin, d.cout, d.kh, d.kw, d.stride, us, fl / us / 1e6, byts / us / 1e3, roof,
+                    "mfma" if fl / 2.5e15 > byts / 8e12 else "hbm", roof / us))
     for name, fl, e0, e1 in events:
         f = fam.setdefault(name, {"launches": 0, "seconds": 0.0, "flops": 0.0})
         f["launches"] += 1

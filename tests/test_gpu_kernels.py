@@ -217,6 +217,8 @@ def _random_boxes(g, B, N, q):
     (1, 22464, 1, 1, 300, 300, 0.7),     # RPN eval configuration (global-scratch sort)
     (3, 1000, 1, 1, 50, 20, 0.3),        # max_total < kept, heavy suppression
     (1, 70, 3, 3, 100, 300, 0.5),        # fewer candidates than any cap
+    (2, 8768, 1, 1, 1000, 1000, 0.7),    # BASELINE config 4: 1000-proposal stress (RPN)
+    (2, 1000, 7, 7, 100, 300, 0.6),      # BASELINE config 4: RCNN NMS over 1000 proposals
 ])
 def test_nms_combined_bit_exact(ops, B, N, q, C, mpc, mt, thr):
     g = torch.Generator().manual_seed(N + C)
