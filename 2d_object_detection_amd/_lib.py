@@ -73,6 +73,7 @@ _SIGNATURES = {
     "frcnn_losses": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P]),
     "frcnn_rpn_head_grad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
     "frcnn_rcnn_head_grad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P]),
+    "frcnn_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, P, c_size_t]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

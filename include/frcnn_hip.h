@@ -259,6 +259,10 @@ int frcnn_rpn_head_grad(const float* dlogits_s, const float* ddeltas_s, const in
 int frcnn_rcnn_head_grad(const float* dlogits_s, const float* ddeltas_s, const int32_t* indices, int b, int r, int c1,
                          int s, frcnn_bf16* dhead_s, int ld, int32_t* rows_out, frcnn_stream_t stream);
 
+/* Host helper (no device work): CRC-32C of data[0..n) continuing from crc (0 = fresh), as used by the TFRecord
+ * framing of the reference's data files (data/build_tf_records.py:128-133, data/input_pipeline.py:31). */
+uint32_t frcnn_crc32c(uint32_t crc, const void* data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif
