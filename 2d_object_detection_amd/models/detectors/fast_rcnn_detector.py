@@ -115,7 +115,6 @@ class FastRCNNDetector:
             self.dpooled_s = torch.empty(rs, self.flat, dtype=BF16, device=dev)
             self.d_wgrad = ops.conv_desc(1, 1, rs, self.flat, 1, 1, 1, 0, 0, 1, rs, HEAD_LD)
             self.d_dgrad = ops.conv_desc(1, 1, rs, HEAD_LD, 1, 1, 1, 0, 0, 1, rs, self.flat)
-            self.gfeat32 = torch.zeros(batch * hf * wf, self.cf, device=dev)
 
     def refresh_weights(self, plan):
         plan.add(ops.weights_transpose_flip, self.store.weight("fast_rcnn_heads/kernel"), self.w_t, HEAD_LD, 1, 1, self.flat)
@@ -142,10 +141,9 @@ class FastRCNNDetector:
         plan.add(ops.colsum_bf16, self.dhead_s, self.rs, HEAD_LD, HEAD_LD, st.grad("fast_rcnn_heads/bias"))
         plan.add(ops.conv2d_wgrad, self.d_wgrad, self.pooled, self.dhead_s, st.grad("fast_rcnn_heads/kernel"), HEAD_LD, self.rows)
         plan.add(ops.conv2d_fprop, self.d_dgrad, self.dhead_s, self.w_t, self.dpooled_s)
-        plan.add(self.gfeat32.zero_)
-        plan.add(ops.roi_crop_pool_bwd, self.dpooled_s, self.argmax, rois, self.rows, self.rs, self.p, self.hf, self.wf, self.cf, self.ps,
-                 self.ks, self.gfeat32)
-        plan.add(ops.cast_f32_bf16, self.gfeat32, g_feat_bf16)
+        # gather form: every element of g_feat is written once, in bf16, without global atomics (no memset / cast passes)
+        plan.add(ops.roi_crop_pool_bwd_bf16, self.dpooled_s, self.argmax, rois, self.rows, self.rs, self.batch, self.p, self.hf, self.wf,
+                 self.cf, self.ps, self.ks, g_feat_bf16)
 
     # ------------------------------------------------------------------ reference call surface
     def __call__(self, feature_maps, rois):

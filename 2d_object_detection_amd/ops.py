@@ -212,6 +212,10 @@ def roi_crop_pool_bwd(gpooled, argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, 
     call("frcnn_roi_crop_pool_bwd", _p(gpooled), _p(argmax), _p(rois), _p(rows), nrows, p, hf, wf, c, ps, ks, _p(gfeat), _stream())
 
 
+def roi_crop_pool_bwd_bf16(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, ps, ks, gfeat):
+    call("frcnn_roi_crop_pool_bwd_bf16", _p(gpooled), _p(argmax), _p(rois), _p(rows), nrows, b, p, hf, wf, c, ps, ks, _p(gfeat), _stream())
+
+
 def rcnn_head_post(logits, ld, bias, r, nc1, scores, deltas):
     call("frcnn_rcnn_head_post", _p(logits), ld, _p(bias), r, nc1, _p(scores), _p(deltas), _stream())
 

@@ -216,6 +216,12 @@ int frcnn_roi_crop_pool_fwd(const frcnn_bf16* feat, const float* rois, int b, in
 int frcnn_roi_crop_pool_bwd(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,
                             int nrows, int p, int hf, int wf, int c, int ps, int ks, float* gfeat,
                             frcnn_stream_t stream);
+/* Same gradient, complete and in bf16: EVERY element of gfeat [B,hf,wf,c] is written exactly once (no pre-zeroing, no
+ * accumulation into existing contents).  One workgroup per (image, feature row, channel slab) gathers the contributions
+ * of the listed rows in LDS -- no global atomics.  c % 64 == 0, wf * 256 B <= 64 KiB. */
+int frcnn_roi_crop_pool_bwd_bf16(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,
+                                 int nrows, int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat,
+                                 frcnn_stream_t stream);
 /* fast_rcnn_detector.py:62-65 after the GEMM: logits [R, ld] fp32 (+bias): softmax over the first
  * nc1 columns -> scores [R,nc1]; columns [nc1, nc1+4*(nc1-1)) -> deltas. */
 int frcnn_rcnn_head_post(const float* logits, int ld, const float* bias, int r, int nc1, float* scores, float* deltas,

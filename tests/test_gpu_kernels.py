@@ -304,6 +304,12 @@ def test_roi_crop_pool_fwd_bwd(ops):
     torch.cuda.synchronize()
     # argmax ties between the oracle (fp32) and the kernel can differ only where samples are equal
     _close(gfeat, fr.grad, 1e-3, 5e-2, "roi grad")
+    # gather form (no global atomics): complete bf16 gradient, every element written once -- also over garbage
+    gbf = torch.full((B, Hf, Wf, C), 7.0, dtype=BF, device=dev)
+    ops.roi_crop_pool_bwd_bf16(gp.to(BF).to(dev), am, rois.to(dev), rows.to(dev), len(rows), B, P, Hf, Wf, C, 7, 2, gbf)
+    torch.cuda.synchronize()
+    _close(gbf, gfeat.to(BF), 2 ** -7, 1e-3, "roi grad (gather) vs atomic kernel")
+    _close(gbf, fr.grad, 2 ** -6, 5e-2, "roi grad (gather) vs oracle")
 
 
 # ------------------------------------------------------------------ targets / sampling / losses
