@@ -15,7 +15,7 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, int NW, bool PIPE>
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, int NW, bool PIPE, bool KWS>
 __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // SMODE 0: plain, 1: BatchNorm statistics of the output (forward), 2: BatchNorm-backward reduce of the consumer layer
@@ -32,7 +32,6 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
     static_assert(S == 2 || (S >= 3 && S <= 6 && A_UNI && B_UNI), "counted waits need a uniform DMA split");
     static_assert(!MULTI || (S == 2 && A_UNI && B_UNI), "tile runs use the two-slot ring with a uniform DMA split");
     static_assert(!F32 || (!MULTI && SMODE == 0), "fp32 / split-K output: one tile per workgroup, no statistics");
-    static_assert(SMODE != 2 || (MULTI ? S * (BM + BN) * BK * 2 + BM * (BN * 2 + 16) : S * (BM + BN) * BK * 2) >= NW * 64 * 64, "reduce tree needs 64 B of LDS per thread");
     constexpr int STG32 = BM * (BN * 4 + 16);   // fp32 staging tile (F32)
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, KK = BK / 32;
     static_assert(MI >= 1 && NI >= 1, "tile too small for the wave grid");
@@ -42,7 +41,15 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
     constexpr int ROWB = BN * 2 + 16;            // staging row pitch (bytes)
     constexpr int C8 = BN / 8, ST_IT = (BM * C8) / T;
     static_assert((BM * C8) % T == 0, "store loop covers the tile in whole passes");
-    constexpr int RING = S * (A_BYTES + B_BYTES), STG = BM * ROWB;
+    // KWS (3x3, stride 1, pad 1): the three kw taps of one (kh, channel chunk) group share ONE staged A image -- the BM + 2
+    // pixel rows around the tile, fetched once instead of three times; tap kw reads it shifted by kw rows.  Pixels whose
+    // left / right neighbour lies in another image row (ox == 0 for kw = 0, ox == Wo-1 for kw = 2) are zeroed in the fragment
+    // registers; vertical validity is a property of the staged source row (per-kh bit mask, zero-filled by the range check).
+    static_assert(!KWS || (!LIN && !MULTI && !F32 && !PIPE && BM == 128 && BK == 64 && S == 3 && NW == 8), "kw-sharing mode: 128-row tiles, 3-slot B ring");
+    constexpr int AK_IT = 3, AK_BYTES = AK_IT * NW * 1024;          // shared A image: 192 rows x 128 B (130 used), two of them
+    constexpr int B_BASE = KWS ? 2 * AK_BYTES : S * A_BYTES;
+    constexpr int RING = KWS ? 2 * AK_BYTES + S * B_BYTES : S * (A_BYTES + B_BYTES), STG = BM * ROWB;
+    static_assert(SMODE != 2 || (MULTI ? RING + STG : RING) >= NW * 64 * 64, "reduce tree needs 64 B of LDS per thread");
     // one tile per workgroup: the staging tile aliases the drained ring.  Tile runs (MULTI): the ring keeps prefetching the
     // next tile while the epilogue runs, so the staging tile has its own LDS.
     constexpr int STAGE_OFF = MULTI ? RING : 0;
@@ -94,10 +101,33 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
     const long long halo = (long long)p.pad_h * p.in_row_stride + (long long)p.pad_w * p.in_pix_stride;
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - halo), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-    unsigned a_voff[A_IT], a_mask[A_IT], b_voff[B_IT];
+    unsigned a_voff[KWS ? AK_IT : A_IT], a_mask[KWS ? AK_IT : A_IT], b_voff[B_IT];
+    unsigned edge_l[MI], edge_r[MI];            // KWS: all-ones, or zero where the lane's pixel has no left / right neighbour in its image row
     const int lrow = lane / CPR, lslot = lane % CPR;
     auto setup_tile = [&](const int m0) {        // per-lane source offsets (and tap validity masks) of the A rows of tile m0
-        if (LIN) {
+        if (KWS) {
+            const int hw = p.Ho * p.Wo;
+#pragma unroll
+            for (int i = 0; i < AK_IT; ++i) {
+                const int q = (wave + NW * i) * RPI + lrow;          // staged row q holds the kw = 1 source of virtual pixel m0 + q - 1
+                const int mv = m0 + q - 1;
+                const bool ok = q < BM + 2 && mv >= 0 && mv < p.M;
+                const int mc = ok ? mv : 0;
+                const int n = mc / hw;
+                const int rem = mc - n * hw;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                a_voff[i] = ok ? (unsigned)(((n * p.Hi + oy) * p.Wi + ox) * p.in_pix_stride * 2) + (unsigned)swz<BK>(lslot, q) * 16u : kOob;
+                a_mask[i] = ((unsigned)(oy - 1) < (unsigned)p.Hi ? 1u : 0u) | 2u | ((unsigned)(oy + 1) < (unsigned)p.Hi ? 4u : 0u);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * WTM + i * 16 + frow;
+                const int ox = m % p.Wo;
+                edge_l[i] = ox == 0 ? 0u : 0xFFFFFFFFu;
+                edge_r[i] = ox == p.Wo - 1 ? 0u : 0xFFFFFFFFu;
+            }
+        } else if (LIN) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const int r = (wave + NW * i) * RPI + lrow;
@@ -148,7 +178,7 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     auto issue_slice = [&](const int slot) {     // DMA the loader's next K slice into ring slot
         unsigned char* sa = ring + slot * A_BYTES;
-        unsigned char* sb = ring + S * A_BYTES + slot * B_BYTES;
+        unsigned char* sb = ring + B_BASE + slot * B_BYTES;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             if (A_UNI || wave + NW * i < A_INSTR) {
@@ -181,6 +211,30 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
         }
     };
 
+    // KWS loader: slices in (channel chunk, kh, kw) order; the kw = 0 slice of a group also brings the group's A image
+    int kl_c0 = 0, kl_kh = 0, kl_kw = 0, kl_abuf = 0;
+    auto issue_slice_kws = [&](const int slot) {
+        unsigned char* sb = ring + B_BASE + slot * B_BYTES;
+        const unsigned soff_b = (unsigned)(((kl_kh * 3 + kl_kw) * p.Cin + kl_c0) * 2);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (wave + NW * i) * 1024), 16, b_voff[i], soff_b, 0, 0);
+        if (kl_kw == 0) {
+            unsigned char* sa = ring + kl_abuf * AK_BYTES;
+            const unsigned soff_a = (unsigned)((kl_kh * p.in_row_stride32 + p.in_pix_stride + kl_c0) * 2);
+#pragma unroll
+            for (int i = 0; i < AK_IT; ++i) {
+                const unsigned vo = ((a_mask[i] >> kl_kh) & 1u) ? a_voff[i] : kOob;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(sa + (wave + NW * i) * 1024), 16, vo, soff_a, 0, 0);
+            }
+            kl_abuf ^= 1;
+        }
+        if (++kl_kw == 3) {
+            kl_kw = 0;
+            if (++kl_kh == 3) { kl_kh = 0; kl_c0 += BK; }
+        }
+    };
+
     // ------------------------------------------------------------------ consumer (MFMA) state
     f32x4 acc[MI][NI];
     // fragment read offsets per 32-wide K step: the swizzle term only depends on the lane (fragments start on multiples
@@ -193,7 +247,7 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
     }
     auto mfma_slice = [&](const int slot) {      // acc += A(slot) * B(slot)^T, fragments of step kk+1 fetched under the MFMAs of kk
         const unsigned char* cA = ring + slot * A_BYTES;
-        const unsigned char* cB = ring + S * A_BYTES + slot * B_BYTES;
+        const unsigned char* cB = ring + B_BASE + slot * B_BYTES;
         bf16x8 af[2][MI], bfr[2][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(cA + i * 16 * (BK * 2) + a_foff[0]);
@@ -213,6 +267,50 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // KWS: fragment offsets of the A image per kw (the swizzle term follows the shifted row)
+    unsigned ak_foff[3][KK];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            ak_foff[kw][kk] = (unsigned)((wm * WTM + frow + kw) * (BK * 2) + swz<BK>(kk * 4 + fchunk, frow + kw) * 16);
+    auto mfma_slice_kws = [&](const int slot, const int abuf, auto kw_c) {
+        constexpr int kw = decltype(kw_c)::value;
+        const unsigned char* cA = ring + abuf * AK_BYTES;
+        const unsigned char* cB = ring + B_BASE + slot * B_BYTES;
+        u32x4 af[2][MI];
+        bf16x8 bfr[2][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const u32x4*>(cA + i * 16 * (BK * 2) + ak_foff[kw][0]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(cB + j * 16 * (BK * 2) + b_foff[0]);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < KK) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[nxt][i] = *reinterpret_cast<const u32x4*>(cA + i * 16 * (BK * 2) + ak_foff[kw][kk + 1]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bfr[nxt][j] = *reinterpret_cast<const bf16x8*>(cB + j * 16 * (BK * 2) + b_foff[kk + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                u32x4 a = af[cur][i];
+                if (kw == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] &= edge_l[i];
+                }
+                if (kw == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] &= edge_r[i];
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[cur][j], __builtin_bit_cast(bf16x8, a), acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -242,7 +340,10 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
     // ------------------------------------------------------------------ K loops of the run's tiles
 #define FRCNN_WAIT_IMM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
     const int total_slices = tile_count * nk;
-    {
+    if (KWS) {
+        issue_slice_kws(0);                      // (nk = 9 * Cin / 64 >= 9)
+        issue_slice_kws(1);
+    } else {
         const int pre = total_slices < S - 1 ? total_slices : S - 1;
         for (int s = 0; s < pre; ++s) issue_slice(s);
     }
@@ -255,6 +356,30 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
 #pragma unroll
             for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         int left = nk;                           // slices of this tile still to consume
+        if (KWS) {
+            // one (channel chunk, kh) group per trip, its three kw slices unrolled: slice s waits until only the DMA of
+            // slice s+1 is outstanding (B piece, plus the next group's A image when s+1 opens a group)
+            constexpr int LCB = B_INSTR / NW;
+            static_assert(!KWS || B_UNI, "kw-sharing mode: uniform B split");
+            int sl = 0, bslot = 0;
+            auto kws_step = [&](auto kw_c, const int abuf) {
+                constexpr int kw = decltype(kw_c)::value;
+                if (sl + 1 < nk) FRCNN_WAIT_IMM(kw == 2 ? LCB + AK_IT : LCB);
+                else FRCNN_WAIT_IMM(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (sl + 2 < nk) issue_slice_kws(bslot == 0 ? 2 : bslot - 1);
+                mfma_slice_kws(bslot, abuf, kw_c);
+                bslot = bslot == 2 ? 0 : bslot + 1;
+                ++sl;
+            };
+            for (int g = 0; 3 * g < nk; ++g) {
+                kws_step(std::integral_constant<int, 0>{}, g & 1);
+                kws_step(std::integral_constant<int, 1>{}, g & 1);
+                kws_step(std::integral_constant<int, 2>{}, g & 1);
+            }
+            left = 0;
+        }
         if (PIPE) {
             // Software-pipelined K loop.  The barrier of iteration s certifies slice s+1 (slice s was certified one iteration
             // earlier), so the fragments of the NEXT 32-wide step -- the first step of slice s+1 included -- are always in flight
@@ -607,17 +732,17 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
 #endif
 }
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, int NW = 8, bool PIPE = false>
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, int NW = 8, bool PIPE = false, bool KWS = false>
 int launch_tile(const ConvParams& p, hipStream_t s) {
-    constexpr int ring = S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
+    constexpr int ring = KWS ? 2 * 3 * NW * 1024 + S * BN * BK * 2 : S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
     constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4;
     static_assert(smem <= 163840, "LDS budget");
     static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
-    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, NW, PIPE>), smem) != 0) {
+    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, NW, PIPE, KWS>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
-    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, NW, PIPE>), dim3(p.items, F32 ? p.split : 1), dim3(NW * 64), smem, s, p);
+    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, NW, PIPE, KWS>), dim3(p.items, F32 ? p.split : 1), dim3(NW * 64), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
     return FRCNN_OK;
 }
@@ -697,6 +822,28 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
     p.tiles_n = (d->cout + bn - 1) / bn;
     p.tiles_per_block = tpb;
     p.items = ((p.tiles_m + tpb - 1) / tpb) * p.tiles_n;
+    {
+        // 3x3 / stride 1 / pad 1: the kw taps share one staged A image (conv_tile_kernel, KWS)
+        const char* e = getenv("FRCNN_KWS");
+        const bool kws_ok = p.taps == 9 && p.KW == 3 && p.stride == 1 && p.pad_h == 1 && p.pad_w == 1 && p.Hi == p.Ho && p.Wi == p.Wo &&
+                            d->cin % 64 == 0 && p.direct_out && !getenv("FRCNN_TILE");
+        // measured (per-layer table of the train step): pays where two workgroups share a CU (conv2 / conv3: -8 % / -14 %);
+        // with one 128 x 64 tile per CU (M = 7488) the slice time is a latency chain that the smaller fill does not shorten,
+        // and the wide 128 x 128 tiles of the RPN data gradient are faster there.  FRCNN_KWS=1 forces it, =0 disables it.
+        const bool kws_pays = tiles_m128 >= 160;
+        if (kws_ok && (e ? e[0] == '1' : kws_pays)) {
+            p.k_tiles = p.Ktot / 64;
+            p.k_tiles_per_split = p.k_tiles;
+            p.tiles_m = (int)((M + 127) / 128);
+            p.tiles_n = (d->cout + 63) / 64;
+            p.tiles_per_block = 1;
+            p.items = p.tiles_m * p.tiles_n;
+            const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
+            if (smode == 2) return launch_tile<128, 64, 64, 3, false, 2, 2, false, false, 8, false, true>(p, s);
+            if (smode == 1) return launch_tile<128, 64, 64, 3, false, 1, 2, false, false, 8, false, true>(p, s);
+            return launch_tile<128, 64, 64, 3, false, 0, 2, false, false, 8, false, true>(p, s);
+        }
+    }
 #define FRCNN_PIPE(BM_, BN_, S_, OCC_, W_) \
     if (tpb == 1 && pipe && waves == W_ && bm == BM_ && bn == BN_ && bk == 64 && stages == S_) return launch_tile_flags<BM_, BN_, 64, S_, OCC_, false, W_, true>(p, s);
     FRCNN_PIPE(128, 64, 3, 2, 8)

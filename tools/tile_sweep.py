@@ -84,7 +84,7 @@ def main():
                 res.append((1e9, cfg))
         res.sort()
         fl = 2.0 * m * cout * k * k * cin
-        print("M=%6d cin=%5d cout=%5d k=%d s=%d : " % (m, cin, cout, k, s) + "  ".join("%s %.1fus(%.0fTF)" % (",".join(map(str, c)), t, fl / t / 1e6) for t, c in res[:5]), flush=True)
+        print("M=%6d cin=%5d cout=%5d k=%d s=%d : " % (m, cin, cout, k, s) + "  ".join("%s %.1fus(%.0fTF)" % (",".join(map(str, c)), t, fl / t / 1e6) for t, c in res[:int(os.environ.get("SWEEP_TOP", "5"))]), flush=True)
     os.environ.pop("FRCNN_TILE", None)
 
 
