@@ -27,8 +27,12 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* roi /*x1,y1,x2,y2 rel*/
     return g;
 }
 
+// KS > 0: pooling window fixed at compile time -- the KS*KS samples of a bin are unrolled, so their 4*KS*KS tap loads are
+// all in flight before the first interpolation (the rolled loop waited for each sample's taps in turn)
+template <int KS>
 __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ rois, int P, int Hf, int Wf,
-                                                      int C8, int ps, int ks, bf16_t* __restrict__ pooled, uint8_t* __restrict__ amax) {
+                                                      int C8, int ps, int ks_rt, bf16_t* __restrict__ pooled, uint8_t* __restrict__ amax) {
+    const int ks = KS > 0 ? KS : ks_rt;
     const int row = blockIdx.x;               // b*P + p
     const int b = row / P;
     const int crop = ps * ks;
@@ -44,7 +48,8 @@ __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__
         unsigned char arg[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = 0; }
-        for (int s = 0; s < ks * ks; ++s) {
+#pragma unroll
+        for (int s = 0; s < (KS > 0 ? KS * KS : ks * ks); ++s) {
             const int i = ph * ks + s / ks, j = pw * ks + s % ks;
             const float in_y = g.y1s + (float)i * g.hs;
             const float in_x = g.x1s + (float)j * g.ws;
@@ -204,8 +209,12 @@ extern "C" int frcnn_roi_crop_pool_fwd(const frcnn_bf16* feat, const float* rois
     FRCNN_CHECK_ARG(feat && rois && pooled && argmax, "roi_crop_pool_fwd: null pointer");
     FRCNN_CHECK_ARG(b > 0 && p > 0 && c % 8 == 0 && ps >= 1 && ks >= 1 && ps * ks >= 2 && ks * ks <= 255 && hf > 1 && wf > 1,
                     "roi_crop_pool_fwd: bad sizes");
-    hipLaunchKernelGGL(roi_fwd_kernel, dim3(b * p), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const bf16_t*>(feat), rois, p, hf, wf, c / 8, ps, ks, reinterpret_cast<bf16_t*>(pooled), argmax);
+    if (ks == 2)
+        hipLaunchKernelGGL(roi_fwd_kernel<2>, dim3(b * p), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const bf16_t*>(feat), rois, p, hf, wf, c / 8, ps, ks, reinterpret_cast<bf16_t*>(pooled), argmax);
+    else
+        hipLaunchKernelGGL(roi_fwd_kernel<0>, dim3(b * p), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           reinterpret_cast<const bf16_t*>(feat), rois, p, hf, wf, c / 8, ps, ks, reinterpret_cast<bf16_t*>(pooled), argmax);
     FRCNN_CHECK_LAUNCH("roi_crop_pool_fwd");
     return FRCNN_OK;
 }
