@@ -18,6 +18,12 @@ class ConvDesc(Structure):
         "ho", "wo", "cout", "out_h", "out_w", "out_scatter", "flags", "split_k")]
 
 
+class WgradItem(Structure):
+    """struct frcnn_wgrad_item (include/frcnn_hip.h)."""
+    _fields_ = [("desc", POINTER(ConvDesc)), ("x", c_void_p), ("dz", c_void_p), ("dw", c_void_p), ("dz_stride", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 class BnReduce(Structure):
     """frcnn_bn_reduce"""
     _fields_ = [("z", c_void_p), ("relu_mask", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("partial", c_void_p)]
@@ -34,6 +40,9 @@ _SIGNATURES = {
     "frcnn_conv2d_fprop": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "frcnn_conv2d_dgrad_bnreduce": (c_int, [POINTER(ConvDesc), P, P, P, P, P, POINTER(BnReduce), P]),
     "frcnn_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
+    "frcnn_wgrad_group_bytes": (c_size_t, []),
+    "frcnn_conv2d_wgrad_group_plan": (c_int, [P, c_int, P, c_size_t]),
+    "frcnn_conv2d_wgrad_grouped": (c_int, [P, P, P]),
     "frcnn_weights_transpose_flip": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "frcnn_weights_transpose_flip_batched": (c_int, [P, c_int, c_int64, P]),
     "frcnn_cast_f32_bf16": (c_int, [P, P, c_int64, P]),

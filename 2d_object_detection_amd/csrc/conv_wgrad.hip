@@ -28,6 +28,7 @@ struct WgradParams {
     int tiles_co, tiles_ci, linear_x;
     int in_row_stride32;
     unsigned x_bytes, dz_bytes;
+    int plain_store;                            // one pixel split: every dw element is written once -> plain stores, no float atomics
 };
 
 // 32-byte-chunk XOR swizzle of a pixel-major tile of W channels: the 4x16 blocks fetched by one
@@ -62,8 +63,16 @@ enum { X_LINEAR = 0, X_ROWIDX = 1, X_GENERAL = 2 };   // how the x operand's pix
 // [2 GiB, 4 GiB), beyond every descriptor (operands are checked to stay below 2 GiB), so the range check zero-fills.
 constexpr unsigned kColOob = 0x80000000u;
 
+// Workgroups are dealt round-robin to the 8 XCDs: give every XCD a contiguous chunk of the logical workgroup list.
+__device__ __forceinline__ int xcd_chunk(int bid, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+// bid: logical workgroup index inside this layer's (pixel split, tile) list, tile fastest
 template <int BM /*co*/, int BN /*ci*/, int S, int MODE, int OCC>
-__global__ __launch_bounds__(512, 2 * OCC) void wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = 8, T = 512, BKP = 64, KK = BKP / 32;
     constexpr int WM = 2, WN = 4;
@@ -86,15 +95,8 @@ __global__ __launch_bounds__(512, 2 * OCC) void wgrad_kernel(const WgradParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
 
-    // Workgroups are dealt round-robin to the 8 XCDs.  Give every XCD a contiguous chunk of the (pixel split, tile) list,
-    // tile fastest: all tiles of one pixel range then run on the same XCD at about the same time, and both operands
-    // of that range come out of HBM once instead of once per XCD.
-    int bid = blockIdx.x;
-    {
-        const int total = gridDim.x, q = total >> 3, r = total & 7;
-        const int xcd = bid & 7, local = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    }
+    // (pixel split, tile) list, tile fastest: all tiles of one pixel range run on the same XCD at about the same time, and both
+    // operands of that range come out of HBM once instead of once per XCD
     const int tiles_all = p.tiles_co * p.taps * p.tiles_ci;
     const int split_idx = bid / tiles_all;
     bid -= split_idx * tiles_all;
@@ -325,10 +327,37 @@ __global__ __launch_bounds__(512, 2 * OCC) void wgrad_kernel(const WgradParams p
         const int co = co0 + r, ci = ci0 + c;
         if (co < p.Cout && ci < p.Cin) {
             const float v = *reinterpret_cast<const float*>(stage + r * SROW + c * 4);
-            atomicAdd(p.dw + ((long long)co * p.taps + tap) * p.Cin + ci, v);
+            float* dst = p.dw + ((long long)co * p.taps + tap) * p.Cin + ci;
+            if (p.plain_store) *dst = v;
+            else atomicAdd(dst, v);
         }
     }
 #endif
+}
+
+template <int BM, int BN, int S, int MODE, int OCC>
+__global__ __launch_bounds__(512, 2 * OCC) void wgrad_kernel(const WgradParams p) {
+    wgrad_body<BM, BN, S, MODE, OCC>(p, xcd_chunk(blockIdx.x, gridDim.x));
+}
+
+// Grouped launch: the weight gradients of several layers (same tile shape and addressing mode) in ONE grid.  A stage of
+// small-M layers (conv4: M = 7488) has enough 64 x 64 tiles in total to fill the chip several times over, so no layer needs
+// a pixel split: no float atomics (110 MB per step at the memory side's 1.3 TB/s for conv4), one ramp-up and one tail
+// instead of one per layer.
+constexpr int kGroupMax = 32;
+struct WgradGroup {
+    int n, total;
+    int first[kGroupMax + 1];                  // first logical workgroup of layer i; first[n] = total
+    WgradParams p[kGroupMax];
+};
+
+template <int BM, int BN, int S, int MODE, int OCC>
+__global__ __launch_bounds__(512, 2 * OCC) void wgrad_group_kernel(const WgradGroup* __restrict__ g) {
+    const int id = xcd_chunk(blockIdx.x, gridDim.x);
+    int layer = 0;
+    while (layer + 1 < g->n && id >= g->first[layer + 1]) ++layer;             // (uniform: scalar loads)
+    const WgradParams p = g->p[layer];
+    wgrad_body<BM, BN, S, MODE, OCC>(p, id - g->first[layer]);
 }
 
 template <int BM, int BN, int S, int MODE, int OCC>
@@ -356,8 +385,9 @@ int launch(const WgradParams& p, int split, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* dz, int dz_stride,
-                                  const int32_t* row_index, float* dw, frcnn_stream_t stream) {
+// validation + geometry of one weight gradient (tile counts and the pixel split are set by the callers)
+static int wgrad_fill(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* dz, int dz_stride, const int32_t* row_index,
+                      float* dw, WgradParams& p) {
     FRCNN_CHECK_ARG(d && x && dz && dw, "conv2d_wgrad: null pointer");
     FRCNN_CHECK_ARG(d->cin % 8 == 0 && d->cout % 8 == 0 && dz_stride % 8 == 0, "conv2d_wgrad: channels must be multiples of 8");
     FRCNN_CHECK_ARG(!row_index || (d->kh == 1 && d->kw == 1), "conv2d_wgrad: row_index only for 1x1");
@@ -365,7 +395,6 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
                         (d->stride * d->in_pix_stride) % 8 == 0 && (d->pad_w * d->in_pix_stride) % 8 == 0 &&
                         ((long long)d->wi * d->in_pix_stride) % 8 == 0,
                     "conv2d_wgrad: pixel addressing breaks 16-byte alignment");
-    WgradParams p;
     p.x = reinterpret_cast<const bf16_t*>(x);
     p.dz = reinterpret_cast<const bf16_t*>(dz);
     p.row_index = row_index;
@@ -392,6 +421,15 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
         p.x_bytes = (unsigned)xb;
         p.dz_bytes = (unsigned)zb;
     }
+    p.plain_store = 0;
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* dz, int dz_stride,
+                                  const int32_t* row_index, float* dw, frcnn_stream_t stream) {
+    WgradParams p;
+    if (const int rc = wgrad_fill(d, x, dz, dz_stride, row_index, dw, p)) return rc;
+    const long long M = p.M;
 
     // measured on the R50-C4 layer shapes (tools/wgrad_sweep.py): 64 x 64 tiles with a 3-slot ring (three workgroups per
     // CU) win nearly everywhere -- small tiles need few pixel splits to fill the chip, and every split costs one fp32 tile
@@ -414,6 +452,7 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
     if (split < 1) split = 1;
     p.p_tiles_per_split = (p.p_tiles + split - 1) / split;
     split = (p.p_tiles + p.p_tiles_per_split - 1) / p.p_tiles_per_split;
+    p.plain_store = split == 1 ? 1 : 0;        // (dw arrives zeroed: a single writer per element may store)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define FRCNN_DISPATCH(BM_, BN_, S_, OCC_) \
     if (bm == BM_ && bn == BN_ && stages == S_) return launch<BM_, BN_, S_, OCC_>(p, split, s);
@@ -430,4 +469,73 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
 #undef FRCNN_DISPATCH
     frcnn_set_error("conv2d_wgrad: no tile configuration");
     return FRCNN_EINVAL;
+}
+
+// ---------------------------------------------------------------------------------------------------- grouped launches
+extern "C" size_t frcnn_wgrad_group_bytes(void) { return 2 * sizeof(WgradGroup); }
+
+// Fill `table_host` (frcnn_wgrad_group_bytes() bytes: one group of 1x1 / stride-1 layers whose x rows are the GEMM rows, one
+// group of everything else) for n weight gradients that are launched together with ONE small pixel split for the whole group
+// (none when the group's tiles fill the chip: every dw element is then stored once; otherwise dw must arrive zeroed).  The caller copies the
+// table to device memory once -- shapes and pointers of a training plan are static -- and passes both copies to
+// frcnn_conv2d_wgrad_grouped.  Layers must have cin, cout multiples of 64 (64 x 64 tiles).
+extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int n, void* table_host, size_t table_bytes) {
+    FRCNN_CHECK_ARG(items && table_host && n > 0 && table_bytes >= 2 * sizeof(WgradGroup), "conv2d_wgrad_group_plan: bad arguments");
+    WgradGroup* g = reinterpret_cast<WgradGroup*>(table_host);
+    g[0].n = g[1].n = 0;
+    g[0].total = g[1].total = 0;
+    int tiles[2] = {0, 0}, min_p_tiles[2] = {1 << 30, 1 << 30};
+    for (int i = 0; i < n; ++i) {
+        WgradParams p;
+        if (const int rc = wgrad_fill(items[i].desc, items[i].x, items[i].dz, items[i].dz_stride, nullptr, items[i].dw, p)) return rc;
+        FRCNN_CHECK_ARG(p.Cin % 64 == 0 && p.Cout % 64 == 0, "conv2d_wgrad_group_plan: layer %d: channels must be multiples of 64", i);
+        p.tiles_co = p.Cout / 64;
+        p.tiles_ci = p.Cin / 64;
+        p.p_tiles = (p.M + 63) / 64;
+        const int m = p.linear_x ? 0 : 1;
+        FRCNN_CHECK_ARG(g[m].n < kGroupMax, "conv2d_wgrad_group_plan: more than %d layers in one group", kGroupMax);
+        g[m].p[g[m].n++] = p;
+        tiles[m] += p.tiles_co * p.taps * p.tiles_ci;
+        if (p.p_tiles < min_p_tiles[m]) min_p_tiles[m] = p.p_tiles;
+    }
+    // one pixel split for the whole group: just enough workgroups for ~2 per CU.  The float atomics of a split cost
+    // split x |dw| bytes at the memory side's 1.3 TB/s; launched alone, a layer with few tiles needs a far larger split to fill
+    // the chip (conv2: 64-128) than the group does (~10)
+    for (int m = 0; m < 2; ++m) {
+        if (g[m].n == 0) continue;
+        int split = (2 * num_cus() + tiles[m] - 1) / tiles[m];
+        if (split > min_p_tiles[m]) split = min_p_tiles[m];
+        if (split < 1) split = 1;
+        for (int i = 0; i < g[m].n; ++i) {
+            WgradParams& p = g[m].p[i];
+            p.p_tiles_per_split = (p.p_tiles + split - 1) / split;
+            const int eff = (p.p_tiles + p.p_tiles_per_split - 1) / p.p_tiles_per_split;
+            p.plain_store = eff == 1 ? 1 : 0;
+            g[m].first[i] = g[m].total;
+            g[m].total += p.tiles_co * p.taps * p.tiles_ci * eff;
+        }
+        g[m].first[g[m].n] = g[m].total;
+    }
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* table_dev, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(table_host && table_dev, "conv2d_wgrad_grouped: null pointer");
+    const WgradGroup* h = reinterpret_cast<const WgradGroup*>(table_host);
+    const WgradGroup* dv = reinterpret_cast<const WgradGroup*>(table_dev);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    constexpr int smem = 3 * 64 * (64 + 64) * 2;             // 64 x 64 tiles, 3-slot ring (staging tile aliases it)
+    if (h[0].n > 0) {
+        FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_group_kernel<64, 64, 3, X_LINEAR, 3>), smem) == 0,
+                        "conv2d_wgrad_grouped: cannot reserve %d B of LDS", smem);
+        hipLaunchKernelGGL((wgrad_group_kernel<64, 64, 3, X_LINEAR, 3>), dim3(h[0].total), dim3(512), smem, s, dv);
+        FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad_grouped(linear)");
+    }
+    if (h[1].n > 0) {
+        FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_group_kernel<64, 64, 3, X_GENERAL, 3>), smem) == 0,
+                        "conv2d_wgrad_grouped: cannot reserve %d B of LDS", smem);
+        hipLaunchKernelGGL((wgrad_group_kernel<64, 64, 3, X_GENERAL, 3>), dim3(h[1].total), dim3(512), smem, s, dv + 1);
+        FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad_grouped(general)");
+    }
+    return FRCNN_OK;
 }

@@ -12,6 +12,8 @@ weight gradient with transposing LDS reads).
 """
 import math
 
+import os
+
 import torch
 
 from .. import ops
@@ -20,6 +22,7 @@ from ..runtime import ParamStore, Plan
 BF16 = torch.bfloat16
 BN_EPS = 1.001e-5          # Keras ResNet50 BatchNormalization epsilon [TF-ext]
 BN_MOMENTUM = 0.99
+GROUPED_WGRAD = os.environ.get("FRCNN_GROUPED_WGRAD", "1") != "0"      # (0: one weight-gradient launch per layer)
 STACKS = {50: ((64, 3, 1), (128, 4, 2), (256, 6, 2)), 101: ((64, 3, 1), (128, 4, 2), (256, 23, 2))}
 
 
@@ -131,8 +134,13 @@ class _ConvBN:
                  self.m, self.cout, relu_mask=mask)
         # the conv bias feeds a training-mode BN: its gradient is identically zero (flat grad buffer is pre-zeroed)
 
-    def backward_weights(self, plan, x):
+    def backward_weights(self, plan, x, defer=None):
+        """defer: list collecting (desc, x, dz, dw) of layers whose weight gradients are launched together at the end of their
+        stage (ops.WgradGroup) instead of one launch each."""
         st = self.store
+        if defer is not None and not self.is_stem and self.cin % 64 == 0 and self.cout % 64 == 0:
+            defer.append((self.desc, x, self.dz, st.grad(self.name + "_conv/kernel")))
+            return
         if self.is_stem:
             plan.add(self.dw_packed.zero_)
             plan.add(ops.conv2d_wgrad, self.desc, x, self.dz, self.dw_packed)
@@ -358,28 +366,43 @@ class FeatureExtractor:
         for (n, ci, f, s, first) in self.specs:
             xs[n] = x
             x = self.acts[n]["out"]
+        # the weight gradients of a stage are launched together (ops.WgradGroup): one pixel split sized for the whole group
+        # instead of one per layer -- none for conv4 (19 layers, 1728 tiles), ~10 instead of 64-128 for conv2 -- i.e. a
+        # fraction of the float atomics, and one ramp-up / tail per stage
+        grouped_stage = (2, 3, 4) if GROUPED_WGRAD else ()
+        deferred = []
+
+        def flush_deferred():
+            if deferred:
+                group = ops.WgradGroup(deferred, self.device)
+                plan.hold(group)
+                plan.add(ops.conv2d_wgrad_grouped, group)
+                del deferred[:]
+
         for (n, ci, f, s, first) in reversed(self.specs):
             stage = int(n[4])
             if prev_stage is not None and stage != prev_stage:
+                flush_deferred()
                 plan.cut("bwd_conv%d" % stage)
             prev_stage = stage
+            defer = deferred if stage in grouped_stage else None
             u, a, xin = self.units[n], self.acts[n], xs[n]
             # every data-gradient kernel also runs the BN-backward reduce of the layer that consumes its output
             # the block-output gradient after the final ReLU (g * mask) is never materialised: its two consumers -- the
             # shortcut branch and the residual add of the block-input gradient -- read gout and the block's ReLU bit mask
             gblock, mblock = gout, u[3].relu_mask
             u[3].backward_bn(plan, gout, a["out"], reduced=gout_reduced)
-            u[3].backward_weights(plan, a["a2"])
+            u[3].backward_weights(plan, a["a2"], defer)
             u[3].backward_data(plan, a["g2"], consumer=u[2])
             u[2].backward_bn(plan, a["g2"], a["a2"], reduced=True)
-            u[2].backward_weights(plan, a["a1"])
+            u[2].backward_weights(plan, a["a1"], defer)
             u[2].backward_data(plan, a["g1"], consumer=u[1])
             u[1].backward_bn(plan, a["g1"], a["a1"], reduced=True)
-            u[1].backward_weights(plan, xin)
+            u[1].backward_weights(plan, xin, defer)
             prev = prev_of[n]                     # block whose output this block's input gradient is (None: max-pool output)
             if first:
                 u[0].backward_bn(plan, gblock, None, mask=mblock)
-                u[0].backward_weights(plan, xin)
+                u[0].backward_weights(plan, xin, defer)
                 if s != 1:
                     plan.add(a["gin"].zero_)
                 u[1].backward_data(plan, a["gin"])
@@ -388,6 +411,9 @@ class FeatureExtractor:
                 u[1].backward_data(plan, a["gin"], res=gblock, consumer=prev, res_mask=mblock)
             gout = a["gin"]
             gout_reduced = prev is not None
+            if len(deferred) >= 24:               # (the parameter table holds 32 layers per addressing mode)
+                flush_deferred()
+        flush_deferred()
         st = self.stem
         plan.add(ops.maxpool_bwd, gout, self.pool_arg, self.g_stem, self.batch, st.ho, st.wo, 64, self.hp1, self.wp1)
         st.backward_bn(plan, self.g_stem, self.a_stem)

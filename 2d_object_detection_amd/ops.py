@@ -66,6 +66,28 @@ def conv2d_wgrad(d, x, dz, dw, dz_stride=None, row_index=None):
     call("frcnn_conv2d_wgrad", byref(d), _p(x), _p(dz), d.cout if dz_stride is None else dz_stride, _p(row_index), _p(dw), _stream())
 
 
+class WgradGroup:
+    """Several weight gradients launched together without a pixel split (frcnn_conv2d_wgrad_grouped).  items: list of
+    (conv_desc, x, dz, dw) with static shapes and buffers; the parameter table is built once and kept on the device."""
+
+    def __init__(self, items, device):
+        self.items = list(items)                 # keeps descriptors and tensors alive
+        n = len(self.items)
+        arr = (_lib.WgradItem * n)()
+        for i, (d, x, dz, dw) in enumerate(self.items):
+            arr[i].desc = ctypes.pointer(d)
+            arr[i].x, arr[i].dz, arr[i].dw = _p(x), _p(dz), _p(dw)
+            arr[i].dz_stride = d.cout
+        nbytes = int(_lib.load().frcnn_wgrad_group_bytes())
+        self.host = torch.zeros(nbytes, dtype=torch.uint8)
+        call("frcnn_conv2d_wgrad_group_plan", ctypes.cast(arr, c_void_p), n, self.host.data_ptr(), nbytes)
+        self.dev = self.host.to(device)
+
+
+def conv2d_wgrad_grouped(group):
+    call("frcnn_conv2d_wgrad_grouped", group.host.data_ptr(), _p(group.dev), _stream())
+
+
 def weights_transpose_flip(w, w_t, cout, kh, kw, cin):
     call("frcnn_weights_transpose_flip", _p(w), _p(w_t), cout, kh, kw, cin, _stream())
 

@@ -64,6 +64,10 @@ def profile_conv_kernels(model, built, steps=3):
                 cin, cout = true_dims(d, fn)
                 name = "conv wgrad (wgrad_kernel)" if fn is ops.conv2d_wgrad else "conv fprop/dgrad (conv_tile_kernel, igemm_kernel)"
                 records.append((fn, args, kwargs, name, conv_flops(d, cin, cout)))
+            elif fn is ops.conv2d_wgrad_grouped:
+                # several layers' weight gradients in one call (two launches: 1x1/stride-1 layers, everything else)
+                fl = sum(conv_flops(d, *true_dims(d, fn)) for (d, _x, _dz, _dw) in args[0].items)
+                records.append((fn, args, kwargs, "conv wgrad (wgrad_kernel)", fl))
             else:
                 records.append((fn, args, kwargs, None, 0.0))
     state = model._snapshot(built["optimizer"])
@@ -108,7 +112,7 @@ def profile_conv_kernels(model, built, steps=3):
                 i += 1
                 key = len(order) if it == 0 else None
                 if it == 0:
-                    order.append((name, args[0], fl))
+                    order.append((name, args[0] if fn is not ops.conv2d_wgrad_grouped else args[0].items[0][0], fl))
                 per.setdefault(i - 1 - it * (len(events) // steps), []).append(ev[2].elapsed_time(ev[3]) * 1e3)
         with open(os.environ["FRCNN_LAYER_TABLE"], "w") as fh:
             for j, (name, d, fl) in enumerate(order):

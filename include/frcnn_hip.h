@@ -93,6 +93,24 @@ int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcn
 int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* dz, int dz_stride,
                        const int32_t* row_index, float* dw, frcnn_stream_t stream);
 
+/* Grouped weight gradients: several layers of one backward stage in ONE launch per addressing mode, with one pixel split
+ * chosen for the whole group (just enough workgroups for ~2 per CU; none -- no float atomics, every dw element stored
+ * once -- when the group's 64x64 tiles fill the chip, e.g. conv4 at 375x1242: 19 layers, 1728 tiles).
+ * frcnn_conv2d_wgrad_group_plan fills a HOST table (frcnn_wgrad_group_bytes() bytes) from n items (cin, cout multiples of
+ * 64; per item the semantics of frcnn_conv2d_wgrad: dw pre-zeroed); the caller uploads the table once and launches with
+ * both copies. */
+typedef struct frcnn_wgrad_item {
+    const frcnn_conv_desc* desc;
+    const frcnn_bf16* x;
+    const frcnn_bf16* dz;
+    float* dw;
+    int32_t dz_stride;
+    int32_t reserved;
+} frcnn_wgrad_item;
+size_t frcnn_wgrad_group_bytes(void);
+int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int n, void* table_host, size_t table_bytes);
+int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* table_dev, frcnn_stream_t stream);
+
 /* w_t[ci][KH-1-kh][KW-1-kw][co] (bf16) = w[co][kh][kw][ci] (fp32 master) : data-gradient weights. */
 int frcnn_weights_transpose_flip(const float* w, frcnn_bf16* w_t, int cout, int kh, int kw, int cin,
                                  frcnn_stream_t stream);

@@ -175,6 +175,36 @@ def test_conv_wgrad(ops, case):
     _close(dw, ref, 2e-4, 2e-3 * (n * ho * wo) ** 0.5, "wgrad")
 
 
+def test_conv_wgrad_grouped(ops):
+    """Five layers (3x3, strided 1x1, plain 1x1 -- both addressing modes) in one grouped launch with a common pixel split."""
+    g = torch.Generator().manual_seed(8)
+    cases = [dict(n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1), dict(n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0),
+             dict(n=2, h=9, w=13, cin=128, cout=256, k=1, s=1, p=0), dict(n=3, h=24, w=26, cin=256, cout=256, k=3, s=1, p=1),
+             dict(n=2, h=10, w=12, cin=64, cout=256, k=1, s=1, p=0)]
+    items, refs = [], []
+    for case in cases:
+        n, h, w, cin, cout, k, s, p = (case[x] for x in ("n", "h", "w", "cin", "cout", "k", "s", "p"))
+        x = _rt(torch.randn(n, cin, h, w, generator=g))
+        wt = torch.zeros(cout, cin, k, k, requires_grad=True)
+        y = F.conv2d(x, wt, stride=s, padding=p)
+        ho, wo = y.shape[2], y.shape[3]
+        dz = _rt(torch.randn(n, cout, ho, wo, generator=g))
+        y.backward(dz)
+        refs.append((_ohwi(wt.grad), n * ho * wo))
+        d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout)
+        dw = torch.zeros(cout, k, k, cin, device="cuda")        # (pre-zeroed: the group may use a pixel split)
+        items.append((d, x.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dz.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dw))
+    group = ops.WgradGroup(items, "cuda")
+    ops.conv2d_wgrad_grouped(group)
+    torch.cuda.synchronize()
+    for (d, x, dz, dw), (ref, m) in zip(items, refs):
+        _close(dw, ref, 2e-4, 2e-3 * m ** 0.5, "grouped wgrad")
+    with pytest.raises(RuntimeError):
+        d = ops.conv_desc(1, 8, 8, 32, 1, 1, 1, 0, 0, 8, 8, 64)                                   # cin = 32: not groupable
+        ops.WgradGroup([(d, torch.zeros(64, 32, dtype=BF, device="cuda"), torch.zeros(64, 64, dtype=BF, device="cuda"),
+                         torch.zeros(64, 32, device="cuda"))], "cuda")
+
+
 def test_conv_wgrad_stem_and_rowindex(ops):
     g = torch.Generator().manual_seed(6)
     # stem: packed [64][7][8][4] gradient, then unpack to [64][7][7][3]
