@@ -11,7 +11,8 @@ pipelines make one ordered pass and keep the final partial batch.
 Sources: the TFRecord files written by the reference's data/build_tf_records.py (or by data/build_records.py here), a list
 of them, or a raw KITTI directory (`image_2/*.png` + `label_2/*.txt`).  Data-parallel rank r of w reads records
 r, r+w, r+2w, ... (the north-star's "shards the KITTI input_pipeline across the GPUs"); decode runs in a small thread pool
-and batches are prefetched on a background thread into pinned host memory, so the H2D copy overlaps the previous step.
+and batches are assembled on a background thread in a ring of pre-allocated pinned buffers (no HIP call off the training
+thread: a host allocation there would invalidate a hipGraph capture in progress) and copied to the device on a side stream.
 
 [TF-ext] `tf.image.resize` semantics restated from the public contract (bilinear, half-pixel centres, no antialias,
 float32 arithmetic, result truncated by the uint8 cast); unverified against TensorFlow here (not installed)."""
@@ -150,10 +151,14 @@ class _Dataset:
                     yield buf[j]
                 buf = []
 
-    def _batches(self):
+    def _batches(self, ring):
+        """ring: pre-allocated pinned (images, classes, boxes) buffers to assemble the batches in, or None.  Nothing here calls
+        the HIP runtime: this runs on a background thread, and a host allocation there would invalidate a stream capture
+        (hipGraph) in progress on the training thread."""
         rng = np.random.default_rng([0x2D0D, self.rank] if self.seed is None else [self.seed, self.rank])
         flips = np.random.default_rng([0xF11B, self.rank] if self.seed is None else [self.seed, self.rank, 1])
         pool = ThreadPoolExecutor(max_workers=max(1, self.num_workers))
+        k = 0
         try:
             stream = self._stream(rng)
             while True:
@@ -166,25 +171,36 @@ class _Dataset:
                     return
                 do_flip = [bool(flips.random() > 0.5) if self.training else False for _ in recs]
                 items = list(pool.map(self.c._decode_and_preprocess, recs, do_flip))
-                images = torch.from_numpy(np.stack([it[0] for it in items]))
-                classes = torch.from_numpy(np.stack([it[1] for it in items]))
-                boxes = torch.from_numpy(np.stack([it[2] for it in items]))
-                if torch.cuda.is_available():
-                    images, classes, boxes = images.pin_memory(), classes.pin_memory(), boxes.pin_memory()
-                yield images, classes, boxes
+                parts = [torch.from_numpy(np.stack([it[j] for it in items])) for j in range(3)]
+                if ring is not None:
+                    slot = ring[k % len(ring)]
+                    k += 1
+                    parts = [buf[:len(recs)].copy_(t) for buf, t in zip(slot, parts)]
+                yield tuple(parts)
                 if len(recs) < self.batch_size:
                     return
         finally:
             pool.shutdown(wait=False)
 
     def __iter__(self):
-        q = queue.Queue(maxsize=max(1, self.prefetch))
+        depth = max(1, self.prefetch)
+        q = queue.Queue(maxsize=depth)
         stop = threading.Event()
         END = object()
+        on_gpu = self.device is not None and torch.device(self.device).type == "cuda"
+        ring, copy_stream = None, None
+        if on_gpu:
+            # allocated here, on the consumer's thread, before the producer starts; depth + 2 slots: `depth` queued, one being
+            # filled, one whose host-to-device copy is being waited for
+            h, w, b, c = self.c.image_shape[0], self.c.image_shape[1], self.batch_size, self.c.num_classes
+            ring = [(torch.empty(b, h, w, 3, dtype=torch.uint8).pin_memory(),
+                     torch.empty(b, self.c.max_num_objects, c + 1).pin_memory(),
+                     torch.empty(b, self.c.max_num_objects, 4).pin_memory()) for _ in range(depth + 2)]
+            copy_stream = torch.cuda.Stream(device=self.device)
 
         def produce():
             try:
-                for batch in self._batches():
+                for batch in self._batches(ring):
                     while not stop.is_set():
                         try:
                             q.put(batch, timeout=0.1)
@@ -206,8 +222,16 @@ class _Dataset:
                     return
                 if isinstance(item, BaseException):
                     raise item
-                if self.device is not None:
-                    item = tuple(x.to(self.device, non_blocking=True) for x in item)
+                if on_gpu:
+                    # copy on a side stream and wait for the COPY only (not for the training stream): the pinned slot is free
+                    # again when the wait returns
+                    with torch.cuda.stream(copy_stream):
+                        item = tuple(x.to(self.device, non_blocking=True) for x in item)
+                    copy_stream.synchronize()
+                    for x in item:
+                        x.record_stream(torch.cuda.current_stream(self.device))
+                elif self.device is not None:
+                    item = tuple(x.to(self.device) for x in item)
                 yield item
         finally:
             stop.set()
