@@ -62,12 +62,12 @@ def profile_conv_kernels(model, built, steps=3):
             if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce or fn is ops.conv2d_wgrad:
                 d = args[0]
                 cin, cout = true_dims(d, fn)
-                name = "conv wgrad (wgrad_kernel)" if fn is ops.conv2d_wgrad else "conv fprop/dgrad (conv_tile_kernel, igemm_kernel)"
+                name = "conv wgrad (wgrad_kernel, wgrad_group_kernel)" if fn is ops.conv2d_wgrad else "conv fprop/dgrad (conv_tile_kernel, igemm_kernel)"
                 records.append((fn, args, kwargs, name, conv_flops(d, cin, cout)))
             elif fn is ops.conv2d_wgrad_grouped:
                 # several layers' weight gradients in one call (two launches: 1x1/stride-1 layers, everything else)
                 fl = sum(conv_flops(d, *true_dims(d, fn)) for (d, _x, _dz, _dw) in args[0].items)
-                records.append((fn, args, kwargs, "conv wgrad (wgrad_kernel)", fl))
+                records.append((fn, args, kwargs, "conv wgrad (wgrad_kernel, wgrad_group_kernel)", fl))
             else:
                 records.append((fn, args, kwargs, None, 0.0))
     state = model._snapshot(built["optimizer"])

@@ -13,8 +13,8 @@ import sys
 def family(name):
     if "conv_tile_kernel" in name or "igemm_kernel" in name:
         return "conv fprop/dgrad (conv_tile_kernel, igemm_kernel)"
-    if "wgrad_kernel" in name:
-        return "conv wgrad (wgrad_kernel)"
+    if "wgrad_kernel" in name or "wgrad_group_kernel" in name:
+        return "conv wgrad (wgrad_kernel, wgrad_group_kernel)"
     if "bn_" in name:
         return "batchnorm (bn_*_kernel)"
     return "other"
