@@ -346,7 +346,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void wgrad_kernel(const WgradParams p
 // instead of one per layer.
 constexpr int kGroupMax = 32;
 struct WgradGroup {
-    int n, total, bm, bn;                      // bm x bn: (cout x cin) tile of this group's launch
+    int n, total, bm, bn, stages;              // bm x bn: (cout x cin) tile of this group's launch; ring slots
     int first[kGroupMax + 1];                  // first logical workgroup of layer i; first[n] = total
     WgradParams p[kGroupMax];
 };
@@ -484,10 +484,10 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
     WgradGroup* g = reinterpret_cast<WgradGroup*>(table_host);
     // tile shape of the grouped launches.  Launched alone a layer wants small tiles (few pixel splits fill the chip); a group
     // has tiles to spare, so it can afford more MFMA work per barrier.  FRCNN_WGRAD_GROUP="bm,bn" overrides (development aid)
-    int gbm = 0, gbn = 64;                     // 0: 128 output channels per tile when every layer of the group has >= 128, else 64
+    int gbm = 0, gbn = 64, gst = 3;            // 0: 128 output channels per tile when every layer of the group has >= 128, else 64
     if (const char* e = getenv("FRCNN_WGRAD_GROUP")) {
-        int a = 0, b = 0;
-        if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 64 || a == 128) && (b == 64 || b == 128)) { gbm = a; gbn = b; }
+        int a = 0, b = 0, c = 3;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) >= 2 && (a == 0 || a == 64 || a == 128) && (b == 64 || b == 128)) { gbm = a; gbn = b; gst = c; }
     }
     g[0].n = g[1].n = 0;
     g[0].total = g[1].total = 0;
@@ -509,6 +509,7 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
         for (int i = 0; i < g[m].n; ++i) min_cout = g[m].p[i].Cout < min_cout ? g[m].p[i].Cout : min_cout;
         g[m].bm = gbm ? gbm : (min_cout >= 128 ? 128 : 64);
         g[m].bn = gbn;
+        g[m].stages = gst;
         for (int i = 0; i < g[m].n; ++i) {
             WgradParams& p = g[m].p[i];
             p.tiles_co = (p.Cout + g[m].bm - 1) / g[m].bm;
@@ -542,8 +543,9 @@ extern "C" int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* ta
     const WgradGroup* h = reinterpret_cast<const WgradGroup*>(table_host);
     const WgradGroup* dv = reinterpret_cast<const WgradGroup*>(table_dev);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int launched = 0;
 #define FRCNN_GROUP_LAUNCH(BM_, BN_, S_, OCC_, MODE_, IDX_)                                                                       \
-    if (h[IDX_].n > 0 && h[IDX_].bm == BM_ && h[IDX_].bn == BN_) {                                                               \
+    if (h[IDX_].n > 0 && h[IDX_].bm == BM_ && h[IDX_].bn == BN_ && h[IDX_].stages == S_) {                                                             \
         constexpr int ring_b = S_ * 64 * (BM_ + BN_) * 2, stage_b = BM_ * (BN_ * 4 + 16);                                          \
         constexpr int smem_b = ring_b > stage_b ? ring_b : stage_b;                                                                \
         static_assert(smem_b * OCC_ <= 163840, "LDS budget");                                                                      \
@@ -551,6 +553,7 @@ extern "C" int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* ta
                         "conv2d_wgrad_grouped: cannot reserve %d B of LDS", smem_b);                                              \
         hipLaunchKernelGGL((wgrad_group_kernel<BM_, BN_, S_, MODE_, OCC_>), dim3(h[IDX_].total), dim3(512), smem_b, s, dv + IDX_);   \
         FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad_grouped");                                                                          \
+        launched |= 1 << IDX_;                                                                                                     \
     }
     FRCNN_GROUP_LAUNCH(64, 64, 3, 3, X_LINEAR, 0)
     FRCNN_GROUP_LAUNCH(64, 64, 3, 3, X_GENERAL, 1)
@@ -560,6 +563,12 @@ extern "C" int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* ta
     FRCNN_GROUP_LAUNCH(64, 128, 3, 2, X_GENERAL, 1)
     FRCNN_GROUP_LAUNCH(128, 128, 2, 2, X_LINEAR, 0)
     FRCNN_GROUP_LAUNCH(128, 128, 2, 2, X_GENERAL, 1)
+    FRCNN_GROUP_LAUNCH(128, 64, 2, 3, X_LINEAR, 0)
+    FRCNN_GROUP_LAUNCH(128, 64, 2, 3, X_GENERAL, 1)
+    FRCNN_GROUP_LAUNCH(64, 64, 2, 3, X_LINEAR, 0)
+    FRCNN_GROUP_LAUNCH(64, 64, 2, 3, X_GENERAL, 1)
 #undef FRCNN_GROUP_LAUNCH
+    FRCNN_CHECK_ARG((h[0].n == 0 || (launched & 1)) && (h[1].n == 0 || (launched & 2)), "conv2d_wgrad_grouped: no kernel for tile %dx%d, %d slots",
+                    h[0].n ? h[0].bm : h[1].bm, h[0].n ? h[0].bn : h[1].bn, h[0].n ? h[0].stages : h[1].stages);
     return FRCNN_OK;
 }
