@@ -46,6 +46,7 @@ _SIGNATURES = {
     "frcnn_weights_transpose_flip": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "frcnn_weights_transpose_flip_batched": (c_int, [P, c_int, c_int64, P]),
     "frcnn_cast_f32_bf16": (c_int, [P, P, c_int64, P]),
+    "frcnn_copy_bytes": (c_int, [P, P, c_int64, P]),
     "frcnn_stem_pack_weights": (c_int, [P, P, c_int, P]),
     "frcnn_stem_unpack_grad": (c_int, [P, P, c_int, P]),
     "frcnn_preprocess_u8_bgr_mean": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -795,6 +795,28 @@ extern "C" int frcnn_step_increment(int64_t* step, frcnn_stream_t stream) {
     return FRCNN_OK;
 }
 
+// Device-to-device copy of nbytes (16-byte aligned pointers) with enough workgroups to run at HBM speed: the runtime's blit
+// kernel moves the 5.6 MB image batch into the plan's static input buffer in 24 us (256 workgroups), this one in ~3.
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const u32x4* __restrict__ s, u32x4* __restrict__ d, int64_t n16, const unsigned char* __restrict__ st,
+                                                         unsigned char* __restrict__ dt, int tail) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) dt[threadIdx.x] = st[threadIdx.x];
+}
+
+extern "C" int frcnn_copy_bytes(const void* src, void* dst, int64_t nbytes, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(src && dst && nbytes >= 0, "copy_bytes: bad arguments");
+    FRCNN_CHECK_ARG((reinterpret_cast<size_t>(src) & 15) == 0 && (reinterpret_cast<size_t>(dst) & 15) == 0, "copy_bytes: pointers must be 16-byte aligned");
+    if (nbytes == 0) return FRCNN_OK;
+    const int64_t n16 = nbytes / 16;
+    const int tail = (int)(nbytes - n16 * 16);
+    const int64_t want = (n16 + 255) / 256;
+    const int grid = (int)(want < 1 ? 1 : want > 4096 ? 4096 : want);
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3(grid), dim3(256), 0, S_(stream), reinterpret_cast<const u32x4*>(src), reinterpret_cast<u32x4*>(dst), n16,
+                       reinterpret_cast<const unsigned char*>(src) + n16 * 16, reinterpret_cast<unsigned char*>(dst) + n16 * 16, tail);
+    FRCNN_CHECK_LAUNCH("copy_bytes");
+    return FRCNN_OK;
+}
+
 extern "C" int frcnn_cast_f32_bf16(const float* src, frcnn_bf16* dst, int64_t n, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(src && dst, "cast: null pointer");
     hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n, 256)), dim3(256), 0, S_(stream), src, BF(dst), n);

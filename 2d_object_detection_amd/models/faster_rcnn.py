@@ -221,7 +221,11 @@ class FasterRCNN:
 
     def _feed(self, built, images, gt_labels, gt_boxes):
         io = built["io"]
-        io["images"].copy_(images, non_blocking=True)
+        if images.is_cuda and images.dtype == io["images"].dtype and images.shape == io["images"].shape and images.is_contiguous() \
+                and images.data_ptr() % 16 == 0:
+            ops.copy_bytes(images, io["images"])             # (the runtime's blit kernel takes 24 us for these 5.6 MB)
+        else:
+            io["images"].copy_(images, non_blocking=True)
         io["gt_labels"].copy_(gt_labels, non_blocking=True)
         io["gt_boxes"].copy_(gt_boxes, non_blocking=True)
 

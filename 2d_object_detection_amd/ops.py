@@ -106,6 +106,11 @@ def weights_transpose_flip_batched(table, total):
     call("frcnn_weights_transpose_flip_batched", _p(table), table.shape[0], total, _stream())
 
 
+def copy_bytes(src, dst):
+    """dst <- src (same dtype / shape, contiguous, 16-byte aligned): a full-width copy kernel instead of the runtime's blit."""
+    call("frcnn_copy_bytes", _p(src), _p(dst), src.numel() * src.element_size(), _stream())
+
+
 def cast_f32_bf16(src, dst, n=None):
     call("frcnn_cast_f32_bf16", _p(src), _p(dst), src.numel() if n is None else n, _stream())
 

@@ -119,6 +119,8 @@ int frcnn_weights_transpose_flip(const float* w, frcnn_bf16* w_t, int cout, int 
 int frcnn_weights_transpose_flip_batched(const int64_t* table, int n, int64_t total, frcnn_stream_t stream);
 /* plain fp32 -> bf16 cast of n elements */
 int frcnn_cast_f32_bf16(const float* src, frcnn_bf16* dst, int64_t n, frcnn_stream_t stream);
+/* device-to-device copy of nbytes (16-byte aligned pointers) at HBM speed: feeds a plan's static input buffers */
+int frcnn_copy_bytes(const void* src, void* dst, int64_t nbytes, frcnn_stream_t stream);
 /* stem weights: master [64][7][7][3] fp32 <-> padded GEMM form [64][7][8][4]
  * (pack: -> bf16; unpack_grad: padded fp32 grad -> compact fp32 grad, overwriting). */
 int frcnn_stem_pack_weights(const float* w, frcnn_bf16* w_packed, int cout, frcnn_stream_t stream);
