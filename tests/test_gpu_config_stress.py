@@ -37,7 +37,9 @@ def run():
     images, gl, gb = O.synthetic_batch(2, cfg["image_shape"], seed=8)
     model = M.FasterRCNN(cfg, depth=101, sampling_seed=5)
     model.set_weights(params)
-    opt = OPT.SGD(learning_rate=OPT.PiecewiseConstantDecay([10, 20], [0.001, 0.0001, 0.00001]), momentum=0.9)
+    # (random init + un-normalised regression loss: the reference's 1e-3 diverges within ~10 steps, so the replay test below
+    # would depend on the summation order of the float atomics; the mechanics under test do not need a large step)
+    opt = OPT.SGD(learning_rate=OPT.PiecewiseConstantDecay([10, 20], [1e-5, 1e-6, 1e-7]), momentum=0.9)
     model.use_graphs = False
     losses, preds = model.train_step(images.cuda(), gl.cuda(), gb.cuda(), opt)
     torch.cuda.synchronize()
