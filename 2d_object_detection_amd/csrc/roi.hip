@@ -28,7 +28,13 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* roi /*x1,y1,x2,y2 rel*/
 }
 
 // KS > 0: pooling window fixed at compile time -- the KS*KS samples of a bin are unrolled, so their 4*KS*KS tap loads are
-// all in flight before the first interpolation (the rolled loop waited for each sample's taps in turn)
+// all in flight before the first interpolation.  The kernel is VALU-bound (rocprofv3 --pmc: 788 VALU instructions per
+// (bin, 8-channel vector) item before this form): crop_and_resize is separable, so the row terms (top / bottom row offset,
+// y weight, validity) of the crop's rows and the column terms of its columns are computed once per workgroup into LDS
+// instead of once per item and sample, and the three interpolations are single FMAs (fmaf is explicit: the file keeps
+// implicit contraction off for the bit-exact box arithmetic elsewhere; the pooled output is bf16 and the oracle comparison
+// carries the matching tolerance).
+constexpr int kMaxCrop = 64;
 template <int KS>
 __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ rois, int P, int Hf, int Wf,
                                                       int C8, int ps, int ks_rt, bf16_t* __restrict__ pooled, uint8_t* __restrict__ amax) {
@@ -36,9 +42,26 @@ __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__
     const int row = blockIdx.x;               // b*P + p
     const int b = row / P;
     const int crop = ps * ks;
-    const RoiGeom g = roi_geom(rois + (int64_t)row * 4, Hf, Wf, crop);
-    const float hm1 = (float)(Hf - 1), wm1 = (float)(Wf - 1);
-    const bf16_t* fb = feat + (int64_t)b * Hf * Wf * C8 * 8;
+    __shared__ int4 ys[kMaxCrop], xs[kMaxCrop];               // {first tap byte offset, second tap byte offset, weight bits, valid}
+    if ((int)threadIdx.x < 2 * crop) {
+        const RoiGeom g = roi_geom(rois + (int64_t)row * 4, Hf, Wf, crop);
+        const bool is_x = (int)threadIdx.x >= crop;
+        const int k = is_x ? threadIdx.x - crop : threadIdx.x;
+        const float in = is_x ? g.x1s + (float)k * g.ws : g.y1s + (float)k * g.hs;
+        const float lim = is_x ? (float)(Wf - 1) : (float)(Hf - 1);
+        const bool ok = in >= 0.f && in <= lim;                // NaN-safe
+        const float lo = floorf(in), hi = ceilf(in), w = in - lo;
+        const int pitch = (is_x ? 1 : Wf) * C8 * 16;           // bytes per column / per row of the NHWC map
+        int4 e;
+        e.x = ok ? (int)lo * pitch : 0;
+        e.y = ok ? (int)hi * pitch : 0;
+        e.z = __float_as_int(w);
+        e.w = ok ? 1 : 0;
+        if (is_x) xs[k] = e;
+        else ys[k] = e;
+    }
+    __syncthreads();
+    const unsigned char* fb = reinterpret_cast<const unsigned char*>(feat + (int64_t)b * Hf * Wf * C8 * 8);
     const int items = ps * ps * C8;
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         const int cv = it % C8;
@@ -50,27 +73,24 @@ __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__
         for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = 0; }
 #pragma unroll
         for (int s = 0; s < (KS > 0 ? KS * KS : ks * ks); ++s) {
-            const int i = ph * ks + s / ks, j = pw * ks + s % ks;
-            const float in_y = g.y1s + (float)i * g.hs;
-            const float in_x = g.x1s + (float)j * g.ws;
+            const int4 yy = ys[ph * ks + s / ks], xx = xs[pw * ks + s % ks];
             float v[8];
-            if (!(in_y >= 0.f && in_y <= hm1 && in_x >= 0.f && in_x <= wm1)) {   // NaN-safe
+            if (!(yy.w & xx.w)) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;
             } else {
-                const float ty = floorf(in_y), by = ceilf(in_y), ly = in_y - ty;
-                const float lx_ = floorf(in_x), rx = ceilf(in_x), lx = in_x - lx_;
-                const int t = (int)ty, bo = (int)by, l = (int)lx_, r = (int)rx;
+                const float ly = __int_as_float(yy.z), lx = __int_as_float(xx.z);
+                const int c16 = cv * 16;
                 float tl[8], tr[8], bl[8], br[8];
-                unpack8(*reinterpret_cast<const u32x4*>(fb + (((int64_t)t * Wf + l) * C8 + cv) * 8), tl);
-                unpack8(*reinterpret_cast<const u32x4*>(fb + (((int64_t)t * Wf + r) * C8 + cv) * 8), tr);
-                unpack8(*reinterpret_cast<const u32x4*>(fb + (((int64_t)bo * Wf + l) * C8 + cv) * 8), bl);
-                unpack8(*reinterpret_cast<const u32x4*>(fb + (((int64_t)bo * Wf + r) * C8 + cv) * 8), br);
+                unpack8(*reinterpret_cast<const u32x4*>(fb + (yy.x + xx.x + c16)), tl);
+                unpack8(*reinterpret_cast<const u32x4*>(fb + (yy.x + xx.y + c16)), tr);
+                unpack8(*reinterpret_cast<const u32x4*>(fb + (yy.y + xx.x + c16)), bl);
+                unpack8(*reinterpret_cast<const u32x4*>(fb + (yy.y + xx.y + c16)), br);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float top = tl[e] + (tr[e] - tl[e]) * lx;
-                    const float bot = bl[e] + (br[e] - bl[e]) * lx;
-                    v[e] = top + (bot - top) * ly;
+                    const float top = fmaf(tr[e] - tl[e], lx, tl[e]);
+                    const float bot = fmaf(br[e] - bl[e], lx, bl[e]);
+                    v[e] = fmaf(bot - top, ly, top);
                 }
             }
 #pragma unroll
@@ -209,6 +229,7 @@ extern "C" int frcnn_roi_crop_pool_fwd(const frcnn_bf16* feat, const float* rois
     FRCNN_CHECK_ARG(feat && rois && pooled && argmax, "roi_crop_pool_fwd: null pointer");
     FRCNN_CHECK_ARG(b > 0 && p > 0 && c % 8 == 0 && ps >= 1 && ks >= 1 && ps * ks >= 2 && ks * ks <= 255 && hf > 1 && wf > 1,
                     "roi_crop_pool_fwd: bad sizes");
+    FRCNN_CHECK_ARG(ps * ks <= kMaxCrop && 2 * ps * ks <= 256 && (long long)hf * wf * c * 2 < (1ll << 31), "roi_crop_pool_fwd: crop or feature map too large");
     if (ks == 2)
         hipLaunchKernelGGL(roi_fwd_kernel<2>, dim3(b * p), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                            reinterpret_cast<const bf16_t*>(feat), rois, p, hf, wf, c / 8, ps, ks, reinterpret_cast<bf16_t*>(pooled), argmax);
