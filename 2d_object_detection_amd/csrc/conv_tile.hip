@@ -676,18 +676,19 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
         // the T / C8 row lanes that share a channel vector meet in an LDS tree (the ring / staging region is idle now), then
         // 2 x BN coalesced float atomics into the consumer layer's slot partial sums
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);             // [T / C8][C8][16]
-        constexpr int RL = T / C8;
+        float* red = reinterpret_cast<float*>(smem);             // [16 sums][T threads]: a plane per sum, threads contiguous
+        constexpr int RL = T / C8;                                // (per-thread rows of 16 floats cost 16-way bank conflicts:
+                                                                  //  rocprofv3 SQ_LDS_BANK_CONFLICT was 45-63 % of the LDS cycles)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            red[(lrow_o * C8 + lc8) * 16 + e] = rsg[e];
-            red[(lrow_o * C8 + lc8) * 16 + 8 + e] = rsgz[e];
+            red[e * T + tid] = rsg[e];
+            red[(8 + e) * T + tid] = rsgz[e];
         }
         __syncthreads();
         for (int st = RL >> 1; st > 0; st >>= 1) {
             if (lrow_o < st) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) red[(lrow_o * C8 + lc8) * 16 + e] += red[((lrow_o + st) * C8 + lc8) * 16 + e];
+                for (int e = 0; e < 16; ++e) red[e * T + tid] += red[e * T + tid + st * C8];
             }
             __syncthreads();
         }
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
             const int st = tid / BN, cl = tid - st * BN;
             const int c = n0 + cl;
             if (c < p.Cout) {
-                const float sg = red[(cl >> 3) * 16 + (cl & 7)], sgz = red[(cl >> 3) * 16 + 8 + (cl & 7)];
+                const float sg = red[(cl & 7) * T + (cl >> 3)], sgz = red[(8 + (cl & 7)) * T + (cl >> 3)];
                 const float v = st == 0 ? sg : p.red_invstd[c] * (sgz - p.red_mean[c] * sg);
                 atomicAdd(p.red_part + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + c, v);
             }
