@@ -275,6 +275,17 @@ def test_rpn_head_post(ops):
     assert torch.equal(d.cpu(), exp_d)
 
 
+def test_copy_bytes(ops):
+    """the full-width device copy that feeds the plan's static image buffer: whole 16-byte words plus a byte tail"""
+    g = torch.Generator().manual_seed(2)
+    for n in (16, 4 * 375 * 1242 * 3, 1000 * 16 + 7, 5):
+        src = torch.randint(0, 256, (n,), dtype=torch.uint8, generator=g).cuda()
+        dst = torch.full((n + 32,), 9, dtype=torch.uint8, device="cuda")
+        ops.copy_bytes(src, dst[:n])
+        torch.cuda.synchronize()
+        assert torch.equal(dst[:n], src) and bool((dst[n:] == 9).all())
+
+
 # ------------------------------------------------------------------ RoI
 def test_roi_crop_pool_fwd_bwd(ops):
     g = torch.Generator().manual_seed(6)
