@@ -36,6 +36,9 @@ _SIGNATURES = {
     # name: (restype, [argtypes])
     "frcnn_abi_version": (c_int, []),
     "frcnn_last_error": (c_char_p, []),
+    "frcnn_last_conv_instantiation": (c_char_p, []),
+    "frcnn_conv2d_describe": (c_char_p, [POINTER(ConvDesc), c_int]),
+    "frcnn_conv2d_wgrad_describe": (c_char_p, [POINTER(ConvDesc), c_int, P]),
     "frcnn_conv2d_stat_tiles": (c_int, [POINTER(ConvDesc)]),
     "frcnn_conv2d_fprop": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "frcnn_conv2d_dgrad_bnreduce": (c_int, [POINTER(ConvDesc), P, P, P, P, P, POINTER(BnReduce), P]),
@@ -70,6 +73,8 @@ _SIGNATURES = {
     "frcnn_rpn_head_post": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P]),
     "frcnn_clip_to_window": (c_int, [P, P, c_int64, c_float, c_float, c_float, c_float, P]),
     "frcnn_decode_boxes": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_float, c_float, P]),
+    "frcnn_encode_boxes": (c_int, [P, P, c_int, P, c_int, c_int, c_int, P]),
+    "frcnn_boxes_divide": (c_int, [P, P, c_int64, c_float, c_float, P]),
     "frcnn_nms_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "frcnn_nms_combined": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                    P, P, P, P, P, c_size_t, P]),

@@ -77,6 +77,34 @@ __global__ void scale_kernel(const float* __restrict__ in, float* __restrict__ o
     }
 }
 
+// utils/boxes.py:86-93 (true division, as tf.divide)
+__global__ void divide_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, float w, float h) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(in + i * 4);
+        b[0] /= w; b[1] /= h; b[2] /= w; b[3] /= h;
+        *reinterpret_cast<f32x4*>(out + i * 4) = b;
+    }
+}
+
+// utils/boxes.py:44-73: t = [(c - c_ref) / size_ref, log(size / size_ref)] (zero-size references divide by zero as the reference does)
+__global__ void encode_kernel(const float* __restrict__ boxes, const float* __restrict__ regions, int rpi, float* __restrict__ out, int B, int R,
+                              int C) {
+    const int64_t total = (int64_t)B * R * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t br = i / C;
+        const int r = (int)(br % R);
+        const int b = (int)(br / R);
+        const f32x4 ref = *reinterpret_cast<const f32x4*>(regions + ((rpi ? (int64_t)b * R : 0) + r) * 4);
+        const f32x4 bx = *reinterpret_cast<const f32x4*>(boxes + i * 4);
+        const float cxr = (ref[2] + ref[0]) / 2.0f, cyr = (ref[3] + ref[1]) / 2.0f;
+        const float wr = ref[2] - ref[0], hr = ref[3] - ref[1];
+        const float cx = (bx[2] + bx[0]) / 2.0f, cy = (bx[3] + bx[1]) / 2.0f;
+        const float w = bx[2] - bx[0], h = bx[3] - bx[1];
+        f32x4 o = {(cx - cxr) / wr, (cy - cyr) / hr, logf(w / wr), logf(h / hr)};
+        *reinterpret_cast<f32x4*>(out + i * 4) = o;
+    }
+}
+
 // utils/boxes.py:20-41 + :86-93
 __global__ void decode_kernel(const float* __restrict__ regions, int rpi, const float* __restrict__ deltas, float* __restrict__ out, int B,
                               int R, int C, float W, float H) {
@@ -452,6 +480,22 @@ extern "C" int frcnn_boxes_scale(const float* in, float* out, int64_t n, float s
     FRCNN_CHECK_ARG(in && out, "boxes_scale: null pointer");
     hipLaunchKernelGGL(scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), in, out, n, sx, sy);
     FRCNN_CHECK_LAUNCH("boxes_scale");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_boxes_divide(const float* in, float* out, int64_t n, float w, float h, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(in && out && n >= 0, "boxes_divide: bad arguments");
+    if (n == 0) return FRCNN_OK;
+    hipLaunchKernelGGL(divide_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), in, out, n, w, h);
+    FRCNN_CHECK_LAUNCH("boxes_divide");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_encode_boxes(const float* boxes, const float* regions, int regions_per_image, float* out, int b, int r, int c,
+                                  frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(boxes && regions && out && b > 0 && r > 0 && c > 0, "encode_boxes: bad arguments");
+    hipLaunchKernelGGL(encode_kernel, dim3(cdiv((int64_t)b * r * c, 256)), dim3(256), 0, S_(stream), boxes, regions, regions_per_image, out, b, r, c);
+    FRCNN_CHECK_LAUNCH("encode_boxes");
     return FRCNN_OK;
 }
 

@@ -11,10 +11,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, "lib2dod_hip.so")
-SOURCES = ["elementwise.hip", "conv_igemm.hip", "conv_tile.hip", "conv_wgrad.hip", "boxes_nms.hip", "roi.hip", "targets_losses.hip", "host_io.hip"]
+SOURCES = ["elementwise.hip", "conv_tile.hip", "conv_wgrad.hip", "boxes_nms.hip", "roi.hip", "targets_losses.hip", "host_io.hip"]
 HEADERS = ["common.h", "conv_common.h", os.path.join("..", "..", "include", "frcnn_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-fgpu-flush-denormals-to-zero" if False else "-DFRCNN_BUILD"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-DFRCNN_BUILD"]
+if os.environ.get("FRCNN_SWEEP"):            # kernel-development build: extra tile instantiations + FRCNN_TILE / FRCNN_KWS / FRCNN_WGRAD overrides
+    FLAGS.append("-DFRCNN_SWEEP")
 
 
 def _newer(target, deps):

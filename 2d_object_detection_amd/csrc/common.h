@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <type_traits>
 
 #include "../../include/frcnn_hip.h"
@@ -18,6 +19,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 void frcnn_set_error(const char* fmt, ...);
+void frcnn_note_instantiation(const char* s);      // conv_tile.hip: what frcnn_last_conv_instantiation() returns
 
 #define FRCNN_CHECK_ARG(cond, ...)                 \
     do {                                           \

@@ -33,6 +33,7 @@ struct ConvParams {
     const unsigned char* res_mask;          // ADD_RES: bit mask applied to the residual (the ReLU mask of the block output whose
                                             // gradient the residual is) or NULL
     long long in_row_stride, in_img_stride;
+    int dry_run;                            // host only: stop before the launch (frcnn_conv2d_describe)
 };
 
 template <int BK>

@@ -1,6 +1,7 @@
 // Implicit-GEMM convolution, bf16 output: ONE output tile per workgroup, several workgroups per CU.
 //
-// Same GEMM view, LDS image and MFMA operand order as conv_igemm.hip (C[M pixels][Cout] = A[M][K] * W[Cout][K]^T,
+// GEMM view: C[M = N*Ho*Wo pixels][Cout] = A[M][K = KH*KW*Cin] * W[Cout][K]^T, A gathered on the fly from the NHWC input (im2col is never
+// materialised); the MFMA is issued with swapped operands so that a lane ends with 4 consecutive output channels of one pixel;
 // K walked in BK-wide slices that never straddle a filter tap, operands DMA'd global -> LDS with the XOR swizzle
 // applied on the source side).  What differs is the schedule: a workgroup owns one BM x BN tile, streams its K slices
 // through a short ring (S = 2 or 3 slots), runs the epilogue and exits.  Latency is hidden by OCCUPANCY instead of
@@ -15,14 +16,14 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, int NW, bool PIPE, bool KWS>
-__global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(const ConvParams p) {
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, bool KWS>
+__global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // SMODE 0: plain, 1: BatchNorm statistics of the output (forward), 2: BatchNorm-backward reduce of the consumer layer
     constexpr bool STATS = SMODE == 1, RED = SMODE == 2;
-    // NW = 8: 2 x 4 waves; NW = 4: 2 x 2 waves with four times the MFMA work per wave and slice -- the loop is
-    // issue-bound, and the per-wave overhead (waits, DMA issue, fragment reads shared by fewer waves) is per wave
-    constexpr int T = NW * 64, WM = 2, WN = NW / 2;
+    // 8 waves as a 2 x 4 grid (a 4-wave variant with four times the MFMA work per wave and a software-pipelined fragment-read
+    // loop were built and measured within +-5 % on every layer shape: removed)
+    constexpr int NW = 8, T = NW * 64, WM = 2, WN = NW / 2;
     constexpr int CPR = BK / 8;                  // 16-byte chunks per tile row
     constexpr int RPI = 64 / CPR;                // rows written by one DMA wave instruction (1 KiB)
     constexpr int A_INSTR = BM / RPI, B_INSTR = BN / RPI;
@@ -36,7 +37,6 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16, KK = BK / 32;
     static_assert(MI >= 1 && NI >= 1, "tile too small for the wave grid");
     static_assert(2 * BN <= T, "statistics flush: one thread per (statistic, channel)");
-    static_assert(!PIPE || (S >= 3 && !MULTI && KK == 2 && MI + NI <= 15), "pipelined K loop: >= 3 slots, one tile, BK = 64");
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int ROWB = BN * 2 + 16;            // staging row pitch (bytes)
     constexpr int C8 = BN / 8, ST_IT = (BM * C8) / T;
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
     // pixel rows around the tile, fetched once instead of three times; tap kw reads it shifted by kw rows.  Pixels whose
     // left / right neighbour lies in another image row (ox == 0 for kw = 0, ox == Wo-1 for kw = 2) are zeroed in the fragment
     // registers; vertical validity is a property of the staged source row (per-kh bit mask, zero-filled by the range check).
-    static_assert(!KWS || (!LIN && !MULTI && !F32 && !PIPE && BM == 128 && BK == 64 && S == 3 && NW == 8), "kw-sharing mode: 128-row tiles, 3-slot B ring");
+    static_assert(!KWS || (!LIN && !MULTI && !F32 && BM == 128 && BK == 64 && S == 3), "kw-sharing mode: 128-row tiles, 3-slot B ring");
     constexpr int AK_IT = 3, AK_BYTES = AK_IT * NW * 1024;          // shared A image: 192 rows x 128 B (130 used), two of them
     constexpr int B_BASE = KWS ? 2 * AK_BYTES : S * A_BYTES;
     constexpr int RING = KWS ? 2 * AK_BYTES + S * B_BYTES : S * (A_BYTES + B_BYTES), STG = BM * ROWB;
@@ -380,85 +380,6 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
             }
             left = 0;
         }
-        if (PIPE) {
-            // Software-pipelined K loop.  The barrier of iteration s certifies slice s+1 (slice s was certified one iteration
-            // earlier), so the fragments of the NEXT 32-wide step -- the first step of slice s+1 included -- are always in flight
-            // while the MFMAs of the current step run: the LDS latency, exposed once per step in the plain loop (which made every
-            // tile shape land on the same time), never reaches the matrix pipe.  The reads are inline asm: counted lgkmcnt
-            // waits that hipcc cannot merge or move, destination registers pinned by in/out operands of the wait.
-            constexpr int NR = MI + NI;          // ds_read_b128 per step
-            const unsigned lbase = lds_addr(ring);
-            u32x4 fa[2][MI], fb[2][NI];
-            auto rd = [&](u32x4& dst, const unsigned addr, auto off_c) {
-                constexpr int off = decltype(off_c)::value;
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
-            };
-            auto read_frags = [&](u32x4 (&a)[MI], u32x4 (&b)[NI], const int slot_, const int kk) {
-                const unsigned aa = lbase + slot_ * A_BYTES + a_foff[kk];
-                const unsigned ba = lbase + S * A_BYTES + slot_ * B_BYTES + b_foff[kk];
-                rd(a[0], aa, std::integral_constant<int, 0>{});
-                if (MI > 1) rd(a[MI > 1 ? 1 : 0], aa, std::integral_constant<int, 1 * 16 * BK * 2>{});
-                if (MI > 2) rd(a[MI > 2 ? 2 : 0], aa, std::integral_constant<int, 2 * 16 * BK * 2>{});
-                if (MI > 3) rd(a[MI > 3 ? 3 : 0], aa, std::integral_constant<int, 3 * 16 * BK * 2>{});
-                rd(b[0], ba, std::integral_constant<int, 0>{});
-                if (NI > 1) rd(b[NI > 1 ? 1 : 0], ba, std::integral_constant<int, 1 * 16 * BK * 2>{});
-                if (NI > 2) rd(b[NI > 2 ? 2 : 0], ba, std::integral_constant<int, 2 * 16 * BK * 2>{});
-                if (NI > 3) rd(b[NI > 3 ? 3 : 0], ba, std::integral_constant<int, 3 * 16 * BK * 2>{});
-            };
-            auto wait_frags = [&](auto pending_c, u32x4 (&a)[MI], u32x4 (&b)[NI]) {
-                constexpr int pending = decltype(pending_c)::value;
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(pending) : "memory");
-#pragma unroll
-                for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(a[i]));
-#pragma unroll
-                for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(b[j]));
-            };
-            auto mfma_step = [&](u32x4 (&a)[MI], u32x4 (&b)[NI]) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[j]), __builtin_bit_cast(bf16x8, a[i]), acc[i][j], 0, 0, 0);
-            };
-            // slice 0 certified by hand, its first fragments requested
-            {
-                // (the prologue issued min(S-1, nk) slices: wait until only the younger ones are outstanding)
-                const int pre = nk < S - 1 ? nk : S - 1;
-                if (pre == S - 1) FRCNN_WAIT_IMM((S - 2) * LC);
-                else FRCNN_WAIT_IMM(0);
-            }
-            __builtin_amdgcn_s_barrier();
-            int cslot = 0, islot = S - 1;        // consumer slot, slot the next DMA goes to
-            read_frags(fa[0], fb[0], 0, 0);
-            for (int sl = 0; sl < nk; ++sl) {
-                const int nslot = cslot + 1 == S ? 0 : cslot + 1;
-                if (sl + 1 < nk) {
-                    // certify slice sl+1: DMA issued after it = slices sl+2 .. sl+S-2 (when they exist)
-                    if (sl + S - 2 < nk) FRCNN_WAIT_IMM((S - 3) * LC);
-                    else FRCNN_WAIT_IMM(0);
-                    __builtin_amdgcn_s_barrier();        // slice sl+1 visible to all; everyone is done reading slice sl-1
-                }
-                if (to_issue > 0) {
-                    issue_slice(islot);                  // slot of slice sl-1
-                    islot = islot + 1 == S ? 0 : islot + 1;
-                    --to_issue;
-                }
-                read_frags(fa[1], fb[1], cslot, 1);
-                wait_frags(std::integral_constant<int, NR>{}, fa[0], fb[0]);
-                mfma_step(fa[0], fb[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (sl + 1 < nk) {
-                    read_frags(fa[0], fb[0], nslot, 0);
-                    wait_frags(std::integral_constant<int, NR>{}, fa[1], fb[1]);
-                } else {
-                    wait_frags(std::integral_constant<int, 0>{}, fa[1], fb[1]);
-                }
-                mfma_step(fa[1], fb[1]);
-                __builtin_amdgcn_sched_barrier(0);
-                cslot = nslot;
-            }
-            left = 0;
-        }
         // a tile's first slice was issued BEFORE the previous tile's epilogue stores: those ST_IT stores may stay in flight
         bool after_epilogue = MULTI && t > 0 && p.direct_out;
         while (left > 0) {
@@ -733,53 +654,77 @@ __global__ __launch_bounds__(NW * 64, (NW / 4) * OCC) void conv_tile_kernel(cons
 #endif
 }
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, int NW = 8, bool PIPE = false, bool KWS = false>
+// Name of the instantiation the calling thread launched last (frcnn_last_conv_instantiation): lets the parity tests assert
+// WHICH kernel a shape dispatched to, so that their coverage cannot rot silently when the heuristics below move.
+thread_local char g_last_inst[192] = "";
+
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false>
 int launch_tile(const ConvParams& p, hipStream_t s) {
-    constexpr int ring = KWS ? 2 * 3 * NW * 1024 + S * BN * BK * 2 : S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
+    constexpr int ring = KWS ? 2 * 3 * 8 * 1024 + S * BN * BK * 2 : S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
     constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4;
     static_assert(smem <= 163840, "LDS budget");
     static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
-    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, NW, PIPE, KWS>), smem) != 0) {
+    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
-    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, NW, PIPE, KWS>), dim3(p.items, F32 ? p.split : 1), dim3(NW * 64), smem, s, p);
+    snprintf(g_last_inst, sizeof(g_last_inst), "conv_tile<BM=%d,BN=%d,BK=%d,S=%d,LIN=%d,SMODE=%d,OCC=%d,MULTI=%d,F32=%d,KWS=%d> grid=%dx%d tpb=%d",
+             BM, BN, BK, S, (int)LIN, SMODE, OCC, (int)MULTI, (int)F32, (int)KWS, p.items, F32 ? p.split : 1, p.tiles_per_block);
+    if (p.dry_run) return FRCNN_OK;              // frcnn_conv2d_describe: the dispatch decision only
+    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS>), dim3(p.items, F32 ? p.split : 1), dim3(512), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
     return FRCNN_OK;
 }
 
-template <int BM, int BN, int BK, int S, int OCC, bool MULTI, int NW = 8, bool PIPE = false>
+template <int BM, int BN, int BK, int S, int OCC, bool MULTI>
 int launch_tile_flags(const ConvParams& p, hipStream_t s) {
     const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
     // the fused reduce needs 64 B of (idle) LDS per thread for its tree
-    constexpr bool red_ok = (MULTI ? S * (BM + BN) * BK * 2 + BM * (BN * 2 + 16) : S * (BM + BN) * BK * 2) >= NW * 64 * 64;
+    constexpr bool red_ok = (MULTI ? S * (BM + BN) * BK * 2 + BM * (BN * 2 + 16) : S * (BM + BN) * BK * 2) >= 512 * 64;
     if (smode == 2) {
         if constexpr (red_ok) {
-            return p.linear_a ? launch_tile<BM, BN, BK, S, true, 2, OCC, MULTI, false, NW, PIPE>(p, s)
-                              : launch_tile<BM, BN, BK, S, false, 2, OCC, MULTI, false, NW, PIPE>(p, s);
+            return p.linear_a ? launch_tile<BM, BN, BK, S, true, 2, OCC, MULTI>(p, s) : launch_tile<BM, BN, BK, S, false, 2, OCC, MULTI>(p, s);
         } else {
             return FRCNN_ENOTSUP;
         }
     }
     if (p.linear_a) {
-        if (smode == 1) return launch_tile<BM, BN, BK, S, true, 1, OCC, MULTI, false, NW, PIPE>(p, s);
-        return launch_tile<BM, BN, BK, S, true, 0, OCC, MULTI, false, NW, PIPE>(p, s);
+        if (smode == 1) return launch_tile<BM, BN, BK, S, true, 1, OCC, MULTI>(p, s);
+        return launch_tile<BM, BN, BK, S, true, 0, OCC, MULTI>(p, s);
     }
-    if (smode == 1) return launch_tile<BM, BN, BK, S, false, 1, OCC, MULTI, false, NW, PIPE>(p, s);
-    return launch_tile<BM, BN, BK, S, false, 0, OCC, MULTI, false, NW, PIPE>(p, s);
+    if (smode == 1) return launch_tile<BM, BN, BK, S, false, 1, OCC, MULTI>(p, s);
+    return launch_tile<BM, BN, BK, S, false, 0, OCC, MULTI>(p, s);
 }
 
-}  // namespace
+#ifdef FRCNN_SWEEP
+// kernel-development builds only (FRCNN_SWEEP=1 python .../build.py --force; tools/tile_sweep.py): tile shape / kw-sharing
+// overrides, read once per process
+struct SweepEnv {
+    int bm = 0, bn = 0, bk = 0, stages = 0, tpb = 1, kws = -1;
+    SweepEnv() {
+        if (const char* e = getenv("FRCNN_TILE")) {              // "bm,bn,bk,stages[,tiles_per_block]"
+            int a = 0, b = 0, c = 0, st = 0, tp = 1;
+            if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &st, &tp) >= 4) { bm = a; bn = b; bk = c; stages = st; tpb = tp; }
+        }
+        if (const char* e = getenv("FRCNN_KWS")) kws = e[0] == '1' ? 1 : 0;
+    }
+};
+const SweepEnv& sweep_env() {
+    static const SweepEnv e;
+    return e;
+}
+#endif
 
-// Tile choice + launch for the bf16-output path (called by frcnn_conv2d_fprop in conv_igemm.hip).  p arrives with the
-// geometry fields filled in; tiles_m / tiles_n / k_tiles are set here.  Returns FRCNN_ENOTSUP when no instantiation fits
-// (the caller then uses the general persistent kernel).
-int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipStream_t s) {
-    ConvParams p = *reinterpret_cast<const ConvParams*>(params);      // private copy: the caller falls back on ENOTSUP
-    if (p.taps > 32) return FRCNN_ENOTSUP;
+// Tile choice + launch.  p arrives with the geometry fields filled in; tiles_m / tiles_n / k_tiles are set here.
+int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
+    if (p.taps > 32) {
+        frcnn_set_error("conv2d_fprop: filters with more than 32 taps are not supported (per-row tap validity masks are 32 bits)");
+        return FRCNN_EINVAL;
+    }
     if (p.flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC)) {
         // fp32 output / split-K partial sums: 1x1 filters whose output rows are the GEMM rows, K a multiple of 64
-        if (p.taps != 1 || !p.linear_a || d->cin % 64 != 0 || (p.flags & (FRCNN_CONV_STATS | FRCNN_CONV_ADD_RES))) return FRCNN_ENOTSUP;
+        FRCNN_CHECK_ARG(p.taps == 1 && p.linear_a && d->cin % 64 == 0 && !(p.flags & (FRCNN_CONV_STATS | FRCNN_CONV_ADD_RES)),
+                        "conv2d_fprop: fp32 / split-K output needs a 1x1 stride-1 filter, cin %% 64 == 0, no STATS / ADD_RES");
         p.k_tiles = p.Ktot / 64;
         int split = d->split_k > 1 ? d->split_k : 1;
         p.k_tiles_per_split = (p.k_tiles + split - 1) / split;
@@ -790,7 +735,7 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
         p.items = p.tiles_m * p.tiles_n;
         return launch_tile<128, 64, 64, 3, true, 0, 2, false, true>(p, s);
     }
-    if (d->split_k > 1) return FRCNN_ENOTSUP;
+    FRCNN_CHECK_ARG(d->split_k <= 1, "conv2d_fprop: split_k needs SPLITK_ATOMIC");
     // measured on the R50-C4 layer shapes (tools/tile_sweep.py): 128-row tiles and BK = 64 win almost everywhere (two
     // workgroups per CU); 128 output channels per tile once that still leaves >= ~200 tiles, else 64; a third ring slot
     // only pays on very long K with the narrow tile
@@ -798,12 +743,11 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
     const long long M = p.M;
     int bm = 128;
     const long long tiles_m128 = (M + 127) / 128;
-    int bn = (d->cout >= 128 && tiles_m128 * ((d->cout + 127) / 128) >= 200) ? 128 : 64;
+    int bn = (bk == 64 && d->cout >= 128 && tiles_m128 * ((d->cout + 127) / 128) >= 200) ? 128 : 64;
     int stages = (bn == 64 && bk == 64 && p.Ktot / bk >= 8) ? 3 : 2;     // (cold-cache sweep: the third slot pays from 8 slices on)
     // short K (<= 4 slices): runs of consecutive m-tiles per workgroup -- the ring prefetches the next tile under the
     // epilogue, bias / statistics / addressing are set up once per run; narrow tiles keep two workgroups per CU
     int tpb = 1;                                                // tiles per workgroup (1: one-tile kernel)
-    int waves = 8, pipe = 0;
     if (bk == 64) {
         const int kt = p.Ktot / 64;
         tpb = kt == 1 ? 8 : kt == 2 ? 4 : kt <= 4 ? 2 : 1;
@@ -811,11 +755,12 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
         while (tpb > 1 && ((tiles_m128 + tpb - 1) / tpb) * tn64 < 512) tpb >>= 1;
         if (tpb > 1) { bn = 64; stages = 2; }
     }
-    if (const char* e = getenv("FRCNN_TILE")) {                 // kernel development aid: "bm,bn,bk,stages[,tiles_per_block]"
-        int a = 0, b = 0, c = 0, st = 0, tp = 1, nw = 8, pp = 0;
-        if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &a, &b, &c, &st, &tp, &nw, &pp) >= 4) { bm = a; bn = b; bk = c; stages = st; tpb = tp; waves = nw; pipe = pp; }
-    }
-    if (d->cin % bk != 0) return FRCNN_ENOTSUP;
+    int force_kws = -1;
+#ifdef FRCNN_SWEEP
+    if (sweep_env().bm) { bm = sweep_env().bm; bn = sweep_env().bn; bk = sweep_env().bk; stages = sweep_env().stages; tpb = sweep_env().tpb; force_kws = 0; }
+    if (sweep_env().kws >= 0) force_kws = sweep_env().kws;
+#endif
+    FRCNN_CHECK_ARG(d->cin % bk == 0, "conv2d_fprop: cin=%d is not a multiple of the K slice %d", d->cin, bk);
     p.k_tiles = p.Ktot / bk;
     p.k_tiles_per_split = p.k_tiles;
     p.split = 1;
@@ -825,14 +770,13 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
     p.items = ((p.tiles_m + tpb - 1) / tpb) * p.tiles_n;
     {
         // 3x3 / stride 1 / pad 1: the kw taps share one staged A image (conv_tile_kernel, KWS)
-        const char* e = getenv("FRCNN_KWS");
         const bool kws_ok = p.taps == 9 && p.KW == 3 && p.stride == 1 && p.pad_h == 1 && p.pad_w == 1 && p.Hi == p.Ho && p.Wi == p.Wo &&
-                            d->cin % 64 == 0 && p.direct_out && !getenv("FRCNN_TILE");
+                            d->cin % 64 == 0 && p.direct_out;
         // measured (per-layer table of the train step): pays where two workgroups share a CU (conv2 / conv3: -8 % / -14 %);
         // with one 128 x 64 tile per CU (M = 7488) the slice time is a latency chain that the smaller fill does not shorten,
-        // and the wide 128 x 128 tiles of the RPN data gradient are faster there.  FRCNN_KWS=1 forces it, =0 disables it.
+        // and the wide 128 x 128 tiles of the RPN data gradient are faster there
         const bool kws_pays = tiles_m128 >= 160;
-        if (kws_ok && (e ? e[0] == '1' : kws_pays)) {
+        if (kws_ok && (force_kws >= 0 ? force_kws == 1 : kws_pays)) {
             p.k_tiles = p.Ktot / 64;
             p.k_tiles_per_split = p.k_tiles;
             p.tiles_m = (int)((M + 127) / 128);
@@ -840,57 +784,158 @@ int frcnn_conv_tile_dispatch(const void* params, const frcnn_conv_desc* d, hipSt
             p.tiles_per_block = 1;
             p.items = p.tiles_m * p.tiles_n;
             const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
-            if (smode == 2) return launch_tile<128, 64, 64, 3, false, 2, 2, false, false, 8, false, true>(p, s);
-            if (smode == 1) return launch_tile<128, 64, 64, 3, false, 1, 2, false, false, 8, false, true>(p, s);
-            return launch_tile<128, 64, 64, 3, false, 0, 2, false, false, 8, false, true>(p, s);
+            if (smode == 2) return launch_tile<128, 64, 64, 3, false, 2, 2, false, false, true>(p, s);
+            if (smode == 1) return launch_tile<128, 64, 64, 3, false, 1, 2, false, false, true>(p, s);
+            return launch_tile<128, 64, 64, 3, false, 0, 2, false, false, true>(p, s);
         }
     }
-#define FRCNN_PIPE(BM_, BN_, S_, OCC_, W_) \
-    if (tpb == 1 && pipe && waves == W_ && bm == BM_ && bn == BN_ && bk == 64 && stages == S_) return launch_tile_flags<BM_, BN_, 64, S_, OCC_, false, W_, true>(p, s);
-    FRCNN_PIPE(128, 64, 3, 2, 8)
-    FRCNN_PIPE(128, 64, 4, 1, 8)
-    FRCNN_PIPE(64, 128, 4, 1, 8)
-    FRCNN_PIPE(128, 128, 3, 1, 8)
-    FRCNN_PIPE(128, 128, 4, 1, 8)
-    FRCNN_PIPE(64, 64, 4, 2, 8)
-    FRCNN_PIPE(128, 128, 4, 1, 4)
-    FRCNN_PIPE(64, 128, 4, 1, 4)
-    FRCNN_PIPE(128, 64, 4, 1, 4)
-#undef FRCNN_PIPE
-    if (pipe) return FRCNN_ENOTSUP;
+    int rc = FRCNN_ENOTSUP;
 #define FRCNN_TILE(BM_, BN_, BK_, S_, OCC_) \
-    if (tpb == 1 && waves == 8 && bm == BM_ && bn == BN_ && bk == BK_ && stages == S_) return launch_tile_flags<BM_, BN_, BK_, S_, OCC_, false>(p, s);
-#define FRCNN_TILE4(BM_, BN_, BK_, S_, OCC_) \
-    if (tpb == 1 && waves == 4 && bm == BM_ && bn == BN_ && bk == BK_ && stages == S_) return launch_tile_flags<BM_, BN_, BK_, S_, OCC_, false, 4>(p, s);
+    if (rc == FRCNN_ENOTSUP && tpb == 1 && bm == BM_ && bn == BN_ && bk == BK_ && stages == S_) rc = launch_tile_flags<BM_, BN_, BK_, S_, OCC_, false>(p, s);
 #define FRCNN_RUN(BM_, BN_, BK_, OCC_) \
-    if (tpb > 1 && waves == 8 && bm == BM_ && bn == BN_ && bk == BK_ && stages == 2) return launch_tile_flags<BM_, BN_, BK_, 2, OCC_, true>(p, s);
-    FRCNN_TILE4(128, 128, 64, 2, 2)
-    FRCNN_TILE4(128, 128, 64, 3, 1)
-    FRCNN_TILE4(64, 128, 64, 3, 2)
-    FRCNN_TILE4(128, 64, 64, 3, 2)
-    FRCNN_TILE4(64, 64, 64, 3, 3)
+    if (rc == FRCNN_ENOTSUP && tpb > 1 && bm == BM_ && bn == BN_ && bk == BK_ && stages == 2) rc = launch_tile_flags<BM_, BN_, BK_, 2, OCC_, true>(p, s);
+    // the instantiations the heuristics above can select
     FRCNN_RUN(128, 64, 64, 2)
-    FRCNN_RUN(128, 128, 64, 1)
-    FRCNN_RUN(64, 64, 64, 3)
     FRCNN_TILE(128, 128, 64, 2, 2)
     FRCNN_TILE(128, 64, 64, 2, 2)
+    FRCNN_TILE(128, 64, 64, 3, 2)
+    FRCNN_TILE(128, 64, 32, 2, 2)
+#ifdef FRCNN_SWEEP
+    FRCNN_RUN(128, 128, 64, 1)
+    FRCNN_RUN(64, 64, 64, 3)
     FRCNN_TILE(64, 128, 64, 2, 2)
     FRCNN_TILE(64, 64, 64, 2, 3)
     FRCNN_TILE(128, 128, 128, 2, 1)
     FRCNN_TILE(128, 64, 128, 2, 1)
     FRCNN_TILE(64, 128, 128, 2, 1)
     FRCNN_TILE(64, 64, 128, 2, 2)
-    FRCNN_TILE(128, 64, 32, 2, 2)
     FRCNN_TILE(128, 128, 64, 3, 1)
-    FRCNN_TILE(128, 64, 64, 3, 2)
     FRCNN_TILE(64, 128, 64, 3, 2)
     FRCNN_TILE(64, 64, 64, 3, 2)
     FRCNN_TILE(128, 64, 64, 4, 1)
     FRCNN_TILE(128, 64, 64, 6, 1)
     FRCNN_TILE(128, 128, 64, 4, 1)
     FRCNN_TILE(64, 64, 64, 6, 1)
+#endif
 #undef FRCNN_TILE
-#undef FRCNN_TILE4
 #undef FRCNN_RUN
-    return FRCNN_ENOTSUP;
+    if (rc == FRCNN_ENOTSUP) {
+        frcnn_set_error("conv2d_fprop: no kernel for tile %dx%dx%d, %d slots, %d tiles per workgroup", bm, bn, bk, stages, tpb);
+        rc = FRCNN_EINVAL;
+    }
+    return rc;
+}
+
+int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias, const frcnn_bf16* res,
+                      const uint8_t* res_mask, void* y, double* stats_partial, const frcnn_bn_reduce* red, frcnn_stream_t stream,
+                      const bool dry_run = false) {
+    FRCNN_CHECK_ARG(d && x && w && y, "conv2d_fprop: null pointer");
+    FRCNN_CHECK_ARG(d->cin > 0 && d->cin % 32 == 0, "conv2d_fprop: cin=%d must be a multiple of 32", d->cin);
+    FRCNN_CHECK_ARG(d->cout > 0 && d->cout % 8 == 0, "conv2d_fprop: cout=%d must be a multiple of 8", d->cout);
+    FRCNN_CHECK_ARG(d->in_pix_stride % 4 == 0 && (d->kw == 1 || d->in_pix_stride % 8 == 0),
+                    "conv2d_fprop: in_pix_stride=%d breaks 16-byte alignment", d->in_pix_stride);
+    FRCNN_CHECK_ARG(d->stride >= 1 && d->kh >= 1 && d->kw >= 1 && d->n >= 1 && d->ho >= 1 && d->wo >= 1,
+                    "conv2d_fprop: bad geometry");
+    FRCNN_CHECK_ARG(((long long)d->wi * d->in_pix_stride) % 8 == 0, "conv2d_fprop: input row pitch not 16-byte aligned");
+    FRCNN_CHECK_ARG((d->stride * d->in_pix_stride) % 8 == 0 && (d->pad_w * d->in_pix_stride) % 8 == 0,
+                    "conv2d_fprop: pixel addressing breaks 16-byte alignment");
+    const int flags = d->flags;
+    FRCNN_CHECK_ARG(!(flags & FRCNN_CONV_BIAS) || bias, "conv2d_fprop: BIAS without bias pointer");
+    FRCNN_CHECK_ARG(!(flags & FRCNN_CONV_ADD_RES) || res, "conv2d_fprop: ADD_RES without res pointer");
+    FRCNN_CHECK_ARG(!(flags & FRCNN_CONV_STATS) || stats_partial, "conv2d_fprop: STATS without buffer");
+    FRCNN_CHECK_ARG(!((flags & FRCNN_CONV_STATS) && (flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC | FRCNN_CONV_ADD_RES))),
+                    "conv2d_fprop: STATS only with plain bf16 output");
+    FRCNN_CHECK_ARG(!((flags & FRCNN_CONV_ADD_RES) && (flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC))),
+                    "conv2d_fprop: ADD_RES only with bf16 output");
+    const int split = d->split_k > 1 ? d->split_k : 1;
+    FRCNN_CHECK_ARG(split == 1 || (flags & FRCNN_CONV_SPLITK_ATOMIC), "conv2d_fprop: split_k needs SPLITK_ATOMIC");
+    FRCNN_CHECK_ARG(!(flags & FRCNN_CONV_SPLITK_ATOMIC) || !(flags & FRCNN_CONV_RELU), "conv2d_fprop: no ReLU with split-K");
+    FRCNN_CHECK_ARG(d->out_scatter >= 1 && (d->ho - 1) * d->out_scatter < d->out_h && (d->wo - 1) * d->out_scatter < d->out_w,
+                    "conv2d_fprop: scatter target out of range");
+
+    ConvParams p;
+    p.x = reinterpret_cast<const bf16_t*>(x);
+    p.w = reinterpret_cast<const bf16_t*>(w);
+    p.bias = bias;
+    p.res = reinterpret_cast<const bf16_t*>(res);
+    p.y = y;
+    p.stats = stats_partial;
+    p.red_z = red ? reinterpret_cast<const bf16_t*>(red->z) : nullptr;
+    p.red_mask = red ? red->relu_mask : nullptr;
+    p.red_mean = red ? red->mean : nullptr;
+    p.red_invstd = red ? red->invstd : nullptr;
+    p.red_part = red ? red->partial : nullptr;
+    p.res_mask = res_mask;
+    p.dry_run = dry_run ? 1 : 0;
+    p.Hi = d->hi; p.Wi = d->wi; p.in_pix_stride = d->in_pix_stride; p.Cin = d->cin; p.KW = d->kw;
+    p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+    p.Ho = d->ho; p.Wo = d->wo; p.Cout = d->cout; p.out_h = d->out_h; p.out_w = d->out_w; p.out_scatter = d->out_scatter;
+    p.flags = flags;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    FRCNN_CHECK_ARG(M < (1ll << 31) - 256, "conv2d_fprop: M too large");
+    p.M = (int)M;
+    p.Ktot = d->kh * d->kw * d->cin;
+    p.k_tiles = p.k_tiles_per_split = 0;         // set by the dispatcher together with the tile shape
+    p.split = 1;
+    p.tiles_m = p.tiles_n = p.items = 0;
+    p.tiles_per_block = 1;
+    p.taps = d->kh * d->kw;
+    p.tap_mask = 1;
+    p.linear_a = (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->ho == d->hi && d->wo == d->wi) ? 1 : 0;
+    p.in_row_stride = (long long)d->wi * d->in_pix_stride;
+    p.in_img_stride = (long long)d->hi * p.in_row_stride;
+    {
+        // 32-bit buffer addressing: voffset (pixel) + soffset (tap) must stay below 2^32 - 16
+        const long long halo = (long long)d->pad_h * p.in_row_stride + (long long)d->pad_w * d->in_pix_stride;
+        const long long x_elems = (long long)d->n * p.in_img_stride + (long long)d->kw * d->in_pix_stride + 64;   // slack: stem tap reads
+        const long long xb = (x_elems + halo) * 2, wb = (long long)d->cout * p.Ktot * 2;
+        FRCNN_CHECK_ARG(xb < 0xFFFF0000ll && wb < 0xFFFF0000ll, "conv2d_fprop: operand larger than 4 GiB (32-bit buffer offsets)");
+        p.x_bytes = (unsigned)xb;
+        p.w_bytes = (unsigned)wb;
+        p.in_row_stride32 = (int)p.in_row_stride;
+        const long long yb = M * d->cout * 2;
+        p.direct_out = (d->out_scatter == 1 && d->out_h == d->ho && d->out_w == d->wo && yb < 0xFFFF0000ll) ? 1 : 0;
+        p.y_bytes = p.direct_out ? (unsigned)yb : 0u;
+    }
+    return conv_tile_dispatch(p, d, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // namespace
+
+extern "C" const char* frcnn_last_conv_instantiation(void) { return g_last_inst; }
+void frcnn_note_instantiation(const char* s) { snprintf(g_last_inst, sizeof(g_last_inst), "%s", s); }    // (conv_wgrad.hip)
+
+extern "C" const char* frcnn_conv2d_describe(const frcnn_conv_desc* d, int with_bn_reduce) {
+    // the dispatch decision for this descriptor without launching anything (no device needed): dummy non-null operands
+    static const uint8_t dummy[16] = {0};
+    frcnn_bn_reduce red;
+    red.z = reinterpret_cast<const frcnn_bf16*>(dummy);
+    red.relu_mask = nullptr;
+    red.mean = red.invstd = reinterpret_cast<const float*>(dummy);
+    red.partial = const_cast<float*>(reinterpret_cast<const float*>(dummy));
+    const void* q = dummy;
+    g_last_inst[0] = 0;
+    const int rc = conv2d_fprop_impl(d, reinterpret_cast<const frcnn_bf16*>(q), reinterpret_cast<const frcnn_bf16*>(q), reinterpret_cast<const float*>(q),
+                                     reinterpret_cast<const frcnn_bf16*>(q), nullptr, const_cast<void*>(q),
+                                     const_cast<double*>(reinterpret_cast<const double*>(q)), with_bn_reduce ? &red : nullptr, nullptr, true);
+    return rc == FRCNN_OK ? g_last_inst : nullptr;
+}
+
+extern "C" int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d) {
+    if (!d) return FRCNN_EINVAL;
+    return FRCNN_STAT_SLOTS;
+}
+
+extern "C" int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
+                                  const frcnn_bf16* res, void* y, double* stats_partial, frcnn_stream_t stream) {
+    return conv2d_fprop_impl(d, x, w, bias, res, nullptr, y, stats_partial, nullptr, stream);
+}
+
+extern "C" int frcnn_conv2d_dgrad_bnreduce(const frcnn_conv_desc* d, const frcnn_bf16* dz, const frcnn_bf16* w_t, const frcnn_bf16* res,
+                                           const uint8_t* res_mask, frcnn_bf16* gx, const frcnn_bn_reduce* red, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(!res_mask || (res && d && (d->flags & FRCNN_CONV_ADD_RES)), "conv2d_dgrad_bnreduce: res_mask without ADD_RES residual");
+    FRCNN_CHECK_ARG(red && red->z && red->mean && red->invstd && red->partial, "conv2d_dgrad_bnreduce: incomplete reduce arguments");
+    FRCNN_CHECK_ARG(d && !(d->flags & (FRCNN_CONV_STATS | FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC | FRCNN_CONV_BIAS | FRCNN_CONV_RELU)),
+                    "conv2d_dgrad_bnreduce: only ADD_RES may be set");
+    return conv2d_fprop_impl(d, dz, w_t, nullptr, res, res_mask, gx, nullptr, red, stream);
 }

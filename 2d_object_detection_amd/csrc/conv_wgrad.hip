@@ -360,17 +360,25 @@ __global__ __launch_bounds__(512, 2 * OCC) void wgrad_group_kernel(const WgradGr
     wgrad_body<BM, BN, S, MODE, OCC>(p, id - g->first[layer]);
 }
 
+thread_local bool t_dry_run = false;            // frcnn_conv2d_wgrad*_describe: stop before the launch
+
 template <int BM, int BN, int S, int MODE, int OCC>
 int launch_mode(const WgradParams& p, int split, hipStream_t s) {
     constexpr int ring_bytes = S * 64 * (BM + BN) * 2;
     constexpr int stage_bytes = BM * (BN * 4 + 16);
     constexpr int smem = ring_bytes > stage_bytes ? ring_bytes : stage_bytes;
     static_assert(smem * OCC <= 163840, "LDS budget");
-    if (frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_kernel<BM, BN, S, MODE, OCC>), smem) != 0) {
+    if (!t_dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_kernel<BM, BN, S, MODE, OCC>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_wgrad: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
     dim3 grid(p.tiles_co * p.taps * p.tiles_ci * split, 1, 1);
+    {
+        char name[160];
+        snprintf(name, sizeof(name), "wgrad<BM=%d,BN=%d,S=%d,MODE=%d,OCC=%d> grid=%d split=%d", BM, BN, S, MODE, OCC, (int)grid.x, split);
+        frcnn_note_instantiation(name);
+    }
+    if (t_dry_run) return FRCNN_OK;
     hipLaunchKernelGGL((wgrad_kernel<BM, BN, S, MODE, OCC>), grid, dim3(512), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad");
     return FRCNN_OK;
@@ -437,10 +445,12 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
     int bm = 64;
     int bn = d->cin >= 64 ? 64 : 32;
     int stages = bn == 32 ? 2 : 3, want_split = 0;
-    if (const char* e = getenv("FRCNN_WGRAD")) {                // kernel development aid: "bm,bn,stages,split"
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_WGRAD")) {                // kernel development builds: "bm,bn,stages,split"
         int a = 0, b = 0, c = 0, sp = 0;
         if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &sp) == 4) { bm = a; bn = b; stages = c; want_split = sp; }
     }
+#endif
     constexpr int BKP = 64;
     p.tiles_co = (d->cout + bm - 1) / bm;
     p.tiles_ci = (d->cin + bn - 1) / bn;
@@ -456,16 +466,18 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define FRCNN_DISPATCH(BM_, BN_, S_, OCC_) \
     if (bm == BM_ && bn == BN_ && stages == S_) return launch<BM_, BN_, S_, OCC_>(p, split, s);
+    FRCNN_DISPATCH(64, 64, 3, 3)           // the two shapes the rule above selects
+    FRCNN_DISPATCH(64, 32, 2, 3)
+#ifdef FRCNN_SWEEP
     FRCNN_DISPATCH(128, 128, 2, 2)
     FRCNN_DISPATCH(128, 64, 2, 3)
     FRCNN_DISPATCH(128, 32, 2, 3)
     FRCNN_DISPATCH(64, 128, 2, 3)
     FRCNN_DISPATCH(64, 64, 2, 3)
-    FRCNN_DISPATCH(64, 32, 2, 3)
     FRCNN_DISPATCH(128, 128, 3, 1)
     FRCNN_DISPATCH(128, 64, 3, 2)
     FRCNN_DISPATCH(64, 128, 3, 2)
-    FRCNN_DISPATCH(64, 64, 3, 3)
+#endif
 #undef FRCNN_DISPATCH
     frcnn_set_error("conv2d_wgrad: no tile configuration");
     return FRCNN_EINVAL;
@@ -485,10 +497,12 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
     // tile shape of the grouped launches.  Launched alone a layer wants small tiles (few pixel splits fill the chip); a group
     // has tiles to spare, so it can afford more MFMA work per barrier.  FRCNN_WGRAD_GROUP="bm,bn" overrides (development aid)
     int gbm = 0, gbn = 64, gst = 3;            // 0: 128 output channels per tile when every layer of the group has >= 128, else 64
+#ifdef FRCNN_SWEEP
     if (const char* e = getenv("FRCNN_WGRAD_GROUP")) {
         int a = 0, b = 0, c = 3;
         if (sscanf(e, "%d,%d,%d", &a, &b, &c) >= 2 && (a == 0 || a == 64 || a == 128) && (b == 64 || b == 128)) { gbm = a; gbn = b; gst = c; }
     }
+#endif
     g[0].n = g[1].n = 0;
     g[0].total = g[1].total = 0;
     int tiles[2] = {0, 0}, min_p_tiles[2] = {1 << 30, 1 << 30};
@@ -538,27 +552,44 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
     return FRCNN_OK;
 }
 
+extern "C" int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* table_dev, frcnn_stream_t stream);
+extern "C" const char* frcnn_conv2d_wgrad_describe(const frcnn_conv_desc* d, int with_row_index, const void* group_table_host) {
+    // dispatch decision only (host logic, no device): of the grouped launch when group_table_host != NULL, else of one layer
+    static const int32_t dummy[4] = {0};
+    const frcnn_bf16* q = reinterpret_cast<const frcnn_bf16*>(dummy);
+    frcnn_note_instantiation("");
+    t_dry_run = true;
+    const int rc = group_table_host ? frcnn_conv2d_wgrad_grouped(group_table_host, dummy, nullptr)
+                                    : frcnn_conv2d_wgrad(d, q, q, d ? d->cout : 0, with_row_index ? dummy : nullptr,
+                                                         const_cast<float*>(reinterpret_cast<const float*>(dummy)), nullptr);
+    t_dry_run = false;
+    return rc == FRCNN_OK ? frcnn_last_conv_instantiation() : nullptr;
+}
+
 extern "C" int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* table_dev, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(table_host && table_dev, "conv2d_wgrad_grouped: null pointer");
     const WgradGroup* h = reinterpret_cast<const WgradGroup*>(table_host);
     const WgradGroup* dv = reinterpret_cast<const WgradGroup*>(table_dev);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int launched = 0;
+    char name[192] = "";
 #define FRCNN_GROUP_LAUNCH(BM_, BN_, S_, OCC_, MODE_, IDX_)                                                                       \
     if (h[IDX_].n > 0 && h[IDX_].bm == BM_ && h[IDX_].bn == BN_ && h[IDX_].stages == S_) {                                                             \
         constexpr int ring_b = S_ * 64 * (BM_ + BN_) * 2, stage_b = BM_ * (BN_ * 4 + 16);                                          \
         constexpr int smem_b = ring_b > stage_b ? ring_b : stage_b;                                                                \
         static_assert(smem_b * OCC_ <= 163840, "LDS budget");                                                                      \
-        FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_group_kernel<BM_, BN_, S_, MODE_, OCC_>), smem_b) == 0, \
+        FRCNN_CHECK_ARG(t_dry_run || frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_group_kernel<BM_, BN_, S_, MODE_, OCC_>), smem_b) == 0, \
                         "conv2d_wgrad_grouped: cannot reserve %d B of LDS", smem_b);                                              \
-        hipLaunchKernelGGL((wgrad_group_kernel<BM_, BN_, S_, MODE_, OCC_>), dim3(h[IDX_].total), dim3(512), smem_b, s, dv + IDX_);   \
-        FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad_grouped");                                                                          \
+        if (!t_dry_run) hipLaunchKernelGGL((wgrad_group_kernel<BM_, BN_, S_, MODE_, OCC_>), dim3(h[IDX_].total), dim3(512), smem_b, s, dv + IDX_);   \
+        snprintf(name + strlen(name), sizeof(name) - strlen(name), "wgrad_group<BM=%d,BN=%d,S=%d,MODE=%d,OCC=%d> grid=%d; ", BM_, BN_, S_, MODE_, OCC_, h[IDX_].total); \
+            if (!t_dry_run) FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad_grouped");                                                          \
         launched |= 1 << IDX_;                                                                                                     \
     }
     FRCNN_GROUP_LAUNCH(64, 64, 3, 3, X_LINEAR, 0)
     FRCNN_GROUP_LAUNCH(64, 64, 3, 3, X_GENERAL, 1)
     FRCNN_GROUP_LAUNCH(128, 64, 3, 2, X_LINEAR, 0)
     FRCNN_GROUP_LAUNCH(128, 64, 3, 2, X_GENERAL, 1)
+#ifdef FRCNN_SWEEP
     FRCNN_GROUP_LAUNCH(64, 128, 3, 2, X_LINEAR, 0)
     FRCNN_GROUP_LAUNCH(64, 128, 3, 2, X_GENERAL, 1)
     FRCNN_GROUP_LAUNCH(128, 128, 2, 2, X_LINEAR, 0)
@@ -567,7 +598,9 @@ extern "C" int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* ta
     FRCNN_GROUP_LAUNCH(128, 64, 2, 3, X_GENERAL, 1)
     FRCNN_GROUP_LAUNCH(64, 64, 2, 3, X_LINEAR, 0)
     FRCNN_GROUP_LAUNCH(64, 64, 2, 3, X_GENERAL, 1)
+#endif
 #undef FRCNN_GROUP_LAUNCH
+    frcnn_note_instantiation(name);
     FRCNN_CHECK_ARG((h[0].n == 0 || (launched & 1)) && (h[1].n == 0 || (launched & 2)), "conv2d_wgrad_grouped: no kernel for tile %dx%d, %d slots",
                     h[0].n ? h[0].bm : h[1].bm, h[0].n ? h[0].bn : h[1].bn, h[0].n ? h[0].stages : h[1].stages);
     return FRCNN_OK;

@@ -518,7 +518,7 @@ __global__ void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, f
                            const int64_t* __restrict__ bounds, const float* __restrict__ values, int nb) {
     const int64_t st = *step;
     int k = 0;
-    while (k < nb && st >= bounds[k]) ++k;
+    while (k < nb && st > bounds[k]) ++k;            // Keras: values[k] while step <= boundaries[k]
     const float lr = values[k];
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float wi = w[i];

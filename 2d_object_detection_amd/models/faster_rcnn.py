@@ -70,7 +70,7 @@ class FasterRCNN:
         self.init_weights(seed)
         self._train_plan = None
         self._eval_plan = None
-        self._fwd_plans = {}
+        self._fwd_train, self._fwd_plan = None, None
         self._eval_step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.status = torch.zeros(4, dtype=torch.int32, device=self.device)     # [0] |= 1: empty background set while sampling
         self.use_graphs = True
@@ -219,6 +219,21 @@ class FasterRCNN:
         aux = {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn, "nms_rcnn": nms_rcnn, "targets": t, "feature_maps": feat}
         return {"plan": plan, "io": io, "losses": losses, "preds": preds, "aux": aux, "batch": batch}
 
+    def _build_forward(self, mods, batch):
+        """Training-mode forward only (reference faster_rcnn.py:39-57 with training=True): BatchNorm on batch statistics (its
+        moving averages are updated, as Keras does), RPN on the in-image anchors, proposal NMS, Fast-RCNN heads."""
+        plan = Plan("call_training")
+        io = {"images": mods.fe.setup(batch, True)}
+        _, gh, gw, cf = mods.fe.output_shape
+        mods.rpn.setup(batch, True)
+        P = int(self._rpn_config["nms"]["max_total_size"])
+        mods.rcnn.setup(batch, P, gh, gw, False)
+        feat = mods.fe.forward_plan(plan, True)
+        rpn_out = mods.rpn.forward_plan(plan, feat.view(batch * gh * gw, cf), True)
+        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"])
+        rcnn_out = mods.rcnn.forward_plan(plan, feat, nms_rpn["pred_boxes"])
+        return {"plan": plan, "io": io, "batch": batch, "aux": {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn, "feature_maps": feat}}
+
     def _feed(self, built, images, gt_labels, gt_boxes):
         io = built["io"]
         if images.is_cuda and images.dtype == io["images"].dtype and images.shape == io["images"].shape and images.is_contiguous() \
@@ -306,7 +321,20 @@ class FasterRCNN:
     def __call__(self, images, training=False):
         """reference faster_rcnn.py:39-57: returns (rpn_output, rcnn_output) dicts."""
         if training:
-            raise NotImplementedError("use train_step for the training-mode forward (BN statistics are updated there)")
+            # its own module instances (activation buffers): the captured train plan's buffers stay untouched
+            b = int(images.shape[0])
+            if self._fwd_train is None:
+                self._fwd_train = _Modules(self.config, self.depth, self.store, self.device, False)
+            if self._fwd_plan is None or self._fwd_plan["batch"] != b:
+                self._fwd_plan = self._build_forward(self._fwd_train, b)
+            built = self._fwd_plan
+            self._sync_derived_weights(self._fwd_train)
+            if images.is_cuda and images.dtype == built["io"]["images"].dtype and images.is_contiguous() and images.data_ptr() % 16 == 0:
+                ops.copy_bytes(images, built["io"]["images"])
+            else:
+                built["io"]["images"].copy_(images, non_blocking=True)
+            built["plan"].run()
+            return built["aux"]["rpn_out"], built["aux"]["rcnn_out"]
         z = torch.zeros
         b = int(images.shape[0])
         self.test_step(images, z(b, 100, self.config["num_classes"] + 1, device=self.device), z(b, 100, 4, device=self.device))

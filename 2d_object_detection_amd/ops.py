@@ -43,6 +43,28 @@ def conv_desc(n, hi, wi, cin, kh, kw, stride, pad_h, pad_w, ho, wo, cout, in_pix
 STAT_SLOTS = 16          # FRCNN_STAT_SLOTS of include/frcnn_hip.h (checked against the library in tests/test_abi.py)
 
 
+def last_conv_instantiation():
+    """Which MFMA conv kernel (template arguments, grid) this thread launched last -- used by the parity tests."""
+    return _lib.load().frcnn_last_conv_instantiation().decode()
+
+
+def conv2d_describe(d, with_bn_reduce=False):
+    """The kernel instantiation conv2d_fprop / conv2d_dgrad_bnreduce would launch for descriptor d (host logic, no device)."""
+    r = _lib.load().frcnn_conv2d_describe(byref(d), 1 if with_bn_reduce else 0)
+    if r is None:
+        raise RuntimeError("frcnn_conv2d_describe: " + _lib.load().frcnn_last_error().decode())
+    return r.decode()
+
+
+def conv2d_wgrad_describe(d=None, with_row_index=False, group=None):
+    """The kernel(s) conv2d_wgrad (or conv2d_wgrad_grouped for a WgradGroup) would launch (host logic, no device)."""
+    r = _lib.load().frcnn_conv2d_wgrad_describe(byref(d) if d is not None else None, 1 if with_row_index else 0,
+                                                c_void_p(group.host.data_ptr()) if group is not None else None)
+    if r is None:
+        raise RuntimeError("frcnn_conv2d_wgrad_describe: " + _lib.load().frcnn_last_error().decode())
+    return r.decode()
+
+
 def conv_stat_tiles(d):
     return _lib.load().frcnn_conv2d_stat_tiles(byref(d))
 
@@ -218,6 +240,14 @@ def boxes_scale(inp, out, sx, sy):
 def decode_boxes(regions, deltas, out, b, r, c, img_w, img_h):
     call("frcnn_decode_boxes", _p(regions), 1 if regions.dim() == 3 else 0, _p(deltas), _p(out), b, r, c, float(img_w), float(img_h),
          _stream())
+
+
+def encode_boxes(boxes, regions, out, b, r, c):
+    call("frcnn_encode_boxes", _p(boxes), _p(regions), 1 if regions.dim() == 3 else 0, _p(out), b, r, c, _stream())
+
+
+def boxes_divide(inp, out, w, h):
+    call("frcnn_boxes_divide", _p(inp), _p(out), inp.numel() // 4, float(w), float(h), _stream())
 
 
 def nms_workspace_bytes(b, n, c, max_per_class, max_total):

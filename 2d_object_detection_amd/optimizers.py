@@ -7,8 +7,10 @@ from . import ops
 
 
 class PiecewiseConstantDecay:
-    """tf.keras.optimizers.schedules.PiecewiseConstantDecay(boundaries, values): values[i] while
-    step < boundaries[i] ... (lr changes AT step == boundary)."""
+    """tf.keras.optimizers.schedules.PiecewiseConstantDecay(boundaries, values) [TF-ext, public contract]: values[0] while
+    step <= boundaries[0], values[i] while boundaries[i-1] < step <= boundaries[i], values[-1] for step > boundaries[-1] -- the
+    rate changes at the first step AFTER a boundary.  `step` is the optimizer's iteration counter before the update (0 for
+    the first update), as Keras passes it (reference train_faster_rcnn.py:62-68,109-112)."""
 
     def __init__(self, boundaries, values):
         assert len(values) == len(boundaries) + 1
@@ -16,7 +18,7 @@ class PiecewiseConstantDecay:
 
     def __call__(self, step):
         for b, v in zip(self.boundaries, self.values):
-            if step < b:
+            if step <= b:
                 return v
         return self.values[-1]
 

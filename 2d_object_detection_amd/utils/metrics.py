@@ -57,7 +57,9 @@ class AveragePrecision:
         self._true_count.append(real.sum())
         self._pos_count += b * p                                           # :73,76 padding predictions count too
         self._true_pos.append(tp.reshape(-1))
-        self._scores.append(pred_scores.reshape(-1))
+        # clone: float32 contiguous inputs pass through .float() / .reshape() as VIEWS, and the training driver hands over the
+        # train step's static prediction buffers, which the next step overwrites
+        self._scores.append(pred_scores.reshape(-1).clone())
 
     def result(self):
         """:24-41."""

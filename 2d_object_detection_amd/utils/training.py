@@ -6,9 +6,14 @@ from .. import ops
 
 
 def generate_targets(gt_labels, gt_boxes, regions, image_shape, foreground_iou_interval, background_iou_interval, objectness=False):
-    """Batched reference utils/training.py:7-77.  gt_labels [B,G,C+1], gt_boxes [B,G,4] relative,
-    regions [R,4] or [B,R,4] absolute.  objectness=True applies rpn_detector.py:141 first.
+    """reference utils/training.py:7-77, per image as there (gt_labels [G,C+1], gt_boxes [G,4] relative, regions [R,4]
+    absolute -> [R,C1], [R,C1-1,4]) or batched (the reference maps it per image with tf.map_fn, rpn_detector.py:143):
+    gt_labels [B,G,C+1], gt_boxes [B,G,4], regions [R,4] or [B,R,4].  objectness=True applies rpn_detector.py:141 first.
     Returns target_labels [B,R,C1], target_boxes [B,R,C1-1,4]."""
+    if gt_labels.dim() == 2:                       # the reference's own per-image form (utils/training.py:7: [G,C+1], [G,4], [R,4])
+        tl, tb = generate_targets(gt_labels[None], gt_boxes[None], regions, image_shape, foreground_iou_interval, background_iou_interval,
+                                  objectness)
+        return tl[0], tb[0]
     b, g, c1g = gt_labels.shape
     r = regions.shape[-2]
     c1 = 2 if objectness else c1g

@@ -80,6 +80,16 @@ typedef struct frcnn_bn_reduce {
 } frcnn_bn_reduce;
 int frcnn_conv2d_dgrad_bnreduce(const frcnn_conv_desc* d, const frcnn_bf16* dz, const frcnn_bf16* w_t, const frcnn_bf16* res,
                                 const uint8_t* res_mask, frcnn_bf16* gx, const frcnn_bn_reduce* red, frcnn_stream_t stream);
+/* Diagnostics: name, template arguments and grid of the MFMA conv kernel(s) the calling thread launched last through
+ * frcnn_conv2d_fprop / _dgrad_bnreduce / _wgrad / _wgrad_grouped (thread-local; "" before the first launch).  The parity tests
+ * assert with it that a shape really dispatched to the instantiation they mean to cover. */
+const char* frcnn_last_conv_instantiation(void);
+/* The same string for the launch frcnn_conv2d_fprop (with_bn_reduce = 0) or frcnn_conv2d_dgrad_bnreduce (1) WOULD make for
+ * this descriptor -- host logic only, nothing is launched and no device is needed; NULL (see frcnn_last_error) when the
+ * descriptor is not supported. */
+const char* frcnn_conv2d_describe(const frcnn_conv_desc* d, int with_bn_reduce);
+/* likewise for frcnn_conv2d_wgrad (group_table_host == NULL) or for frcnn_conv2d_wgrad_grouped on a planned host table */
+const char* frcnn_conv2d_wgrad_describe(const frcnn_conv_desc* d, int with_row_index, const void* group_table_host);
 /* rows of the stats_partial buffer [rows][2][cout] (== FRCNN_STAT_SLOTS) */
 int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d);
 int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
@@ -189,7 +199,7 @@ int frcnn_maxpool3x3s2_bwd(const frcnn_bf16* gy, const uint8_t* argmax, frcnn_bf
  * models/faster_rcnn.py:104) fused with the L2 kernel regulariser gradient 2*l2*w
  * (models/faster_rcnn.py:101) and the bf16 working-copy refresh:
  *   g' = g*grad_scale + 2*l2*w ; v = momentum*v - lr*g' ; w += v ; w_bf16 = bf16(w)
- * lr = values[i] for the first i with step < boundaries[i] (values has nb+1 entries):
+ * lr = values[i] for the first i with step <= boundaries[i], values[nb] beyond the last boundary (values has nb+1 entries):
  * tf.keras.optimizers.schedules.PiecewiseConstantDecay evaluated on the device step counter. */
 int frcnn_sgd_momentum(float* w, const float* g, float* v, frcnn_bf16* w_bf16, int64_t n, float momentum, float l2,
                        float grad_scale, const int64_t* step, const int64_t* boundaries, const float* values, int nb,
@@ -214,6 +224,12 @@ int frcnn_clip_to_window(const float* boxes, float* out, int64_t n, float x0, fl
  * regions [R,4] (regions_per_image = 0) or [B,R,4]; deltas [B,R,C,4] -> out [B,R,C,4]. */
 int frcnn_decode_boxes(const float* regions, int regions_per_image, const float* deltas, float* out, int b, int r,
                        int c, float img_w, float img_h, frcnn_stream_t stream);
+/* utils/boxes.py:44-73: out[b,r,c] = encode(boxes[b,r,c], regions[r] or regions[b,r]) = [(centre - centre_ref) / size_ref,
+ * log(size / size_ref)]; the inverse of frcnn_decode_boxes with img_w = img_h = 1. */
+int frcnn_encode_boxes(const float* boxes, const float* regions, int regions_per_image, float* out, int b, int r, int c,
+                       frcnn_stream_t stream);
+/* utils/boxes.py:86-93: out = in / [w, h, w, h] (true division, as tf.divide) over n boxes */
+int frcnn_boxes_divide(const float* in, float* out, int64_t n, float w, float h, frcnn_stream_t stream);
 /* tf.image.combined_non_max_suppression as called at utils/post_processing.py:53-55.
  * boxes [B,N,q,4] (q = 1 or C), scores [B,N,*] with row stride score_stride, class c at column
  * score_offset + c.  Outputs [B,T,4], [B,T], int32 [B,T], int32 [B]. */

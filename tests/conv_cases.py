@@ -1,0 +1,152 @@
+"""Oracle-compared GPU cases for the MFMA conv family, shared by tests/test_gpu_conv.py (runs them on the GPU against
+torch-CPU fp32) and tests/test_conv_dispatch.py (CPU: proves, through the dispatcher's dry-run entry points, that every
+kernel instantiation the BASELINE train plans launch is hit by one of these cases).
+
+Shapes are the reference network's own layer shapes (Keras ResNet50 v1 to conv4_block6_out, reference
+models/feature_extractor.py:4-11; RPN / Dense heads, models/detectors/*.py) at 375x1242: the dispatch heuristics depend on
+M = batch * Ho * Wo, so the cases keep batch 4 where the tile choice needs it and shrink the batch where it does not.
+"""
+
+# ---- forward convolutions: n, h, w (input grid), cin, cout, k, stride, pad, epilogue flags
+FPROP = [
+    # 128 x 128 tiles
+    dict(id="c4_1x1_256_1024_stats", n=4, h=24, w=78, cin=256, cout=1024, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    dict(id="c4_s2_512_1024_stats", n=4, h=47, w=156, cin=512, cout=1024, k=1, s=2, p=0, bias=True, relu=False, stats=True),
+    # kw-sharing 3x3 (>= 160 m-tiles); Wo = 311 is prime, M = 29234 is not a multiple of 128
+    dict(id="c2_3x3_64_64_relu", n=1, h=94, w=311, cin=64, cout=64, k=3, s=1, p=1, bias=True, relu=True, stats=False),
+    dict(id="c2_3x3_64_64_stats", n=1, h=94, w=311, cin=64, cout=64, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+    dict(id="c3_3x3_128_128_stats", n=3, h=47, w=156, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+    # tile runs (short K)
+    dict(id="c2_1x1_64_256_stats_run4", n=4, h=94, w=311, cin=64, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    dict(id="c3_s2_256_512_stats_run2", n=4, h=94, w=311, cin=256, cout=512, k=1, s=2, p=0, bias=True, relu=False, stats=True),
+    # one 128 x 64 tile per workgroup at the benchmark's sizes
+    dict(id="c2_1x1_256_64_stats", n=4, h=94, w=311, cin=256, cout=64, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    dict(id="c4_1x1_1024_256_stats", n=4, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    dict(id="c4_3x3_256_256_stats", n=4, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+    dict(id="rpn_3x3_1024_256_relu", n=1, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),
+    # small shapes (tails, odd grids)
+    dict(id="small_1x1_stats", n=2, h=13, w=17, cin=64, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    dict(id="small_3x3_relu", n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1, bias=True, relu=True, stats=False),
+    dict(id="small_s2_stats", n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0, bias=False, relu=False, stats=True),
+    dict(id="small_run_512", n=4, h=64, w=64, cin=64, cout=512, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    dict(id="small_3x3_128_stats", n=1, h=9, w=11, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+    dict(id="c4_3x3_256_256_b2", n=2, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+]
+
+# ---- data gradients: dz grid n x h x w with cin channels -> gx with cout channels; k = 1 or 3 (stride 1, pad k//2);
+# scatter 2: the gradient of a stride-2 1x1 convolution, written to every second pixel of a 2h x 2w (-1) grid.
+# res: residual added (ADD_RES); res_mask: bit mask on the residual; red: fused BatchNorm-backward reduce (mask: with ReLU bits)
+DGRAD = [
+    # 128 x 128 tiles
+    dict(id="c3_dg_512_128_red", n=4, h=47, w=156, cin=512, cout=128, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="c3_dg_128_512_res_red", n=2, h=47, w=156, cin=128, cout=512, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
+    dict(id="rpn_dg_3x3_256_1024_res_red", n=4, h=24, w=78, cin=256, cout=1024, k=3, res=True, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="c3_dg_s2_128_256_scatter", n=4, h=47, w=156, cin=128, cout=256, k=1, res=False, res_mask=False, red=False, mask=False, scatter=2),
+    dict(id="c3_dg_s2_512_256_scatter_res_red", n=4, h=47, w=156, cin=512, cout=256, k=1, res=True, res_mask=False, red=True, mask=True, scatter=2),
+    # kw-sharing 3x3
+    dict(id="c2_dg_3x3_64_64_red", n=1, h=94, w=311, cin=64, cout=64, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="c3_dg_3x3_128_128_red", n=3, h=47, w=156, cin=128, cout=128, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    # tile runs
+    dict(id="c2_dg_64_256_res_red_run4", n=4, h=94, w=311, cin=64, cout=256, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
+    dict(id="c2_dg_64_256_plain_run", n=4, h=94, w=311, cin=64, cout=256, k=1, res=False, res_mask=False, red=False, mask=False, scatter=1),
+    # one 128 x 64 tile per workgroup
+    dict(id="c2_dg_256_64_red", n=4, h=94, w=311, cin=256, cout=64, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="c2_dg_64_64_plain", n=4, h=94, w=311, cin=64, cout=64, k=1, res=False, res_mask=False, red=False, mask=False, scatter=1),
+    dict(id="c4_dg_1024_256_red", n=4, h=24, w=78, cin=1024, cout=256, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="c4_dg_3x3_256_256_red", n=4, h=24, w=78, cin=256, cout=256, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="rpn_heads_dg_128_256", n=4, h=24, w=78, cin=128, cout=256, k=1, res=False, res_mask=False, red=False, mask=False, scatter=1),
+    # small shapes
+    dict(id="small_dg_run", n=2, h=12, w=39, cin=256, cout=64, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
+    dict(id="small_dg_3x3", n=2, h=13, w=17, cin=128, cout=128, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="small_dg_nomask", n=1, h=24, w=78, cin=1024, cout=256, k=1, res=False, res_mask=False, red=True, mask=False, scatter=1),
+    dict(id="small_dg_scatter", n=2, h=12, w=39, cin=512, cout=256, k=1, res=True, res_mask=False, red=True, mask=True, scatter=2),
+]
+
+# ---- fp32-output / split-K GEMMs (RPN heads, Dense heads)
+F32 = [
+    dict(id="rpn_heads_f32", m=4 * 24 * 78, k=256, cout=128, split=1, bias=True),
+    dict(id="dense_heads_splitk", m=1200, k=50176, cout=64, split=8, bias=False),
+    dict(id="small_f32", m=300, k=6400, cout=64, split=1, bias=True),
+    dict(id="small_splitk", m=300, k=6400, cout=64, split=8, bias=False),
+]
+
+# ---- weight gradients (single launches)
+WGRAD = [
+    dict(id="rpn_3x3_1024_256", n=1, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1),            # general addressing
+    dict(id="rpn_heads_256_128", n=4, h=24, w=78, cin=256, cout=128, k=1, s=1, p=0),            # linear
+    dict(id="small_3x3", n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1),
+    dict(id="small_s2", n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0),
+    dict(id="small_1x1", n=2, h=9, w=13, cin=128, cout=256, k=1, s=1, p=0),
+    dict(id="c4_3x3", n=3, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1),
+    dict(id="c2_1x1", n=2, h=30, w=40, cin=64, cout=256, k=1, s=1, p=0),
+]
+
+# ---- grouped weight gradients: one launch per addressing mode; tile 128 x 64 when every layer of the mode has cout >= 128
+WGRAD_GROUPS = [
+    dict(id="mixed_64x64", layers=[dict(n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1), dict(n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0),
+                                   dict(n=2, h=9, w=13, cin=128, cout=256, k=1, s=1, p=0), dict(n=3, h=24, w=26, cin=256, cout=256, k=3, s=1, p=1),
+                                   dict(n=2, h=10, w=12, cin=64, cout=64, k=1, s=1, p=0)]),
+    dict(id="wide_128x64", layers=[dict(n=2, h=24, w=39, cin=256, cout=256, k=3, s=1, p=1), dict(n=2, h=24, w=39, cin=256, cout=1024, k=1, s=1, p=0),
+                                   dict(n=2, h=24, w=39, cin=1024, cout=256, k=1, s=1, p=0), dict(n=1, h=47, w=77, cin=512, cout=256, k=1, s=2, p=0)]),
+]
+
+
+def conv_desc(ops, c, **kw):
+    ho, wo = (c["h"] + 2 * c["p"] - c["k"]) // c["s"] + 1, (c["w"] + 2 * c["p"] - c["k"]) // c["s"] + 1
+    return ops.conv_desc(c["n"], c["h"], c["w"], c["cin"], c["k"], c["k"], c["s"], c["p"], c["p"], ho, wo, c["cout"], **kw)
+
+
+def fprop_desc(ops, c):
+    flags = (ops.CONV_BIAS if c["bias"] else 0) | (ops.CONV_RELU if c["relu"] else 0) | (ops.CONV_STATS if c["stats"] else 0)
+    return conv_desc(ops, c, flags=flags)
+
+
+def dgrad_desc(ops, c):
+    n, h, w, k, sc = c["n"], c["h"], c["w"], c["k"], c["scatter"]
+    flags = ops.CONV_ADD_RES if c["res"] else 0
+    if sc == 1:
+        return ops.conv_desc(n, h, w, c["cin"], k, k, 1, k // 2, k // 2, h, w, c["cout"], flags=flags)
+    return ops.conv_desc(n, h, w, c["cin"], 1, 1, 1, 0, 0, h, w, c["cout"], out_h=sc * h, out_w=sc * w - 1, out_scatter=sc, flags=flags)     # (odd width, as 311 -> 156)
+
+
+def f32_desc(ops, c):
+    if c["split"] > 1:
+        return ops.conv_desc(1, 1, c["m"], c["k"], 1, 1, 1, 0, 0, 1, c["m"], c["cout"], flags=ops.CONV_SPLITK_ATOMIC, split_k=c["split"])
+    return ops.conv_desc(1, 1, c["m"], c["k"], 1, 1, 1, 0, 0, 1, c["m"], c["cout"], flags=ops.CONV_OUT_F32 | (ops.CONV_BIAS if c["bias"] else 0))
+
+
+def _strip(name):
+    return name.split(" grid")[0]
+
+
+def covered_instantiations(ops):
+    """{instantiation name: [case ids]} for every case above (dry-run of the dispatcher: no GPU needed)."""
+    import torch
+    out = {}
+
+    def note(name, cid):
+        out.setdefault(_strip(name), []).append(cid)
+
+    for c in FPROP:
+        note(ops.conv2d_describe(fprop_desc(ops, c), False), c["id"])
+    for c in DGRAD:
+        note(ops.conv2d_describe(dgrad_desc(ops, c), c["red"]), c["id"])
+    for c in F32:
+        note(ops.conv2d_describe(f32_desc(ops, c), False), c["id"])
+    for c in WGRAD:
+        note(ops.conv2d_wgrad_describe(conv_desc(ops, c)), c["id"])
+    note(ops.conv2d_wgrad_describe(ops.conv_desc(1, 1, 24, 1024, 1, 1, 1, 0, 0, 1, 24, 64), with_row_index=True), "head wgrad (row_index)")
+    note(ops.conv2d_wgrad_describe(ops.conv_desc(2, 43, 52, 32, 7, 1, 2, 0, 0, 19, 23, 64, in_pix_stride=4)), "stem wgrad")
+    note(ops.conv2d_describe(ops.conv_desc(2, 43, 52, 32, 7, 1, 2, 0, 0, 19, 23, 64, in_pix_stride=4, flags=ops.CONV_BIAS | ops.CONV_STATS)), "stem fprop")
+    for grp in WGRAD_GROUPS:
+        items = []
+        for c in grp["layers"]:
+            d = conv_desc(ops, c)
+            m = d.n * d.ho * d.wo
+            items.append((d, torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8)))
+            del m
+        g = ops.WgradGroup(items, "cpu")
+        for part in ops.conv2d_wgrad_describe(group=g).split("; "):
+            if part.strip():
+                note(part, grp["id"])
+    return out

@@ -1,0 +1,64 @@
+"""CPU: every MFMA conv kernel instantiation the BASELINE train plans launch is covered by an oracle-compared GPU case.
+
+The dispatcher (csrc/conv_tile.hip: conv_tile_dispatch, csrc/conv_wgrad.hip) is host logic; its dry-run entry points
+frcnn_conv2d_describe / frcnn_conv2d_wgrad_describe name the kernel a descriptor would launch without touching a device.
+Here the full train plans of BASELINE.json configs[1] (ResNet-50, batch 4, 375x1242) and configs[3] (ResNet-101, batch 2,
+1000 proposals) are built on CPU tensors (nothing is launched), the instantiation of every conv launch is collected, and
+each must appear among the instantiations that tests/conv_cases.py's cases dispatch to -- the cases tests/test_gpu_conv.py
+runs against torch-CPU on the GPU box, asserting there again which kernel really ran.  When the tile heuristics move, this
+test names the instantiation that lost its parity case."""
+import copy
+import importlib
+
+import pytest
+import torch
+
+import conv_cases
+
+
+def _plan_instantiations(monkeypatch, depth, batch, proposals=None):
+    ops = importlib.import_module("2d_object_detection_amd.ops")
+    # the two init-time kernels of the RPN detector (anchor table, clip) need a device; their values do not matter here
+    monkeypatch.setattr(ops, "anchors_generate", lambda out, *a, **k: out.zero_())
+    monkeypatch.setattr(ops, "clip_to_window", lambda boxes, out, w: out.copy_(boxes))
+    M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
+    C = importlib.import_module("2d_object_detection_amd.config")
+    OPT = importlib.import_module("2d_object_detection_amd.optimizers")
+    cfg = copy.deepcopy(C.default_config())
+    if proposals:
+        cfg["rpn"]["nms"]["max_total_size"] = cfg["rpn"]["nms"]["max_output_size_per_class"] = proposals
+    model = M.FasterRCNN(cfg, depth=depth, device="cpu")
+    opt = OPT.SGD(learning_rate=1e-3, momentum=0.9)
+    opt.bind(model.store)
+    plan = model._build(model._train, batch, True, opt)["plan"]
+    names = {}
+    for seg in plan.segments:
+        for fn, args, kwargs, _br in seg:
+            found = []
+            if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce:
+                found = [ops.conv2d_describe(args[0], fn is ops.conv2d_dgrad_bnreduce)]
+            elif fn is ops.conv2d_wgrad:
+                found = [ops.conv2d_wgrad_describe(args[0], with_row_index=kwargs.get("row_index") is not None)]
+            elif fn is ops.conv2d_wgrad_grouped:
+                found = [p for p in ops.conv2d_wgrad_describe(group=args[0]).split("; ") if p.strip()]
+            for f in found:
+                key = f.split(" grid")[0]
+                names[key] = names.get(key, 0) + 1
+    return names, plan.num_launches
+
+
+@pytest.mark.parametrize("depth,batch,proposals", [(50, 4, None), (101, 2, 1000)])
+def test_every_plan_instantiation_has_a_parity_case(monkeypatch, ops, depth, batch, proposals):
+    used, launches = _plan_instantiations(monkeypatch, depth, batch, proposals)
+    covered = conv_cases.covered_instantiations(ops)
+    assert len(used) >= 20 and launches >= 200
+    missing = sorted(k for k in used if k not in covered)
+    assert not missing, "conv kernels of the R%d batch-%d train plan without an oracle-compared GPU case:\n  %s" % (depth, batch, "\n  ".join(missing))
+
+
+def test_describe_reports_errors(ops):
+    d = ops.conv_desc(1, 8, 8, 64, 7, 7, 1, 3, 3, 8, 8, 64)            # 49 taps: unsupported
+    with pytest.raises(RuntimeError, match="32 taps"):
+        ops.conv2d_describe(d)
+    assert "KWS=1" in ops.conv2d_describe(ops.conv_desc(1, 94, 311, 64, 3, 3, 1, 1, 1, 94, 311, 64))
+    assert "KWS=0" in ops.conv2d_describe(ops.conv_desc(1, 24, 78, 64, 3, 3, 1, 1, 1, 24, 78, 64))

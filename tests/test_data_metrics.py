@@ -41,6 +41,22 @@ def test_average_precision_known_answer():
     assert e.result() == 0.0
 
 
+def test_average_precision_keeps_its_own_copy_of_reused_buffers():
+    """The training driver passes the train step's STATIC prediction buffers (overwritten every step): update_state must not
+    keep views of them.  Two updates through the same reused buffers == two updates with fresh tensors (loop oracle)."""
+    g = torch.Generator().manual_seed(3)
+    B, G, P, C = 2, 6, 24, 3
+    boxes_buf, scores_buf = torch.zeros(B, P, 4), torch.zeros(B, P)
+    ap, apo = MET.AveragePrecision(0.5), om.AveragePrecisionOracle(0.5)
+    for _ in range(2):
+        gt, lab, pb, ps, pc = _random_case(g, B, G, P, C)
+        boxes_buf.copy_(pb)
+        scores_buf.copy_(ps)
+        ap.update_state(gt, boxes_buf, scores_buf)
+        apo.update_state(gt, pb.clone(), ps.clone())
+    assert abs(ap.result() - apo.result()) < 1e-6
+
+
 def _random_case(g, B, G, P, C):
     gt, lab = torch.zeros(B, G, 4), torch.zeros(B, G, C + 1)
     pb, ps, pc = torch.zeros(B, P, 4), torch.zeros(B, P), torch.zeros(B, P, dtype=torch.int32)

@@ -28,16 +28,27 @@ def mism(a, b):
     return float((a != b).float().mean())
 
 
+# (image shape, batch): the small geometry, and BASELINE.json configs[1] -- ResNet-50, 375 x 1242, batch 4 -- whose layers
+# dispatch to the 128x128-tile, kw-sharing and tile-run kernels that carry the benchmark (tests/test_conv_dispatch.py)
+GEOMETRIES = [((128, 192, 3), 2), ((375, 1242, 3), 4)]
+GEOM_IDS = ["128x192-b2", "375x1242-b4"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("training", [True, False])
-def test_backbone_teacher_forced(training):
+@pytest.mark.parametrize("geom", GEOMETRIES, ids=GEOM_IDS)
+def test_backbone_teacher_forced(training, geom):
     FE = importlib.import_module("2d_object_detection_amd.models.feature_extractor")
-    cfg = O.default_config((128, 192, 3))
+    shape, B = geom
+    if not training and B > 2:
+        pytest.skip("inference-mode BN at full size adds no kernel the training-mode case does not run")
+    H, W = shape[0], shape[1]
+    cfg = O.default_config(shape)
     params = O.init_params(cfg, seed=3, randomize_affine=True)
     for k in params:
         if k.endswith("/kernel"):
             params[k] = params[k].to(BF).float()
-    images, _, _ = O.synthetic_batch(2, cfg["image_shape"], seed=5)
+    images, _, _ = O.synthetic_batch(B, cfg["image_shape"], seed=5)
     m = FE.get_feature_extractor_model(cfg["image_shape"])
     m.set_weights(params)
     m(images.cuda(), training=training)
@@ -51,17 +62,17 @@ def test_backbone_teacher_forced(training):
     # stem
     st = m.stem
     x = Q(R.preprocess(images))
-    xpad = m.xpad.float().cpu()[:, 3:3 + 128, 3:3 + 192, :3].permute(0, 3, 1, 2)
+    xpad = m.xpad.float().cpu()[:, 3:3 + H, 3:3 + W, :3].permute(0, 3, 1, 2)
     assert mism(xpad, x) == 0.0
     worst = []
     z_ref = R._conv(x, p, "conv1", 2, 3, Q)
-    z_hip = nchw(st.z, 2, st.ho, st.wo)
+    z_hip = nchw(st.z, B, st.ho, st.wo)
     worst.append(("stem z", rel(z_hip, z_ref), mism(z_hip, z_ref)))
     a_ref = Q(F.relu(R._bn(z_hip, p, "conv1", training, ns)))
-    a_hip = nchw(m.a_stem, 2, st.ho, st.wo)
+    a_hip = nchw(m.a_stem, B, st.ho, st.wo)
     worst.append(("stem act", rel(a_hip, a_ref), mism(a_hip, a_ref)))
     pool_ref = F.max_pool2d(F.pad(a_hip, (1, 1, 1, 1)), 3, 2)
-    pool_hip = nchw(m.pool, 2, m.hp1, m.wp1)
+    pool_hip = nchw(m.pool, B, m.hp1, m.wp1)
     assert mism(pool_hip, pool_ref) == 0.0
     xin = pool_hip
     for (n, ci, f, s, first) in m.specs:
@@ -70,26 +81,26 @@ def test_backbone_teacher_forced(training):
         out = {}
         if first:
             z0 = R._conv(xin, p, n + "_0", s, 0, Q)
-            out["z0"] = (nchw(u[0].z, 2, ho, wo), z0)
-            sc = Q(R._bn(nchw(u[0].z, 2, ho, wo), p, n + "_0", training, ns))
-            out["sc"] = (nchw(a["sc"], 2, ho, wo), sc)
-            sc_in = nchw(a["sc"], 2, ho, wo)
+            out["z0"] = (nchw(u[0].z, B, ho, wo), z0)
+            sc = Q(R._bn(nchw(u[0].z, B, ho, wo), p, n + "_0", training, ns))
+            out["sc"] = (nchw(a["sc"], B, ho, wo), sc)
+            sc_in = nchw(a["sc"], B, ho, wo)
         else:
             sc_in = xin
         z1 = R._conv(xin, p, n + "_1", s, 0, Q)
-        out["z1"] = (nchw(u[1].z, 2, ho, wo), z1)
-        a1 = Q(F.relu(R._bn(nchw(u[1].z, 2, ho, wo), p, n + "_1", training, ns)))
-        out["a1"] = (nchw(a["a1"], 2, ho, wo), a1)
-        z2 = R._conv(nchw(a["a1"], 2, ho, wo), p, n + "_2", 1, 1, Q)
-        out["z2"] = (nchw(u[2].z, 2, ho, wo), z2)
-        a2 = Q(F.relu(R._bn(nchw(u[2].z, 2, ho, wo), p, n + "_2", training, ns)))
-        out["a2"] = (nchw(a["a2"], 2, ho, wo), a2)
-        z3 = R._conv(nchw(a["a2"], 2, ho, wo), p, n + "_3", 1, 0, Q)
-        out["z3"] = (nchw(u[3].z, 2, ho, wo), z3)
-        o = Q(F.relu(sc_in + R._bn(nchw(u[3].z, 2, ho, wo), p, n + "_3", training, ns)))
-        out["out"] = (nchw(a["out"], 2, ho, wo), o)
+        out["z1"] = (nchw(u[1].z, B, ho, wo), z1)
+        a1 = Q(F.relu(R._bn(nchw(u[1].z, B, ho, wo), p, n + "_1", training, ns)))
+        out["a1"] = (nchw(a["a1"], B, ho, wo), a1)
+        z2 = R._conv(nchw(a["a1"], B, ho, wo), p, n + "_2", 1, 1, Q)
+        out["z2"] = (nchw(u[2].z, B, ho, wo), z2)
+        a2 = Q(F.relu(R._bn(nchw(u[2].z, B, ho, wo), p, n + "_2", training, ns)))
+        out["a2"] = (nchw(a["a2"], B, ho, wo), a2)
+        z3 = R._conv(nchw(a["a2"], B, ho, wo), p, n + "_3", 1, 0, Q)
+        out["z3"] = (nchw(u[3].z, B, ho, wo), z3)
+        o = Q(F.relu(sc_in + R._bn(nchw(u[3].z, B, ho, wo), p, n + "_3", training, ns)))
+        out["out"] = (nchw(a["out"], B, ho, wo), o)
         worst.extend((n + " " + k, rel(h, r), mism(h, r)) for k, (h, r) in out.items())
-        xin = nchw(a["out"], 2, ho, wo)
+        xin = nchw(a["out"], B, ho, wo)
 
 
     bad = [w for w in worst if w[1] > 1e-3 or w[2] > 5e-3]
@@ -116,21 +127,25 @@ def _unit_backward(p, name, x, stride, pad, gout, res=None, relu=True):
 
 
 @pytest.mark.gpu
-def test_backbone_backward_teacher_forced():
+@pytest.mark.parametrize("geom", GEOMETRIES, ids=GEOM_IDS)
+def test_backbone_backward_teacher_forced(geom):
     """Per-unit backward parity: every oracle unit gets the HIP path's own input activation and upstream gradient;
-    data gradients (bf16) must agree to 1.5% relative L2, parameter gradients (fp32) to 1%."""
+    data gradients (bf16) must agree to 1.5% relative L2, parameter gradients (fp32) to 1%.  At 375 x 1242, batch 4 (the
+    benchmark's configuration, reference hyper-parameters) the first and last block of every stage are compared."""
     M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
     OPT = importlib.import_module("2d_object_detection_amd.optimizers")
-    cfg = O.default_config((128, 192, 3))
-    cfg["rpn"]["anchors"]["base_anchor_shape"] = [32, 32]
-    cfg["rpn"]["nms"].update(max_total_size=40, max_output_size_per_class=40)
-    cfg["rpn"]["sampling"]["num_samples"] = 32
-    cfg["rcnn"]["sampling"]["num_samples"] = 16
+    shape, B = geom
+    cfg = O.default_config(shape)
+    if shape[0] < 300:
+        cfg["rpn"]["anchors"]["base_anchor_shape"] = [32, 32]
+        cfg["rpn"]["nms"].update(max_total_size=40, max_output_size_per_class=40)
+        cfg["rpn"]["sampling"]["num_samples"] = 32
+        cfg["rcnn"]["sampling"]["num_samples"] = 16
     params = O.init_params(cfg, seed=3, randomize_affine=True)
     for k in params:
         if k.endswith("/kernel"):
             params[k] = params[k].to(BF).float()
-    images, gl, gb = O.synthetic_batch(2, cfg["image_shape"], seed=5)
+    images, gl, gb = O.synthetic_batch(B, cfg["image_shape"], seed=5)
     model = M.FasterRCNN(cfg, sampling_seed=11)
     model.use_graphs = False
     model.set_weights(params)
@@ -140,7 +155,7 @@ def test_backbone_backward_teacher_forced():
     t = model._train_plan["aux"]["targets"]
 
     def nchw(t2d, h, w):
-        return t2d.float().cpu().view(2, h, w, -1).permute(0, 3, 1, 2).contiguous()
+        return t2d.float().cpu().view(B, h, w, -1).permute(0, 3, 1, 2).contiguous()
 
     def hwio(name):
         return st.grad(name + "_conv/kernel").permute(1, 2, 3, 0).cpu()
@@ -163,8 +178,14 @@ def test_backbone_backward_teacher_forced():
         xin_of[n], hw_in[n] = x, (hi, wi)
         x, hi, wi = fe.acts[n]["out"], fe.units[n][1].ho, fe.units[n][1].wo
     gout = t["g_feat"]
+    stage_blocks = {}
+    for spec in specs:
+        stage_blocks.setdefault(spec[0][:5], []).append(spec[0])
     for (n, ci, f, s, first) in reversed(specs):
         u, a = fe.units[n], fe.acts[n]
+        if B > 2 and n not in (stage_blocks[n[:5]][0], stage_blocks[n[:5]][-1]):
+            gout = a["gin"]                         # (the HIP path's own gradient: every compared unit is teacher-forced)
+            continue
         ho, wo = u[1].ho, u[1].wo
         hi, wi = hw_in[n]
         xin = nchw(xin_of[n], hi, wi)

@@ -25,18 +25,29 @@ def _close(a, b, rtol, atol, what):
     assert bad == 0, "%s: %d/%d mismatches, max err %g (ref max %g)" % (what, bad, a.numel(), float(err.max()), float(b.abs().max()))
 
 
-CASES = [
-    # n, h, w, cin, cout, k, stride, pad, flags
-    dict(n=2, h=13, w=17, cin=64, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
-    dict(n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1, bias=True, relu=True, stats=False),
-    dict(n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0, bias=False, relu=False, stats=True),
-    dict(n=4, h=64, w=64, cin=64, cout=512, k=1, s=1, p=0, bias=True, relu=False, stats=True),   # 128x128 tiles
-    dict(n=1, h=9, w=11, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
-    dict(n=2, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=True),
-]
+from conv_cases import DGRAD, F32, FPROP, WGRAD, WGRAD_GROUPS, conv_desc, dgrad_desc, f32_desc, fprop_desc
 
 
-@pytest.mark.parametrize("case", CASES)
+def _inst(ops):
+    return ops.last_conv_instantiation().split(" grid")[0]
+
+
+def _assert_dispatch(ops, expected_full, what):
+    """the kernel that really ran == the one the dispatcher's dry run names (tests/test_conv_dispatch.py ties those names to
+    the train plans' launches)"""
+    got = _inst(ops)
+    assert got == expected_full.split(" grid")[0], "%s: launched %s, dry run said %s" % (what, got, expected_full)
+
+
+def _edge_masks(n, ho, wo):
+    """boolean [n*ho*wo] masks of the pixels where a 3x3 window leaves the image row / the image"""
+    ox = torch.arange(wo).repeat(n * ho)
+    oy = torch.arange(ho).repeat_interleave(wo).repeat(n)
+    return {"first pixel of an image row": ox == 0, "last pixel of an image row": ox == wo - 1, "first image row": oy == 0,
+            "last image row": oy == ho - 1}
+
+
+@pytest.mark.parametrize("case", FPROP, ids=[c["id"] for c in FPROP])
 def test_conv_fprop(ops, case):
     g = torch.Generator().manual_seed(0)
     n, h, w, cin, cout, k, s, p = (case[x] for x in ("n", "h", "w", "cin", "cout", "k", "s", "p"))
@@ -48,19 +59,92 @@ def test_conv_fprop(ops, case):
         ref = F.relu(ref)
     ref = ref.permute(0, 2, 3, 1).contiguous()
     ho, wo = ref.shape[1], ref.shape[2]
-    flags = (ops.CONV_BIAS if case["bias"] else 0) | (ops.CONV_RELU if case["relu"] else 0) | (ops.CONV_STATS if case["stats"] else 0)
-    d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout, flags=flags)
+    d = fprop_desc(ops, case)
+    assert (d.ho, d.wo) == (ho, wo)
     xd, wd, bd = x.to(BF).cuda(), _ohwi(wt).to(BF).cuda(), bias.cuda()
     y = torch.full((n, ho, wo, cout), float("nan"), dtype=BF, device="cuda")
     tiles = ops.conv_stat_tiles(d)
     stats = torch.zeros(tiles, 2, cout, dtype=torch.float64, device="cuda")
     ops.conv2d_fprop(d, xd, wd, y, bias=bd, stats=stats if case["stats"] else None)
+    _assert_dispatch(ops, ops.conv2d_describe(d), case["id"])
     torch.cuda.synchronize()
-    _close(y, ref, 2 ** -7, 2e-2, "conv output")
+    yc, rc = y.float().cpu().reshape(-1, cout), ref.reshape(-1, cout)
+    if k == 3:
+        for name, mk in _edge_masks(n, ho, wo).items():
+            _close(yc[mk], rc[mk], 2 ** -7, 2e-2, "conv output, " + name)
+    _close(yc, rc, 2 ** -7, 2e-2, "conv output")
     if case["stats"]:
-        yb = y.float().cpu().reshape(-1, cout)
-        _close(stats[:, 0].sum(0), yb.sum(0), 1e-4, 1e-2, "stats sum")
-        _close(stats[:, 1].sum(0), (yb * yb).sum(0), 1e-4, 1e-2, "stats sumsq")
+        _close(stats[:, 0].sum(0), yc.double().sum(0), 1e-4, 1e-2, "stats sum")
+        _close(stats[:, 1].sum(0), (yc.double() * yc.double()).sum(0), 1e-4, 1e-2, "stats sumsq")
+
+
+@pytest.mark.parametrize("case", DGRAD, ids=[c["id"] for c in DGRAD])
+def test_conv_dgrad(ops, case):
+    """Data-gradient launches (the forward kernel on transposed, tap-flipped weights): gx = conv(dz, w_t) [+ res (* mask bits)],
+    plain or scattered with stride 2, with or without the fused BatchNorm-backward reduce of the consuming layer.  gx against
+    torch-CPU fp32; the partial sums against an fp64 evaluation of their definition on the kernel's own (bf16) gx."""
+    g = torch.Generator().manual_seed(11)
+    n, h, w, cin, cout, k, sc = (case[x] for x in ("n", "h", "w", "cin", "cout", "k", "scatter"))
+    d = dgrad_desc(ops, case)
+    oh, ow = d.out_h, d.out_w
+    m, mo = n * h * w, n * oh * ow
+    dz = _rt(torch.randn(n, h, w, cin, generator=g))
+    wt = _rt(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5)           # the kernel's "w_t" operand (OIHW here)
+    conv = F.conv2d(dz.permute(0, 3, 1, 2), wt, None, stride=1, padding=k // 2).permute(0, 2, 3, 1).contiguous()
+    base = _rt(torch.randn(n, oh, ow, cout, generator=g)) if (case["res"] or sc > 1) else None
+    rmask = torch.randint(0, 256, (mo, cout // 8), generator=g, dtype=torch.uint8) if case["res_mask"] else None
+    res_eff = base
+    if rmask is not None:
+        bits = ((rmask[:, :, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(n, oh, ow, cout).bool()
+        res_eff = torch.where(bits, base, torch.zeros_like(base))
+    if sc == 1:
+        ref = conv + (res_eff if case["res"] else 0)
+        touched = torch.ones(mo, dtype=torch.bool)
+    else:
+        ref = base.clone() if case["res"] else torch.zeros(n, oh, ow, cout)
+        ref[:, ::sc, ::sc][:, :h, :w] = conv + (res_eff[:, ::sc, ::sc][:, :h, :w] if case["res"] else 0)
+        t2 = torch.zeros(n, oh, ow, dtype=torch.bool)
+        t2[:, ::sc, ::sc][:, :h, :w] = True
+        touched = t2.reshape(-1)
+    z = _rt(torch.randn(mo, cout, generator=g) * 2 + 0.5)
+    zmask = torch.randint(0, 256, (mo, cout // 8), generator=g, dtype=torch.uint8) if case["mask"] else None
+    mean = z.mean(0).contiguous()
+    invstd = (1.0 / (z.var(0, unbiased=False) + 1e-5).sqrt()).contiguous()
+    if case["res"]:
+        out = base.to(BF).cuda()                        # the residual aliases the output, as in the training plan
+        res_d = out
+    else:
+        out = torch.zeros(n, oh, ow, cout, dtype=BF, device="cuda") if sc > 1 else torch.full((n, oh, ow, cout), float("nan"), dtype=BF, device="cuda")
+        res_d = None
+    part = torch.zeros(ops.STAT_SLOTS, 2, cout, device="cuda")
+    dz_d, w_d = dz.to(BF).cuda(), _ohwi(wt).to(BF).cuda()
+    z_d = z.to(BF).cuda()
+    if case["red"]:
+        red = ops.bn_reduce_args(z_d, zmask.cuda() if zmask is not None else None, mean.cuda(), invstd.cuda(), part)
+        ops.conv2d_dgrad_bnreduce(d, dz_d, w_d, out, red, res=res_d, res_mask=rmask.cuda() if rmask is not None else None)
+    else:
+        assert rmask is None
+        ops.conv2d_fprop(d, dz_d, w_d, out, res=res_d)
+    _assert_dispatch(ops, ops.conv2d_describe(d, case["red"]), case["id"])
+    torch.cuda.synchronize()
+    oc, rc = out.float().cpu().reshape(mo, cout), ref.reshape(mo, cout)
+    if k == 3:
+        for name, mk in _edge_masks(n, h, w).items():
+            _close(oc[mk], rc[mk], 2 ** -7, 3e-2, "data gradient, " + name)
+    _close(oc, rc, 2 ** -7, 3e-2, "data gradient")
+    if case["red"]:
+        gm = oc.double()[touched]
+        if zmask is not None:
+            zb = ((zmask[:, :, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(mo, cout).bool()[touched]
+            gm = torch.where(zb, gm, torch.zeros_like(gm))
+        zt = z.double()[touched]
+        sg = gm.sum(0)
+        sgz = invstd.double() * ((gm * zt).sum(0) - mean.double() * sg)
+        got = part.sum(0).double().cpu()
+        for name, a, b in (("sum g*m", got[0], sg), ("sum g*m*xhat", got[1], sgz)):
+            scale = float(b.abs().max()) + 1e-6
+            err = float((a - b).abs().max()) / scale
+            assert err < 2e-4, "%s: fused reduce %s off by %.3g of its scale" % (case["id"], name, err)
 
 
 def test_conv_stem(ops):
@@ -128,38 +212,24 @@ def test_conv_dgrad_stride2_scatter(ops):
     _close(out, ref, 2 ** -7, 3e-2, "dgrad stride-2 scatter")
 
 
-def test_conv_f32_out_and_splitk(ops):
+@pytest.mark.parametrize("case", F32, ids=[c["id"] for c in F32])
+def test_conv_f32_out_and_splitk(ops, case):
     g = torch.Generator().manual_seed(4)
-    m, k, cout = 300, 6400, 64
+    m, k, cout = case["m"], case["k"], case["cout"]
     x = _rt(torch.randn(m, k, generator=g))
     wt = _rt(torch.randn(cout, k, generator=g) / k ** 0.5)
-    wt[36:] = 0
+    wt[cout * 9 // 16:] = 0                                       # zero-padded filter rows, as the merged head banks have
     bias = torch.randn(cout, generator=g)
-    ref = x @ wt.t()
-    xd, wd = x.to(BF).cuda(), wt.to(BF).cuda()
-    d = ops.conv_desc(1, 1, m, k, 1, 1, 1, 0, 0, 1, m, cout, flags=ops.CONV_OUT_F32 | ops.CONV_BIAS)
-    y = torch.empty(m, cout, device="cuda")
-    ops.conv2d_fprop(d, xd, wd, y, bias=bias.cuda())
-    _close(y, ref + bias, 1e-4, 1e-3, "fp32 output")
-    d2 = ops.conv_desc(1, 1, m, k, 1, 1, 1, 0, 0, 1, m, cout, flags=ops.CONV_SPLITK_ATOMIC, split_k=8)
-    y2 = torch.zeros(m, cout, device="cuda")
-    ops.conv2d_fprop(d2, xd, wd, y2)
+    ref = x @ wt.t() + (bias if case["bias"] else 0)
+    d = f32_desc(ops, case)
+    y = torch.zeros(m, cout, device="cuda")
+    ops.conv2d_fprop(d, x.to(BF).cuda(), wt.to(BF).cuda(), y, bias=bias.cuda() if case["bias"] else None)
+    _assert_dispatch(ops, ops.conv2d_describe(d), case["id"])
     torch.cuda.synchronize()
-    _close(y2, ref, 1e-4, 1e-3, "split-K atomic output")
+    _close(y, ref, 1e-4, 1e-3 * max(1.0, (k / 6400) ** 0.5), "fp32 / split-K output")
 
 
-WGRAD_CASES = [
-    dict(n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1),
-    dict(n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0),
-    dict(n=2, h=9, w=13, cin=128, cout=256, k=1, s=1, p=0),
-    dict(n=3, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1),
-    dict(n=2, h=30, w=40, cin=64, cout=256, k=1, s=1, p=0),
-]
-
-
-@pytest.mark.parametrize("case", WGRAD_CASES)
-def test_conv_wgrad(ops, case):
-    g = torch.Generator().manual_seed(5)
+def _wgrad_problem(case, g):
     n, h, w, cin, cout, k, s, p = (case[x] for x in ("n", "h", "w", "cin", "cout", "k", "s", "p"))
     x = _rt(torch.randn(n, cin, h, w, generator=g))
     wt = torch.zeros(cout, cin, k, k, requires_grad=True)
@@ -167,38 +237,42 @@ def test_conv_wgrad(ops, case):
     ho, wo = y.shape[2], y.shape[3]
     dz = _rt(torch.randn(n, cout, ho, wo, generator=g))
     y.backward(dz)
-    ref = _ohwi(wt.grad)
-    d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout)
-    dw = torch.zeros(cout, k, k, cin, device="cuda")
-    ops.conv2d_wgrad(d, x.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dz.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dw)
+    return x.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dz.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), _ohwi(wt.grad), n * ho * wo
+
+
+@pytest.mark.parametrize("case", WGRAD, ids=[c["id"] for c in WGRAD])
+def test_conv_wgrad(ops, case):
+    g = torch.Generator().manual_seed(5)
+    x, dz, ref, m = _wgrad_problem(case, g)
+    d = conv_desc(ops, case)
+    dw = torch.zeros(case["cout"], case["k"], case["k"], case["cin"], device="cuda")
+    ops.conv2d_wgrad(d, x, dz, dw)
+    _assert_dispatch(ops, ops.conv2d_wgrad_describe(d), case["id"])
     torch.cuda.synchronize()
-    _close(dw, ref, 2e-4, 2e-3 * (n * ho * wo) ** 0.5, "wgrad")
+    _close(dw, ref, 2e-4, 2e-3 * m ** 0.5, "wgrad")
 
 
-def test_conv_wgrad_grouped(ops):
-    """Five layers (3x3, strided 1x1, plain 1x1 -- both addressing modes) in one grouped launch with a common pixel split."""
+@pytest.mark.parametrize("grp", WGRAD_GROUPS, ids=[c["id"] for c in WGRAD_GROUPS])
+def test_conv_wgrad_grouped(ops, grp):
+    """Several layers (3x3, strided 1x1, plain 1x1 -- both addressing modes) in one grouped launch with a common pixel split."""
     g = torch.Generator().manual_seed(8)
-    cases = [dict(n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1), dict(n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0),
-             dict(n=2, h=9, w=13, cin=128, cout=256, k=1, s=1, p=0), dict(n=3, h=24, w=26, cin=256, cout=256, k=3, s=1, p=1),
-             dict(n=2, h=10, w=12, cin=64, cout=256, k=1, s=1, p=0)]
     items, refs = [], []
-    for case in cases:
-        n, h, w, cin, cout, k, s, p = (case[x] for x in ("n", "h", "w", "cin", "cout", "k", "s", "p"))
-        x = _rt(torch.randn(n, cin, h, w, generator=g))
-        wt = torch.zeros(cout, cin, k, k, requires_grad=True)
-        y = F.conv2d(x, wt, stride=s, padding=p)
-        ho, wo = y.shape[2], y.shape[3]
-        dz = _rt(torch.randn(n, cout, ho, wo, generator=g))
-        y.backward(dz)
-        refs.append((_ohwi(wt.grad), n * ho * wo))
-        d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout)
-        dw = torch.zeros(cout, k, k, cin, device="cuda")        # (pre-zeroed: the group may use a pixel split)
-        items.append((d, x.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dz.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dw))
+    for case in grp["layers"]:
+        x, dz, ref, m = _wgrad_problem(case, g)
+        refs.append((ref, m))
+        dw = torch.zeros(case["cout"], case["k"], case["k"], case["cin"], device="cuda")        # (pre-zeroed: the group may use a pixel split)
+        items.append((conv_desc(ops, case), x, dz, dw))
     group = ops.WgradGroup(items, "cuda")
     ops.conv2d_wgrad_grouped(group)
+    got = ops.last_conv_instantiation()
+    want = ops.conv2d_wgrad_describe(group=group)
+    assert [p.split(" grid")[0] for p in got.split("; ")] == [p.split(" grid")[0] for p in want.split("; ")], (got, want)
     torch.cuda.synchronize()
     for (d, x, dz, dw), (ref, m) in zip(items, refs):
         _close(dw, ref, 2e-4, 2e-3 * m ** 0.5, "grouped wgrad")
+
+
+def test_conv_wgrad_group_rejects_narrow_layers(ops):
     with pytest.raises(RuntimeError):
         d = ops.conv_desc(1, 8, 8, 32, 1, 1, 1, 0, 0, 8, 8, 64)                                   # cin = 32: not groupable
         ops.WgradGroup([(d, torch.zeros(64, 32, dtype=BF, device="cuda"), torch.zeros(64, 64, dtype=BF, device="cuda"),

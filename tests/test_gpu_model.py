@@ -270,3 +270,36 @@ def test_test_step_runs_and_matches_stagewise(setup):
     assert _rel(aux["rpn_out"]["pred_scores"], rpn_ref["pred_scores"]) < 0.08
     assert preds["rcnn_boxes"].shape == (2, 30, 4) and preds["rpn_boxes"].shape == (2, 40, 4)
     assert all(torch.isfinite(v).all() for v in losses.values())
+
+
+def test_call_training_mode_equals_the_train_step_forward(setup):
+    """FasterRCNN.__call__(images, training=True) (reference faster_rcnn.py:39-57: BN on batch statistics, in-image anchors,
+    proposal NMS, Fast-RCNN heads) returns what the train step's own forward pass computes from the same weights, and
+    updates the BatchNorm moving averages as Keras does."""
+    cfg, params = setup["cfg"], setup["params"]
+    images, gl, gb = setup["images"], setup["gl"], setup["gb"]
+    a = setup["M"].FasterRCNN(cfg, sampling_seed=11)
+    a.set_weights(params)
+    rpn_o, rcnn_o = a(images.cuda(), training=True)
+    torch.cuda.synchronize()
+    assert set(rpn_o) == {"regions", "pred_scores", "pred_boxes"} and set(rcnn_o) == {"regions", "pred_scores", "pred_boxes"}
+    n_in = rpn_o["regions"].shape[0]
+    assert rpn_o["pred_scores"].shape == (2, n_in, 2) and rpn_o["pred_boxes"].shape == (2, n_in, 1, 4)
+    assert rcnn_o["pred_scores"].shape == (2, 40, 8) and rcnn_o["pred_boxes"].shape == (2, 40, 7, 4)
+    got = {k: v.clone() for k, v in list(rpn_o.items())}, {k: v.clone() for k, v in list(rcnn_o.items())}
+    stats_a = {k: v.clone() for k, v in a.get_weights().items() if "moving" in k}
+    assert any(float((stats_a[k] - params[k]).abs().max()) > 0 for k in stats_a), "moving statistics were not updated"
+    b = setup["M"].FasterRCNN(cfg, sampling_seed=11)
+    b.use_graphs = False
+    b.set_weights(params)
+    b.train_step(images.cuda(), gl.cuda(), gb.cuda(), setup["OPT"].SGD(learning_rate=1e-4))
+    torch.cuda.synchronize()
+    aux = b._train_plan["aux"]
+    for k in ("regions", "pred_scores", "pred_boxes"):
+        assert torch.equal(got[0][k], aux["rpn_out"][k]), "rpn " + k            # same kernels, f64 BN statistics: reproducible
+    assert torch.equal(got[1]["regions"], aux["rcnn_out"]["regions"])
+    for k in ("pred_scores", "pred_boxes"):                                     # (Dense heads: split-K float atomics)
+        assert float((got[1][k] - aux["rcnn_out"][k]).abs().max()) < 1e-4, "rcnn " + k
+    stats_b = {k: v for k, v in b.get_weights().items() if "moving" in k}
+    for k in stats_a:
+        assert torch.equal(stats_a[k], stats_b[k]), k

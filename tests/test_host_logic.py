@@ -68,9 +68,11 @@ def test_plan_branches_are_recorded():
 
 
 def test_piecewise_constant_decay_matches_reference_schedule():
-    # train_faster_rcnn.py:62-68,109-112: 1e-3 until step 40000, 1e-4 until 80000, then 1e-5
+    # train_faster_rcnn.py:62-68,109-112 with Keras' boundary rule (values[i] while step <= boundaries[i]): 1e-3 up to and
+    # including step 40000, 1e-4 for 40001..80000, then 1e-5
     s = OPT.PiecewiseConstantDecay([40000, 80000], [1e-3, 1e-4, 1e-5])
-    assert s(0) == 1e-3 and s(39999) == 1e-3 and s(40000) == 1e-4 and s(79999) == 1e-4 and s(80000) == 1e-5
+    assert s(0) == 1e-3 and s(39999) == 1e-3 and s(40000) == 1e-3 and s(40001) == 1e-4
+    assert s(79999) == 1e-4 and s(80000) == 1e-4 and s(80001) == 1e-5
     assert OPT.SGD(0.01).schedule(123) == 0.01
 
 

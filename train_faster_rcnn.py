@@ -175,7 +175,8 @@ def main(argv=None):
 
     learning_rate = OPT.PiecewiseConstantDecay(boundaries=args.decay_steps, values=args.learning_rates)
     optimizer = OPT.SGD(learning_rate=learning_rate, momentum=0.9)
-    model = M.FasterRCNN(config, depth=args.depth, device=dev, seed=args.seed, sampling_seed=args.seed, world_size=world)
+    # every rank draws its own fg/bg sample positions (the Philox key differs per rank); the weights' seed is shared
+    model = M.FasterRCNN(config, depth=args.depth, device=dev, seed=args.seed, sampling_seed=args.seed + rank, world_size=world)
     if args.init_weights:
         model.load_weights(args.init_weights)
     optimizer.bind(model.store)
@@ -206,7 +207,11 @@ def main(argv=None):
                            ("Losses/RPN/regression_loss", rpn_train_reg), ("Metrics/RPN/AP@IoU=.50", rpn_train_ap)):
                 train_writer.scalar(tag, m.result(), step)
 
-            if chief:                                     # validation: one ordered pass on rank 0 (the reference is single-device)
+            # validation: one ordered pass on rank 0 (the reference is single-device).  The other ranks wait at an explicit
+            # barrier instead of inside the next step's first all-reduce (whose time-out a long validation set could hit)
+            if world > 1:
+                torch.distributed.barrier()
+            if chief:
                 for vimages, vclasses, vboxes in dataset_valid():
                     vlosses, vpreds = model.test_step(vimages, vclasses, vboxes)
                     valid_cls.update_state(vlosses["rcnn_cls"])
@@ -230,6 +235,8 @@ def main(argv=None):
                 s += f"\t\tReg Loss       --> Train: {rpn_train_reg.result():.2f}, Valid: {rpn_valid_reg.result():.2f}\n"
                 s += f"\t\tAP at IoU=.50  --> Train: {rpn_train_ap.result():.2f}, Valid: {rpn_valid_ap.result():.2f}\n"
                 print(s, flush=True)
+            if world > 1:
+                torch.distributed.barrier()
             for m in every:
                 m.reset_states()
 
