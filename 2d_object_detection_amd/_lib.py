@@ -50,6 +50,7 @@ _SIGNATURES = {
     "frcnn_weights_transpose_flip_batched": (c_int, [P, c_int, c_int64, P]),
     "frcnn_cast_f32_bf16": (c_int, [P, P, c_int64, P]),
     "frcnn_copy_bytes": (c_int, [P, P, c_int64, P]),
+    "frcnn_fill_zero_multi": (c_int, [P, c_int, c_int64, P]),
     "frcnn_stem_pack_weights": (c_int, [P, P, c_int, P]),
     "frcnn_stem_unpack_grad": (c_int, [P, P, c_int, P]),
     "frcnn_preprocess_u8_bgr_mean": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -57,7 +58,7 @@ _SIGNATURES = {
     "frcnn_bn_finalize_eval": (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
     "frcnn_bn_apply": (c_int, [P, P, P, P, c_int, P, c_int64, c_int, P]),
     "frcnn_bn_train_apply": (c_int, [P, P, c_int, c_int64, P, P, P, P, c_float, c_float, P, c_int, P, P, P, P, c_int64, c_int, P]),
-    "frcnn_bn_bwd_apply_fused": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, c_int64, c_int, P]),
+    "frcnn_bn_bwd_apply_fused": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int64, c_float, P]),
     "frcnn_bn_bwd_blocks": (c_int, [c_int64]),
     "frcnn_bn_bwd_reduce": (c_int, [P, P, P, P, P, P, P, c_int64, c_int, P]),
     "frcnn_bn_bwd_finalize": (c_int, [P, c_int, c_int, c_int64, P, P, P, P, P]),

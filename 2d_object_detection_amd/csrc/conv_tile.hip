@@ -698,7 +698,7 @@ int launch_tile_flags(const ConvParams& p, hipStream_t s) {
 
 #ifdef FRCNN_SWEEP
 // kernel-development builds only (FRCNN_SWEEP=1 python .../build.py --force; tools/tile_sweep.py): tile shape / kw-sharing
-// overrides, read once per process
+// overrides, re-read per launch (the sweep tool changes them between launches; production builds contain no getenv)
 struct SweepEnv {
     int bm = 0, bn = 0, bk = 0, stages = 0, tpb = 1, kws = -1;
     SweepEnv() {
@@ -709,10 +709,7 @@ struct SweepEnv {
         if (const char* e = getenv("FRCNN_KWS")) kws = e[0] == '1' ? 1 : 0;
     }
 };
-const SweepEnv& sweep_env() {
-    static const SweepEnv e;
-    return e;
-}
+SweepEnv sweep_env() { return SweepEnv(); }
 #endif
 
 // Tile choice + launch.  p arrives with the geometry fields filled in; tiles_m / tiles_n / k_tiles are set here.

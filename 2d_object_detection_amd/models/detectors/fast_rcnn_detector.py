@@ -126,7 +126,7 @@ class FastRCNNDetector:
         st = self.store
         plan.add(ops.roi_crop_pool_fwd, feature_maps, rois, self.batch, self.p, self.hf, self.wf, self.cf, self.ps, self.ks, self.pooled,
                  self.argmax)
-        plan.add(self.logits.zero_)
+        plan.zero(self.logits)                      # (split-K float atomics)
         plan.add(ops.conv2d_fprop, self.d_fwd, self.pooled, st.weight_bf16("fast_rcnn_heads/kernel"), self.logits)
         plan.add(ops.rcnn_head_post, self.logits, HEAD_LD, st.weight("fast_rcnn_heads/bias"), self.r, self.c1, self.scores, self.deltas)
         plan.add(ops.boxes_scale, rois, self.regions_abs, float(self._image_shape[1]), float(self._image_shape[0]))   # :67

@@ -157,7 +157,7 @@ class RPNDetector:
         """Everything of the RPN backward pass that does not need the RoI-branch gradient (a side-stream branch of the
         training step runs it next to the Fast-RCNN backward pass)."""
         st = self.store
-        plan.add(self.dhead32.zero_)
+        plan.zero(self.dhead32)
         plan.add(ops.rpn_head_grad, dlogits_s, ddeltas_s, indices, self._keep, self.batch, num_samples, self.num_anchors, self.apl,
                  self.dhead32, HEAD_LD)
         plan.add(ops.cast_f32_bf16, self.dhead32, self.dhead)

@@ -28,7 +28,7 @@ LOSS_NAMES = ("rpn_cls", "rpn_reg", "rcnn_cls", "rcnn_reg")
 class _Modules:
     """One set of module instances (= one set of activation buffers) attached to the shared store."""
 
-    def __init__(self, config, depth, store, device, first):
+    def __init__(self, config, depth, store, device, first, sync_bn_world=1):
         image_shape = config["image_shape"]
         # registration order = gradient-bucket order: regularised kernels, head biases, then backbone
         fe_shape = _feature_shape(image_shape, depth)
@@ -38,7 +38,7 @@ class _Modules:
         self.rcnn.register_biases()
         self.rpn.register_biases()
         store.end_bucket("heads")
-        self.fe = get_feature_extractor_model(image_shape, depth=depth, store=store, device=device)
+        self.fe = get_feature_extractor_model(image_shape, depth=depth, store=store, device=device, sync_bn_world=sync_bn_world)
         assert tuple(self.fe.output_shape) == tuple(fe_shape)
 
 
@@ -51,8 +51,11 @@ def _feature_shape(image_shape, depth):
 
 
 class FasterRCNN:
-    def __init__(self, config, name="faster_rcnn", depth=50, device="cuda", seed=0, sampling_seed=0, world_size=1):
-        """reference faster_rcnn.py:11-37.  `config`: dict with the reference's config.json schema."""
+    def __init__(self, config, name="faster_rcnn", depth=50, device="cuda", seed=0, sampling_seed=0, world_size=1, sync_bn=False):
+        """reference faster_rcnn.py:11-37.  `config`: dict with the reference's config.json schema.
+        world_size: data-parallel ranks (classification losses are means over the GLOBAL batch).  sync_bn: BatchNorm batch
+        statistics and their backward sums are all-reduced over the ranks, so world_size x b images behave like the reference's
+        one device with world_size*b images (faster_rcnn.py:50); off (default) every replica normalises with its own batch."""
         self.name = name
         self.config = config
         self._image_shape = tuple(config["image_shape"])
@@ -62,8 +65,9 @@ class FasterRCNN:
         self.device = torch.device(device)
         self.sampling_seed = int(sampling_seed)
         self.world_size = int(world_size)
+        self.sync_bn = bool(sync_bn)
         self.store = ParamStore(self.device)
-        self._train = _Modules(config, depth, self.store, self.device, True)
+        self._train = _Modules(config, depth, self.store, self.device, True, self.world_size if self.sync_bn else 1)
         self.store.finalize()
         self._eval = None
         self.feature_extractor, self.rpn_detector, self.rcnn_detector = self._train.fe, self._train.rpn, self._train.rcnn
@@ -136,7 +140,7 @@ class FasterRCNN:
         step = optimizer.iterations if training else self._eval_step
 
         if training:
-            plan.add(self.store.g.zero_)
+            plan.zero(self.store.g)
             # derived weights for the backward pass: all tap-flipped transposes (backbone, RPN, heads) in ONE launch, on a
             # side stream under the forward pass (first needed by the head backward passes)
             table, total = ops.make_transpose_flip_table(mods.fe.flip_entries() + mods.rpn.flip_entries() + mods.rcnn.flip_entries(), dev)
@@ -266,7 +270,7 @@ class FasterRCNN:
             if self.use_graphs:
                 # warm-up eagerly on a scratch copy of the mutable state, then capture
                 state = self._snapshot(optimizer)
-                built["plan"].run()
+                self._run_with_collectives(built["plan"])
                 torch.cuda.synchronize()
                 self._restore(state, optimizer)
                 built["plan"].capture()
@@ -278,17 +282,26 @@ class FasterRCNN:
         self._feed(built, images, gt_labels, gt_boxes)
         plan = built["plan"]
         nseg = len(plan.segments)
-        if sync_fn is None and plan.captured:
+        collectives = self.world_size > 1 and bool(plan.pre_sync)
+        if sync_fn is None and plan.captured and not collectives:
             plan.replay()                        # nothing to interleave between segments: the whole step is one graph
             return self._losses_dict(built), built["preds"]
+        done = 0                                 # gradient buckets handed to the data-parallel hook so far
         for i in range(nseg):
+            if collectives:
+                plan.sync_before(i)              # synchronised BatchNorm: partial sums of every rank -> sums of the global batch
             if plan.captured:
                 plan.replay_segment(i)
             else:
                 plan.run_segment(i)
-            if sync_fn is not None and i < nseg - 1:
-                sync_fn(i, nseg)
+            if sync_fn is not None and done < len(plan.bucket_ends) and i == plan.bucket_ends[done]:
+                sync_fn(done, len(plan.bucket_ends) + 1)     # (hook protocol: bucket index, buckets + the update segment)
+                done += 1
         return self._losses_dict(built), built["preds"]
+
+    def _run_with_collectives(self, plan):
+        """Eager run of a plan, with the all-reduces of its sync points (synchronised BatchNorm) when there are several ranks."""
+        plan.run_synced()
 
     def _snapshot(self, optimizer):
         st = self.store
@@ -324,7 +337,7 @@ class FasterRCNN:
             # its own module instances (activation buffers): the captured train plan's buffers stay untouched
             b = int(images.shape[0])
             if self._fwd_train is None:
-                self._fwd_train = _Modules(self.config, self.depth, self.store, self.device, False)
+                self._fwd_train = _Modules(self.config, self.depth, self.store, self.device, False, self.world_size if self.sync_bn else 1)
             if self._fwd_plan is None or self._fwd_plan["batch"] != b:
                 self._fwd_plan = self._build_forward(self._fwd_train, b)
             built = self._fwd_plan
@@ -333,7 +346,7 @@ class FasterRCNN:
                 ops.copy_bytes(images, built["io"]["images"])
             else:
                 built["io"]["images"].copy_(images, non_blocking=True)
-            built["plan"].run()
+            self._run_with_collectives(built["plan"])
             return built["aux"]["rpn_out"], built["aux"]["rcnn_out"]
         z = torch.zeros
         b = int(images.shape[0])

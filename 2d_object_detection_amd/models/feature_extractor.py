@@ -35,9 +35,10 @@ def _out_hw(h, w):
 class _ConvBN:
     """One conv + BatchNorm unit (Keras names <name>_conv / <name>_bn)."""
 
-    def __init__(self, store, name, cin, cout, k, stride, pad):
+    def __init__(self, store, name, cin, cout, k, stride, pad, sync_world=1):
         self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
         self.store = store
+        self.sync_world = int(sync_world)            # > 1: BatchNorm statistics are summed over this many data-parallel ranks
         store.register(name + "_conv/kernel", (cout, k, k, cin))          # OHWI (Keras: HWIO)
         store.register(name + "_conv/bias", (cout,))
         store.register(name + "_bn/gamma", (cout,))
@@ -99,6 +100,8 @@ class _ConvBN:
         plan.add(ops.conv2d_fprop, self.desc, x, self.w_fwd(), self.z, bias=st.weight(self.name + "_conv/bias"),
                  stats=self.stats if training else None)
         self._training = training
+        if training and self.sync_world > 1:
+            plan.sync_point(self.name + "_bn_stats", [self.stats])       # f64 slot sums of every rank -> sums of the global batch
         if not training:
             g, b = st.weight(self.name + "_bn/gamma"), st.weight(self.name + "_bn/beta")
             plan.add(ops.bn_finalize_eval, self.cout, g, b, self.mm, self.mv, BN_EPS, self.scale, self.shift)
@@ -107,7 +110,7 @@ class _ConvBN:
         if self._training:
             # batch statistics -> scale/shift inside the apply kernel (every workgroup reduces its own 64 channels)
             st = self.store
-            plan.add(ops.bn_train_apply, self.z, self.stats, self.tiles, self.m, st.weight(self.name + "_bn/gamma"),
+            plan.add(ops.bn_train_apply, self.z, self.stats, self.tiles, self.m * self.sync_world, st.weight(self.name + "_bn/gamma"),
                      st.weight(self.name + "_bn/beta"), self.mm, self.mv, BN_MOMENTUM, BN_EPS, out, self.mean, self.invstd, self.m,
                      self.cout, res=res, relu=relu, relu_mask=self.relu_mask if relu else None)
         else:
@@ -129,9 +132,11 @@ class _ConvBN:
             mask = self.relu_mask if act is not None else None   # (act only says whether the layer ends in a ReLU)
         if not reduced:
             plan.add(ops.bn_bwd_reduce, gout, None, self.z, self.mean, self.invstd, self.bwd_partial, self.m, self.cout, relu_mask=mask)
+        if self.sync_world > 1:
+            plan.sync_point(self.name + "_bn_bwd", [self.bwd_partial])
         plan.add(ops.bn_bwd_apply_fused, gout, None, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"),
                  self.bwd_partial, self.bwd_blocks, st.grad(self.name + "_bn/gamma"), st.grad(self.name + "_bn/beta"), self.dz, gpre,
-                 self.m, self.cout, relu_mask=mask)
+                 self.m, self.cout, relu_mask=mask, count=self.m * self.sync_world, param_grad_scale=1.0 / self.sync_world)
         # the conv bias feeds a training-mode BN: its gradient is identically zero (flat grad buffer is pre-zeroed)
 
     def backward_weights(self, plan, x, defer=None):
@@ -142,7 +147,7 @@ class _ConvBN:
             defer.append((self.desc, x, self.dz, st.grad(self.name + "_conv/kernel")))
             return
         if self.is_stem:
-            plan.add(self.dw_packed.zero_)
+            plan.zero(self.dw_packed)
             plan.add(ops.conv2d_wgrad, self.desc, x, self.dz, self.dw_packed)
             plan.add(ops.stem_unpack_grad, self.dw_packed, st.grad(self.name + "_conv/kernel"), self.cout)
         else:
@@ -172,8 +177,14 @@ class _ConvBN:
 class FeatureExtractor:
     """ResNet-50/101 C4 backbone (callable like the Keras model returned by the reference)."""
 
-    def __init__(self, image_shape, depth=50, store=None, device="cuda"):
+    def __init__(self, image_shape, depth=50, store=None, device="cuda", sync_bn_world=1):
+        """sync_bn_world > 1: synchronised BatchNorm over that many data-parallel ranks -- the plan gets a sync point (an
+        all-reduce of the layer's partial sums, runtime.Plan.sync_point) between every statistics-producing kernel and the
+        kernel that consumes them, so that N ranks x b images reproduce the reference's single device with N*b images
+        (models/faster_rcnn.py:50).  One small collective per BatchNorm layer and direction: the statistics of layer k+1
+        depend on layer k's normalised output, so they cannot be batched across layers."""
         self.image_shape = tuple(image_shape)
+        self.sync_bn_world = int(sync_bn_world)
         self.depth = depth
         self.device = torch.device(device)
         self.own_store = store is None
@@ -197,12 +208,12 @@ class FeatureExtractor:
             last_stage = stage_of(n)
             u = {}
             if first:
-                u[0] = _ConvBN(self.store, n + "_0", ci, 4 * f, 1, s, 0)
-            u[1] = _ConvBN(self.store, n + "_1", ci, f, 1, s, 0)
-            u[2] = _ConvBN(self.store, n + "_2", f, f, 3, 1, 1)
-            u[3] = _ConvBN(self.store, n + "_3", f, 4 * f, 1, 1, 0)
+                u[0] = _ConvBN(self.store, n + "_0", ci, 4 * f, 1, s, 0, self.sync_bn_world)
+            u[1] = _ConvBN(self.store, n + "_1", ci, f, 1, s, 0, self.sync_bn_world)
+            u[2] = _ConvBN(self.store, n + "_2", f, f, 3, 1, 1, self.sync_bn_world)
+            u[3] = _ConvBN(self.store, n + "_3", f, 4 * f, 1, 1, 0, self.sync_bn_world)
             units[n] = u
-        self.stem = _ConvBN(self.store, "conv1", 3, 64, 7, 2, 3)
+        self.stem = _ConvBN(self.store, "conv1", 3, 64, 7, 2, 3, self.sync_bn_world)
         self.store.end_bucket("conv2+stem")
         self.specs = specs
         self.units = units
@@ -325,7 +336,7 @@ class FeatureExtractor:
         st = self.stem
         if training:
             # BN statistics / backward partial sums are accumulated with atomics: one multi-tensor zero per step
-            plan.add(self.acc_flat.zero_)
+            plan.zero(self.acc_flat)
         plan.add(ops.preprocess, self.images, self.xpad, 3)
         st.forward(plan, self.xpad_flat, training)
         st.apply(plan, self.a_stem, relu=True)
@@ -404,7 +415,7 @@ class FeatureExtractor:
                 u[0].backward_bn(plan, gblock, None, mask=mblock)
                 u[0].backward_weights(plan, xin, defer)
                 if s != 1:
-                    plan.add(a["gin"].zero_)
+                    plan.zero(a["gin"])             # (scatter target of the stride-2 data gradients)
                 u[1].backward_data(plan, a["gin"])
                 u[0].backward_data(plan, a["gin"], res=a["gin"], consumer=prev)   # gin is complete here (untouched pixels are zero)
             else:
@@ -430,10 +441,10 @@ class FeatureExtractor:
             self.forward_plan(plan, training)
             self._plans = {key: plan}           # buffers are re-created per geometry: keep only the live plan
         self.images.copy_(images)
-        self._plans[key].run()
+        self._plans[key].run_synced()
         return self.feature_maps
 
 
-def get_feature_extractor_model(image_shape, depth=50, store=None, device="cuda"):
+def get_feature_extractor_model(image_shape, depth=50, store=None, device="cuda", sync_bn_world=1):
     """reference models/feature_extractor.py:4 (weights: seeded synthetic init; load real ones with set_weights)."""
-    return FeatureExtractor(image_shape, depth=depth, store=store, device=device)
+    return FeatureExtractor(image_shape, depth=depth, store=store, device=device, sync_bn_world=sync_bn_world)

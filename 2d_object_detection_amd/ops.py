@@ -133,6 +133,23 @@ def copy_bytes(src, dst):
     call("frcnn_copy_bytes", _p(src), _p(dst), src.numel() * src.element_size(), _stream())
 
 
+def make_zero_table(tensors, device):
+    """Table for fill_zero_multi over `tensors` (contiguous, 16-byte aligned, byte sizes multiples of 16)."""
+    rows, chunk = [], 0
+    for t in tensors:
+        nbytes = t.numel() * t.element_size()
+        if not t.is_contiguous() or t.data_ptr() % 16 or nbytes % 16:
+            raise ValueError("fill_zero_multi: buffers must be contiguous, 16-byte aligned, a multiple of 16 bytes long")
+        rows.append([t.data_ptr(), chunk])
+        chunk += nbytes // 16
+    rows.append([0, chunk])
+    return torch.tensor(rows, dtype=torch.int64, device=device), len(tensors), chunk
+
+
+def fill_zero_multi(table, n, total_chunks):
+    call("frcnn_fill_zero_multi", _p(table), n, total_chunks, _stream())
+
+
 def cast_f32_bf16(src, dst, n=None):
     call("frcnn_cast_f32_bf16", _p(src), _p(dst), src.numel() if n is None else n, _stream())
 
@@ -171,9 +188,10 @@ def bn_train_apply(z, stats, slots, count, gamma, beta, mm, mv, momentum, eps, o
          1 if relu else 0, _p(out), _p(relu_mask), _p(mean), _p(invstd), m, c, _stream())
 
 
-def bn_bwd_apply_fused(gout, act, z, mean, invstd, gamma, partial, slots, dgamma, dbeta, dz, gpre, m, c, relu_mask=None):
+def bn_bwd_apply_fused(gout, act, z, mean, invstd, gamma, partial, slots, dgamma, dbeta, dz, gpre, m, c, relu_mask=None, count=0,
+                       param_grad_scale=1.0):
     call("frcnn_bn_bwd_apply_fused", _p(gout), _p(act), _p(relu_mask), _p(z), _p(mean), _p(invstd), _p(gamma), _p(partial), slots,
-         _p(dgamma), _p(dbeta), _p(dz), _p(gpre), m, c, _stream())
+         _p(dgamma), _p(dbeta), _p(dz), _p(gpre), m, c, count, float(param_grad_scale), _stream())
 
 
 def bn_bwd_blocks(m):

@@ -45,6 +45,9 @@ class Plan:
         self._whole = None
         self._branch = None
         self._streams = {}
+        self._zeros, self._zero_built, self._zero_table = [], False, None
+        self.bucket_ends = []     # indices of the segments whose end completes the next gradient bucket (in bucket order)
+        self.pre_sync = {}        # segment index -> tensors that must be SUM all-reduced over the ranks before it runs
 
     # -- construction
     def add(self, fn, *args, **kwargs):
@@ -59,14 +62,40 @@ class Plan:
     def join(self, name):
         self.segments[-1].append((None, (name,), {}, None))
 
-    def cut(self, name):
-        """Start a new segment (a gradient bucket of the previous segment is complete here)."""
+    def cut(self, name, bucket=True):
+        """Start a new segment.  bucket=True: the segment that ends here completes the next gradient bucket (the data-parallel
+        driver all-reduces it while the following segments run)."""
         assert self._branch is None
         if self.segments[-1]:
+            if bucket:
+                self.bucket_ends.append(len(self.segments) - 1)
             self.segments.append([])
             self.segment_names.append(name)
         else:
             self.segment_names[-1] = name
+
+    def sync_point(self, name, tensors):
+        """Everything enqueued so far produced per-rank partial sums in `tensors`; what follows needs their SUM over all ranks
+        (synchronised BatchNorm statistics).  Starts a new segment whose runner all-reduces `tensors` first (a no-op on one
+        rank); collectives are not captured into the segment graphs."""
+        self.cut(name, bucket=False)
+        self.pre_sync.setdefault(len(self.segments) - 1, []).extend(tensors)
+
+    def zero(self, tensor):
+        """`tensor` must be all zeros when the plan starts (an accumulation target: atomics, scatter, split-K).  All such
+        buffers of a plan are zeroed by ONE fill launch at the head of its first segment (frcnn_fill_zero_multi); none of them
+        carries state from one run of the plan to the next."""
+        assert not self._zero_built, "plan already ran: its zero table is frozen"
+        self._zeros.append(tensor)
+
+    def _zero_prologue(self):
+        if not self._zeros:
+            return
+        from . import ops
+        if not self._zero_built:
+            self._zero_table = ops.make_zero_table(self._zeros, self._zeros[0].device)
+            self._zero_built = True
+        ops.fill_zero_multi(*self._zero_table)
 
     def hold(self, *tensors):
         self.keep.extend(tensors)
@@ -74,7 +103,7 @@ class Plan:
 
     @property
     def num_launches(self):
-        return sum(1 for s in self.segments for e in s if e[0] is not None)
+        return sum(1 for s in self.segments for e in s if e[0] is not None) + (1 if self._zeros else 0)
 
     # -- execution
     def _join(self, main, side, name):
@@ -84,6 +113,8 @@ class Plan:
 
     def run_segment(self, i):
         main = None                                # (no CUDA call for plans without branches: host-logic tests run on CPU)
+        if i == 0:
+            self._zero_prologue()
         side = {}
         prev_branch = None
         for fn, args, kwargs, br in self.segments[i]:
@@ -112,6 +143,20 @@ class Plan:
 
     def run(self):
         for i in range(len(self.segments)):
+            self.run_segment(i)
+
+    def sync_before(self, i):
+        """All-reduce (SUM over the default process group) the partial sums segment i waits for (sync_point)."""
+        if i in self.pre_sync:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                for t in self.pre_sync[i]:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def run_synced(self):
+        """Eager run including the collectives of the plan's sync points (synchronised BatchNorm on several ranks)."""
+        for i in range(len(self.segments)):
+            self.sync_before(i)
             self.run_segment(i)
 
     def capture(self):

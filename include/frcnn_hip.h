@@ -131,6 +131,11 @@ int frcnn_weights_transpose_flip_batched(const int64_t* table, int n, int64_t to
 int frcnn_cast_f32_bf16(const float* src, frcnn_bf16* dst, int64_t n, frcnn_stream_t stream);
 /* device-to-device copy of nbytes (16-byte aligned pointers) at HBM speed: feeds a plan's static input buffers */
 int frcnn_copy_bytes(const void* src, void* dst, int64_t nbytes, frcnn_stream_t stream);
+/* zero n device buffers (16-byte aligned, sizes multiples of 16 bytes) in one launch.  table (device, int64 [n + 1][2]): row i =
+ * {pointer, first 16-byte chunk of buffer i in the concatenation of all buffers}, row n = {0, total_chunks}.  Replaces the
+ * per-buffer zero fills in front of the atomically accumulated buffers of a train step (flat gradient, BatchNorm partial
+ * sums, scatter / split-K targets). */
+int frcnn_fill_zero_multi(const int64_t* table, int n, int64_t total_chunks, frcnn_stream_t stream);
 /* stem weights: master [64][7][7][3] fp32 <-> padded GEMM form [64][7][8][4]
  * (pack: -> bf16; unpack_grad: padded fp32 grad -> compact fp32 grad, overwriting). */
 int frcnn_stem_pack_weights(const float* w, frcnn_bf16* w_packed, int cout, frcnn_stream_t stream);
@@ -173,15 +178,20 @@ int frcnn_bn_bwd_apply(const frcnn_bf16* gout, const frcnn_bf16* act, const frcn
  * train_apply    : out = [relu](z*scale + shift [+ res]); writes mean / invstd, updates the moving statistics; optionally
  *                  writes relu_mask [m][c/8]: bit e of byte (row, c/8) = (out[row][8*(c/8)+e] > 0).  The backward kernels take
  *                  EITHER the activation tensor (act) OR that bit mask (relu_mask) as the ReLU mask, or neither (no ReLU)
- * bwd_apply_fused: dz = gamma*invstd*(g - c1 - xhat*c2), gpre (optional) = g; writes dgamma / dbeta */
+ * bwd_apply_fused: dz = gamma*invstd*(g - c1 - xhat*c2), gpre (optional) = g; writes dgamma / dbeta.
+ * Synchronised BatchNorm over data-parallel ranks (the reference is ONE device whose BatchNorm sees the whole batch,
+ * models/faster_rcnn.py:50): the caller SUM-all-reduces stats_partial (forward) / partial (backward) over the ranks between
+ * the kernel that accumulates them and these kernels, and passes count = m * world (rows of the GLOBAL batch; 0 = m) and
+ * param_grad_scale = 1 / world (each rank publishes its share of dgamma / dbeta, which the gradient all-reduce sums again;
+ * 1 on a single rank). */
 int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_partial, int slots, int64_t count, const float* gamma,
                          const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
                          const frcnn_bf16* res, int relu, frcnn_bf16* out, uint8_t* relu_mask, float* mean, float* invstd,
                          int64_t m, int c, frcnn_stream_t stream);
 int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z,
                              const float* mean, const float* invstd, const float* gamma, const float* partial, int slots,
-                             float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c,
-                             frcnn_stream_t stream);
+                             float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, int64_t count,
+                             float param_grad_scale, frcnn_stream_t stream);
 /* g_out = g * (act > 0): ReLU backward without BN (RPN intermediate layer) */
 int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, int64_t n, frcnn_stream_t stream);
 /* per-channel column sum of a bf16 [m,c] matrix ADDED (float atomics) to fp32 out[c] (bias gradients;

@@ -116,6 +116,26 @@ KNOWN = {
                   {"ctr": [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], "key": [0xa4093822, 0x299f31d0],
                    "out": [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]}],
     },
+    "keras_resnet50_v1_summary": {
+        "derivation": "tf.keras.applications.ResNet50 as printed by model.summary() in the public Keras documentation / every tutorial "
+                      "that shows it (input 224x224x3): parameter count per layer (Conv2D: kh*kw*cin*cout + cout -- every conv has a "
+                      "bias; BatchNormalization: 4*C incl. the two moving statistics) and output shapes of the stage outputs.  Total of "
+                      "include_top=False is the published 23,587,712; minus conv5_x (block1 6,054,912 + 2 x 4,471,808 = 14,998,528) "
+                      "leaves 8,589,184 up to conv4_block6_out, the tensor models/feature_extractor.py:9 taps.  Strides: the FIRST 1x1 "
+                      "of block1 and the shortcut carry the stride (v1), so conv3_block1_1_conv maps 56x56 -> 28x28.",
+        "layer_params": {"conv1_conv": 9472, "conv1_bn": 256,
+                         "conv2_block1_0_conv": 16640, "conv2_block1_1_conv": 4160, "conv2_block1_2_conv": 36928, "conv2_block1_3_conv": 16640,
+                         "conv2_block1_3_bn": 1024, "conv2_block2_1_conv": 16448,
+                         "conv3_block1_0_conv": 131584, "conv3_block1_1_conv": 32896, "conv3_block1_2_conv": 147584, "conv3_block1_3_conv": 66048,
+                         "conv3_block2_1_conv": 65664,
+                         "conv4_block1_0_conv": 525312, "conv4_block1_1_conv": 131328, "conv4_block1_2_conv": 590080, "conv4_block1_3_conv": 263168,
+                         "conv4_block2_1_conv": 262400, "conv4_block6_3_bn": 4096},
+        "blocks_per_stage": {"conv2": 3, "conv3": 4, "conv4": 6},
+        "total_params_to_conv4_block6_out": 8589184,
+        "non_trainable_to_conv4_block6_out": 30592,       # published 53,120 minus conv5_x BN statistics 2 * (5120 + 2 * 3072)
+        "output_shapes_224": {"conv1_conv": [112, 112, 64], "pool1_pool": [56, 56, 64], "conv2_block3_out": [56, 56, 256],
+                              "conv3_block1_1_conv": [28, 28, 128], "conv3_block4_out": [28, 28, 512], "conv4_block6_out": [14, 14, 1024]},
+    },
     "work_per_image": {
         "derivation": "SURVEY A.1/A.2: trainable parameter count of R50-C4 + RPN + heads",
         "trainable_params": 12743020,

@@ -75,6 +75,59 @@ def _worker(rank, world, port, tmp):
     ref = torch.cat([x.reshape(-1) for x in gref])
     err = float((flat - ref).norm() / ref.norm())
     assert err < 1e-4, err
+    # 3. synchronised BatchNorm: the sync-point protocol of the train plan (runtime.Plan.sync_point / run_synced: partial sums
+    #    of every rank are SUM all-reduced between the kernel that accumulates them and the kernel that consumes them, the
+    #    consumer normalises with count = m * world and publishes dgamma / dbeta scaled by 1 / world) makes world x b images
+    #    equal ONE process with world*b images (reference: single device, whole-batch BN, models/faster_rcnn.py:50).  The
+    #    arithmetic below is what frcnn_bn_train_apply / frcnn_bn_bwd_apply_fused evaluate (include/frcnn_hip.h).
+    RT = importlib.import_module("2d_object_detection_amd.runtime")
+    gen = torch.Generator().manual_seed(7)
+    m, C, eps = 48, 16, 1.001e-5
+    z_all = torch.randn(world * m, C, generator=gen, dtype=torch.float64) * 2 + 0.5
+    g_all = torch.randn(world * m, C, generator=gen, dtype=torch.float64)
+    gamma, beta = torch.rand(C, generator=gen, dtype=torch.float64) + 0.5, torch.randn(C, generator=gen, dtype=torch.float64)
+    z, gout = z_all[rank * m:(rank + 1) * m], g_all[rank * m:(rank + 1) * m]
+    st = {"stats": torch.zeros(2, C, dtype=torch.float64), "part": torch.zeros(2, C, dtype=torch.float64)}
+    count = m * world
+
+    def conv_stats():
+        st["stats"][0], st["stats"][1] = z.sum(0), (z * z).sum(0)
+
+    def train_apply():
+        mean = st["stats"][0] / count
+        var = st["stats"][1] / count - mean * mean
+        st["mean"], st["invstd"] = mean, 1.0 / torch.sqrt(var + eps)
+        st["y"] = (z - mean) * st["invstd"] * gamma + beta
+
+    def bwd_reduce():
+        xh = (z - st["mean"]) * st["invstd"]
+        st["part"][0], st["part"][1] = gout.sum(0), (gout * xh).sum(0)
+
+    def bwd_apply():
+        xh = (z - st["mean"]) * st["invstd"]
+        st["dz"] = gamma * st["invstd"] * (gout - st["part"][0] / count - xh * st["part"][1] / count)
+        st["dgamma"], st["dbeta"] = st["part"][1] / world, st["part"][0] / world
+
+    plan = RT.Plan("sync_bn")
+    plan.add(conv_stats)
+    plan.sync_point("bn_stats", [st["stats"]])
+    plan.add(train_apply)
+    plan.add(bwd_reduce)
+    plan.sync_point("bn_bwd", [st["part"]])
+    plan.add(bwd_apply)
+    plan.run_synced()
+    grads = torch.cat([st["dgamma"], st["dbeta"]])
+    dist.all_reduce(grads)                                   # the gradient bucket all-reduce
+    zr = z_all.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = torch.nn.functional.batch_norm(zr, None, None, gr, br, training=True, eps=eps)
+    y_ref.backward(g_all)
+    sl = slice(rank * m, (rank + 1) * m)
+    assert torch.allclose(st["y"], y_ref[sl].detach(), rtol=1e-10, atol=1e-10)
+    assert torch.allclose(st["dz"], zr.grad[sl], rtol=1e-9, atol=1e-10)
+    assert torch.allclose(grads, torch.cat([gr.grad, br.grad]), rtol=1e-9, atol=1e-10)
+    # per-replica statistics (no sync) are measurably different: the test can tell the two apart
+    assert not torch.allclose(z.mean(0), st["mean"], rtol=1e-3, atol=1e-3)
     open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
     dist.destroy_process_group()
 

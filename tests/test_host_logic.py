@@ -111,3 +111,74 @@ def test_gradient_synchronizer_single_process_is_a_noop():
         s.after_segment(seg, 4)
     assert torch.equal(g, torch.arange(10, dtype=torch.float32)) and s.bytes_per_step == 40
     assert DIST.shard_batch(32, 3, 8) == (12, 16)
+
+
+def test_plan_bucket_cuts_and_sync_points():
+    p = RT.Plan("s")
+    log = []
+    p.add(log.append, "fwd")
+    t = torch.ones(3)
+    p.sync_point("bn0", [t])                      # a new segment that needs sum-over-ranks(t) first; completes no bucket
+    p.add(log.append, "apply")
+    p.cut("bwd_conv4")                            # heads bucket done
+    p.add(log.append, "conv4")
+    p.sync_point("bn1", [t])
+    p.add(log.append, "conv4b")
+    p.cut("update")                               # conv4 bucket done
+    p.add(log.append, "sgd")
+    assert p.segment_names == ["main", "bn0", "bwd_conv4", "bn1", "update"]
+    assert p.bucket_ends == [1, 3] and sorted(p.pre_sync) == [1, 3]
+    p.run_synced()                                # no process group: the collectives are no-ops
+    assert log == ["fwd", "apply", "conv4", "conv4b", "sgd"] and torch.equal(t, torch.ones(3))
+
+
+def _grad_writes(ops, store, fn, args, kwargs):
+    """flat-gradient offsets written by one plan launch (tensor arguments that are views of store.g)"""
+    base = store.g.untyped_storage().data_ptr()
+    tensors = [a for a in list(args) + list(kwargs.values()) if torch.is_tensor(a)]
+    if fn is ops.conv2d_wgrad_grouped:
+        tensors += [dw for (_d, _x, _dz, dw) in args[0].items]
+    return [a.storage_offset() for a in tensors if a.dtype == torch.float32 and a.untyped_storage().data_ptr() == base and a is not store.g
+            and a.numel() < store.g.numel()]
+
+
+def test_gradient_buckets_coincide_with_plan_segments(monkeypatch):
+    """No 8-GPU run can catch a mis-cut: on the real train plan (built on CPU tensors, nothing launched) every launch that
+    writes into gradient bucket j lies in a segment that ends no later than the j-th bucket cut -- with and without the
+    extra segments synchronised BatchNorm inserts -- and the last bucket cut precedes the optimizer update."""
+    import copy
+    ops = importlib.import_module("2d_object_detection_amd.ops")
+    monkeypatch.setattr(ops, "anchors_generate", lambda out, *a, **k: out.zero_())
+    monkeypatch.setattr(ops, "clip_to_window", lambda boxes, out, w: out.copy_(boxes))
+    M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
+    cfg = copy.deepcopy(CFG.default_config())
+    cfg["image_shape"] = [128, 192, 3]
+    for sync_bn in (False, True):
+        model = M.FasterRCNN(cfg, device="cpu", world_size=2, sync_bn=sync_bn)
+        opt = OPT.SGD(learning_rate=1e-3, momentum=0.9)
+        opt.bind(model.store)
+        plan = model._build(model._train, 2, True, opt)["plan"]
+        buckets = model.store.buckets
+        assert [b[0] for b in buckets] == ["heads", "conv4", "conv3", "conv2+stem"]
+        assert len(plan.bucket_ends) == len(buckets), (plan.bucket_ends, plan.segment_names)
+        assert (len(plan.pre_sync) > 80) == sync_bn
+        last_write = [-1] * len(buckets)
+        first_update = None
+        for si, seg in enumerate(plan.segments):
+            for fn, args, kwargs, _br in seg:
+                if fn is None:
+                    continue
+                if fn is ops.sgd_momentum and first_update is None:
+                    first_update = si
+                if fn is ops.sgd_momentum:
+                    continue
+                for off in _grad_writes(ops, model.store, fn, args, kwargs):
+                    j = next(i for i, (_n, b, e) in enumerate(buckets) if b <= off < e)
+                    last_write[j] = max(last_write[j], si)
+        assert all(lw >= 0 for lw in last_write), last_write
+        for j, lw in enumerate(last_write):
+            assert lw <= plan.bucket_ends[j], "bucket %s is still written in segment %d (%s) after its cut at segment %d" % (
+                buckets[j][0], lw, plan.segment_names[lw], plan.bucket_ends[j])
+            if j > 0:
+                assert lw > plan.bucket_ends[j - 1], "bucket %s is complete before the previous cut: buckets and cuts are out of step" % buckets[j][0]
+        assert first_update is not None and first_update > plan.bucket_ends[-1]

@@ -140,3 +140,108 @@ def test_oracle_small_step_regression():
         assert abs(float(ls[k]) - v) <= 2e-3 * max(1.0, abs(v)), k
     assert aux["nmsed_rpn"]["num_valid_detections"].tolist() == pin["num_valid_rpn"]
     assert aux["rpn_samples"]["sample_indices"][:, :8].tolist() == pin["rpn_sample_indices_first8"]
+
+
+# ------------------------------------------------------------------ hardening of the (parity-unpinned) [TF-ext] restatements
+def test_keras_resnet50_topology_known_answers():
+    """oracle/resnet.py against the layer table tf.keras.applications.ResNet50 prints (model.summary(), public): parameter
+    count per layer name, blocks per stage, total up to conv4_block6_out, and the stage output shapes at 224 x 224."""
+    from oracle import resnet as R
+    k = K["keras_resnet50_v1_summary"]
+    shapes = R.param_shapes(50)
+    count = lambda n: int(np.prod(shapes[n]))
+    for layer, want in k["layer_params"].items():
+        if layer.endswith("_conv"):
+            got = count(layer + "/kernel") + count(layer + "/bias")
+        else:
+            got = sum(count(layer + "/" + s) for s in ("gamma", "beta", "moving_mean", "moving_variance"))
+        assert got == want, (layer, got, want)
+    for stage, nb in k["blocks_per_stage"].items():
+        assert sorted({n.split("_")[1] for n in shapes if n.startswith(stage + "_")}) == ["block%d" % (i + 1) for i in range(nb)]
+    assert not any(n.startswith("conv5") for n in shapes)
+    assert sum(count(n) for n in shapes) == k["total_params_to_conv4_block6_out"]
+    assert sum(count(n) for n in shapes if "moving" in n) == k["non_trainable_to_conv4_block6_out"]
+    taps = {}
+    p = R.init_params(50, seed=0)
+    out, _ = R.forward(p, torch.zeros(1, 224, 224, 3, dtype=torch.uint8), False, taps=taps)
+    assert [out.shape[1], out.shape[2], out.shape[3]] == k["output_shapes_224"]["conv4_block6_out"]
+    checked = 0
+    for name, shp in k["output_shapes_224"].items():
+        if name in taps:
+            t = taps[name]
+            assert sorted(t.shape[1:]) == sorted(shp), (name, tuple(t.shape))
+            checked += 1
+    assert checked >= 2, sorted(taps)
+
+
+def _random_boxes(g, n, lo=-0.2, hi=1.2):
+    """normalised corner boxes incl. out-of-range coordinates, inverted corners and zero-area boxes"""
+    a, b = torch.rand(n, 2, generator=g) * (hi - lo) + lo, torch.rand(n, 2, generator=g) * (hi - lo) + lo
+    bx = torch.cat([a, b], 1)
+    bx[::7, 2:] = bx[::7, :2]                         # zero area
+    bx[3::11] = 0.0                                   # NMS zero padding
+    return bx
+
+
+def test_crop_and_resize_two_independent_restatements_agree():
+    """oracle/roi.py (vectorised torch) vs oracle/indep.c (scalar loops written from the published contract): bit-equal forward
+    on random boxes incl. out-of-range, inverted, zero-area and all-zero (padding) boxes, odd and 1-wide crops."""
+    from oracle import indep
+    g = torch.Generator().manual_seed(2)
+    for (B, H, W, C, n, cs) in ((2, 7, 9, 3, 40, (14, 14)), (1, 24, 78, 8, 30, (14, 14)), (3, 5, 4, 2, 25, (3, 5)), (1, 6, 6, 1, 10, (1, 1))):
+        img = torch.randn(B, H, W, C, generator=g)
+        bx = _random_boxes(g, n)
+        bi = torch.randint(0, B, (n,), generator=g)
+        a = roi.crop_and_resize(img, bx, bi, cs)
+        b = indep.crop_and_resize(img, bx, bi, cs)
+        assert torch.equal(a, b), float((a - b).abs().max())
+        # the all-zero padding proposal samples pixel (0, 0) everywhere (SURVEY A.4)
+        z = roi.crop_and_resize(img, torch.zeros(1, 4), torch.tensor([0]), cs)
+        assert torch.equal(z, img[0, 0, 0].expand_as(z))
+
+
+def test_crop_and_resize_gradient_gradcheck_and_scatter_form():
+    """fp64 finite-difference check of the autograd gradient the oracle's RoI backward relies on, and agreement with the
+    independent 4-tap scatter (CropAndResizeGradImage form) in oracle/indep.c."""
+    from oracle import indep
+    g = torch.Generator().manual_seed(3)
+    img64 = torch.randn(2, 5, 6, 2, generator=g, dtype=torch.float64, requires_grad=True)
+    bx = torch.tensor([[0.1, 0.05, 0.9, 0.8], [0.0, 0.0, 1.0, 1.0], [-0.3, 0.2, 0.7, 1.4], [0.5, 0.5, 0.5, 0.5], [0.0, 0.0, 0.0, 0.0]])
+    bi = torch.tensor([0, 1, 1, 0, 1])
+    assert torch.autograd.gradcheck(lambda im: roi.crop_and_resize(im, bx, bi, (4, 3)), (img64,), eps=1e-6, atol=1e-6)
+    for (B, H, W, C, n, cs) in ((2, 7, 9, 3, 40, (14, 14)), (1, 24, 30, 4, 64, (14, 14))):
+        img = torch.randn(B, H, W, C, generator=g, requires_grad=True)
+        bxs, bis = _random_boxes(g, n), torch.randint(0, B, (n,), generator=g)
+        out = roi.crop_and_resize(img, bxs, bis, cs)
+        up = torch.randn(out.shape, generator=g)
+        out.backward(up)
+        ref = indep.crop_and_resize_grad_image(up, (B, H, W, C), bxs, bis)
+        err = float((img.grad - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+        assert err < 1e-5, err
+    # through the 2x2 max-pool: every pooled element routes its gradient to exactly one crop sample, whose four bilinear
+    # weights sum to one -> for in-range RoIs the image gradient of sum(pooled) sums to the number of pooled elements
+    feat = torch.randn(1, 6, 7, 3, generator=g, requires_grad=True)
+    rois = torch.tensor([[[0.1, 0.2, 0.8, 0.9], [0.3, 0.1, 0.6, 0.7]]])
+    pooled = roi.roi_pooling(feat, rois, pooled_size=2, kernel_size=2)
+    pooled.sum().backward()
+    assert float(feat.grad.sum()) == pytest.approx(float(pooled.numel()), rel=1e-5)
+
+
+def test_combined_nms_three_restatements_agree():
+    """oracle/nms.c (sorted walk against a kept list), its Python twin and oracle/indep.c (textbook take-best / kill-overlaps,
+    top-k by repeated arg-max): identical outputs on random inputs with out-of-range, inverted and zero-area boxes, score
+    thresholds that cut candidates, and per-class / total caps that bind."""
+    from oracle import indep
+    g = torch.Generator().manual_seed(4)
+    for (B, N, q, C, mpc, mt, thr, sthr) in ((2, 80, 1, 1, 10, 15, 0.5, 0.1), (1, 60, 3, 3, 4, 7, 0.3, 0.3), (2, 200, 1, 1, 300, 300, 0.7, 0.0),
+                                              (1, 50, 7, 7, 10, 30, 0.5, 0.0), (1, 30, 1, 2, 50, 100, 0.5, 0.95)):
+        bx = _random_boxes(g, B * N * q).reshape(B, N, q, 4)
+        sc = torch.rand(B, N, C, generator=g)
+        a = nms.combined_nms(bx, sc, mpc, mt, thr, sthr)
+        b = indep.combined_nms(bx, sc, mpc, mt, thr, sthr)
+        for x, y, what in zip(a, b, ("boxes", "scores", "classes", "valid")):
+            assert torch.equal(x, y), (what, (B, N, q, C))
+        assert float(a[0].min()) >= 0.0 and float(a[0].max()) <= 1.0            # clip_boxes
+    bx = _random_boxes(g, 40).reshape(1, 40, 1, 4)
+    sc = torch.rand(1, 40, 1, generator=g)
+    assert all(torch.equal(x, y) for x, y in zip(nms.combined_nms_py(bx, sc, 5, 8, 0.4, 0.2), indep.combined_nms(bx, sc, 5, 8, 0.4, 0.2)))

@@ -1,5 +1,7 @@
 """Sweep the tile configurations of the one-tile conv kernel over the layer shapes of the R50-C4 step
-(kernel development aid).  usage: python tools/tile_sweep.py [iters]"""
+(kernel development aid).  Needs a sweep build of the library: FRCNN_SWEEP=1 python 2d_object_detection_amd/csrc/build.py --force
+(production builds carry only the instantiations the dispatcher selects and read no environment variables).
+usage: python tools/tile_sweep.py [iters]"""
 import importlib
 import os
 import sys
@@ -22,9 +24,6 @@ SHAPES = [  # n, h, w, cin, cout, k, stride, pad
 ]
 CONFIGS = [(bm, bn, bk, s, 1) for bk in (64, 128) for bm in (128, 64) for bn in (128, 64) for s in (2, 3) if not (bk == 128 and s == 3)]
 CONFIGS += [(128, 64, 64, 4, 1), (128, 64, 64, 6, 1), (128, 128, 64, 4, 1), (64, 64, 64, 6, 1)]               # deep rings
-CONFIGS += [(128, 64, 64, 3, 1, 8, 1), (128, 64, 64, 4, 1, 8, 1), (64, 128, 64, 4, 1, 8, 1), (128, 128, 64, 3, 1, 8, 1), (128, 128, 64, 4, 1, 8, 1), (64, 64, 64, 4, 1, 8, 1),
-            (128, 128, 64, 4, 1, 4, 1), (64, 128, 64, 4, 1, 4, 1), (128, 64, 64, 4, 1, 4, 1)]       # software-pipelined K loop
-CONFIGS += [(128, 128, 64, 2, 1, 4), (128, 128, 64, 3, 1, 4), (64, 128, 64, 3, 1, 4), (128, 64, 64, 3, 1, 4), (64, 64, 64, 3, 1, 4)]   # 4 waves
 CONFIGS += [(bm, bn, 64, 2, t) for (bm, bn) in ((128, 64), (128, 128), (64, 64)) for t in (2, 4, 8, 16)]      # tile runs
 
 
