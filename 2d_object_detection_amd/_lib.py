@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib2dod_hip.so")
+# FRCNN_LIB: a kernel-development variant of the library (csrc/build.py: lib2dod_hip_sweep.so, lib2dod_hip_stamps.so)
+LIB_PATH = os.path.join(_PKG, os.environ.get("FRCNN_LIB", "lib2dod_hip.so"))
 
 
 class ConvDesc(Structure):

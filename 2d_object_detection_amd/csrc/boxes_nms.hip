@@ -15,7 +15,6 @@
 //   3. one workgroup per image merges the classes: bitonic sort of the <= C*max_per_class kept
 //      (score, class, slot) keys, top max_total written clipped to [0,1], remainder zero.
 #include "common.h"
-#include <hipcub/hipcub.hpp>
 
 #pragma clang fp contract(off)
 
@@ -164,7 +163,10 @@ __device__ __forceinline__ float key_float(unsigned int k) {
 }
 
 constexpr int NMS_T = 1024;
-constexpr int NMS_LDS_KEYS = 16384;
+constexpr int NMS_LDS_KEYS = 16384;          // merge kernel: C * max_per_class keys sorted in LDS
+constexpr int NMS_RK = 1024;                 // candidates selected, sorted and resolved per round
+constexpr int NMS_HC = 16;                   // copies of the digit histogram (spreads same-address LDS atomics)
+constexpr int NMS_CH = 256;                  // candidates resolved per iteration of the greedy loop
 
 // descending bitonic sort of n_pad (power of two) u64 keys by NMS_T threads
 __device__ void bitonic_desc(unsigned long long* keys, int n_pad) {
@@ -182,72 +184,33 @@ __device__ void bitonic_desc(unsigned long long* keys, int n_pad) {
     }
 }
 
-// Descending sort of 1024 * IPT keys held in LDS.  The composite key is (score bits << 32 | ~index) with the candidates
-// initially in index order, so a STABLE descending radix sort of the 32-bit score with the low word as payload gives the
-// same order as sorting the 64-bit keys -- in 8 four-bit passes over registers instead of ~100 LDS stages of a bitonic
-// network (measured: 367 us of the 439 us RPN-proposal NMS were the bitonic sort of 16384 keys).  rocPRIM's block radix sort
-// does the digit ranking; its scratch aliases the key array (the keys live in registers during the sort).
-template <int IPT>
-__device__ void radix_sort_desc(unsigned long long* keys, void* scratch) {
-    using Sort = hipcub::BlockRadixSort<unsigned int, NMS_T, IPT, unsigned int>;
-    unsigned int k[IPT], v[IPT];
-#pragma unroll
-    for (int e = 0; e < IPT; ++e) {
-        const unsigned long long x = keys[threadIdx.x * IPT + e];
-        k[e] = (unsigned int)(x >> 32);
-        v[e] = (unsigned int)x;
-    }
-    __syncthreads();
-    Sort(*reinterpret_cast<typename Sort::TempStorage*>(scratch)).SortDescending(k, v);
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < IPT; ++e) keys[threadIdx.x * IPT + e] = ((unsigned long long)k[e] << 32) | v[e];
-    __syncthreads();
-}
-constexpr size_t NMS_RADIX_SCRATCH = sizeof(hipcub::BlockRadixSort<unsigned int, NMS_T, 16, unsigned int>::TempStorage) >
-                                             sizeof(hipcub::BlockRadixSort<unsigned int, NMS_T, 4, unsigned int>::TempStorage)
-                                         ? sizeof(hipcub::BlockRadixSort<unsigned int, NMS_T, 16, unsigned int>::TempStorage)
-                                         : sizeof(hipcub::BlockRadixSort<unsigned int, NMS_T, 4, unsigned int>::TempStorage);
-
-// keys: LDS or global; scratch: LDS (may alias keys -- they live in registers during the radix sort)
-__device__ void sort_keys_desc(unsigned long long* keys, void* scratch, int n_pad) {
-    if (n_pad == 16 * NMS_T) radix_sort_desc<16>(keys, scratch);
-    else if (n_pad == 8 * NMS_T) radix_sort_desc<8>(keys, scratch);
-    else if (n_pad == 4 * NMS_T) radix_sort_desc<4>(keys, scratch);
-    else bitonic_desc(keys, n_pad);
-}
-
-// Where the candidate keys of one (image, class) live: in LDS when they fit next to the kept list, else in a global slab
-// (the radix sort still runs in LDS scratch for n_pad <= NMS_LDS_KEYS).  Returns the dynamic LDS size of nms_class_kernel.
-static size_t nms_class_lds(int n_pad, int max_per_class, bool* keys_global) {
-    constexpr size_t kLdsMax = 160 * 1024;
-    const size_t fixed = (size_t)max_per_class * 20 + 256 /*NMS_CH*/ * (16 + 32 + 4 + 4 + 4) + 16 + 8;
-    const bool radix = n_pad >= 4 * NMS_T && n_pad <= NMS_LDS_KEYS;
-    const size_t lds_keys = ((size_t)n_pad * 8 > NMS_RADIX_SCRATCH || !radix) ? (size_t)n_pad * 8 : NMS_RADIX_SCRATCH;
-    if (n_pad <= NMS_LDS_KEYS && fixed + lds_keys <= kLdsMax) { *keys_global = false; return fixed + lds_keys; }
-    *keys_global = true;
-    return fixed + (radix ? NMS_RADIX_SCRATCH : 0);
-}
-
 struct NmsParams {
     const float* boxes; const float* scores;
-    int N, q, C, score_stride, score_offset, max_per_class, n_pad, keys_global;
+    int N, q, C, score_stride, score_offset, max_per_class, lds_keys;
     float iou_thr, score_thr;
-    unsigned long long* gkeys;       // global scratch [B*C][n_pad] (only when keys_global)
     unsigned long long* kept_keys;   // [B][C*max_per_class]: (score key << 32 | ~(class*max_per_class + slot)) or 0
     int* kept_idx;                   // [B][C*max_per_class] box index
 };
 
-constexpr int NMS_CH = 256;                  // candidates resolved per iteration of the greedy loop (nms_class_lds assumes 256)
-static_assert(NMS_CH == 256, "nms_class_lds sizes the chunk arrays for 256 candidates");
+// LDS of nms_class_kernel; *lds_keys: the 32-bit score keys of the N candidates are staged in LDS (else re-read from global)
+static size_t nms_class_lds(int n, int max_per_class, bool* lds_keys) {
+    const size_t fixed = (size_t)max_per_class * 20 + NMS_CH * (16 + 32 + 4 + 4 + 4) + 64 + (size_t)NMS_HC * 256 * 4 + (size_t)NMS_RK * 8 + 16;
+    *lds_keys = fixed + (size_t)n * 4 <= 150 * 1024;
+    return fixed + (*lds_keys ? (size_t)n * 4 : 0);
+}
 
-// One workgroup per (image, class): sort the candidates by score, then greedy suppression in chunks of NMS_CH candidates:
-//   1. every candidate of the chunk is tested against the boxes kept so far (4 threads per candidate);
+// One workgroup per (image, class).  Greedy NMS visits candidates in descending score order and usually stops long before the
+// list ends (max_per_class boxes kept), so the candidates are NOT sorted as a whole: in rounds, the next NMS_RK best ones are
+// SELECTED (MSB-first radix select of the composite key (score bits << 32 | ~index): one histogram pass per byte, ending as
+// soon as the boundary does not split a digit), compacted, sorted with an in-LDS bitonic network and resolved:
+//   1. every candidate of a 256-chunk is tested against the boxes kept so far (4 threads per candidate);
 //   2. for the survivors only, the chunk's upper-triangular suppression matrix is built with wave ballots
 //      (row i, word w: which later candidates 64w..64w+63 box i would suppress);
 //   3. one wave walks the survivors in score order -- ctz over the alive mask, one v_readlane per matrix word -- so the
 //      sequential part costs one step per KEPT box, not per candidate.
-// Four barriers per 256 candidates; the loop ends as soon as max_per_class boxes are kept or the scores run out.
+// The order of visits is exactly the descending composite-key order (every key of a round is larger than every key of the
+// next; inside a round the sort is total): bit-identical results to a full sort.  No host sync, no library sort.
+template <bool LDSK>
 __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4* kept_box = reinterpret_cast<f32x4*>(smem);                                       // [max_per_class] corner-normalised
@@ -257,132 +220,226 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     float* chunk_area = kept_area + p.max_per_class;                                        // [NMS_CH]
     int* dead = reinterpret_cast<int*>(chunk_area + NMS_CH);                                // [NMS_CH] invalid or suppressed by the kept list
     int* rows = dead + NMS_CH;                                                              // [NMS_CH] compacted list of surviving rows
-    int* misc = rows + NMS_CH;                                                              // [0] = kept count, [1] = survivors
-    unsigned long long* lkeys = reinterpret_cast<unsigned long long*>((reinterpret_cast<size_t>(misc + 4) + 7) & ~(size_t)7);
+    int* misc = rows + NMS_CH;                                                              // [16] scalars shared through LDS
+    int* hist = misc + 16;                                                                  // [256][NMS_HC]
+    unsigned long long* rkeys = reinterpret_cast<unsigned long long*>((reinterpret_cast<size_t>(hist + NMS_HC * 256) + 7) & ~(size_t)7);   // [NMS_RK]
+    unsigned int* skeys = reinterpret_cast<unsigned int*>(rkeys + NMS_RK);                  // [N] (LDSK)
 
     const int b = blockIdx.x / p.C, c = blockIdx.x % p.C;
     const int bc = (p.q == 1) ? 0 : c;
     const float* boxes = p.boxes + (int64_t)b * p.N * p.q * 4;
-    unsigned long long* keys = p.keys_global ? p.gkeys + (int64_t)blockIdx.x * p.n_pad : lkeys;
-
-    for (int i = threadIdx.x; i < p.n_pad; i += blockDim.x) {
-        unsigned long long k = 0ull;
-        if (i < p.N) {
-            const float s = p.scores[((int64_t)b * p.N + i) * p.score_stride + p.score_offset + c];
-            if (s > p.score_thr) k = ((unsigned long long)float_key(s) << 32) | (unsigned int)(~(unsigned int)i);
-        }
-        keys[i] = k;
-    }
-    if (threadIdx.x == 0) { misc[0] = 0; }
-    __syncthreads();
-    sort_keys_desc(keys, lkeys, p.n_pad);
-
+    const float* scores = p.scores + (int64_t)b * p.N * p.score_stride + p.score_offset + c;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    auto score_key = [&](const int i) -> unsigned int {       // 0: not a candidate (score <= threshold)
+        if (LDSK) return skeys[i];
+        const float s = scores[(int64_t)i * p.score_stride];
+        return s > p.score_thr ? float_key(s) : 0u;
+    };
+    auto composite = [](const unsigned int sk, const int i) -> unsigned long long {
+        return ((unsigned long long)sk << 32) | (unsigned int)(~(unsigned int)i);
+    };
+
+    if (threadIdx.x < 16) misc[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        int valid = 0;
+        for (int i = threadIdx.x; i < p.N; i += NMS_T) {
+            const float s = scores[(int64_t)i * p.score_stride];
+            const unsigned int sk = s > p.score_thr ? float_key(s) : 0u;
+            if (LDSK) skeys[i] = sk;
+            valid += sk != 0u;
+        }
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) valid += __shfl_xor(valid, sh);
+        if (lane == 0 && valid) atomicAdd(&misc[2], valid);
+    }
+    __syncthreads();
+    int remaining = misc[2];
+    unsigned long long prev = ~0ull;                          // candidates with a composite key below prev are still unvisited
     int kept = 0;
-    for (int base = 0; base < p.n_pad; base += NMS_CH) {
-        // ---- 1. load the chunk
-        if (threadIdx.x < NMS_CH) {
-            const unsigned long long k = base + threadIdx.x < p.n_pad ? keys[base + threadIdx.x] : 0ull;
-            f32x4 bx = {0.f, 0.f, 0.f, 0.f};
-            if (k != 0ull) {
-                const unsigned int idx = ~(unsigned int)(k & 0xFFFFFFFFull);
-                bx = nms_norm(*reinterpret_cast<const f32x4*>(boxes + ((int64_t)idx * p.q + bc) * 4));
-            }
-            chunk_box[threadIdx.x] = bx;
-            chunk_area[threadIdx.x] = nms_area(bx);
-            dead[threadIdx.x] = (k == 0ull) ? 1 : 0;
-        }
-        __syncthreads();
-        if (keys[base] == 0ull) break;        // sorted: nothing valid left (uniform: same value for all threads)
-        // ---- 2. test against the kept list: 4 threads per candidate
-        {
-            const int cand = threadIdx.x >> 2, sub = threadIdx.x & 3;
-            const f32x4 cb = chunk_box[cand];
-            const float ca = chunk_area[cand];
-            int hit = 0;
-            for (int j = sub; j < kept; j += 4)
-                if (nms_over(cb, ca, kept_box[j], kept_area[j], p.iou_thr)) { hit = 1; break; }
-            hit |= __shfl_xor(hit, 1);
-            hit |= __shfl_xor(hit, 2);
-            if (sub == 0 && hit) dead[cand] = 1;
-        }
-        __syncthreads();
-        // ---- 3. compact the survivors (wave 0), then build their rows of the suppression matrix
-        if (threadIdx.x < 64) {
-            int n_alive = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool al = dead[r * 64 + lane] == 0;
-                const unsigned long long m = __ballot(al);
-                if (al) rows[n_alive + __popcll(m & ((1ull << lane) - 1ull))] = r * 64 + lane;
-                n_alive += __popcll(m);
-            }
-            if (lane == 0) misc[1] = n_alive;
-        }
-        __syncthreads();
-        const int n_alive = misc[1];
-        for (int pair = wave; pair < n_alive * 4; pair += NMS_T / 64) {
-            const int i = rows[pair >> 2], w = pair & 3;
-            unsigned long long m = 0ull;
-            if (w * 64 + 63 > i) {                          // (wave-uniform) something later than i lives in this word
-                const int j = w * 64 + lane;
-                const bool sgt = j > i && !dead[j] && nms_over(chunk_box[j], chunk_area[j], chunk_box[i], chunk_area[i], p.iou_thr);
-                m = __ballot(sgt);
-            }
-            if (lane == 0) sup_of[i * 4 + w] = m;
-        }
-        __syncthreads();
-        // ---- 4. walk the survivors in score order (wave 0): one step per kept box
-        if (threadIdx.x < 64) {
-            unsigned long long alive[4], kmask[4];
-            unsigned int slo[4][4], shi[4][4];              // row r*64+lane, word w (only w >= r is ever read)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool al = dead[r * 64 + lane] == 0;
-                alive[r] = __ballot(al);
-                kmask[r] = 0ull;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const unsigned long long v = (w >= r && al) ? sup_of[(r * 64 + lane) * 4 + w] : 0ull;
-                    slo[r][w] = (unsigned int)v;
-                    shi[r][w] = (unsigned int)(v >> 32);
+    while (remaining > 0 && kept < p.max_per_class) {
+        const int K = remaining < NMS_RK ? remaining : NMS_RK;
+        unsigned long long T = 1ull;                          // this round takes the keys in [T, prev)
+        if (remaining > NMS_RK) {
+            // ---- radix select: T = the K-th largest unvisited composite key
+            unsigned long long prefix = 0ull;
+            int want = K;
+            bool found = false;
+            for (int pass = 0; pass < 8 && !found; ++pass) {
+                const int shift = 56 - 8 * pass;
+                for (int t = threadIdx.x; t < NMS_HC * 256; t += NMS_T) hist[t] = 0;
+                __syncthreads();
+                for (int i = threadIdx.x; i < p.N; i += NMS_T) {
+                    const unsigned int sk = score_key(i);
+                    if (sk == 0u) continue;
+                    const unsigned long long k = composite(sk, i);
+                    if (k < prev && (pass == 0 || (k >> (shift + 8)) == prefix))
+                        atomicAdd(&hist[(int)((k >> shift) & 255ull) * NMS_HC + (threadIdx.x & (NMS_HC - 1))], 1);
                 }
-            }
-            int k_now = kept;
+                __syncthreads();
+                if (threadIdx.x < 64) {                       // the digit d with  #(digits above d) < want <= #(digits >= d)
+                    int cnt[4], mine = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                while (alive[r] != 0ull && k_now < p.max_per_class) {
-                    const int i = __builtin_ctzll(alive[r]);
-                    kmask[r] |= 1ull << i;
-                    ++k_now;
-                    alive[r] &= ~(1ull << i);
+                    for (int e = 0; e < 4; ++e) {
+                        int sum = 0;
 #pragma unroll
-                    for (int w = r; w < 4; ++w) {
-                        const unsigned long long sp = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)shi[r][w], i) << 32) |
-                                                      (unsigned int)__builtin_amdgcn_readlane((int)slo[r][w], i);
-                        alive[w] &= ~sp;
+                        for (int h = 0; h < NMS_HC; ++h) sum += hist[(lane * 4 + e) * NMS_HC + h];
+                        cnt[e] = sum;
+                        mine += sum;
+                    }
+                    int incl = mine;                          // inclusive suffix sum over the lanes (Hillis-Steele, doubling)
+#pragma unroll
+                    for (int sh = 1; sh < 64; sh <<= 1) {
+                        const int v = __shfl_down(incl, sh);
+                        if (lane + sh < 64) incl += v;
+                    }
+                    int running = incl - mine;                // candidates in the digits of higher lanes
+#pragma unroll
+                    for (int e = 3; e >= 0; --e) {
+                        if (running < want && running + cnt[e] >= want) {
+                            misc[3] = lane * 4 + e;
+                            misc[4] = running;
+                            misc[5] = cnt[e];
+                        }
+                        running += cnt[e];
                     }
                 }
-            }
-            int before = kept;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if ((kmask[r] >> lane) & 1ull) {
-                    const int slot = before + __popcll(kmask[r] & ((1ull << lane) - 1ull));
-                    kept_box[slot] = chunk_box[r * 64 + lane];
-                    kept_area[slot] = chunk_area[r * 64 + lane];
-                    const unsigned long long k = keys[base + r * 64 + lane];
-                    const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + slot;
-                    p.kept_keys[o] = (k & 0xFFFFFFFF00000000ull) | (unsigned int)(~(unsigned int)(c * p.max_per_class + slot));
-                    p.kept_idx[o] = (int)(~(unsigned int)(k & 0xFFFFFFFFull));
+                __syncthreads();
+                prefix = (prefix << 8) | (unsigned long long)misc[3];
+                want -= misc[4];
+                if (want == misc[5] || pass == 7) {           // the boundary does not split this digit: every key with this prefix is taken
+                    T = prefix << shift;
+                    found = true;
                 }
-                before += __popcll(kmask[r]);
+                __syncthreads();
             }
-            if (lane == 0) misc[0] = k_now;
+        }
+        // ---- compact the round's keys, pad, sort
+        if (threadIdx.x == 0) misc[6] = 0;
+        const int n_sort = K <= NMS_CH ? NMS_CH : K <= 512 ? 512 : NMS_RK;
+        for (int t = threadIdx.x; t < n_sort; t += NMS_T) rkeys[t] = 0ull;
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.N; i += NMS_T) {
+            const unsigned int sk = score_key(i);
+            if (sk == 0u) continue;
+            const unsigned long long k = composite(sk, i);
+            if (k >= T && k < prev) {
+                const int pos = atomicAdd(&misc[6], 1);
+                if (pos < NMS_RK) rkeys[pos] = k;             // (pos < K always; the guard keeps a logic error from corrupting LDS)
+            }
         }
         __syncthreads();
-        kept = misc[0];
-        if (kept >= p.max_per_class) break;
+        bitonic_desc(rkeys, n_sort);
+
+        for (int base = 0; base < n_sort; base += NMS_CH) {
+            // ---- 1. load the chunk
+            if (threadIdx.x < NMS_CH) {
+                const unsigned long long k = rkeys[base + threadIdx.x];
+                f32x4 bx = {0.f, 0.f, 0.f, 0.f};
+                if (k != 0ull) {
+                    const unsigned int idx = ~(unsigned int)(k & 0xFFFFFFFFull);
+                    bx = nms_norm(*reinterpret_cast<const f32x4*>(boxes + ((int64_t)idx * p.q + bc) * 4));
+                }
+                chunk_box[threadIdx.x] = bx;
+                chunk_area[threadIdx.x] = nms_area(bx);
+                dead[threadIdx.x] = (k == 0ull) ? 1 : 0;
+            }
+            __syncthreads();
+            if (rkeys[base] == 0ull) break;       // sorted: nothing valid left in this round (uniform: same value for all threads)
+            // ---- 2. test against the kept list: 4 threads per candidate
+            {
+                const int cand = threadIdx.x >> 2, sub = threadIdx.x & 3;
+                const f32x4 cb = chunk_box[cand];
+                const float ca = chunk_area[cand];
+                int hit = 0;
+                for (int j = sub; j < kept; j += 4)
+                    if (nms_over(cb, ca, kept_box[j], kept_area[j], p.iou_thr)) { hit = 1; break; }
+                hit |= __shfl_xor(hit, 1);
+                hit |= __shfl_xor(hit, 2);
+                if (sub == 0 && hit) dead[cand] = 1;
+            }
+            __syncthreads();
+            // ---- 3. compact the survivors (wave 0), then build their rows of the suppression matrix
+            if (threadIdx.x < 64) {
+                int n_alive = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool al = dead[r * 64 + lane] == 0;
+                    const unsigned long long m = __ballot(al);
+                    if (al) rows[n_alive + __popcll(m & ((1ull << lane) - 1ull))] = r * 64 + lane;
+                    n_alive += __popcll(m);
+                }
+                if (lane == 0) misc[1] = n_alive;
+            }
+            __syncthreads();
+            const int n_alive = misc[1];
+            for (int pair = wave; pair < n_alive * 4; pair += NMS_T / 64) {
+                const int i = rows[pair >> 2], w = pair & 3;
+                unsigned long long m = 0ull;
+                if (w * 64 + 63 > i) {                          // (wave-uniform) something later than i lives in this word
+                    const int j = w * 64 + lane;
+                    const bool sgt = j > i && !dead[j] && nms_over(chunk_box[j], chunk_area[j], chunk_box[i], chunk_area[i], p.iou_thr);
+                    m = __ballot(sgt);
+                }
+                if (lane == 0) sup_of[i * 4 + w] = m;
+            }
+            __syncthreads();
+            // ---- 4. walk the survivors in score order (wave 0): one step per kept box
+            if (threadIdx.x < 64) {
+                unsigned long long alive[4], kmask[4];
+                unsigned int slo[4][4], shi[4][4];              // row r*64+lane, word w (only w >= r is ever read)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool al = dead[r * 64 + lane] == 0;
+                    alive[r] = __ballot(al);
+                    kmask[r] = 0ull;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned long long v = (w >= r && al) ? sup_of[(r * 64 + lane) * 4 + w] : 0ull;
+                        slo[r][w] = (unsigned int)v;
+                        shi[r][w] = (unsigned int)(v >> 32);
+                    }
+                }
+                int k_now = kept;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    while (alive[r] != 0ull && k_now < p.max_per_class) {
+                        const int i = __builtin_ctzll(alive[r]);
+                        kmask[r] |= 1ull << i;
+                        ++k_now;
+                        alive[r] &= ~(1ull << i);
+#pragma unroll
+                        for (int w = r; w < 4; ++w) {
+                            const unsigned long long sp = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)shi[r][w], i) << 32) |
+                                                          (unsigned int)__builtin_amdgcn_readlane((int)slo[r][w], i);
+                            alive[w] &= ~sp;
+                        }
+                    }
+                }
+                int before = kept;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if ((kmask[r] >> lane) & 1ull) {
+                        const int slot = before + __popcll(kmask[r] & ((1ull << lane) - 1ull));
+                        kept_box[slot] = chunk_box[r * 64 + lane];
+                        kept_area[slot] = chunk_area[r * 64 + lane];
+                        const unsigned long long k = rkeys[base + r * 64 + lane];
+                        const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + slot;
+                        p.kept_keys[o] = (k & 0xFFFFFFFF00000000ull) | (unsigned int)(~(unsigned int)(c * p.max_per_class + slot));
+                        p.kept_idx[o] = (int)(~(unsigned int)(k & 0xFFFFFFFFull));
+                    }
+                    before += __popcll(kmask[r]);
+                }
+                if (lane == 0) misc[0] = k_now;
+            }
+            __syncthreads();
+            kept = misc[0];
+            if (kept >= p.max_per_class) break;
+        }
+        prev = T;
+        remaining -= K;
+        __syncthreads();
     }
     // zero the unused kept slots of this (image, class)
     for (int s = kept + threadIdx.x; s < p.max_per_class; s += blockDim.x) {
@@ -510,12 +567,8 @@ extern "C" int frcnn_decode_boxes(const float* regions, int regions_per_image, c
 }
 
 extern "C" size_t frcnn_nms_workspace_bytes(int b, int n, int c, int max_per_class, int max_total) {
-    (void)max_total;
-    const int n_pad = next_pow2(n);
-    size_t bytes = (size_t)b * c * max_per_class * (sizeof(unsigned long long) + sizeof(int));
-    bool keys_global;
-    nms_class_lds(n_pad, max_per_class, &keys_global);
-    if (keys_global) bytes += (size_t)b * c * n_pad * sizeof(unsigned long long) + 8;
+    (void)max_total; (void)n;
+    const size_t bytes = (size_t)b * c * max_per_class * (sizeof(unsigned long long) + sizeof(int));
     return (bytes + 255) & ~(size_t)255;
 }
 
@@ -527,25 +580,27 @@ extern "C" int frcnn_nms_combined(const float* boxes, const float* scores, int b
     FRCNN_CHECK_ARG(b > 0 && n > 0 && c > 0 && (q == 1 || q == c) && max_per_class > 0 && max_total > 0, "nms_combined: bad sizes");
     FRCNN_CHECK_ARG(workspace_bytes >= frcnn_nms_workspace_bytes(b, n, c, max_per_class, max_total), "nms_combined: workspace too small");
     FRCNN_CHECK_ARG(max_per_class <= 4096, "nms_combined: max_output_size_per_class=%d > 4096 unsupported", max_per_class);
-    const int n_pad = next_pow2(n);
-    FRCNN_CHECK_ARG(n_pad <= (1 << 20), "nms_combined: N too large");
+    FRCNN_CHECK_ARG(n <= (1 << 24), "nms_combined: N too large");
+    FRCNN_CHECK_ARG(iou_thr >= 0.0f, "nms_combined: negative IoU threshold");
     const int m_pad = next_pow2(c * max_per_class);
     FRCNN_CHECK_ARG(m_pad <= NMS_LDS_KEYS, "nms_combined: C*max_per_class=%d too large", c * max_per_class);
 
     unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
     NmsParams p;
     p.boxes = boxes; p.scores = scores; p.N = n; p.q = q; p.C = c; p.score_stride = score_stride; p.score_offset = score_offset;
-    p.max_per_class = max_per_class; p.n_pad = n_pad; p.iou_thr = iou_thr; p.score_thr = score_thr;
+    p.max_per_class = max_per_class; p.iou_thr = iou_thr; p.score_thr = score_thr;
     p.kept_keys = reinterpret_cast<unsigned long long*>(ws);
     p.kept_idx = reinterpret_cast<int*>(ws + (size_t)b * c * max_per_class * sizeof(unsigned long long));
-    p.gkeys = reinterpret_cast<unsigned long long*>(ws + (size_t)b * c * max_per_class * (sizeof(unsigned long long) + sizeof(int)));
-    // keep the u64 scratch 8-byte aligned
-    if (((size_t)b * c * max_per_class * sizeof(int)) % 8) p.gkeys = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(p.gkeys) + 4);
-    bool keys_global;
-    const size_t smem = nms_class_lds(n_pad, max_per_class, &keys_global);
-    p.keys_global = keys_global ? 1 : 0;
-    FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(nms_class_kernel), smem) == 0, "nms_combined: cannot reserve %zu B of LDS", smem);
-    hipLaunchKernelGGL(nms_class_kernel, dim3(b * c), dim3(NMS_T), smem, S_(stream), p);
+    bool lds_keys;
+    const size_t smem = nms_class_lds(n, max_per_class, &lds_keys);
+    p.lds_keys = lds_keys ? 1 : 0;
+    if (lds_keys) {
+        FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(nms_class_kernel<true>), smem) == 0, "nms_combined: cannot reserve %zu B of LDS", smem);
+        hipLaunchKernelGGL(nms_class_kernel<true>, dim3(b * c), dim3(NMS_T), smem, S_(stream), p);
+    } else {
+        FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(nms_class_kernel<false>), smem) == 0, "nms_combined: cannot reserve %zu B of LDS", smem);
+        hipLaunchKernelGGL(nms_class_kernel<false>, dim3(b * c), dim3(NMS_T), smem, S_(stream), p);
+    }
     FRCNN_CHECK_LAUNCH("nms_combined(class)");
 
     MergeParams m;

@@ -14,8 +14,18 @@ LIB = os.path.join(PKG, "lib2dod_hip.so")
 SOURCES = ["elementwise.hip", "conv_tile.hip", "conv_wgrad.hip", "boxes_nms.hip", "roi.hip", "targets_losses.hip", "host_io.hip"]
 HEADERS = ["common.h", "conv_common.h", os.path.join("..", "..", "include", "frcnn_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-DFRCNN_BUILD"]
-if os.environ.get("FRCNN_SWEEP"):            # kernel-development build: extra tile instantiations + FRCNN_TILE / FRCNN_KWS / FRCNN_WGRAD overrides
+# kernel-development variants live in their own library file and object directory (FRCNN_LIB selects it at load time):
+#   FRCNN_SWEEP=1  extra tile instantiations + FRCNN_TILE / FRCNN_KWS / FRCNN_WGRAD overrides  -> lib2dod_hip_sweep.so
+#   FRCNN_STAMPS=1 per-workgroup phase stamps in the conv kernel (tools/conv_stamps.py)          -> lib2dod_hip_stamps.so
+VARIANT = ""
+if os.environ.get("FRCNN_SWEEP"):
     FLAGS.append("-DFRCNN_SWEEP")
+    VARIANT += "_sweep"
+if os.environ.get("FRCNN_STAMPS"):
+    FLAGS.append("-DFRCNN_STAMPS")
+    VARIANT += "_stamps"
+if VARIANT:
+    LIB = os.path.join(PKG, "lib2dod_hip%s.so" % VARIANT)
 
 
 def _newer(target, deps):
@@ -27,7 +37,7 @@ def _newer(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "_obj")
+    objdir = os.path.join(HERE, "_obj" + VARIANT)
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
     jobs = []

@@ -34,6 +34,7 @@ struct ConvParams {
                                             // gradient the residual is) or NULL
     long long in_row_stride, in_img_stride;
     int dry_run;                            // host only: stop before the launch (frcnn_conv2d_describe)
+    unsigned long long* dbg;                // FRCNN_STAMPS builds: per-workgroup phase stamps (NULL otherwise)
 };
 
 template <int BK>

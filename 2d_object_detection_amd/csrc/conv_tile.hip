@@ -62,6 +62,19 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+#ifdef FRCNN_STAMPS
+    // kernel-development build (tools/conv_stamps.py): wave 0 records shader-clock stamps of the workgroup's phases
+    // dbg[blockIdx.x][8] = {entry, K loop start, K loop end (last tile), epilogue stores issued (last tile), exit, HW_ID, realtime, -}
+#define FRCNN_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    if (p.dbg && tid == 0) {
+        p.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, 32 bits
+        p.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    }
+#else
+#define FRCNN_STAMP(i) do { } while (0)
+#endif
+    FRCNN_STAMP(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
     const int frow = lane & 15, fchunk = lane >> 4;
@@ -339,6 +352,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
 
     // ------------------------------------------------------------------ K loops of the run's tiles
 #define FRCNN_WAIT_IMM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    FRCNN_STAMP(1);
     const int total_slices = tile_count * nk;
     if (KWS) {
         issue_slice_kws(0);                      // (nk = 9 * Cin / 64 >= 9)
@@ -416,6 +430,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
             __builtin_amdgcn_s_barrier();        // every wave is done with the ring: the staging tile may overwrite it
         }
 
+        FRCNN_STAMP(2);
         // -------------------------------------------------------------- epilogue of tile t
         // lane holds, for fragment (i,j): pixel = wm*WTM + i*16 + (lane&15); couts = wn*WTN + j*16 + (lane>>4)*4 + 0..3
         if (F32) {
@@ -589,6 +604,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
                 }
             }
         }
+        FRCNN_STAMP(3);
         // (MULTI) the next tile's convert phase writes the staging tile only after >= 1 barrier of its K loop
     }
 #undef FRCNN_WAIT_IMM
@@ -651,12 +667,15 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
                 atomicAdd(p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + n0 + cl, (double)stat_t[tid]);
         }
     }
+    FRCNN_STAMP(4);
+#undef FRCNN_STAMP
 #endif
 }
 
 // Name of the instantiation the calling thread launched last (frcnn_last_conv_instantiation): lets the parity tests assert
 // WHICH kernel a shape dispatched to, so that their coverage cannot rot silently when the heuristics below move.
 thread_local char g_last_inst[192] = "";
+unsigned long long* g_stamp_buffer = nullptr;    // FRCNN_STAMPS builds: set through frcnn_debug_set_stamp_buffer (tools/conv_stamps.py)
 
 template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false>
 int launch_tile(const ConvParams& p, hipStream_t s) {
@@ -864,6 +883,7 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     p.red_part = red ? red->partial : nullptr;
     p.res_mask = res_mask;
     p.dry_run = dry_run ? 1 : 0;
+    p.dbg = g_stamp_buffer;
     p.Hi = d->hi; p.Wi = d->wi; p.in_pix_stride = d->in_pix_stride; p.Cin = d->cin; p.KW = d->kw;
     p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
     p.Ho = d->ho; p.Wo = d->wo; p.Cout = d->cout; p.out_h = d->out_h; p.out_w = d->out_w; p.out_scatter = d->out_scatter;
@@ -900,6 +920,9 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
 }  // namespace
 
 extern "C" const char* frcnn_last_conv_instantiation(void) { return g_last_inst; }
+#ifdef FRCNN_STAMPS
+extern "C" void frcnn_debug_set_stamp_buffer(unsigned long long* dev_buffer) { g_stamp_buffer = dev_buffer; }
+#endif
 void frcnn_note_instantiation(const char* s) { snprintf(g_last_inst, sizeof(g_last_inst), "%s", s); }    // (conv_wgrad.hip)
 
 extern "C" const char* frcnn_conv2d_describe(const frcnn_conv_desc* d, int with_bn_reduce) {
