@@ -119,9 +119,12 @@ def test_conv_dgrad(ops, case):
     part = torch.zeros(ops.STAT_SLOTS, 2, cout, device="cuda")
     dz_d, w_d = dz.to(BF).cuda(), _ohwi(wt).to(BF).cuda()
     z_d = z.to(BF).cuda()
+    # (frcnn_bn_reduce holds raw pointers: every operand stays referenced until the kernel has run)
+    zmask_d, rmask_d = (zmask.cuda() if zmask is not None else None), (rmask.cuda() if rmask is not None else None)
+    mean_d, invstd_d = mean.cuda(), invstd.cuda()
     if case["red"]:
-        red = ops.bn_reduce_args(z_d, zmask.cuda() if zmask is not None else None, mean.cuda(), invstd.cuda(), part)
-        ops.conv2d_dgrad_bnreduce(d, dz_d, w_d, out, red, res=res_d, res_mask=rmask.cuda() if rmask is not None else None)
+        red = ops.bn_reduce_args(z_d, zmask_d, mean_d, invstd_d, part)
+        ops.conv2d_dgrad_bnreduce(d, dz_d, w_d, out, red, res=res_d, res_mask=rmask_d)
     else:
         assert rmask is None
         ops.conv2d_fprop(d, dz_d, w_d, out, res=res_d)

@@ -1,5 +1,5 @@
-"""Debug aid: at 375x1242 batch 4, compare every grouped weight gradient of the train step with an fp64 GEMM of the SAME
-bf16 operands (x, dz as the HIP path stored them): isolates the weight-gradient kernels from BatchNorm-backward rounding."""
+"""Debug aid: at 375x1242 batch 4, re-derive the BatchNorm-backward of a few units from the tensors the HIP path stored
+(torch-GPU fp64 as a calculator) and compare: partial sums, dgamma / dbeta, dz bits, sum(dz)."""
 import importlib
 import os
 import sys
@@ -20,19 +20,31 @@ model.set_weights(params)
 model.train_step(images.cuda(), gl.cuda(), gb.cuda(), OPT.SGD(learning_rate=1e-3))
 torch.cuda.synchronize()
 fe, st = model._train.fe, model.store
-x = fe.pool
-for (n, ci, f, s, first) in fe.specs:
-    u, a = fe.units[n], fe.acts[n]
-    for k in sorted(u):
-        unit = u[k]
-        if unit.k != 1 or unit.stride != 1:
-            continue
-        xin = {0: x, 1: x, 3: a["a2"]}[k]
-        dz = unit.dz.double()
-        ref = dz.t() @ xin.double()                                   # [cout, cin]
-        got = st.grad(unit.name + "_conv/kernel").view(unit.cout, unit.cin).double()
-        err = float((got - ref).norm() / ref.norm())
-        sdz = float(unit.dz.float().sum(0).abs().max()), float(unit.dz.float().abs().mean())
-        print("%-18s M=%6d %4d->%4d  wgrad vs fp64 GEMM of the same operands: %.2e   |sum dz|max %.3e  mean|dz| %.3e  mean x %.3f std x %.3f" % (
-            unit.name, unit.m, unit.cin, unit.cout, err, sdz[0], sdz[1], float(xin.float().mean()), float(xin.float().std())), flush=True)
-    x = a["out"]
+for (bn, k, gname) in (("conv2_block1", 1, "g1"), ("conv2_block1", 2, "g2"), ("conv2_block3", 1, "g1"), ("conv3_block2", 1, "g1"), ("conv4_block6", 2, "g2")):
+    u, a = fe.units[bn][k], fe.acts[bn]
+    g = a[gname].double()
+    bits = ((u.relu_mask[:, :, None] >> torch.arange(8, dtype=torch.uint8, device="cuda")) & 1).reshape(g.shape).bool()
+    gm = torch.where(bits, g, torch.zeros_like(g))
+    z = u.z.double()
+    mean_true = z.mean(0)
+    var_true = z.var(0, unbiased=False)
+    mean, invstd = u.mean.double(), u.invstd.double()
+    xh = (z - mean) * invstd
+    S, Sx = gm.sum(0), (gm * xh).sum(0)
+    part = u.bwd_partial.double().sum(0)
+    gamma = st.weight(u.name + "_bn/gamma").double()
+    m = g.shape[0]
+    dz_ref = (gamma * invstd * (gm - S / m - xh * Sx / m))
+    dz_ref_bf = dz_ref.to(torch.bfloat16)
+    dz_part = (gamma * invstd * (gm - part[0] / m - xh * part[1] / m)).to(torch.bfloat16)
+    dz = u.dz
+    print("%s_%d: M=%d  mean err %.2e  invstd err %.2e | partial sums vs fp64: sum g*m %.2e (abs %.3e of max |S| %.3e), sum g*m*xhat %.2e | "
+          "dbeta err %.2e dgamma err %.2e | dz != bf16(fp64 formula): %.4f%% of elements, != formula with HIP's sums: %.4f%% | "
+          "max|sum dz| HIP %.3e, fp64-formula->bf16 %.3e, fp64 unrounded %.3e | sum xhat max %.3e" % (
+              bn, k, m, float((mean - mean_true).abs().max() / mean_true.abs().max()), float((invstd - 1 / torch.sqrt(var_true + 1.001e-5)).abs().max() / invstd.abs().max()),
+              float((part[0] - S).abs().max() / S.abs().max()), float((part[0] - S).abs().max()), float(S.abs().max()),
+              float((part[1] - Sx).abs().max() / Sx.abs().max()),
+              float((st.grad(u.name + "_bn/beta").double() - S).abs().max() / S.abs().max()), float((st.grad(u.name + "_bn/gamma").double() - Sx).abs().max() / Sx.abs().max()),
+              100.0 * float((dz != dz_ref_bf).float().mean()), 100.0 * float((dz != dz_part).float().mean()),
+              float(dz.double().sum(0).abs().max()), float(dz_ref_bf.double().sum(0).abs().max()), float(dz_ref.sum(0).abs().max()),
+              float(xh.sum(0).abs().max())), flush=True)
