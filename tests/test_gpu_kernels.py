@@ -90,12 +90,12 @@ def test_bn_forward_backward(ops):
     assert torch.equal(out2, out) and torch.equal(mean2, mean) and torch.equal(invstd2, invstd), "fused train apply"
     assert torch.equal(mm2, mm) and torch.equal(mv2, mv), "fused moving statistics"
     assert torch.equal(gpre2, gpre) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta), "fused bwd apply"
-    # dz of the fused kernel is rounded with first-order error feedback along each thread's rows (the column sums of dz, zero in
-    # exact arithmetic, stay exact to an ulp per chain instead of collecting the correlated rounding errors of the masked
-    # elements): every element within ONE bf16 ulp of the exact value, and closer column sums than plain round-to-nearest
-    _close(dz2, zz.grad, 2 ** -6, 2e-3, "dz (fused)")
-    one_ulp = dz.float().abs() * 2 ** -7 + 1e-30
-    assert bool(((dz2.float() - dz.float()).abs() <= one_ulp).all()), "error-feedback rounding moves an element by more than one ulp"
+    # dz of the fused kernel is rounded with first-order error feedback along each thread's rows: the column sums of dz (zero in
+    # exact arithmetic) stay exact to an ulp per chain instead of collecting the correlated rounding errors of a bf16-valued
+    # gradient; an element is off by at most half an ulp of itself plus half an ulp of its predecessor in the chain
+    col_max = zz.grad.abs().max(0).values
+    bound = 2.0 ** -8 * (zz.grad.abs() + col_max) * 1.05 + 2e-3
+    assert bool(((dz2.float().cpu() - zz.grad).abs() <= bound).all()), "dz (fused): beyond the error-feedback rounding bound"
     s_fb, s_rne = dz2.double().sum(0).abs().max(), dz.double().sum(0).abs().max()
     assert float(s_fb) <= float(s_rne) + 1e-6, (float(s_fb), float(s_rne))
     # ReLU bit mask: written by the forward kernel, read by the backward kernels instead of the activation tensor

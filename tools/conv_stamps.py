@@ -93,8 +93,9 @@ def main():
             torch.cuda.synchronize()
             lib.frcnn_debug_set_stamp_buffer(None)
             t = dbg.view(grid, 8).cpu()
-            t0, t1, t2, t3, t4 = (t[:, i].double() for i in range(5))
-            rt = t[:, 6].double()
+            base = t[:, 0].min()                                             # (64-bit counters: subtract in integers first)
+            t0, t1, t2, t3, t4 = ((t[:, i] - base).double() for i in range(5))
+            rt = (t[:, 6] - t[:, 6].min()).double()
             span_ticks = float(t4.max() - t0.min())
             span_rt = float(rt.max() - rt.min())                          # 100 MHz ticks between the first and the last workgroup START
             start_span = float(t0.max() - t0.min())
