@@ -49,7 +49,6 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     constexpr int AK_IT = 3, AK_BYTES = AK_IT * NW * 1024;          // shared A image: 192 rows x 128 B (130 used), two of them
     constexpr int B_BASE = KWS ? 2 * AK_BYTES : S * A_BYTES;
     constexpr int RING = KWS ? 2 * AK_BYTES + S * B_BYTES : S * (A_BYTES + B_BYTES), STG = BM * ROWB;
-    static_assert(SMODE != 2 || (MULTI ? RING + STG : RING) >= NW * 64 * 64, "reduce tree needs 64 B of LDS per thread");
     // one tile per workgroup: the staging tile aliases the drained ring.  Tile runs (MULTI): the ring keeps prefetching the
     // next tile while the epilogue runs, so the staging tile has its own LDS.
     constexpr int STAGE_OFF = MULTI ? RING : 0;
@@ -58,7 +57,6 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;                  // [S A tiles][S B tiles]
     unsigned char* stage = smem + STAGE_OFF;     // [BM][ROWB]
-    float* stat_t = reinterpret_cast<float*>(smem + BIG);   // [2][BN] partial sums of this workgroup (STATS)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -96,9 +94,6 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     }
     const int n0 = tn * BN;
 
-    if (STATS) {
-        if (tid < 2 * BN) stat_t[tid] = 0.f;     // published by the K loop's barriers
-    }
     // bias of this tile's channels (lane: 4 consecutive channels per 16-wide fragment column), issued before the K loop
     float bv[NI][4];
 #pragma unroll
@@ -609,39 +604,52 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     }
 #undef FRCNN_WAIT_IMM
 
+    // ---- flushes of the per-workgroup sums.  Nothing here may wait for the epilogue's global stores (a __syncthreads() or a
+    // DS operation the compiler orders behind vmcnt(0) costs the store round trip, measured 1.3 - 3 us of a 9 - 12 us workgroup
+    // lifetime with only two workgroups per CU): cross-lane shuffles, asm LDS writes, an lgkmcnt-only wait, a raw barrier.
+    // The scratch lies in the drained ring, beside the staging tile (the last tile's store loop may still be reading it).
+    constexpr int FLUSH_OFF = MULTI ? 0 : STG;
+    static_assert(FLUSH_OFF + NW * 2 * BN * 4 <= BIG + 2 * BN * 4, "flush scratch must fit the idle ring");
+    float* fl = reinterpret_cast<float*>(smem + FLUSH_OFF);      // [NW waves][2 sums][BN channels]
+    const unsigned fl_a = lds_addr(fl);
     if (RED) {
-        // the T / C8 row lanes that share a channel vector meet in an LDS tree (the ring / staging region is idle now), then
-        // 2 x BN coalesced float atomics into the consumer layer's slot partial sums
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);             // [16 sums][T threads]: a plane per sum, threads contiguous
-        constexpr int RL = T / C8;                                // (per-thread rows of 16 floats cost 16-way bank conflicts:
-                                                                  //  rocprofv3 SQ_LDS_BANK_CONFLICT was 45-63 % of the LDS cycles)
+        // the T / C8 row lanes that share a channel vector: first inside the wave (lanes with equal lane % C8), then the eight
+        // waves through LDS; 2 x BN coalesced float atomics into the consumer layer's slot partial sums
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[e * T + tid] = rsg[e];
-            red[(8 + e) * T + tid] = rsgz[e];
-        }
-        __syncthreads();
-        for (int st = RL >> 1; st > 0; st >>= 1) {
-            if (lrow_o < st) {
+        for (int sh = C8; sh < 64; sh <<= 1) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) red[e * T + tid] += red[e * T + tid + st * C8];
+            for (int e = 0; e < 8; ++e) {
+                rsg[e] += __shfl_xor(rsg[e], sh);
+                rsgz[e] += __shfl_xor(rsgz[e], sh);
             }
-            __syncthreads();
         }
+        if (lane < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                lds_write_b64(fl_a + ((wave * 2 + 0) * BN + lane * 8 + e) * 4, u32x2{__float_as_uint(rsg[e]), __float_as_uint(rsg[e + 1])});
+                lds_write_b64(fl_a + ((wave * 2 + 1) * BN + lane * 8 + e) * 4, u32x2{__float_as_uint(rsgz[e]), __float_as_uint(rsgz[e + 1])});
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         if (tid < 2 * BN) {
             const int st = tid / BN, cl = tid - st * BN;
             const int c = n0 + cl;
+            float sg = 0.f, sgz = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {                       // fixed order: the workgroup's partial is reproducible
+                sg += fl[(w * 2 + 0) * BN + cl];
+                sgz += fl[(w * 2 + 1) * BN + cl];
+            }
             if (c < p.Cout) {
-                const float sg = red[(cl & 7) * T + (cl >> 3)], sgz = red[(8 + (cl & 7)) * T + (cl >> 3)];
                 const float v = st == 0 ? sg : p.red_invstd[c] * (sgz - p.red_mean[c] * sg);
                 atomicAdd(p.red_part + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + c, v);
             }
         }
     }
     if (STATS) {
-        // the run's tiles share one n-tile: 16-lane butterflies, the two row halves (wm) meet in LDS, then one float atomic
-        // per channel and statistic into one of FRCNN_STAT_SLOTS pre-zeroed slots (consecutive lanes: consecutive channels).
+        // the run's tiles share one n-tile: 16-lane butterflies, the two row halves (wm) meet in LDS, then one f64 atomic per
+        // channel and statistic into one of FRCNN_STAT_SLOTS pre-zeroed slots (consecutive lanes: consecutive channels).
         // The workgroup's own partial is an fp32 sum in a fixed order; the cross-workgroup sum is accumulated in f64, whose
         // rounding (1e-16) makes the arrival order of the atomics invisible in the fp32 statistics derived from it
 #pragma unroll
@@ -654,17 +662,26 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
                     a += __shfl_xor(a, sh);
                     b += __shfl_xor(b, sh);
                 }
-                if (frow == 0) {
-                    const int cl = wn * WTN + j * 16 + fchunk * 4 + e;
-                    atomicAdd(stat_t + cl, a);
-                    atomicAdd(stat_t + BN + cl, b);
-                }
+                ssum[j][e] = a;
+                ssq[j][e] = b;
             }
-        __syncthreads();
+        if (frow == 0) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int cl = wn * WTN + j * 16 + fchunk * 4;
+                lds_write_b64(fl_a + ((wm * 2 + 0) * BN + cl) * 4, u32x2{__float_as_uint(ssum[j][0]), __float_as_uint(ssum[j][1])});
+                lds_write_b64(fl_a + ((wm * 2 + 0) * BN + cl + 2) * 4, u32x2{__float_as_uint(ssum[j][2]), __float_as_uint(ssum[j][3])});
+                lds_write_b64(fl_a + ((wm * 2 + 1) * BN + cl) * 4, u32x2{__float_as_uint(ssq[j][0]), __float_as_uint(ssq[j][1])});
+                lds_write_b64(fl_a + ((wm * 2 + 1) * BN + cl + 2) * 4, u32x2{__float_as_uint(ssq[j][2]), __float_as_uint(ssq[j][3])});
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         if (tid < 2 * BN) {
             const int st = tid / BN, cl = tid - st * BN;
+            const float v = fl[(0 * 2 + st) * BN + cl] + fl[(1 * 2 + st) * BN + cl];          // wm = 0, 1
             if (n0 + cl < p.Cout)
-                atomicAdd(p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + n0 + cl, (double)stat_t[tid]);
+                atomicAdd(p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + n0 + cl, (double)v);
         }
     }
     FRCNN_STAMP(4);
@@ -698,15 +715,8 @@ int launch_tile(const ConvParams& p, hipStream_t s) {
 template <int BM, int BN, int BK, int S, int OCC, bool MULTI>
 int launch_tile_flags(const ConvParams& p, hipStream_t s) {
     const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
-    // the fused reduce needs 64 B of (idle) LDS per thread for its tree
-    constexpr bool red_ok = (MULTI ? S * (BM + BN) * BK * 2 + BM * (BN * 2 + 16) : S * (BM + BN) * BK * 2) >= 512 * 64;
-    if (smode == 2) {
-        if constexpr (red_ok) {
-            return p.linear_a ? launch_tile<BM, BN, BK, S, true, 2, OCC, MULTI>(p, s) : launch_tile<BM, BN, BK, S, false, 2, OCC, MULTI>(p, s);
-        } else {
-            return FRCNN_ENOTSUP;
-        }
-    }
+    if (smode == 2)
+        return p.linear_a ? launch_tile<BM, BN, BK, S, true, 2, OCC, MULTI>(p, s) : launch_tile<BM, BN, BK, S, false, 2, OCC, MULTI>(p, s);
     if (p.linear_a) {
         if (smode == 1) return launch_tile<BM, BN, BK, S, true, 1, OCC, MULTI>(p, s);
         return launch_tile<BM, BN, BK, S, true, 0, OCC, MULTI>(p, s);
@@ -813,7 +823,7 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
     // the instantiations the heuristics above can select
     FRCNN_RUN(128, 64, 64, 2)
     FRCNN_TILE(128, 128, 64, 2, 2)
-    FRCNN_TILE(128, 64, 64, 2, 2)
+    FRCNN_TILE(128, 64, 64, 2, 3)          // (48 KB of LDS, <= 80 VGPRs: three workgroups per CU)
     FRCNN_TILE(128, 64, 64, 3, 2)
     FRCNN_TILE(128, 64, 32, 2, 2)
 #ifdef FRCNN_SWEEP

@@ -46,6 +46,9 @@ def pct(v, q):
     return v[min(len(v) - 1, int(q * len(v)))]
 
 
+RAW = {}
+
+
 def main():
     lib = _lib.load()
     lib.frcnn_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
@@ -93,6 +96,7 @@ def main():
             torch.cuda.synchronize()
             lib.frcnn_debug_set_stamp_buffer(None)
             t = dbg.view(grid, 8).cpu()
+            RAW["%s|%s" % (name, "cold" if cold else "warm")] = t.clone()
             base = t[:, 0].min()                                             # (64-bit counters: subtract in integers first)
             t0, t1, t2, t3, t4 = ((t[:, i] - base).double() for i in range(5))
             rt = (t[:, 6] - t[:, 6].min()).double()
@@ -115,3 +119,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+    if os.path.isdir("gpurun_out"):
+        torch.save(RAW, "gpurun_out/stamps_raw.pt")
