@@ -270,12 +270,22 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                 const int shift = 56 - 8 * pass;
                 for (int t = threadIdx.x; t < NMS_HC * 256; t += NMS_T) hist[t] = 0;
                 __syncthreads();
-                for (int i = threadIdx.x; i < p.N; i += NMS_T) {
-                    const unsigned int sk = score_key(i);
-                    if (sk == 0u) continue;
+                for (int i0 = 0; i0 < p.N; i0 += NMS_T) {         // (all lanes stay in the loop: ballots below)
+                    const int i = i0 + threadIdx.x;
+                    const unsigned int sk = i < p.N ? score_key(i) : 0u;
                     const unsigned long long k = composite(sk, i);
-                    if (k < prev && (pass == 0 || (k >> (shift + 8)) == prefix))
-                        atomicAdd(&hist[(int)((k >> shift) & 255ull) * NMS_HC + (threadIdx.x & (NMS_HC - 1))], 1);
+                    const bool in = sk != 0u && k < prev && (pass == 0 || (k >> (shift + 8)) == prefix);
+                    const int dg = (int)((k >> shift) & 255ull);
+                    // scores cluster (an untrained RPN puts every objectness near 0.5): thousands of same-address LDS atomics
+                    // would serialise, so each wave first merges its lanes with equal digits -- one atomic per distinct digit
+                    unsigned long long todo = __ballot(in);
+                    while (todo != 0ull) {
+                        const int leader = __builtin_ctzll(todo);
+                        const int d0 = __builtin_amdgcn_readlane(dg, leader);
+                        const unsigned long long same = __ballot(in && dg == d0);
+                        if (lane == leader) atomicAdd(&hist[d0 * NMS_HC + (wave & (NMS_HC - 1))], __popcll(same));
+                        todo &= ~same;
+                    }
                 }
                 __syncthreads();
                 if (threadIdx.x < 64) {                       // the digit d with  #(digits above d) < want <= #(digits >= d)
@@ -320,13 +330,19 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
         const int n_sort = K <= NMS_CH ? NMS_CH : K <= 512 ? 512 : NMS_RK;
         for (int t = threadIdx.x; t < n_sort; t += NMS_T) rkeys[t] = 0ull;
         __syncthreads();
-        for (int i = threadIdx.x; i < p.N; i += NMS_T) {
-            const unsigned int sk = score_key(i);
-            if (sk == 0u) continue;
+        for (int i0 = 0; i0 < p.N; i0 += NMS_T) {
+            const int i = i0 + threadIdx.x;
+            const unsigned int sk = i < p.N ? score_key(i) : 0u;
             const unsigned long long k = composite(sk, i);
-            if (k >= T && k < prev) {
-                const int pos = atomicAdd(&misc[6], 1);
-                if (pos < NMS_RK) rkeys[pos] = k;             // (pos < K always; the guard keeps a logic error from corrupting LDS)
+            const bool take = sk != 0u && k >= T && k < prev;
+            const unsigned long long m = __ballot(take);      // one returning atomic per wave, not per candidate
+            if (m != 0ull) {
+                const int leader = __builtin_ctzll(m);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&misc[6], __popcll(m));
+                base = __builtin_amdgcn_readlane(base, leader);
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (take && pos < NMS_RK) rkeys[pos] = k;     // (pos < K always; the guard keeps a logic error from corrupting LDS)
             }
         }
         __syncthreads();

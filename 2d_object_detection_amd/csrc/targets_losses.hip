@@ -69,6 +69,7 @@ __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams
         if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(keep_mask);
     }
     __syncthreads();
+    bool live = false;                    // a kept row whose box has positive width and height (any other row's IoU is 0 with every region)
     if (keep) {
         const int g = threadIdx.x;
         const int n = ((threadIdx.x >> 6) ? wave_cnt[0] : 0) + __popcll(keep_mask & ((1ull << (threadIdx.x & 63)) - 1ull));
@@ -77,10 +78,30 @@ __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams
         garea[n] = (bx[2] - bx[0]) * (bx[3] - bx[1]);
         gsrc[n] = g;
         gobj[n] = obj;
+        live = (bx[2] - bx[0] > 0.0f) && (bx[3] - bx[1] > 0.0f);
     }
     if (threadIdx.x == 0) nvalid = wave_cnt[0] + wave_cnt[1];
     __syncthreads();
     const int ng = nvalid;
+    // The RPN path keeps all G = 100 rows (the objectness conversion turns zero padding into a "background" row,
+    // rpn_detector.py:141 -- SURVEY A.6) although a handful are real boxes.  A row of zero or negative extent has IoU exactly 0
+    // with every region (utils/metrics.py:150-208: its intersection width or height clamps to 0), so it can only decide the
+    // arg-max when NO row has a positive IoU -- and then the first maximum is row 0 whatever the rows are.  The IoU loop
+    // therefore runs over the live rows only (compacted, in order): max / first-arg-max are unchanged, the work drops ~10x.
+    __shared__ int live_idx[kMaxGt];
+    __shared__ int live_cnt[3];
+    {
+        const unsigned long long lm = threadIdx.x < kMaxGt ? __ballot(live) : 0ull;
+        if (threadIdx.x < kMaxGt && (threadIdx.x & 63) == 0) live_cnt[threadIdx.x >> 6] = __popcll(lm);
+        __syncthreads();
+        if (live) {
+            const int n = ((threadIdx.x >> 6) ? wave_cnt[0] : 0) + __popcll(keep_mask & ((1ull << (threadIdx.x & 63)) - 1ull));   // compacted row
+            live_idx[((threadIdx.x >> 6) ? live_cnt[0] : 0) + __popcll(lm & ((1ull << (threadIdx.x & 63)) - 1ull))] = n;
+        }
+        if (threadIdx.x == 0) live_cnt[2] = live_cnt[0] + live_cnt[1];
+        __syncthreads();
+    }
+    const int nlive = live_cnt[2];
 
     // ---- pass 1: per-region max IoU / first argmax; stash them in the output buffers
     float best_v = -1.f;
@@ -88,13 +109,13 @@ __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams
     for (int r = threadIdx.x; r < p.R; r += blockDim.x) {
         const f32x4 rb = *reinterpret_cast<const f32x4*>(regions + (int64_t)r * 4);
         const float ra = (rb[2] - rb[0]) * (rb[3] - rb[1]);
-        float mx = -INFINITY;
-        int am = 0;
-        for (int g = 0; g < ng; ++g) {
+        float mx = 0.f;                   // (every kept row contributes an IoU >= 0; rows of no extent exactly 0)
+        int am = 0;                       // first maximum when all IoUs are 0: row 0
+        for (int l = 0; l < nlive; ++l) {
+            const int g = live_idx[l];
             const float v = ref_iou(rb, ra, gbox[g], garea[g]);
             if (v > mx) { mx = v; am = g; }
         }
-        if (ng == 0) mx = 0.f;
         tl[(int64_t)r * p.C1] = mx;
         tl[(int64_t)r * p.C1 + 1] = __int_as_float(am);
         if (mx > best_v || (mx == best_v && r < best_i)) { best_v = mx; best_i = r; }
@@ -164,60 +185,73 @@ struct SampleParams {
 constexpr int kFgLds = 8192;
 
 __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
-    __shared__ int cnt_fg[256], cnt_bg[256];
+    __shared__ int wave_fg[4], wave_bg[4];
     __shared__ int fg_lds[kFgLds];
-    __shared__ int tot[2];
+    __shared__ int swap_j[1024];          // partner position of step i of the partial Fisher-Yates (S <= 1024)
     const int b = blockIdx.x;
     const float* tl = p.tl + (int64_t)b * p.R * p.C1;
     int* fg_list = p.ws + (int64_t)b * 2 * p.R;
     int* bg_list = fg_list + p.R;
-    const int seg = (p.R + 255) / 256;
-    const int r0 = threadIdx.x * seg, r1 = min(p.R, r0 + seg);
-    int nf = 0, nb = 0;
-    for (int r = r0; r < r1; ++r) {
-        float s = 0.f;
-        for (int c = 0; c < p.C1; ++c) s += tl[(int64_t)r * p.C1 + c];
-        const float l0 = tl[(int64_t)r * p.C1];
-        if (s != 0.0f && l0 == 0.0f) ++nf;
-        if (s != 0.0f && l0 == 1.0f) ++nb;
-    }
-    cnt_fg[threadIdx.x] = nf;
-    cnt_bg[threadIdx.x] = nb;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int af = 0, ab = 0;
-        for (int t = 0; t < 256; ++t) {
-            const int f = cnt_fg[t], g = cnt_bg[t];
-            cnt_fg[t] = af; cnt_bg[t] = ab;
-            af += f; ab += g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // candidate lists in ascending region order (training.py:99-104).  Every wave owns a contiguous quarter of the regions and
+    // walks it 64 rows at a time (coalesced); ballots give the order-preserving slots.  Two sweeps: count, then write.
+    const int per_wave = ((p.R + 3) / 4 + 63) / 64 * 64;
+    const int w0 = wave * per_wave, w1 = min(p.R, w0 + per_wave);
+    auto classify = [&](const int r, bool& is_fg, bool& is_bg) {
+        float s = 0.f, l0 = 0.f;
+        if (r < w1) {
+            l0 = tl[(int64_t)r * p.C1];
+            for (int c = 0; c < p.C1; ++c) s += tl[(int64_t)r * p.C1 + c];
         }
-        tot[0] = af; tot[1] = ab;
+        is_fg = r < w1 && s != 0.0f && l0 == 0.0f;
+        is_bg = r < w1 && s != 0.0f && l0 == 1.0f;
+    };
+    int nf = 0, nb = 0;
+    for (int r0 = w0; r0 < w1; r0 += 64) {
+        bool f, g;
+        classify(r0 + lane, f, g);
+        nf += __popcll(__ballot(f));
+        nb += __popcll(__ballot(g));
     }
+    if (lane == 0) { wave_fg[wave] = nf; wave_bg[wave] = nb; }
     __syncthreads();
-    int of = cnt_fg[threadIdx.x], ob = cnt_bg[threadIdx.x];
-    for (int r = r0; r < r1; ++r) {
-        float s = 0.f;
-        for (int c = 0; c < p.C1; ++c) s += tl[(int64_t)r * p.C1 + c];
-        const float l0 = tl[(int64_t)r * p.C1];
-        if (s != 0.0f && l0 == 0.0f) fg_list[of++] = r;
-        if (s != 0.0f && l0 == 1.0f) bg_list[ob++] = r;
+    int of = 0, ob = 0, nfg = 0, nbg = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) { of += wave_fg[w]; ob += wave_bg[w]; }
+        nfg += wave_fg[w];
+        nbg += wave_bg[w];
     }
-    __syncthreads();
-    const int nfg = tot[0], nbg = tot[1];
+    const bool in_lds = nfg <= kFgLds;
+    for (int r0 = w0; r0 < w1; r0 += 64) {
+        bool f, g;
+        classify(r0 + lane, f, g);
+        const unsigned long long mf = __ballot(f), mg = __ballot(g);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (f) {
+            const int pos = of + __popcll(mf & below);
+            fg_list[pos] = r0 + lane;
+            if (in_lds) fg_lds[pos] = r0 + lane;
+        }
+        if (g) bg_list[ob + __popcll(mg & below)] = r0 + lane;
+        of += __popcll(mf);
+        ob += __popcll(mg);
+    }
     const int n_fg = min(nfg, p.max_fg);
     const int n_bg = p.S - n_fg;
     const unsigned int step = (unsigned int)(*p.step);
     int* out = p.out + (int64_t)b * p.S;
-    // fg: partial Fisher-Yates (== shuffle then take), sequential by construction
-    const bool in_lds = nfg <= kFgLds;
-    if (in_lds)
-        for (int i = threadIdx.x; i < nfg; i += blockDim.x) fg_lds[i] = fg_list[i];
-    __syncthreads();
+    // fg: partial Fisher-Yates (== shuffle then take).  The swap chain is sequential by construction, its random partners are
+    // not: all threads draw them first (Philox + the modulo were 3/4 of this kernel's time on the one lane walking the chain)
+    for (int i = threadIdx.x; i < n_fg; i += blockDim.x) {
+        const unsigned int rnd = philox_first((unsigned)i, (unsigned)b, step, (unsigned)(p.stream_base + 0), p.k0, p.k1);
+        swap_j[i] = i + (int)(rnd % (unsigned)(nfg - i));
+    }
+    __syncthreads();                       // (also publishes fg_list / fg_lds / bg_list inside the workgroup)
     if (threadIdx.x == 0) {
         int* lst = in_lds ? fg_lds : fg_list;
         for (int i = 0; i < n_fg; ++i) {
-            const unsigned int rnd = philox_first((unsigned)i, (unsigned)b, step, (unsigned)(p.stream_base + 0), p.k0, p.k1);
-            const int j = i + (int)(rnd % (unsigned)(nfg - i));
+            const int j = swap_j[i];
             const int a = lst[i], c = lst[j];
             lst[i] = c; lst[j] = a;
             out[i] = c;
@@ -382,6 +416,7 @@ extern "C" int frcnn_sample_indices(const float* target_labels, int b, int r, in
                                     const int64_t* step, int stream_base, int32_t* indices, int32_t* workspace, int32_t* status,
                                     frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(target_labels && step && indices && workspace && status && b > 0 && r > 0 && num_samples > 0, "sample_indices: bad arguments");
+    FRCNN_CHECK_ARG(num_samples <= 1024, "sample_indices: num_samples=%d > 1024 unsupported", num_samples);
     SampleParams p;
     p.tl = target_labels; p.R = r; p.C1 = c1; p.S = num_samples;
     p.max_fg = (int)nearbyint((double)num_samples * (double)fg_proportion);   // tf.math.round: half to even
