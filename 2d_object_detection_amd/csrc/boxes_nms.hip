@@ -373,8 +373,13 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                 const f32x4 cb = chunk_box[cand];
                 const float ca = chunk_area[cand];
                 int hit = 0;
-                for (int j = sub; j < kept; j += 4)
-                    if (nms_over(cb, ca, kept_box[j], kept_area[j], p.iou_thr)) { hit = 1; break; }
+                for (int j0 = sub; j0 < kept && !hit; j0 += 16) {          // four independent tests per trip (LDS latency overlaps)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + 4 * u;
+                        if (j < kept && nms_over(cb, ca, kept_box[j], kept_area[j], p.iou_thr)) hit = 1;
+                    }
+                }
                 hit |= __shfl_xor(hit, 1);
                 hit |= __shfl_xor(hit, 2);
                 if (sub == 0 && hit) dead[cand] = 1;
@@ -394,15 +399,31 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
             }
             __syncthreads();
             const int n_alive = misc[1];
-            for (int pair = wave; pair < n_alive * 4; pair += NMS_T / 64) {
-                const int i = rows[pair >> 2], w = pair & 3;
-                unsigned long long m = 0ull;
-                if (w * 64 + 63 > i) {                          // (wave-uniform) something later than i lives in this word
-                    const int j = w * 64 + lane;
-                    const bool sgt = j > i && !dead[j] && nms_over(chunk_box[j], chunk_area[j], chunk_box[i], chunk_area[i], p.iou_thr);
-                    m = __ballot(sgt);
+            {
+                // a lane's four column candidates (j = 64 w + lane) stay in registers for all the rows of its wave; a row costs
+                // one broadcast read of its box and four independent overlap tests (the per-(row, word) loop with its chain of
+                // dependent LDS reads was the largest single piece of this kernel)
+                f32x4 cb[4];
+                float ca[4];
+                bool cdead[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    cb[w] = chunk_box[w * 64 + lane];
+                    ca[w] = chunk_area[w * 64 + lane];
+                    cdead[w] = dead[w * 64 + lane] != 0;
                 }
-                if (lane == 0) sup_of[i * 4 + w] = m;
+                for (int ri = wave; ri < n_alive; ri += NMS_T / 64) {
+                    const int i = rows[ri];
+                    const f32x4 rb = chunk_box[i];
+                    const float ra = chunk_area[i];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int j = w * 64 + lane;
+                        const bool sgt = j > i && !cdead[w] && nms_over(cb[w], ca[w], rb, ra, p.iou_thr);
+                        const unsigned long long m = __ballot(sgt);
+                        if (lane == 0) sup_of[i * 4 + w] = m;
+                    }
+                }
             }
             __syncthreads();
             // ---- 4. walk the survivors in score order (wave 0): one step per kept box

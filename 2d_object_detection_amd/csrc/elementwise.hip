@@ -222,22 +222,6 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
     __shared__ double red[2][4][64];
     __shared__ float s_scale[64], s_shift[64];
     const int c0 = blockIdx.x * 64;
-    // The first PF rows of this thread are requested BEFORE the statistics prologue (slot sums -> mean / invstd -> scale / shift:
-    // a dependent chain of global loads, two barriers and an f64 square root, ~2-3 us in every one of the ~1000 workgroups):
-    // their HBM latency runs under it instead of after it.
-    constexpr int PF = 4;
-    const int pv = threadIdx.x & 7, prl = threadIdx.x >> 3;
-    const int pC8 = C / 8, pcv = c0 / 8 + pv;
-    const int64_t prow_begin = (int64_t)blockIdx.y * rows_per_block;
-    const int64_t prow_end = min(M, prow_begin + (int64_t)rows_per_block);
-    u32x4 pz[PF], pr[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int64_t r = prow_begin + prl + 32 * u;
-        const bool ok = pcv < pC8 && r < prow_end;
-        pz[u] = ok ? *reinterpret_cast<const u32x4*>(z + (r * pC8 + pcv) * 8) : u32x4{0u, 0u, 0u, 0u};
-        pr[u] = (ok && res) ? *reinterpret_cast<const u32x4*>(res + (r * pC8 + pcv) * 8) : u32x4{0u, 0u, 0u, 0u};
-    }
     {
         const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
         const int c = c0 + cl;
@@ -275,16 +259,18 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = s_scale[v * 8 + e]; sh[e] = s_shift[v * 8 + e]; }
-    const int64_t row_begin = prow_begin, row_end = prow_end;
-    auto process = [&](const int64_t r, const u32x4 zv, const u32x4 rv) {
+    const int64_t row_begin = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
+#pragma unroll 4
+    for (int64_t r = row_begin + rl; r < row_end; r += 32) {
         const int64_t i = r * C8 + cv;
         float x[8];
-        unpack8(zv, x);
+        unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), x);
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = x[e] * sc[e] + sh[e];
         if (res) {
             float q[8];
-            unpack8(rv, q);
+            unpack8(*reinterpret_cast<const u32x4*>(res + i * 8), q);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] += q[e];
         }
@@ -314,16 +300,6 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
                 relu_mask[i] = (uint8_t)m;
             }
         }
-    };
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int64_t r = row_begin + rl + 32 * u;
-        if (r < row_end) process(r, pz[u], pr[u]);
-    }
-#pragma unroll 4
-    for (int64_t r = row_begin + rl + 32 * PF; r < row_end; r += 32) {
-        const int64_t i = r * C8 + cv;
-        process(r, *reinterpret_cast<const u32x4*>(z + i * 8), res ? *reinterpret_cast<const u32x4*>(res + i * 8) : u32x4{0u, 0u, 0u, 0u});
     }
 }
 
@@ -341,24 +317,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
     __shared__ float s_par[4][64];                // gamma*invstd, mean, invstd (xhat), c1, c2 folded: a, mu, is, k1, k2
     __shared__ float s_c2[64];
     const int c0 = blockIdx.x * 64;
-    // the first PF rows are requested before the partial-sum prologue (as in bn_train_apply_kernel)
-    constexpr int PF = 4;
-    const int pv = threadIdx.x & 7, prl = threadIdx.x >> 3;
-    const int pC8 = C / 8, pcv = c0 / 8 + pv;
-    const int64_t prow_begin = (int64_t)blockIdx.y * rows_per_block;
-    const int64_t prow_end = min(M, prow_begin + (int64_t)rows_per_block);
-    u32x4 pg[PF], pz[PF], pa[PF];
-    unsigned pm[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int64_t r = prow_begin + prl + 32 * u;
-        const bool ok = pcv < pC8 && r < prow_end;
-        const int64_t i = r * pC8 + pcv;
-        pg[u] = ok ? *reinterpret_cast<const u32x4*>(gout + i * 8) : u32x4{0u, 0u, 0u, 0u};
-        pz[u] = ok ? *reinterpret_cast<const u32x4*>(z + i * 8) : u32x4{0u, 0u, 0u, 0u};
-        pa[u] = (ok && MASK == 1) ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(act) + i * 8) : u32x4{0u, 0u, 0u, 0u};
-        pm[u] = (ok && MASK == 2) ? reinterpret_cast<const uint8_t*>(act)[i] : 0u;
-    }
     {
         const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
         const int c = c0 + cl;
@@ -396,7 +354,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
         ga[e] = s_par[0][v * 8 + e]; mu[e] = s_par[1][v * 8 + e]; is[e] = s_par[2][v * 8 + e];
         k1[e] = s_par[3][v * 8 + e]; k2[e] = s_c2[v * 8 + e];
     }
-    const int64_t row_begin = prow_begin, row_end = prow_end;
+    const int64_t row_begin = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
     // dz is stored in bf16, and sum_rows(dz) is exactly zero in exact arithmetic.  Plain round-to-nearest breaks that by far more
     // than a random walk: the incoming gradient g is itself bf16, so per channel dz = a*(g - c1 - xhat*c2) takes ~1000 distinct
     // values a*g shifted by the tiny c1, each with ITS fixed rounding error, repeated over 10^5 rows -- the errors add coherently
@@ -408,17 +367,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
     float carry[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) carry[e] = 0.f;
-    auto process = [&](const int64_t r, const u32x4 gv, const u32x4 zv, const u32x4 av, const unsigned m) {
+#pragma unroll 2
+    for (int64_t r = row_begin + rl; r < row_end; r += 32) {
         const int64_t i = r * C8 + cv;
         float g[8], zz[8], o[8];
-        unpack8(gv, g);
-        unpack8(zv, zz);
+        unpack8(*reinterpret_cast<const u32x4*>(gout + i * 8), g);
+        unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), zz);
         if (MASK == 1) {
             float a[8];
-            unpack8(av, a);
+            unpack8(*reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(act) + i * 8), a);
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
         } else if (MASK == 2) {
+            const unsigned m = reinterpret_cast<const uint8_t*>(act)[i];
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
         }
@@ -431,18 +392,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
         }
         *reinterpret_cast<u32x4*>(dz + i * 8) = pack8(o);
         if (gpre) *reinterpret_cast<u32x4*>(gpre + i * 8) = pack8(g);
-    };
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int64_t r = row_begin + rl + 32 * u;
-        if (r < row_end) process(r, pg[u], pz[u], pa[u], pm[u]);
-    }
-#pragma unroll 2
-    for (int64_t r = row_begin + rl + 32 * PF; r < row_end; r += 32) {
-        const int64_t i = r * C8 + cv;
-        process(r, *reinterpret_cast<const u32x4*>(gout + i * 8), *reinterpret_cast<const u32x4*>(z + i * 8),
-                MASK == 1 ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(act) + i * 8) : u32x4{0u, 0u, 0u, 0u},
-                MASK == 2 ? (unsigned)reinterpret_cast<const uint8_t*>(act)[i] : 0u);
     }
 }
 
