@@ -104,7 +104,9 @@ class FastRCNNDetector:
         self.scores = torch.empty(batch, num_rois, self.c1, device=dev)
         self.deltas = torch.empty(batch, num_rois, self.num_classes, 4, device=dev)
         self.regions_abs = torch.empty(batch, num_rois, 4, device=dev)
-        split = max(1, min(64, self.flat // 64 // 8))
+        # K split of the Dense-head GEMM ([B*P] x 50176 x 64): every split adds one fp32 tile of float atomics (memory side,
+        # 1.3 TB/s); measured over 4..98 splits (tools/head_gemm_bench.py): 12-24 are fastest (29-30 us against 36 at 64)
+        split = max(1, min(16, self.flat // 64 // 8))
         self.d_fwd = ops.conv_desc(1, 1, r, self.flat, 1, 1, 1, 0, 0, 1, r, HEAD_LD, flags=ops.CONV_SPLITK_ATOMIC, split_k=split)
         self.w_t = torch.zeros(self.flat, 1, 1, HEAD_LD, dtype=BF16, device=dev)
         if training:
