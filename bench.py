@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--lr-scale", type=float, default=0.01)
+    ap.add_argument("--depth", type=int, default=50, help="ResNet depth (101 with --proposals 1000 --batch-per-gpu 2 = BASELINE.json configs[3])")
+    ap.add_argument("--proposals", type=int, default=0, help="RPN NMS max_total_size / max_output_size_per_class (0: config.json's 300)")
     args = ap.parse_args()
 
     D = importlib.import_module("2d_object_detection_amd.distributed")
@@ -277,8 +279,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cfg = C.default_config()                                   # 375 x 1242, 7 classes, reference hyper-parameters
+    if args.proposals:
+        cfg["rpn"]["nms"]["max_total_size"] = cfg["rpn"]["nms"]["max_output_size_per_class"] = args.proposals
     B = args.batch_per_gpu
-    model = M.FasterRCNN(cfg, device=dev, seed=0, sampling_seed=rank, world_size=world)   # (per-rank fg/bg sample positions)
+    model = M.FasterRCNN(cfg, depth=args.depth, device=dev, seed=0, sampling_seed=rank, world_size=world)   # (per-rank fg/bg sample positions)
     model.use_graphs = not args.no_graphs
     # Reference schedule shape (train_faster_rcnn.py:62-68: boundaries 40k/80k), scaled by --lr-scale: the reference's
     # 1e-3 presumes ImageNet-pretrained weights; with the seeded random init used here (no network) and the un-normalised
@@ -328,8 +332,9 @@ def main():
         "metric": METRIC, "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic",
-        "config": {"workload": "ResNet-50(C4) Faster-RCNN full train step, bf16, batch %d per GPU, 375x1242 synthetic KITTI, "
-                               "300 proposals, 7 classes (BASELINE.json configs[%d])" % (B, 1 if world == 1 else 2),
+        "config": {"workload": "ResNet-%d(C4) Faster-RCNN full train step, bf16, batch %d per GPU, 375x1242 synthetic KITTI, "
+                               "%d proposals, 7 classes (BASELINE.json configs[%d])" % (
+                                   args.depth, B, args.proposals or 300, 3 if args.depth == 101 else 1 if world == 1 else 2),
                    "global_batch": world * B, "image_shape": cfg["image_shape"], "parallelism": "dp%d" % world,
                    "hip_graphs": model.use_graphs, "kernel_launches_per_step": model._train_plan["plan"].num_launches},
         "windows": {"steps_each": args.steps, "ms_per_step": [round(x, 4) for x in window_ms], "min": round(srt[0], 4),
