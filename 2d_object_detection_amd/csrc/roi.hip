@@ -63,6 +63,53 @@ __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__
     __syncthreads();
     const unsigned char* fb = reinterpret_cast<const unsigned char*>(feat + (int64_t)b * Hf * Wf * C8 * 8);
     const int items = ps * ps * C8;
+    if (KS == 2) {
+        // 2 x 2 pooling window, fully unrolled.  Taps come through a buffer descriptor of this image's map: 32-bit offsets (no
+        // 64-bit address arithmetic per tap), and an invalid sample points all four taps beyond the descriptor -- the range check
+        // returns zeros and the interpolation of zeros with a zeroed weight is exactly 0, the extrapolation value -- so the loop
+        // has no branch.  The maximum is a v_max3 + v_max; the arg-max (first maximum, as the strict '>' scan gives) is
+        // recovered afterwards from the four kept samples.
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fb, 0, Hf * Wf * C8 * 16, 0x00020000);
+        constexpr unsigned kBeyond = 0xFFFFFFF0u;
+        for (int it = threadIdx.x; it < items; it += blockDim.x) {
+            const int cv = it % C8;
+            const int bin = it / C8;
+            const int ph = bin / ps, pw = bin - ph * ps;
+            const unsigned c16 = (unsigned)cv * 16u;
+            float v[4][8];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const int4 yy = ys[ph * 2 + (s_ >> 1)], xx = xs[pw * 2 + (s_ & 1)];
+                const bool ok = (yy.w & xx.w) != 0;
+                const float ly = ok ? __int_as_float(yy.z) : 0.f, lx = ok ? __int_as_float(xx.z) : 0.f;
+                float tl[8], tr[8], bl[8], br[8];
+                unpack8(__builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(yy.x + xx.x) + c16 : kBeyond, 0, 0), tl);
+                unpack8(__builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(yy.x + xx.y) + c16 : kBeyond, 0, 0), tr);
+                unpack8(__builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(yy.y + xx.x) + c16 : kBeyond, 0, 0), bl);
+                unpack8(__builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(yy.y + xx.y) + c16 : kBeyond, 0, 0), br);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float top = fmaf(tr[e] - tl[e], lx, tl[e]);
+                    const float bot = fmaf(br[e] - bl[e], lx, bl[e]);
+                    v[s_][e] = fmaf(bot - top, ly, top);
+                }
+            }
+            float best[8];
+            unsigned arg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                best[e] = fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0][e], v[1][e]), v[2][e]), v[3][e]);
+                arg[e] = v[0][e] == best[e] ? 0u : v[1][e] == best[e] ? 1u : v[2][e] == best[e] ? 2u : 3u;
+            }
+            const int64_t o = ((int64_t)row * ps * ps + bin) * C8 + cv;
+            *reinterpret_cast<u32x4*>(pooled + o * 8) = pack8(best);
+            u32x2 a;
+            a[0] = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+            a[1] = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+            *reinterpret_cast<u32x2*>(amax + o * 8) = a;
+        }
+        return;
+    }
     for (int it = threadIdx.x; it < items; it += blockDim.x) {
         const int cv = it % C8;
         const int bin = it / C8;
@@ -71,8 +118,7 @@ __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__
         unsigned char arg[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = 0; }
-#pragma unroll
-        for (int s = 0; s < (KS > 0 ? KS * KS : ks * ks); ++s) {
+        for (int s = 0; s < ks * ks; ++s) {
             const int4 yy = ys[ph * ks + s / ks], xx = xs[pw * ks + s % ks];
             float v[8];
             if (!(yy.w & xx.w)) {
