@@ -140,8 +140,11 @@ class FastRCNNDetector:
         st = self.store
         plan.add(ops.rcnn_head_grad, dlogits_s, ddeltas_s, indices, self.batch, self.p, self.c1, num_samples, self.dhead_s, HEAD_LD,
                  self.rows)
-        plan.add(ops.colsum_bf16, self.dhead_s, self.rs, HEAD_LD, HEAD_LD, st.grad("fast_rcnn_heads/bias"))
-        plan.add(ops.conv2d_wgrad, self.d_wgrad, self.pooled, self.dhead_s, st.grad("fast_rcnn_heads/kernel"), HEAD_LD, self.rows)
+        # the head's parameter gradients are needed by nobody before the update: off the chain that leads to the RoI backward
+        # pass and the backbone (the branch is joined at the end of the plan segment)
+        with plan.branch("head_param_grads"):
+            plan.add(ops.colsum_bf16, self.dhead_s, self.rs, HEAD_LD, HEAD_LD, st.grad("fast_rcnn_heads/bias"))
+            plan.add(ops.conv2d_wgrad, self.d_wgrad, self.pooled, self.dhead_s, st.grad("fast_rcnn_heads/kernel"), HEAD_LD, self.rows)
         plan.add(ops.conv2d_fprop, self.d_dgrad, self.dhead_s, self.w_t, self.dpooled_s)
         # gather form: every element of g_feat is written once, in bf16, without global atomics (no memset / cast passes)
         plan.add(ops.roi_crop_pool_bwd_bf16, self.dpooled_s, self.argmax, rois, self.rows, self.rs, self.batch, self.p, self.hf, self.wf,

@@ -25,3 +25,11 @@ python3 profiles/summarize.py $STATS $STEPS 60 > profiles/${TAG}_summary.txt
 python3 profiles/hbm_traffic.py $TAG $STEPS $STATS $FETCH $WRITE "rocprofv3 --kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python3 $CMD" > $OUT/families.json
 cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_summary.txt profiles/${TAG}_hbm_per_kernel.csv profiles/r02_offline.json $OUT/
 head -12 profiles/${TAG}_summary.txt
+# optional 4th pass (PMC_TABLE=1): SQ counters of an eager run -> profiles/<tag>_pmc_counters.txt (matrix-pipe / LDS busy per kernel)
+if [ -n "$PMC_TABLE" ]; then
+  PCMD="bench.py --steps 3 --warmup 1 --windows 1 --no-graphs --profile-steps 0 --no-cpu-baseline"
+  rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU -d $OUT/sq -o p --output-format csv -- python3 $PCMD > $OUT/bench_sq.json 2> $OUT/sq.err
+  python3 profiles/pmc_table.py $(find $OUT/sq -name '*counter_collection.csv' | head -1) "python3 $PCMD" > profiles/${TAG}_pmc_counters.txt
+  cp profiles/${TAG}_pmc_counters.txt $OUT/
+  echo "SQ counter pass done"
+fi
