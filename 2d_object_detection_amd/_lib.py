@@ -51,6 +51,7 @@ _SIGNATURES = {
     "frcnn_weights_transpose_flip_batched": (c_int, [P, c_int, c_int64, P]),
     "frcnn_cast_f32_bf16": (c_int, [P, P, c_int64, P]),
     "frcnn_copy_bytes": (c_int, [P, P, c_int64, P]),
+    "frcnn_copy_bytes_multi": (c_int, [P, P, P, c_int, P]),
     "frcnn_fill_zero_multi": (c_int, [P, c_int, c_int64, P]),
     "frcnn_stem_pack_weights": (c_int, [P, P, c_int, P]),
     "frcnn_stem_unpack_grad": (c_int, [P, P, c_int, P]),
@@ -73,6 +74,7 @@ _SIGNATURES = {
     "frcnn_anchors_generate": (c_int, [P, c_int, c_int, POINTER(c_float), c_int, POINTER(c_float), c_int,
                                        c_float, c_float, c_float, c_float, P]),
     "frcnn_rpn_head_post": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P]),
+    "frcnn_rpn_head_post_decode": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, c_float, P]),
     "frcnn_clip_to_window": (c_int, [P, P, c_int64, c_float, c_float, c_float, c_float, P]),
     "frcnn_decode_boxes": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_float, c_float, P]),
     "frcnn_encode_boxes": (c_int, [P, P, c_int, P, c_int, c_int, c_int, P]),
@@ -89,6 +91,8 @@ _SIGNATURES = {
                                      c_float, c_float, c_float, P, P, P]),
     "frcnn_sample_indices": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_uint64, P, c_int, P, P, P, P]),
     "frcnn_losses": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P]),
+    "frcnn_losses_rpn_head_grad": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_int, c_int, P, c_int, P]),
+    "frcnn_losses_head_grad": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_int, P, P]),
     "frcnn_rpn_head_grad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
     "frcnn_rcnn_head_grad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P]),
     "frcnn_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, P, c_size_t]),

@@ -36,9 +36,19 @@ __global__ void anchors_kernel(float* __restrict__ out, int gh, int gw, AnchorSh
     }
 }
 
-// ---------------------------------------------------------------- RPN head post
+// utils/boxes.py:20-41 + :86-93: region + regression deltas -> box, relative to the image
+__device__ __forceinline__ f32x4 decode_one(const f32x4 ref, const f32x4 d, const float W, const float H) {
+    const float cxr = (ref[2] + ref[0]) / 2.0f, cyr = (ref[3] + ref[1]) / 2.0f;
+    const float wr = ref[2] - ref[0], hr = ref[3] - ref[1];
+    const float cx = d[0] * wr + cxr, cy = d[1] * hr + cyr;
+    const float w = expf(d[2]) * wr, h = expf(d[3]) * hr;
+    return f32x4{(cx - 0.5f * w) / W, (cy - 0.5f * h) / H, (cx + 0.5f * w) / W, (cy + 0.5f * h) / H};
+}
+
+// ---------------------------------------------------------------- RPN head post (+ optionally the decode of proposal NMS)
 __global__ void rpn_head_post_kernel(const float* __restrict__ head, int ld, int B, int A_total, int apl, const int* __restrict__ keep,
-                                     int n, float* __restrict__ scores, float* __restrict__ deltas) {
+                                     int n, float* __restrict__ scores, float* __restrict__ deltas, const float* __restrict__ regions,
+                                     float* __restrict__ decoded, float W, float H) {
     const int total = B * n;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int b = i / n, j = i - b * n;
@@ -53,7 +63,9 @@ __global__ void rpn_head_post_kernel(const float* __restrict__ head, int ld, int
         scores[(int64_t)i * 2] = e0 * inv;
         scores[(int64_t)i * 2 + 1] = e1 * inv;
         const float* d = row + 2 * apl + 4 * k;
-        *reinterpret_cast<f32x4*>(deltas + (int64_t)i * 4) = f32x4{d[0], d[1], d[2], d[3]};
+        const f32x4 dv = {d[0], d[1], d[2], d[3]};
+        *reinterpret_cast<f32x4*>(deltas + (int64_t)i * 4) = dv;
+        if (decoded) *reinterpret_cast<f32x4*>(decoded + (int64_t)i * 4) = decode_one(*reinterpret_cast<const f32x4*>(regions + (int64_t)j * 4), dv, W, H);
     }
 }
 
@@ -104,7 +116,6 @@ __global__ void encode_kernel(const float* __restrict__ boxes, const float* __re
     }
 }
 
-// utils/boxes.py:20-41 + :86-93
 __global__ void decode_kernel(const float* __restrict__ regions, int rpi, const float* __restrict__ deltas, float* __restrict__ out, int B,
                               int R, int C, float W, float H) {
     const int64_t total = (int64_t)B * R * C;
@@ -114,12 +125,7 @@ __global__ void decode_kernel(const float* __restrict__ regions, int rpi, const 
         const int b = (int)(br / R);
         const f32x4 ref = *reinterpret_cast<const f32x4*>(regions + ((rpi ? (int64_t)b * R : 0) + r) * 4);
         const f32x4 d = *reinterpret_cast<const f32x4*>(deltas + i * 4);
-        const float cxr = (ref[2] + ref[0]) / 2.0f, cyr = (ref[3] + ref[1]) / 2.0f;
-        const float wr = ref[2] - ref[0], hr = ref[3] - ref[1];
-        const float cx = d[0] * wr + cxr, cy = d[1] * hr + cyr;
-        const float w = expf(d[2]) * wr, h = expf(d[3]) * hr;
-        f32x4 o = {(cx - 0.5f * w) / W, (cy - 0.5f * h) / H, (cx + 0.5f * w) / W, (cy + 0.5f * h) / H};
-        *reinterpret_cast<f32x4*>(out + i * 4) = o;
+        *reinterpret_cast<f32x4*>(out + i * 4) = decode_one(ref, d, W, H);
     }
 }
 
@@ -200,6 +206,9 @@ struct NmsParams {
     float iou_thr, score_thr;
     unsigned long long* kept_keys;   // [B][C*max_per_class]: (score key << 32 | ~(class*max_per_class + slot)) or 0
     int* kept_idx;                   // [B][C*max_per_class] box index
+    // C == 1 only (proposal NMS): the class list IS the image's merged list, so this kernel also writes the final outputs
+    // (no nms_merge_kernel launch); null otherwise
+    float* out_boxes; float* out_scores; int* out_classes; int* out_valid; int max_total;
 };
 
 // LDS of nms_class_kernel; *lds_keys: the 32-bit score keys of the N candidates are staged in LDS (else re-read from global)
@@ -514,6 +523,29 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
         p.kept_keys[o] = 0ull;
         p.kept_idx[o] = 0;
     }
+    if (p.out_boxes) {
+        // single class: slots are already in the merged order (descending score, earlier slot first among equals); what
+        // nms_merge_kernel would emit, from this workgroup's own kept list (written by wave 0 above: fence + barrier)
+        __threadfence_block();
+        __syncthreads();
+        const int nv = kept < p.max_total ? kept : p.max_total;
+        for (int t = threadIdx.x; t < p.max_total; t += blockDim.x) {
+            f32x4 bx = {0.f, 0.f, 0.f, 0.f};
+            float s = 0.f;
+            if (t < nv) {
+                const int64_t o = (int64_t)b * p.max_per_class + t;
+                const int idx = p.kept_idx[o];
+                bx = *reinterpret_cast<const f32x4*>(boxes + ((int64_t)idx * p.q + bc) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bx[e] = fminf(fmaxf(bx[e], 0.0f), 1.0f);
+                s = key_float((unsigned int)(p.kept_keys[o] >> 32));
+            }
+            *reinterpret_cast<f32x4*>(p.out_boxes + ((int64_t)b * p.max_total + t) * 4) = bx;
+            p.out_scores[(int64_t)b * p.max_total + t] = s;
+            p.out_classes[(int64_t)b * p.max_total + t] = 0;
+        }
+        if (threadIdx.x == 0) p.out_valid[b] = nv;
+    }
 }
 
 struct MergeParams {
@@ -584,13 +616,20 @@ extern "C" int frcnn_anchors_generate(float* anchors, int gh, int gw, const floa
     return FRCNN_OK;
 }
 
-extern "C" int frcnn_rpn_head_post(const float* head, int ld, int b, int num_anchors_total, int a_per_loc, const int32_t* keep, int n,
-                                   float* scores, float* deltas, frcnn_stream_t stream) {
+extern "C" int frcnn_rpn_head_post_decode(const float* head, int ld, int b, int num_anchors_total, int a_per_loc, const int32_t* keep, int n,
+                                          float* scores, float* deltas, const float* regions, float* decoded, float img_w, float img_h,
+                                          frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(head && scores && deltas && ld >= 6 * a_per_loc && num_anchors_total % a_per_loc == 0 && n > 0, "rpn_head_post: bad arguments");
+    FRCNN_CHECK_ARG(!decoded || regions, "rpn_head_post_decode: decoded boxes need the regions");
     hipLaunchKernelGGL(rpn_head_post_kernel, dim3(cdiv((int64_t)b * n, 256)), dim3(256), 0, S_(stream), head, ld, b, num_anchors_total,
-                       a_per_loc, keep, n, scores, deltas);
+                       a_per_loc, keep, n, scores, deltas, regions, decoded, img_w, img_h);
     FRCNN_CHECK_LAUNCH("rpn_head_post");
     return FRCNN_OK;
+}
+
+extern "C" int frcnn_rpn_head_post(const float* head, int ld, int b, int num_anchors_total, int a_per_loc, const int32_t* keep, int n,
+                                   float* scores, float* deltas, frcnn_stream_t stream) {
+    return frcnn_rpn_head_post_decode(head, ld, b, num_anchors_total, a_per_loc, keep, n, scores, deltas, nullptr, nullptr, 1.f, 1.f, stream);
 }
 
 extern "C" int frcnn_clip_to_window(const float* boxes, float* out, int64_t n, float x0, float y0, float x1, float y1, frcnn_stream_t stream) {
@@ -658,6 +697,9 @@ extern "C" int frcnn_nms_combined(const float* boxes, const float* scores, int b
     p.max_per_class = max_per_class; p.iou_thr = iou_thr; p.score_thr = score_thr;
     p.kept_keys = reinterpret_cast<unsigned long long*>(ws);
     p.kept_idx = reinterpret_cast<int*>(ws + (size_t)b * c * max_per_class * sizeof(unsigned long long));
+    const bool fused_merge = c == 1;
+    p.out_boxes = fused_merge ? out_boxes : nullptr; p.out_scores = out_scores; p.out_classes = out_classes; p.out_valid = out_valid;
+    p.max_total = max_total;
     bool lds_keys;
     const size_t smem = nms_class_lds(n, max_per_class, &lds_keys);
     p.lds_keys = lds_keys ? 1 : 0;
@@ -669,6 +711,7 @@ extern "C" int frcnn_nms_combined(const float* boxes, const float* scores, int b
         hipLaunchKernelGGL(nms_class_kernel<false>, dim3(b * c), dim3(NMS_T), smem, S_(stream), p);
     }
     FRCNN_CHECK_LAUNCH("nms_combined(class)");
+    if (fused_merge) return FRCNN_OK;
 
     MergeParams m;
     m.boxes = boxes; m.kept_keys = p.kept_keys; m.kept_idx = p.kept_idx; m.N = n; m.q = q; m.C = c; m.max_per_class = max_per_class;

@@ -273,74 +273,142 @@ struct LossParams {
     const float* scores; const float* deltas; const float* tl; const float* tb; const int* idx;
     int B, R, C1, S; float cls_scale, reg_scale;
     float* losses; float* dlog; float* ddel;
+    bf16_t* dhead; int ld; int* rows_out;          // optional fused Fast-RCNN head-gradient rows (what rcnn_head_grad_kernel writes)
+    float* rpn_dhead; const int* keep; int locs, apl, rpn_ld;   // optional fused RPN scatter-add (what rpn_head_grad_kernel does; C1 == 2)
 };
 
-__global__ __launch_bounds__(256) void losses_kernel(const LossParams p) {
-    __shared__ float red[2][256];
+// One workgroup, one thread per sampled row (rows beyond 1024: strided).  MAXC bounds C1 at compile time (2 / 8 / 32): the row's
+// scores, targets and box terms are loaded into registers in fully unrolled, predicated loops -- every load of a row is in flight
+// at once.  (With runtime-bounded loops each class cost a memory round trip: 4 passes x C1 trips made this kernel 19-31 us.)
+template <int MAXC>
+__global__ __launch_bounds__(1024) void losses_kernel(const LossParams p) {
+    __shared__ float red[2][16];
     const int C = p.C1 - 1;
     const int rows = p.B * p.S;
     const float inv_rows = 1.0f / (float)rows;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float cls = 0.f, reg = 0.f;
     for (int i = threadIdx.x; i < rows; i += blockDim.x) {
         const int b = i / p.S;
         const int r = p.idx[i];
         const float* sc = p.scores + ((int64_t)b * p.R + r) * p.C1;
         const float* t = p.tl + ((int64_t)b * p.R + r) * p.C1;
+        const float* tbr = p.tb + ((int64_t)b * p.R + r) * C * 4;
+        const float* pvr = p.deltas + ((int64_t)b * p.R + r) * C * 4;
+        float pr[MAXC], tt[MAXC];
+        f32x4 tv[MAXC - 1], pv[MAXC - 1];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            pr[c] = c < p.C1 ? sc[c] : 0.f;
+            tt[c] = c < p.C1 ? t[c] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC - 1; ++c) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            tv[c] = c < C ? *reinterpret_cast<const f32x4*>(tbr + c * 4) : z4;
+            pv[c] = c < C ? *reinterpret_cast<const f32x4*>(pvr + c * 4) : z4;
+        }
+        bf16_t* hrow = p.dhead ? p.dhead + (int64_t)i * p.ld : nullptr;
+        float* arow = nullptr;                       // RPN: the dense head-gradient row of this sample's location, and its anchor slot
+        int ak = 0;
+        if (p.rpn_dhead) {
+            const int a = p.keep ? p.keep[r] : r;
+            const int loc = a / p.apl;
+            ak = a - loc * p.apl;
+            arow = p.rpn_dhead + ((int64_t)b * p.locs + loc) * p.rpn_ld;
+        }
         // Keras categorical_crossentropy on probabilities: renormalise, clip, -sum t log p
-        float pr[kMaxC1], gq[kMaxC1];
         float s = 0.f;
-        for (int c = 0; c < p.C1; ++c) { pr[c] = sc[c]; s += pr[c]; }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < p.C1) s += pr[c];
+        float gq[MAXC];
         float row_loss = 0.f, dot = 0.f;
-        for (int c = 0; c < p.C1; ++c) {
-            const float q = pr[c] / s;
-            const float qc = fminf(fmaxf(q, 1e-7f), 1.0f - 1e-7f);
-            row_loss -= t[c] * logf(qc);
-            const bool pass = (q >= 1e-7f) && (q <= 1.0f - 1e-7f);
-            gq[c] = pass ? -t[c] / qc : 0.f;
-            dot += gq[c] * pr[c];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            gq[c] = 0.f;
+            if (c < p.C1) {
+                const float q = pr[c] / s;
+                const float qc = fminf(fmaxf(q, 1e-7f), 1.0f - 1e-7f);
+                row_loss -= tt[c] * logf(qc);
+                const bool pass = (q >= 1e-7f) && (q <= 1.0f - 1e-7f);
+                gq[c] = pass ? -tt[c] / qc : 0.f;
+                dot += gq[c] * pr[c];
+            }
         }
         cls += row_loss;
-        if (p.dlog) {
+        if (p.dlog || hrow || arow) {
             // d/dp_j = gq_j/s - dot/s^2 ; softmax backward: dz_i = p_i (dp_i - sum_j p_j dp_j)
-            float dp[kMaxC1];
+            float dp[MAXC];
             float pdot = 0.f;
-            for (int c = 0; c < p.C1; ++c) { dp[c] = gq[c] / s - dot / (s * s); pdot += pr[c] * dp[c]; }
-            for (int c = 0; c < p.C1; ++c) p.dlog[(int64_t)i * p.C1 + c] = p.cls_scale * inv_rows * pr[c] * (dp[c] - pdot);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                dp[c] = 0.f;
+                if (c < p.C1) { dp[c] = gq[c] / s - dot / (s * s); pdot += pr[c] * dp[c]; }
+            }
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                if (c < p.C1) {
+                    const float dz = p.cls_scale * inv_rows * pr[c] * (dp[c] - pdot);
+                    if (p.dlog) p.dlog[(int64_t)i * p.C1 + c] = dz;
+                    if (hrow) hrow[c] = (bf16_t)dz;
+                    if (arow) atomicAdd(arow + 2 * ak + c, dz);
+                }
+            }
         }
         // Huber(delta=1), mean over the 4 coords, rows with sum(target) != 0, summed (losses.py:35-41)
-        for (int c = 0; c < C; ++c) {
-            const f32x4 tv = *reinterpret_cast<const f32x4*>(p.tb + (((int64_t)b * p.R + r) * C + c) * 4);
-            const f32x4 pv = *reinterpret_cast<const f32x4*>(p.deltas + (((int64_t)b * p.R + r) * C + c) * 4);
-            const bool keep = (tv[0] + tv[1] + tv[2] + tv[3]) != 0.0f;
-            f32x4 g = {0.f, 0.f, 0.f, 0.f};
-            if (keep) {
-                float h = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = pv[e] - tv[e];
-                    const float ad = fabsf(d);
-                    h += (ad <= 1.0f) ? 0.5f * d * d : ad - 0.5f;
-                    g[e] = p.reg_scale * 0.25f * ((ad <= 1.0f) ? d : (d > 0.f ? 1.f : -1.f));
+        for (int c = 0; c < MAXC - 1; ++c) {
+            if (c < C) {
+                const bool keep = (tv[c][0] + tv[c][1] + tv[c][2] + tv[c][3]) != 0.0f;
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                if (keep) {
+                    float h = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = pv[c][e] - tv[c][e];
+                        const float ad = fabsf(d);
+                        h += (ad <= 1.0f) ? 0.5f * d * d : ad - 0.5f;
+                        g[e] = p.reg_scale * 0.25f * ((ad <= 1.0f) ? d : (d > 0.f ? 1.f : -1.f));
+                    }
+                    reg += h * 0.25f;
                 }
-                reg += h * 0.25f;
+                if (p.ddel) *reinterpret_cast<f32x4*>(p.ddel + ((int64_t)i * C + c) * 4) = g;
+                if (hrow) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hrow[p.C1 + 4 * c + e] = (bf16_t)g[e];
+                }
+                if (arow) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(arow + 2 * p.apl + 4 * ak + e, g[e]);
+                }
             }
-            if (p.ddel) *reinterpret_cast<f32x4*>(p.ddel + ((int64_t)i * C + c) * 4) = g;
+        }
+        if (hrow) {
+            for (int c = p.C1 + 4 * C; c < p.ld; ++c) hrow[c] = (bf16_t)0.f;
+            p.rows_out[i] = b * p.R + r;
         }
     }
-    red[0][threadIdx.x] = cls;
-    red[1][threadIdx.x] = reg;
+    // fixed-order sums: lanes (xor tree), then the 16 waves in ascending order
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        cls += __shfl_xor(cls, sh);
+        reg += __shfl_xor(reg, sh);
+    }
+    if (lane == 0) { red[0][wave] = cls; red[1][wave] = reg; }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + s];
-            red[1][threadIdx.x] += red[1][threadIdx.x + s];
-        }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        p.losses[0] = red[0][0] * inv_rows;
-        p.losses[1] = red[1][0];
+        float a = 0.f, c2 = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += red[0][w]; c2 += red[1][w]; }
+        p.losses[0] = a * inv_rows;
+        p.losses[1] = c2;
     }
+}
+
+static void launch_losses(const LossParams& p, hipStream_t stream) {
+    if (p.C1 <= 2) hipLaunchKernelGGL(losses_kernel<2>, dim3(1), dim3(1024), 0, stream, p);
+    else if (p.C1 <= 8) hipLaunchKernelGGL(losses_kernel<8>, dim3(1), dim3(1024), 0, stream, p);
+    else hipLaunchKernelGGL(losses_kernel<kMaxC1>, dim3(1), dim3(1024), 0, stream, p);
 }
 
 // RPN: scatter-add per-sample gradients into the dense fp32 head-gradient matrix
@@ -375,21 +443,26 @@ __global__ void rcnn_head_grad_kernel(const float* __restrict__ dlog, const floa
     }
 }
 
-// RCNN head post: bias + softmax / split
-__global__ void rcnn_head_post_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ bias, int R, int C1,
-                                      float* __restrict__ scores, float* __restrict__ deltas) {
+// RCNN head post: bias + softmax / split.  One wave per row, lane = column (C1 <= kMaxC1 <= 64): coalesced row reads, the
+// class maximum and the exponentials' sum by wave reductions.  The sum runs over the classes in ascending order (a serial
+// chain of C1 v_readlane adds, not a tree), so the probabilities are the same bits a one-thread-per-row loop produces.
+__global__ __launch_bounds__(256) void rcnn_head_post_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ bias, int R,
+                                                             int C1, float* __restrict__ scores, float* __restrict__ deltas) {
     const int nreg = 4 * (C1 - 1);
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
-        const float* row = logits + (int64_t)r * ld;
-        float l[kMaxC1];
-        float mx = -INFINITY;
-        for (int c = 0; c < C1; ++c) { l[c] = row[c] + bias[c]; mx = fmaxf(mx, l[c]); }
-        float s = 0.f;
-        for (int c = 0; c < C1; ++c) { l[c] = expf(l[c] - mx); s += l[c]; }
-        const float inv = 1.f / s;
-        for (int c = 0; c < C1; ++c) scores[(int64_t)r * C1 + c] = l[c] * inv;
-        for (int c = 0; c < nreg; ++c) deltas[(int64_t)r * nreg + c] = row[C1 + c] + bias[C1 + c];
-    }
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* row = logits + (int64_t)r * ld;
+    const float l = lane < C1 ? row[lane] + bias[lane] : -INFINITY;
+    float mx = l;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
+    const float e = lane < C1 ? expf(l - mx) : 0.f;
+    float s = 0.f;
+    for (int c = 0; c < C1; ++c) s += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), c));
+    const float inv = 1.f / s;
+    if (lane < C1) scores[(int64_t)r * C1 + lane] = e * inv;
+    for (int c = lane; c < nreg; c += 64) deltas[(int64_t)r * nreg + c] = row[C1 + c] + bias[C1 + c];
 }
 
 }  // namespace
@@ -427,18 +500,46 @@ extern "C" int frcnn_sample_indices(const float* target_labels, int b, int r, in
     return FRCNN_OK;
 }
 
-extern "C" int frcnn_losses(const float* scores, const float* deltas, const float* target_labels, const float* target_boxes,
-                            const int32_t* indices, int b, int r, int c1, int s, float cls_scale, float reg_scale, float* losses,
-                            float* dlogits_s, float* ddeltas_s, frcnn_stream_t stream) {
+extern "C" int frcnn_losses_head_grad(const float* scores, const float* deltas, const float* target_labels, const float* target_boxes,
+                                      const int32_t* indices, int b, int r, int c1, int s, float cls_scale, float reg_scale,
+                                      float* losses, float* dlogits_s, float* ddeltas_s, frcnn_bf16* dhead_s, int ld, int32_t* rows_out,
+                                      frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(scores && deltas && target_labels && target_boxes && indices && losses, "losses: null pointer");
     FRCNN_CHECK_ARG(c1 >= 2 && c1 <= kMaxC1 && b > 0 && s > 0, "losses: bad sizes");
+    FRCNN_CHECK_ARG(!dhead_s || (rows_out && ld >= c1 + 4 * (c1 - 1)), "losses: fused head gradient needs rows_out and ld >= 5*(C+1)-4");
     LossParams p;
     p.scores = scores; p.deltas = deltas; p.tl = target_labels; p.tb = target_boxes; p.idx = indices;
     p.B = b; p.R = r; p.C1 = c1; p.S = s; p.cls_scale = cls_scale; p.reg_scale = reg_scale;
     p.losses = losses; p.dlog = dlogits_s; p.ddel = ddeltas_s;
-    hipLaunchKernelGGL(losses_kernel, dim3(1), dim3(256), 0, S_(stream), p);
+    p.dhead = reinterpret_cast<bf16_t*>(dhead_s); p.ld = ld; p.rows_out = rows_out;
+    p.rpn_dhead = nullptr; p.keep = nullptr; p.locs = 0; p.apl = 1; p.rpn_ld = 0;
+    launch_losses(p, S_(stream));
     FRCNN_CHECK_LAUNCH("losses");
     return FRCNN_OK;
+}
+
+extern "C" int frcnn_losses_rpn_head_grad(const float* scores, const float* deltas, const float* target_labels, const float* target_boxes,
+                                          const int32_t* indices, int b, int r, int s, float cls_scale, float reg_scale, float* losses,
+                                          float* dlogits_s, float* ddeltas_s, const int32_t* keep, int num_anchors_total, int a_per_loc,
+                                          float* dhead, int ld, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(scores && deltas && target_labels && target_boxes && indices && losses && dhead, "losses_rpn_head_grad: null pointer");
+    FRCNN_CHECK_ARG(b > 0 && s > 0 && a_per_loc > 0 && num_anchors_total % a_per_loc == 0 && ld >= 6 * a_per_loc, "losses_rpn_head_grad: bad sizes");
+    LossParams p;
+    p.scores = scores; p.deltas = deltas; p.tl = target_labels; p.tb = target_boxes; p.idx = indices;
+    p.B = b; p.R = r; p.C1 = 2; p.S = s; p.cls_scale = cls_scale; p.reg_scale = reg_scale;
+    p.losses = losses; p.dlog = dlogits_s; p.ddel = ddeltas_s;
+    p.dhead = nullptr; p.ld = 0; p.rows_out = nullptr;
+    p.rpn_dhead = dhead; p.keep = keep; p.locs = num_anchors_total / a_per_loc; p.apl = a_per_loc; p.rpn_ld = ld;
+    launch_losses(p, S_(stream));
+    FRCNN_CHECK_LAUNCH("losses");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_losses(const float* scores, const float* deltas, const float* target_labels, const float* target_boxes,
+                            const int32_t* indices, int b, int r, int c1, int s, float cls_scale, float reg_scale, float* losses,
+                            float* dlogits_s, float* ddeltas_s, frcnn_stream_t stream) {
+    return frcnn_losses_head_grad(scores, deltas, target_labels, target_boxes, indices, b, r, c1, s, cls_scale, reg_scale, losses, dlogits_s,
+                                  ddeltas_s, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int frcnn_rpn_head_grad(const float* dlogits_s, const float* ddeltas_s, const int32_t* indices, const int32_t* keep, int b, int s,
@@ -462,7 +563,7 @@ extern "C" int frcnn_rcnn_head_grad(const float* dlogits_s, const float* ddeltas
 extern "C" int frcnn_rcnn_head_post(const float* logits, int ld, const float* bias, int r, int nc1, float* scores, float* deltas,
                                     frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(logits && bias && scores && deltas && nc1 >= 2 && nc1 <= kMaxC1 && ld >= nc1 + 4 * (nc1 - 1), "rcnn_head_post: bad arguments");
-    hipLaunchKernelGGL(rcnn_head_post_kernel, dim3(cdiv(r, 256)), dim3(256), 0, S_(stream), logits, ld, bias, r, nc1, scores, deltas);
+    hipLaunchKernelGGL(rcnn_head_post_kernel, dim3(cdiv(r, 4)), dim3(256), 0, S_(stream), logits, ld, bias, r, nc1, scores, deltas);
     FRCNN_CHECK_LAUNCH("rcnn_head_post");
     return FRCNN_OK;
 }

@@ -137,14 +137,24 @@ class RPNDetector:
         return [(st.weight("rpn_intermediate_layer/kernel"), self.w_inter_t, 256, self.ws, self.ws, self.cf),
                 (st.weight("rpn_heads/kernel"), self.w_heads_t, HEAD_LD, 1, 1, 256)]
 
-    def forward_plan(self, plan, feature_maps, training):
+    def regions(self, training):
+        """The regions the RPN predicts on: the anchors inside the image when training (reference rpn_detector.py:112-117),
+        all anchors clipped to the image otherwise."""
+        return self._anchors_inside if training else self._anchors_clipped
+
+    def forward_plan(self, plan, feature_maps, training, decoded=None):
+        """decoded [B,n,1,4]: also receives the decoded proposals (first launch of post-processing) from the head-post kernel."""
         st = self.store
         plan.add(ops.conv2d_fprop, self.d_inter, feature_maps, st.weight_bf16("rpn_intermediate_layer/kernel"), self.f,
                  bias=st.weight("rpn_intermediate_layer/bias"))
         plan.add(ops.conv2d_fprop, self.d_heads, self.f, st.weight_bf16("rpn_heads/kernel"), self.head, bias=st.weight("rpn_heads/bias"))
         keep = self._keep if training else None
-        plan.add(ops.rpn_head_post, self.head, HEAD_LD, self.batch, self.num_anchors, self.apl, keep, self.n, self.scores, self.deltas)
-        regions = self._anchors_inside if training else self._anchors_clipped
+        regions = self.regions(training)
+        if decoded is None:
+            plan.add(ops.rpn_head_post, self.head, HEAD_LD, self.batch, self.num_anchors, self.apl, keep, self.n, self.scores, self.deltas)
+        else:
+            plan.add(ops.rpn_head_post_decode, self.head, HEAD_LD, self.batch, self.num_anchors, self.apl, keep, self.n, self.scores,
+                     self.deltas, regions, decoded, float(self._image_shape[1]), float(self._image_shape[0]))
         return {"regions": regions, "pred_scores": self.scores, "pred_boxes": self.deltas}
 
     def backward_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, feature_maps, g_feat):
@@ -153,13 +163,21 @@ class RPNDetector:
         self.backward_params_plan(plan, dlogits_s, ddeltas_s, indices, num_samples, feature_maps)
         self.backward_data_plan(plan, g_feat)
 
-    def backward_params_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, feature_maps):
-        """Everything of the RPN backward pass that does not need the RoI-branch gradient (a side-stream branch of the
-        training step runs it next to the Fast-RCNN backward pass)."""
-        st = self.store
+    def head_grad_target(self, plan):
+        """(keep, num_anchors, anchors per location, dhead32, ld): where the fused loss launch (ops.losses_rpn_head_grad)
+        scatter-adds the per-sample gradients; registers dhead32 with the plan's zero fill."""
         plan.zero(self.dhead32)
-        plan.add(ops.rpn_head_grad, dlogits_s, ddeltas_s, indices, self._keep, self.batch, num_samples, self.num_anchors, self.apl,
-                 self.dhead32, HEAD_LD)
+        return self._keep, self.num_anchors, self.apl, self.dhead32, HEAD_LD
+
+    def backward_params_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, feature_maps, head_grad_done=False):
+        """Everything of the RPN backward pass that does not need the RoI-branch gradient (a side-stream branch of the
+        training step runs it next to the Fast-RCNN backward pass).  head_grad_done: dhead32 already holds the scattered
+        per-sample gradients (head_grad_target)."""
+        st = self.store
+        if not head_grad_done:
+            plan.zero(self.dhead32)
+            plan.add(ops.rpn_head_grad, dlogits_s, ddeltas_s, indices, self._keep, self.batch, num_samples, self.num_anchors, self.apl,
+                     self.dhead32, HEAD_LD)
         plan.add(ops.cast_f32_bf16, self.dhead32, self.dhead)
         plan.add(ops.colsum_bf16, self.dhead, self.m, HEAD_LD, HEAD_LD, st.grad("rpn_heads/bias"))
         plan.add(ops.conv2d_wgrad, self.d_heads, self.f, self.dhead, st.grad("rpn_heads/kernel"))

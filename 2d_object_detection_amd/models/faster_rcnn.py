@@ -147,12 +147,8 @@ class FasterRCNN:
             plan.hold(table)
             with plan.branch("weight_flips"):
                 plan.add(ops.weights_transpose_flip_batched, table, total)
-        feat = mods.fe.forward_plan(plan, training)
-        feat2d = feat.view(batch * gh * gw, cf)
-        rpn_out = mods.rpn.forward_plan(plan, feat2d, training)
-        n = rpn_out["pred_scores"].shape[1]
-
         # ---- targets, sampling, losses (+ per-sample gradients)
+        n = mods.rpn.n
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         t = {}
@@ -171,42 +167,73 @@ class FasterRCNN:
         # The RPN target / loss chain only needs the RPN outputs: it runs on a side stream next to proposal NMS, RoI pooling
         # and the Fast-RCNN heads, and continues with the part of the RPN backward pass that does not need the RoI-branch
         # gradient.  The detection NMS of the step's predictions is a second branch under the head backward passes.
-        def rpn_targets_and_losses():
-            plan.add(ops.assign_targets, rpn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
+        def rpn_targets(regions):
+            plan.add(ops.assign_targets, regions, io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
                      rs["foreground_iou_interval"], rs["background_iou_interval"], t["rpn_tl"], t["rpn_tb"])
             plan.add(ops.sample_indices, t["rpn_tl"], batch, n, 2, S_rpn, rs["foreground_proportion"], self.sampling_seed, step, 0,
                      t["rpn_idx"], t["rpn_ws"], self.status)
-            plan.add(ops.losses, rpn_out["pred_scores"], rpn_out["pred_boxes"], t["rpn_tl"], t["rpn_tb"], t["rpn_idx"], batch, n, 2, S_rpn,
-                     cls_scale, 1.0, losses[0:2], t.get("rpn_dl"), t.get("rpn_dd"))
 
-        def rcnn_targets_and_losses():
-            plan.add(ops.assign_targets, rcnn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, P, G, nc1, False, W, H,
+        def rpn_losses():
+            if training:
+                # loss, per-sample gradients and their scatter into the dense head gradient in one launch
+                plan.add(ops.losses_rpn_head_grad, rpn_out["pred_scores"], rpn_out["pred_boxes"], t["rpn_tl"], t["rpn_tb"], t["rpn_idx"],
+                         batch, n, S_rpn, cls_scale, 1.0, losses[0:2], t["rpn_dl"], t["rpn_dd"], *mods.rpn.head_grad_target(plan))
+            else:
+                plan.add(ops.losses, rpn_out["pred_scores"], rpn_out["pred_boxes"], t["rpn_tl"], t["rpn_tb"], t["rpn_idx"], batch, n, 2,
+                         S_rpn, cls_scale, 1.0, losses[0:2], None, None)
+
+        def rcnn_targets(regions):
+            plan.add(ops.assign_targets, regions, io["gt_labels"], io["gt_boxes"], batch, P, G, nc1, False, W, H,
                      cs["foreground_iou_interval"], cs["background_iou_interval"], t["rcnn_tl"], t["rcnn_tb"])
             plan.add(ops.sample_indices, t["rcnn_tl"], batch, P, nc1, S_rcnn, cs["foreground_proportion"], self.sampling_seed, step, 2,
                      t["rcnn_idx"], t["rcnn_ws"], self.status)
-            plan.add(ops.losses, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"], batch, P, nc1,
-                     S_rcnn, cls_scale, 1.0, losses[2:4], t.get("rcnn_dl"), t.get("rcnn_dd"))
 
+        def rcnn_losses():
+            if training:
+                # loss, per-sample gradients and the head's bf16 gradient rows in one launch (frcnn_losses_head_grad)
+                plan.add(ops.losses_head_grad, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"],
+                         batch, P, nc1, S_rcnn, cls_scale, 1.0, losses[2:4], t["rcnn_dl"], t["rcnn_dd"], *mods.rcnn.head_grad_rows())
+            else:
+                plan.add(ops.losses, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"], batch, P,
+                         nc1, S_rcnn, cls_scale, 1.0, losses[2:4], None, None)
+
+        feat = mods.fe.forward_plan(plan, training)
+        feat2d = feat.view(batch * gh * gw, cf)
+        nms_cfg = self._rpn_config["nms"]
+        rpn_nms = NmsBuffers(batch, mods.rpn.n, 1, nms_cfg["max_output_size_per_class"], nms_cfg["max_total_size"], dev)
+        rpn_out = mods.rpn.forward_plan(plan, feat2d, training, decoded=rpn_nms.decoded)
+        assert n == rpn_out["pred_scores"].shape[1]
         if training:
             g_feat = torch.empty(batch * gh * gw, cf, dtype=BF16, device=dev)
             plan.hold(g_feat)
             t["g_feat"] = g_feat
             plan.join("weight_flips")
             with plan.branch("rpn_side"):
-                rpn_targets_and_losses()
-                mods.rpn.backward_params_plan(plan, t["rpn_dl"], t["rpn_dd"], t["rpn_idx"], S_rpn, feat2d)
+                rpn_targets(rpn_out["regions"])
+                rpn_losses()
+                mods.rpn.backward_params_plan(plan, None, None, t["rpn_idx"], S_rpn, feat2d, head_grad_done=True)
         else:
-            rpn_targets_and_losses()
-        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"])
+            rpn_targets(rpn_out["regions"])
+            rpn_losses()
+        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"], buffers=rpn_nms, decoded_done=True)
         rois = nms_rpn["pred_boxes"]
-        rcnn_out = mods.rcnn.forward_plan(plan, feat, rois)
+        # Target assignment and sampling of the Fast-RCNN stage need the proposals and the ground truth, not the head's
+        # predictions: a side stream under RoI pooling and the head GEMM (the chain from the proposals to the head's loss
+        # gradient is a string of one-workgroup kernels with the chip idle).  Branches are not free -- a forked hipGraph is
+        # enqueued node by node with cross-queue waits, a linear one in one piece: of the seven branches tried in round 2
+        # (tools/ab_plan.sh, one box) this one, the RPN side chain and the detection NMS pay; targets of the RPN at the head
+        # of the step (+0.25 ms), a late zero fill (+0.12 ms), the step counter and the head's parameter gradients do not.
+        with plan.branch("rcnn_targets"):
+            rcnn_targets(mods.rcnn.regions_plan(plan, rois))
+        rcnn_out = mods.rcnn.forward_plan(plan, feat, rois, regions_done=True)
+        plan.join("rcnn_targets")
         if training:
             with plan.branch("detections"):
                 nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
-        rcnn_targets_and_losses()
+        rcnn_losses()
 
         if training:
-            mods.rcnn.backward_plan(plan, t["rcnn_dl"], t["rcnn_dd"], t["rcnn_idx"], S_rcnn, rois, g_feat)
+            mods.rcnn.backward_plan(plan, None, None, t["rcnn_idx"], S_rcnn, rois, g_feat, head_grad_done=True)
             plan.join("rpn_side")
             mods.rpn.backward_data_plan(plan, g_feat, consumer=mods.fe.last_unit())
             plan.join("detections")
@@ -240,13 +267,14 @@ class FasterRCNN:
 
     def _feed(self, built, images, gt_labels, gt_boxes):
         io = built["io"]
-        if images.is_cuda and images.dtype == io["images"].dtype and images.shape == io["images"].shape and images.is_contiguous() \
-                and images.data_ptr() % 16 == 0:
-            ops.copy_bytes(images, io["images"])             # (the runtime's blit kernel takes 24 us for these 5.6 MB)
+        pairs = ((images, io["images"]), (gt_labels, io["gt_labels"]), (gt_boxes, io["gt_boxes"]))
+        if all(s.is_cuda and s.dtype == d.dtype and s.shape == d.shape and s.is_contiguous() and s.data_ptr() % 16 == 0 for s, d in pairs):
+            # device-resident inputs of the right types: ONE copy launch into the plan's static buffers (three launches of the
+            # runtime's blit kernel were 22 us at the head of every step; its 5.6 MB image copy alone took 24 us in round 1)
+            ops.copy_bytes_multi(pairs)
         else:
-            io["images"].copy_(images, non_blocking=True)
-        io["gt_labels"].copy_(gt_labels, non_blocking=True)
-        io["gt_boxes"].copy_(gt_boxes, non_blocking=True)
+            for s, d in pairs:
+                d.copy_(s, non_blocking=True)
 
     def _losses_dict(self, built):
         l = built["losses"]

@@ -133,6 +133,17 @@ def copy_bytes(src, dst):
     call("frcnn_copy_bytes", _p(src), _p(dst), src.numel() * src.element_size(), _stream())
 
 
+def copy_bytes_multi(pairs):
+    """[(src, dst), ...] (1..4 pairs of contiguous device tensors of equal byte size, 16-byte aligned): one launch."""
+    n = len(pairs)
+    srcs = (c_void_p * n)(*[s.data_ptr() for s, _ in pairs])
+    dsts = (c_void_p * n)(*[d.data_ptr() for _, d in pairs])
+    sizes = (ctypes.c_int64 * n)(*[s.numel() * s.element_size() for s, _ in pairs])
+    for s_, d_ in pairs:
+        assert s_.numel() * s_.element_size() == d_.numel() * d_.element_size() and s_.is_contiguous() and d_.is_contiguous()
+    call("frcnn_copy_bytes_multi", srcs, dsts, sizes, n, _stream())
+
+
 def make_zero_table(tensors, device):
     """Table for fill_zero_multi over `tensors` (contiguous, 16-byte aligned, byte sizes multiples of 16)."""
     rows, chunk = [], 0
@@ -246,6 +257,12 @@ def rpn_head_post(head, ld, b, num_anchors_total, a_per_loc, keep, n, scores, de
     call("frcnn_rpn_head_post", _p(head), ld, b, num_anchors_total, a_per_loc, _p(keep), n, _p(scores), _p(deltas), _stream())
 
 
+def rpn_head_post_decode(head, ld, b, num_anchors_total, a_per_loc, keep, n, scores, deltas, regions, decoded, img_w, img_h):
+    """rpn_head_post + the decode launch of proposal NMS (shared regions [n,4]) in one kernel."""
+    call("frcnn_rpn_head_post_decode", _p(head), ld, b, num_anchors_total, a_per_loc, _p(keep), n, _p(scores), _p(deltas), _p(regions),
+         _p(decoded), float(img_w), float(img_h), _stream())
+
+
 def clip_to_window(boxes, out, window):
     x0, y0, x1, y1 = [float(v) for v in window]
     call("frcnn_clip_to_window", _p(boxes), _p(out), boxes.numel() // 4, x0, y0, x1, y1, _stream())
@@ -311,6 +328,21 @@ def losses(scores, deltas, target_labels, target_boxes, indices, b, r, c1, s, cl
            ddeltas_s=None):
     call("frcnn_losses", _p(scores), _p(deltas), _p(target_labels), _p(target_boxes), _p(indices), b, r, c1, s, float(cls_scale),
          float(reg_scale), _p(out_losses), _p(dlogits_s), _p(ddeltas_s), _stream())
+
+
+def losses_head_grad(scores, deltas, target_labels, target_boxes, indices, b, r, c1, s, cls_scale, reg_scale, out_losses, dlogits_s,
+                     ddeltas_s, dhead_s, ld, rows_out):
+    """losses() + rcnn_head_grad() in one launch."""
+    call("frcnn_losses_head_grad", _p(scores), _p(deltas), _p(target_labels), _p(target_boxes), _p(indices), b, r, c1, s,
+         float(cls_scale), float(reg_scale), _p(out_losses), _p(dlogits_s), _p(ddeltas_s), _p(dhead_s), ld, _p(rows_out), _stream())
+
+
+def losses_rpn_head_grad(scores, deltas, target_labels, target_boxes, indices, b, r, s, cls_scale, reg_scale, out_losses, dlogits_s,
+                         ddeltas_s, keep, num_anchors_total, a_per_loc, dhead, ld):
+    """losses() (objectness: C1 = 2) + rpn_head_grad() in one launch."""
+    call("frcnn_losses_rpn_head_grad", _p(scores), _p(deltas), _p(target_labels), _p(target_boxes), _p(indices), b, r, s,
+         float(cls_scale), float(reg_scale), _p(out_losses), _p(dlogits_s), _p(ddeltas_s), _p(keep), num_anchors_total, a_per_loc,
+         _p(dhead), ld, _stream())
 
 
 def rpn_head_grad(dlogits_s, ddeltas_s, indices, keep, b, s, num_anchors_total, a_per_loc, dhead, ld):

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 
+_NOBRANCH = set(filter(None, os.environ.get("FRCNN_NOBRANCH", "").split(",")))   # measuring aid (tools/ab_plan.sh): these branches stay on the main stream
 _SERIAL = bool(os.environ.get("FRCNN_SERIAL_PLAN"))      # debugging aid: run branch launches on the main stream
 
 
@@ -51,7 +52,10 @@ class Plan:
 
     # -- construction
     def add(self, fn, *args, **kwargs):
-        self.segments[-1].append((fn, args, kwargs, None if _SERIAL else self._branch))
+        br = None if _SERIAL else self._branch
+        if br is not None and br[0] in _NOBRANCH:
+            br = None
+        self.segments[-1].append((fn, args, kwargs, br))
 
     def branch(self, name, follow=False):
         """follow=True: the block's first launch additionally waits for everything enqueued on the main stream so far, even

@@ -131,6 +131,9 @@ int frcnn_weights_transpose_flip_batched(const int64_t* table, int n, int64_t to
 int frcnn_cast_f32_bf16(const float* src, frcnn_bf16* dst, int64_t n, frcnn_stream_t stream);
 /* device-to-device copy of nbytes (16-byte aligned pointers) at HBM speed: feeds a plan's static input buffers */
 int frcnn_copy_bytes(const void* src, void* dst, int64_t nbytes, frcnn_stream_t stream);
+/* n (1..4) such copies in one launch: srcs / dsts / nbytes are HOST arrays of n device pointers (16-byte aligned) and sizes.
+ * The train step feeds its three inputs (reference faster_rcnn.py:83 train_step(images, gt_labels, gt_boxes)) this way. */
+int frcnn_copy_bytes_multi(const void* const* srcs, void* const* dsts, const int64_t* nbytes, int n, frcnn_stream_t stream);
 /* zero n device buffers (16-byte aligned, sizes multiples of 16 bytes) in one launch.  table (device, int64 [n + 1][2]): row i =
  * {pointer, first 16-byte chunk of buffer i in the concatenation of all buffers}, row n = {0, total_chunks}.  Replaces the
  * per-buffer zero fills in front of the atomically accumulated buffers of a train step (flat gradient, BatchNorm partial
@@ -227,6 +230,11 @@ int frcnn_anchors_generate(float* anchors, int gh, int gw, const float* scales /
  * keep[i] (or all anchors when keep == NULL): pair softmax -> scores[B,n,2]; deltas[B,n,4]. */
 int frcnn_rpn_head_post(const float* head, int ld, int b, int num_anchors_total, int a_per_loc, const int32_t* keep,
                         int n, float* scores, float* deltas, frcnn_stream_t stream);
+/* The same, and in the same launch the decode step of proposal NMS (frcnn_decode_boxes with the n shared `regions` [n,4] and
+ * C = 1): decoded [B,n,4] relative boxes.  decoded == NULL: plain frcnn_rpn_head_post. */
+int frcnn_rpn_head_post_decode(const float* head, int ld, int b, int num_anchors_total, int a_per_loc, const int32_t* keep,
+                               int n, float* scores, float* deltas, const float* regions, float* decoded, float img_w,
+                               float img_h, frcnn_stream_t stream);
 /* utils/boxes.py:4-17 */
 int frcnn_clip_to_window(const float* boxes, float* out, int64_t n, float x0, float y0, float x1, float y1,
                          frcnn_stream_t stream);
@@ -300,6 +308,19 @@ int frcnn_sample_indices(const float* target_labels, int b, int r, int c1, int n
 int frcnn_losses(const float* scores, const float* deltas, const float* target_labels, const float* target_boxes,
                  const int32_t* indices, int b, int r, int c1, int s, float cls_scale, float reg_scale, float* losses,
                  float* dlogits_s, float* ddeltas_s, frcnn_stream_t stream);
+/* frcnn_losses followed by frcnn_rcnn_head_grad in ONE launch (the Fast-RCNN training chain: every kernel boundary on it
+ * costs ~4 us with the chip idle): additionally writes dhead_s [B*S, ld] (bf16 gradient rows, zero padded) and rows_out
+ * [B*S] exactly as frcnn_rcnn_head_grad would from dlogits_s / ddeltas_s (which may be NULL here). */
+int frcnn_losses_head_grad(const float* scores, const float* deltas, const float* target_labels, const float* target_boxes,
+                           const int32_t* indices, int b, int r, int c1, int s, float cls_scale, float reg_scale,
+                           float* losses, float* dlogits_s, float* ddeltas_s, frcnn_bf16* dhead_s, int ld, int32_t* rows_out,
+                           frcnn_stream_t stream);
+/* frcnn_losses (C1 = 2) followed by frcnn_rpn_head_grad in ONE launch: the per-sample gradients are scatter-ADDED into dhead
+ * [B*gh*gw, ld] (pre-zeroed) as frcnn_rpn_head_grad would; dlogits_s / ddeltas_s may be NULL. */
+int frcnn_losses_rpn_head_grad(const float* scores, const float* deltas, const float* target_labels,
+                               const float* target_boxes, const int32_t* indices, int b, int r, int s, float cls_scale,
+                               float reg_scale, float* losses, float* dlogits_s, float* ddeltas_s, const int32_t* keep,
+                               int num_anchors_total, int a_per_loc, float* dhead, int ld, frcnn_stream_t stream);
 /* RPN: scatter-ADD the per-sample gradients (dlogits_s [B,S,2], ddeltas_s [B,S,4]) into the dense
  * fp32 head-gradient matrix dhead [B*gh*gw, ld] (pre-zeroed).  Sample (b,s) refers to kept anchor
  * indices[b,s], i.e. anchor keep[indices[b,s]] (keep == NULL: identity). */

@@ -285,6 +285,52 @@ def test_rpn_head_post(ops):
     assert torch.equal(d.cpu(), exp_d)
 
 
+def test_rpn_head_post_decode_equals_two_launches(ops):
+    """the head-post kernel can also emit the decoded proposals (first launch of proposal NMS): same bits as decode_boxes"""
+    g = torch.Generator().manual_seed(6)
+    B, locs, apl, ld, n = 2, 30, 12, 128, 100
+    head = torch.randn(B * locs, ld, generator=g).cuda()
+    keep = torch.randperm(locs * apl, generator=g)[:n].sort().values.to(torch.int32).cuda()
+    ctr, sz = torch.rand(n, 2, generator=g) * 300 + 50, torch.rand(n, 2, generator=g) * 80 + 4
+    regions = torch.cat([ctr - sz / 2, ctr + sz / 2], -1).cuda()
+    s_a, d_a = torch.empty(B, n, 2, device="cuda"), torch.empty(B, n, 1, 4, device="cuda")
+    s_b, d_b = torch.empty_like(s_a), torch.empty_like(d_a)
+    dec_a, dec_b = torch.empty(B, n, 1, 4, device="cuda"), torch.empty(B, n, 1, 4, device="cuda")
+    ops.rpn_head_post(head, ld, B, locs * apl, apl, keep, n, s_a, d_a)
+    ops.decode_boxes(regions, d_a, dec_a, B, n, 1, 400, 375)
+    ops.rpn_head_post_decode(head, ld, B, locs * apl, apl, keep, n, s_b, d_b, regions, dec_b, 400, 375)
+    torch.cuda.synchronize()
+    assert torch.equal(s_a, s_b) and torch.equal(d_a, d_b)
+    assert torch.equal(dec_a, dec_b) and bool(torch.isfinite(dec_b).all())
+
+
+@pytest.mark.parametrize("m,c,ld", [(7488, 64, 64), (1000, 256, 256), (256, 64, 64), (300, 40, 64), (77, 36, 37), (5, 8, 8)])
+def test_colsum_vector_and_scalar_paths(ops, m, c, ld):
+    """bias gradients: column sums of the first c columns of a bf16 [m, ld] matrix, ADDED into the output"""
+    g = torch.Generator().manual_seed(m + c)
+    x = torch.randn(m, ld, generator=g).to(BF)
+    out = torch.full((c,), 2.0, device="cuda")
+    ops.colsum_bf16(x.cuda(), m, c, ld, out)
+    torch.cuda.synchronize()
+    _close(out, x[:, :c].double().sum(0).float() + 2.0, 1e-5, 1e-4, "colsum m=%d c=%d ld=%d" % (m, c, ld))
+
+
+def test_copy_bytes_multi(ops):
+    """one launch for the step's three input copies: different sizes, byte tails, an empty slot"""
+    g = torch.Generator().manual_seed(3)
+    sizes = (4 * 375 * 1242 * 3, 4 * 100 * 8 * 4, 1607)
+    srcs = [torch.randint(0, 256, (n,), dtype=torch.uint8, generator=g).cuda() for n in sizes]
+    dsts = [torch.full((n + 32,), 9, dtype=torch.uint8, device="cuda") for n in sizes]
+    ops.copy_bytes_multi([(s, d[:s.numel()]) for s, d in zip(srcs, dsts)])
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(d[:s.numel()], s) and bool((d[s.numel():] == 9).all())
+    one = torch.zeros(48, dtype=torch.uint8, device="cuda")
+    ops.copy_bytes_multi([(srcs[2][:48].clone(), one)])
+    torch.cuda.synchronize()
+    assert torch.equal(one, srcs[2][:48])
+
+
 def test_copy_bytes(ops):
     """the full-width device copy that feeds the plan's static image buffer: whole 16-byte words plus a byte tail"""
     g = torch.Generator().manual_seed(2)
@@ -414,10 +460,10 @@ def test_sample_indices_matches_oracle_and_contract(ops):
     assert int(status.item()) == 1
 
 
-@pytest.mark.parametrize("c1,C", [(2, 1), (8, 7)])
-def test_losses_and_gradients(ops, c1, C):
+@pytest.mark.parametrize("c1,C,B,S", [(2, 1, 3, 64), (8, 7, 3, 64), (2, 1, 5, 256)])      # (the last: more rows than threads)
+def test_losses_and_gradients(ops, c1, C, B, S):
     g = torch.Generator().manual_seed(13 + c1)
-    B, R, S = 3, 400, 64
+    R = 400
     logits = torch.randn(B, R, c1, generator=g).requires_grad_(True)
     deltas = (torch.randn(B, R, C, 4, generator=g) * 1.5).requires_grad_(True)
     scores = torch.softmax(logits, -1)
@@ -482,6 +528,68 @@ def test_head_grad_scatter_gather(ops):
     exp2[:, 8:36] = dd2.reshape(-1, 28)
     _close(out, exp2, 2 ** -8, 0, "rcnn head grad rows")
     assert torch.equal(rows.cpu().long(), (torch.arange(B)[:, None] * R + idx2.long()).reshape(-1))
+
+
+def test_losses_head_grad_fused_equals_two_launches(ops):
+    """frcnn_losses_head_grad == frcnn_losses followed by frcnn_rcnn_head_grad, bit for bit (the train plan uses the fused form)."""
+    g = torch.Generator().manual_seed(21)
+    dev = "cuda"
+    B, R, S, c1, C, ld = 4, 300, 64, 8, 7, 64
+    scores = torch.softmax(torch.randn(B, R, c1, generator=g), -1).to(dev)
+    deltas = (torch.randn(B, R, C, 4, generator=g) * 1.5).to(dev)
+    tl = F.one_hot(torch.randint(0, c1, (B, R), generator=g), c1).float()
+    tb = torch.zeros(B, R, C, 4)
+    fg = tl[..., 0] == 0
+    tb[fg, tl[..., 1:].argmax(-1)[fg]] = torch.randn(int(fg.sum()), 4, generator=g)
+    idx = torch.randint(0, R, (B, S), generator=g, dtype=torch.int32).to(dev)
+    tl, tb = tl.to(dev), tb.to(dev)
+    out_a, out_b = torch.empty(2, device=dev), torch.empty(2, device=dev)
+    dl_a, dd_a = torch.empty(B, S, c1, device=dev), torch.empty(B, S, C, 4, device=dev)
+    dl_b, dd_b = torch.empty_like(dl_a), torch.empty_like(dd_a)
+    rows_a, rows_b = torch.full((B * S,), -1, dtype=torch.int32, device=dev), torch.full((B * S,), -1, dtype=torch.int32, device=dev)
+    h_a = torch.full((B * S, ld), 7.0, dtype=BF, device=dev)
+    h_b = torch.full((B * S, ld), 7.0, dtype=BF, device=dev)
+    ops.losses(scores, deltas, tl, tb, idx, B, R, c1, S, 0.25, 1.0, out_a, dl_a, dd_a)
+    ops.rcnn_head_grad(dl_a, dd_a, idx, B, R, c1, S, h_a, ld, rows_a)
+    ops.losses_head_grad(scores, deltas, tl, tb, idx, B, R, c1, S, 0.25, 1.0, out_b, dl_b, dd_b, h_b, ld, rows_b)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b) and torch.equal(dl_a, dl_b) and torch.equal(dd_a, dd_b)
+    assert torch.equal(rows_a, rows_b)
+    assert torch.equal(h_a.view(torch.int16), h_b.view(torch.int16)), "fused head-gradient rows differ"
+    assert float(h_b.float().abs().sum()) > 0 and bool((h_b[:, c1 + 4 * C:] == 0).all())
+    # the f32 per-sample gradients are optional in the fused form
+    h_c = torch.full((B * S, ld), 7.0, dtype=BF, device=dev)
+    ops.losses_head_grad(scores, deltas, tl, tb, idx, B, R, c1, S, 0.25, 1.0, out_b, None, None, h_c, ld, rows_b)
+    torch.cuda.synchronize()
+    assert torch.equal(h_c.view(torch.int16), h_a.view(torch.int16))
+
+
+def test_losses_rpn_head_grad_fused_equals_two_launches(ops):
+    """frcnn_losses_rpn_head_grad == frcnn_losses + frcnn_rpn_head_grad (float atomics: equal up to the order of additions)."""
+    g = torch.Generator().manual_seed(22)
+    dev = "cuda"
+    B, S, locs, apl, ld, n = 3, 256, 60, 12, 128, 500
+    A = locs * apl
+    keep = torch.randperm(A, generator=g)[:n].sort().values.to(torch.int32).to(dev)
+    scores = torch.softmax(torch.randn(B, n, 2, generator=g), -1).to(dev)
+    deltas = (torch.randn(B, n, 1, 4, generator=g) * 1.5).to(dev)
+    tl = F.one_hot(torch.randint(0, 2, (B, n), generator=g), 2).float()
+    tb = torch.zeros(B, n, 1, 4)
+    fg = tl[..., 1] == 1
+    tb[fg] = torch.randn(int(fg.sum()), 1, 4, generator=g)
+    idx = torch.randint(0, n, (B, S), generator=g, dtype=torch.int32)
+    idx[:, 5] = idx[:, 4]                                                 # duplicated samples accumulate
+    tl, tb, idx = tl.to(dev), tb.to(dev), idx.to(dev)
+    out_a, out_b = torch.empty(2, device=dev), torch.empty(2, device=dev)
+    dl, dd = torch.empty(B, S, 2, device=dev), torch.empty(B, S, 1, 4, device=dev)
+    h_a, h_b = torch.zeros(B * locs, ld, device=dev), torch.zeros(B * locs, ld, device=dev)
+    ops.losses(scores, deltas, tl, tb, idx, B, n, 2, S, 0.5, 1.0, out_a, dl, dd)
+    ops.rpn_head_grad(dl, dd, idx, keep, B, S, A, apl, h_a, ld)
+    ops.losses_rpn_head_grad(scores, deltas, tl, tb, idx, B, n, S, 0.5, 1.0, out_b, None, None, keep, A, apl, h_b, ld)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    assert float(h_a.abs().sum()) > 0
+    _close(h_b, h_a, 1e-6, 1e-9, "fused RPN head-gradient scatter")
 
 
 def test_rcnn_head_post(ops):
