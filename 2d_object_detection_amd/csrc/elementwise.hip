@@ -122,13 +122,30 @@ __global__ void bn_apply_kernel(const bf16_t* __restrict__ z, const float* __res
 // invstd of its 8 channels in registers and streams its rows with independent 16-byte loads (unrolled: 12 loads in flight per
 // thread); the 32 row lanes meet in an LDS tree and the workgroup adds its 2 x 64 partial sums to one of
 // FRCNN_STAT_SLOTS pre-zeroed slots with coalesced float atomics (consecutive lanes: consecutive channels).
+// (strip, row chunk) of a workgroup of the strip kernels.  1-D grid of strips * 8 * ceil(chunks / 8) workgroups; consecutive
+// workgroup ids go to consecutive XCDs, so id = (slot << 3) | xcd with slot = group * strips + strip puts ALL strips of a row chunk
+// on one XCD, a few dispatches apart: the 128-byte pieces of a row (and the 8-byte pieces of its ReLU-mask bytes, which otherwise
+// reach memory as partial sectors from four different L2s) meet in one L2.  Workgroups with chunk >= chunks have nothing to do.
+__device__ __forceinline__ void strip_chunk(const int strips, int& strip, int& chunk) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    strip = slot % strips;
+    chunk = (slot / strips) * 8 + xcd;
+}
+
+__device__ __forceinline__ u32x4 load_stream(const bf16_t* p) {      // last use of these 16 bytes: do not keep them in the caches
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+
 template <int MASK>    // 0: no ReLU, 1: mask from the activation tensor, 2: mask from the forward pass's bit mask
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ gout, const void* __restrict__ act,
                                                             const bf16_t* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ part,
-                                                            int64_t M, int C, int rows_per_block) {
+                                                            int64_t M, int C, int rows_per_block, int strips, int chunks) {
     __shared__ float red[32][8][17];             // [row lane][vector][16 sums + pad]
-    const int c0 = blockIdx.x * 64;
+    int strip, chunk;
+    strip_chunk(strips, strip, chunk);
+    if (chunk >= chunks) return;
+    const int c0 = strip * 64;
     const int v = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int C8 = C / 8, cv = c0 / 8 + v;
     float sg[8], sgx[8];
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
         float mu[8], is[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mu[e] = mean[cv * 8 + e]; is[e] = invstd[cv * 8 + e]; }
-        const int64_t row_begin = (int64_t)blockIdx.y * rows_per_block;
+        const int64_t row_begin = (int64_t)chunk * rows_per_block;
         const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
 #pragma unroll 4
         for (int64_t r = row_begin + rl; r < row_end; r += 32) {
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
         const int stat = threadIdx.x >> 6, cl = threadIdx.x & 63;
         const int c = c0 + cl;
         if (c < C) {
-            const int slot = (int)((blockIdx.y * gridDim.x + blockIdx.x) & (FRCNN_STAT_SLOTS - 1));
+            const int slot = (chunk * strips + strip) & (FRCNN_STAT_SLOTS - 1);
             atomicAdd(part + ((int64_t)slot * 2 + stat) * C + c, red[0][cl >> 3][stat * 8 + (cl & 7)]);
         }
     }
@@ -212,19 +229,36 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int block
 // thread's 8 channels in registers for all its rows, so the streaming loop issues one 16-byte load per stream and one
 // 16-byte store, no parameter loads.  The row-chunk-0 workgroups also publish mean / invstd (for the backward pass) and
 // update the moving statistics.
+template <int VAR>   // 0: production; 4: round-1 form (2-D placement, cached loads) for FRCNN_SWEEP A/B runs (tools/ab_lib.sh)
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __restrict__ z, const double* __restrict__ part, int slots,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
                                                              float inv_count, float unbias, const bf16_t* __restrict__ res, int relu,
                                                              bf16_t* __restrict__ out, uint8_t* __restrict__ relu_mask,
                                                              float* __restrict__ mean_o, float* __restrict__ invstd_o, int64_t M, int C,
-                                                             int rows_per_block) {
+                                                             int rows_per_block, int strips, int chunks) {
     __shared__ double red[2][4][64];
     __shared__ float s_scale[64], s_shift[64];
-    const int c0 = blockIdx.x * 64;
+    int strip, chunk;
+    if (VAR == 4) { strip = blockIdx.x % strips; chunk = blockIdx.x / strips; }      // (the round-1 placement, for A/B runs)
+    else strip_chunk(strips, strip, chunk);
+    if (chunk >= chunks) return;
+    const int c0 = strip * 64;
+    const int v = threadIdx.x & 7, rl = threadIdx.x >> 3;        // 8 channel vectors x 32 row lanes
+    const int C8 = C / 8, cv = c0 / 8 + v;
+    const bool live = cv < C8;
+    const int64_t row_begin = (int64_t)chunk * rows_per_block;
+    const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
+    // z and the residual are read for the last time before the backward pass: streamed past the caches (measured on the
+    // 375x1242 batch-4 shapes, tools/bn_bench.py: 46 -> 42 us on conv2's 256-channel layers with z warm, 62 -> 45 cold)
+    constexpr bool NT = VAR != 4;
+    // (The statistics prologue below is ~2 us of every launch during which a workgroup streams nothing.  Requesting each
+    // thread's first four rows BEFORE it was tried twice, in both rounds' forms of this kernel: 0.05 ms per step SLOWER.)
     {
         const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
         const int c = c0 + cl;
+        float ga = 0.f, be = 0.f;
+        if (sl == 0 && c < C) { ga = gamma[c]; be = beta[c]; }   // (requested with the partial sums, not after the barrier)
         double s = 0.0, ss = 0.0;
         if (c < C)
             for (int t = sl; t < slots; t += 4) {
@@ -241,10 +275,10 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
             double var = ss * inv_count - mean * mean;
             if (var < 0.0) var = 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-            const float sc = gamma[c] * invstd;
+            const float sc = ga * invstd;
             s_scale[cl] = sc;
-            s_shift[cl] = beta[c] - (float)mean * sc;
-            if (blockIdx.y == 0) {
+            s_shift[cl] = be - (float)mean * sc;
+            if (chunk == 0) {
                 mean_o[c] = (float)mean;
                 invstd_o[c] = invstd;
                 mm[c] = mm[c] * momentum + (float)mean * (1.f - momentum);
@@ -253,24 +287,18 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
         }
         __syncthreads();
     }
-    const int v = threadIdx.x & 7, rl = threadIdx.x >> 3;        // 8 channel vectors x 32 row lanes
-    const int C8 = C / 8, cv = c0 / 8 + v;
-    if (cv >= C8) return;
+    if (!live) return;
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = s_scale[v * 8 + e]; sh[e] = s_shift[v * 8 + e]; }
-    const int64_t row_begin = (int64_t)blockIdx.y * rows_per_block;
-    const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
-#pragma unroll 4
-    for (int64_t r = row_begin + rl; r < row_end; r += 32) {
-        const int64_t i = r * C8 + cv;
+    auto finish = [&](const int64_t i, const u32x4 zraw, const u32x4 qraw) {
         float x[8];
-        unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), x);
+        unpack8(zraw, x);
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = x[e] * sc[e] + sh[e];
         if (res) {
             float q[8];
-            unpack8(*reinterpret_cast<const u32x4*>(res + i * 8), q);
+            unpack8(qraw, q);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] += q[e];
         }
@@ -290,36 +318,50 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
                 m |= ((pk[q] & 0x7FFF0000u) != 0u && !(pk[q] & 0x80000000u)) ? (1u << (2 * q + 1)) : 0u;
             }
             // the 8 channel-vector lanes of a row (consecutive lanes) pool their bytes: one 8-byte store per row and strip
-            unsigned x = m << (8 * (v & 3));
-            x |= __shfl_xor(x, 1);
-            x |= __shfl_xor(x, 2);
-            const unsigned y = __shfl_xor(x, 4);
+            unsigned lo = m << (8 * (v & 3));
+            lo |= __shfl_xor(lo, 1);
+            lo |= __shfl_xor(lo, 2);
+            const unsigned hi = __shfl_xor(lo, 4);
             if (C8 % 8 == 0) {
-                if (v == 0) *reinterpret_cast<u32x2*>(relu_mask + i) = u32x2{x, y};      // i = r*C8 + cv, cv % 8 == 0 here
+                if (v == 0) *reinterpret_cast<u32x2*>(relu_mask + i) = u32x2{lo, hi};      // i = r*C8 + cv, cv % 8 == 0 here
             } else {
                 relu_mask[i] = (uint8_t)m;
             }
         }
+    };
+#pragma unroll 4
+    for (int64_t r = row_begin + rl; r < row_end; r += 32) {
+        const int64_t i = r * C8 + cv;
+        const u32x4 zraw = NT ? load_stream(z + i * 8) : *reinterpret_cast<const u32x4*>(z + i * 8);
+        u32x4 qraw = {0u, 0u, 0u, 0u};
+        if (res) qraw = NT ? load_stream(res + i * 8) : *reinterpret_cast<const u32x4*>(res + i * 8);
+        finish(i, zraw, qraw);
     }
 }
 
 // fused BN backward finalize + apply: c1 = sum(g)/m, c2 = sum(g*xhat)/m of the workgroup's 64 channels from the reduce
 // kernel's slot partials; the row-chunk-0 workgroups publish dgamma / dbeta.
-template <int MASK>
+template <int MASK, int LEGACY = 0>          // LEGACY 1: round-1 placement and cached loads (FRCNN_SWEEP A/B runs only)
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* __restrict__ gout, const void* __restrict__ act,
                                                                  const bf16_t* __restrict__ z, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                  const float* __restrict__ part, int slots, float inv_m, float pscale,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                  bf16_t* __restrict__ dz, bf16_t* __restrict__ gpre, int64_t M, int C,
-                                                                 int rows_per_block) {
+                                                                 int rows_per_block, int strips, int chunks) {
     __shared__ double red[2][4][64];
     __shared__ float s_par[4][64];                // gamma*invstd, mean, invstd (xhat), c1, c2 folded: a, mu, is, k1, k2
     __shared__ float s_c2[64];
-    const int c0 = blockIdx.x * 64;
+    int strip, chunk;
+    if (LEGACY == 1) { strip = blockIdx.x % strips; chunk = blockIdx.x / strips; }
+    else strip_chunk(strips, strip, chunk);
+    if (chunk >= chunks) return;
+    const int c0 = strip * 64;
     {
         const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
         const int c = c0 + cl;
+        float is = 0.f, ga_c = 0.f, mu_c = 0.f;                 // (requested with the partial sums, not after the barrier)
+        if (sl == 0 && c < C) { is = invstd[c]; ga_c = gamma[c]; mu_c = mean[c]; }
         double s = 0.0, sx = 0.0;
         if (c < C)
             for (int t = sl; t < slots; t += 4) {
@@ -332,13 +374,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
         if (sl == 0 && c < C) {
             s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
             sx = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-            const float is = invstd[c];
-            s_par[0][cl] = gamma[c] * is;
-            s_par[1][cl] = mean[c];
+            s_par[0][cl] = ga_c * is;
+            s_par[1][cl] = mu_c;
             s_par[2][cl] = is;
             s_par[3][cl] = (float)(s * inv_m);
             s_c2[cl] = (float)(sx * inv_m);
-            if (blockIdx.y == 0) {
+            if (chunk == 0) {
                 dbeta[c] = (float)s * pscale;      // (synchronised BN: s, sx are sums over ALL ranks; every rank publishes its 1/world share)
                 dgamma[c] = (float)sx * pscale;
             }
@@ -354,7 +395,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
         ga[e] = s_par[0][v * 8 + e]; mu[e] = s_par[1][v * 8 + e]; is[e] = s_par[2][v * 8 + e];
         k1[e] = s_par[3][v * 8 + e]; k2[e] = s_c2[v * 8 + e];
     }
-    const int64_t row_begin = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t row_begin = (int64_t)chunk * rows_per_block;
     const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
     // dz is stored in bf16, and sum_rows(dz) is exactly zero in exact arithmetic.  Plain round-to-nearest breaks that by far more
     // than a random walk: the incoming gradient g is itself bf16, so per channel dz = a*(g - c1 - xhat*c2) takes ~1000 distinct
@@ -371,8 +412,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
     for (int64_t r = row_begin + rl; r < row_end; r += 32) {
         const int64_t i = r * C8 + cv;
         float g[8], zz[8], o[8];
-        unpack8(*reinterpret_cast<const u32x4*>(gout + i * 8), g);
-        unpack8(*reinterpret_cast<const u32x4*>(z + i * 8), zz);
+        unpack8(LEGACY ? *reinterpret_cast<const u32x4*>(gout + i * 8) : load_stream(gout + i * 8), g);   // (last use of the incoming
+        unpack8(LEGACY == 1 ? *reinterpret_cast<const u32x4*>(z + i * 8) : load_stream(z + i * 8), zz);    //  gradient and of z: streamed)
         if (MASK == 1) {
             float a[8];
             unpack8(*reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(act) + i * 8), a);
@@ -712,10 +753,20 @@ extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_par
                     "bn_train_apply: bad arguments");
     const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
     const int rows = strip_rows_per_block(m, c);
-    const dim3 grid((c + 63) / 64, (unsigned)((m + rows - 1) / rows));
-    hipLaunchKernelGGL(bn_train_apply_kernel, grid, dim3(256), 0, S_(stream), CBF(z), stats_partial, slots, gamma, beta, moving_mean,
-                       moving_var, momentum, eps, (float)(1.0 / (double)count), unbias, CBF(res), relu, BF(out), relu_mask, mean, invstd,
-                       m, c, rows);
+    const int strips = (c + 63) / 64, chunks = (int)((m + rows - 1) / rows);
+    const dim3 grid((unsigned)(strips * 8 * ((chunks + 7) / 8)));
+#define FRCNN_BN_LAUNCH(V)                                                                                                          \
+    hipLaunchKernelGGL(bn_train_apply_kernel<V>, grid, dim3(256), 0, S_(stream), CBF(z), stats_partial, slots, gamma, beta, moving_mean, \
+                       moving_var, momentum, eps, (float)(1.0 / (double)count), unbias, CBF(res), relu, BF(out), relu_mask, mean, invstd, \
+                       m, c, rows, strips, chunks)
+#ifdef FRCNN_SWEEP
+    const char* ev = getenv("FRCNN_BN_VAR");
+    const int var = ev ? atoi(ev) : 0;
+    if (var == 4) FRCNN_BN_LAUNCH(4);
+    else
+#endif
+    FRCNN_BN_LAUNCH(0);
+#undef FRCNN_BN_LAUNCH
     FRCNN_CHECK_LAUNCH("bn_train_apply");
     return FRCNN_OK;
 }
@@ -728,14 +779,23 @@ extern "C" int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16
                         !(act && relu_mask),
                     "bn_bwd_apply_fused: bad arguments");
     const int rows = strip_rows_per_block(m, c);
-    const dim3 grid((c + 63) / 64, (unsigned)((m + rows - 1) / rows));
+    const int strips = (c + 63) / 64, chunks = (int)((m + rows - 1) / rows);
+    const dim3 grid((unsigned)(strips * 8 * ((chunks + 7) / 8)));
     const float inv_m = (float)(1.0 / (double)(count > 0 ? count : m));
-#define FRCNN_LAUNCH(MODE, PTR)                                                                                                      \
-    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<MODE>, grid, dim3(256), 0, S_(stream), CBF(gout), (const void*)(PTR), CBF(z), mean, \
-                       invstd, gamma, partial, slots, inv_m, param_grad_scale, dgamma, dbeta, BF(dz), BF(gpre), m, c, rows)
-    if (relu_mask) FRCNN_LAUNCH(2, relu_mask);
-    else if (act) FRCNN_LAUNCH(1, act);
-    else FRCNN_LAUNCH(0, nullptr);
+#define FRCNN_LAUNCH(MODE, PTR, LEG)                                                                                                      \
+    hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<MODE, LEG>), grid, dim3(256), 0, S_(stream), CBF(gout), (const void*)(PTR), CBF(z), mean, \
+                       invstd, gamma, partial, slots, inv_m, param_grad_scale, dgamma, dbeta, BF(dz), BF(gpre), m, c, rows, strips, chunks)
+#ifdef FRCNN_SWEEP
+    const char* ev = getenv("FRCNN_BN_VAR");
+    if (ev && atoi(ev) == 4) {
+        if (relu_mask) FRCNN_LAUNCH(2, relu_mask, 1);
+        else if (act) FRCNN_LAUNCH(1, act, 1);
+        else FRCNN_LAUNCH(0, nullptr, 1);
+    } else
+#endif
+    if (relu_mask) FRCNN_LAUNCH(2, relu_mask, 0);
+    else if (act) FRCNN_LAUNCH(1, act, 0);
+    else FRCNN_LAUNCH(0, nullptr, 0);
 #undef FRCNN_LAUNCH
     FRCNN_CHECK_LAUNCH("bn_bwd_apply_fused");
     return FRCNN_OK;
@@ -747,10 +807,11 @@ extern "C" int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act
                                    const float* mean, const float* invstd, float* partial, int64_t m, int c, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(gout && z && mean && invstd && partial && c % 8 == 0 && m > 0 && !(act && relu_mask), "bn_bwd_reduce: bad arguments");
     const int rows = strip_rows_per_block(m, c);
-    const dim3 grid((c + 63) / 64, (unsigned)((m + rows - 1) / rows));
+    const int strips = (c + 63) / 64, chunks = (int)((m + rows - 1) / rows);
+    const dim3 grid((unsigned)(strips * 8 * ((chunks + 7) / 8)));
 #define FRCNN_LAUNCH(MODE, PTR)                                                                                                    \
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<MODE>, grid, dim3(256), 0, S_(stream), CBF(gout), (const void*)(PTR), CBF(z), mean, invstd, \
-                       partial, m, c, rows)
+                       partial, m, c, rows, strips, chunks)
     if (relu_mask) FRCNN_LAUNCH(2, relu_mask);
     else if (act) FRCNN_LAUNCH(1, act);
     else FRCNN_LAUNCH(0, nullptr);

@@ -1,5 +1,8 @@
-"""Achieved HBM bandwidth of the BatchNorm apply kernels on the R50-C4 layer shapes (kernel development aid).
-usage: python tools/bn_bench.py   -- prints us and GB/s, L2/MALL-warm and behind a cache flush"""
+"""BatchNorm forward (bn_train_apply) alone, on the backbone's shapes: where do its microseconds go?  Kernel-development aid.
+Needs the sweep library for the FRCNN_BN_VAR experiments:  FRCNN_SWEEP=1 python 2d_object_detection_amd/csrc/build.py
+usage (GPU box):  FRCNN_LIB=lib2dod_hip_sweep.so python tools/bn_bench.py
+  FRCNN_BN_VAR  0 production | 4 round-1 form (2-D placement, cached loads)
+Each shape: cold (384 MB flush before) and warm-z (z rewritten by a copy just before, as the conv kernel leaves it)."""
 import importlib
 import os
 import sys
@@ -9,62 +12,48 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module("2d_object_detection_amd.ops")
 BF = torch.bfloat16
-SHAPES = [(466992, 64), (116936, 64), (116936, 256), (29328, 128), (29328, 512), (7488, 256), (7488, 1024)]
-
-
-def timed(fn, flush, iters=10):
-    out = []
-    for cold in (False, True):
-        ts = []
-        for _ in range(iters):
-            if cold:
-                flush.add_(1.0)
-            else:
-                torch.cuda._sleep(100000)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn()
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1) * 1e3)
-        out.append(sorted(ts)[len(ts) // 2])
-    return out
+SHAPES = [("conv2 C=256 +res", 4 * 94 * 311, 256, True), ("conv2 C=256", 4 * 94 * 311, 256, False), ("conv2 C=64", 4 * 94 * 311, 64, False),
+          ("conv3 C=512 +res", 4 * 47 * 156, 512, True), ("conv3 C=128", 4 * 47 * 156, 128, False),
+          ("conv4 C=1024 +res", 4 * 24 * 78, 1024, True), ("conv4 C=256", 4 * 24 * 78, 256, False)]
 
 
 def main():
-    flush = torch.zeros(160 * 1024 * 1024, device="cuda")
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ov = []
-    for _ in range(50):
-        e0.record(); e1.record(); torch.cuda.synchronize(); ov.append(e0.elapsed_time(e1) * 1e3)
-    ov = sorted(ov)[25]
-    print("event pair overhead %.1f us (subtracted)" % ov)
-    for (m, c) in SHAPES:
-        z = torch.randn(m, c, device="cuda").to(BF)
-        res = torch.randn(m, c, device="cuda").to(BF)
-        out = torch.empty_like(z)
-        mask = torch.empty(m * c // 8, dtype=torch.uint8, device="cuda")
-        stats = torch.zeros(ops.STAT_SLOTS, 2, c, dtype=torch.float64, device="cuda")
-        stats[0, 0] = z.float().sum(0).double()
-        stats[0, 1] = (z.float() ** 2).sum(0).double()
-        gamma, beta = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda")
-        mm, mv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
-        mean, invstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
-        g = torch.randn(m, c, device="cuda").to(BF)
-        dz = torch.empty_like(z)
-        partial = torch.zeros(ops.STAT_SLOTS, 2, c, device="cuda")
-        dgamma, dbeta = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
-        for name, fn, byts in (
-            ("fwd", lambda: ops.bn_train_apply(z, stats, ops.STAT_SLOTS, m, gamma, beta, mm, mv, 0.99, 1e-5, out, mean, invstd, m, c, relu=True, relu_mask=mask), m * c * 4.125),
-            ("fwd+res", lambda: ops.bn_train_apply(z, stats, ops.STAT_SLOTS, m, gamma, beta, mm, mv, 0.99, 1e-5, out, mean, invstd, m, c, res=res, relu=True, relu_mask=mask), m * c * 6.125),
-            ("bwd_reduce", lambda: ops.bn_bwd_reduce(g, None, z, mean, invstd, partial, m, c, relu_mask=mask), m * c * 4.125),
-            ("bwd_apply", lambda: ops.bn_bwd_apply_fused(g, None, z, mean, invstd, gamma, partial, ops.STAT_SLOTS, dgamma, dbeta, dz, None, m, c, relu_mask=mask), m * c * 6.125),
-        ):
-            fn()
-            torch.cuda.synchronize()
-            w, cd = timed(fn, flush)
-            w, cd = max(w - ov, 0.1), max(cd - ov, 0.1)
-            print("M=%6d C=%4d %-10s %6.1f MB  warm %6.1f us %5.0f GB/s   cold %6.1f us %5.0f GB/s" % (m, c, name, byts / 1e6, w, byts / w / 1e3, cd, byts / cd / 1e3), flush=True)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    flush = torch.zeros(96 * 1024 * 1024, device="cuda")
+    for var in os.environ.get("BN_VARS", "0 4").split():
+        os.environ["FRCNN_BN_VAR"] = var
+        for name, m, c, with_res in SHAPES:
+            z = torch.randn(m, c, device="cuda", generator=g).to(BF)
+            zsrc = z.clone()
+            res = torch.randn(m, c, device="cuda", generator=g).to(BF) if with_res else None
+            stats = torch.zeros(16, 2, c, dtype=torch.float64, device="cuda")
+            stats[0, 0] = z.double().sum(0)
+            stats[0, 1] = (z.double() ** 2).sum(0)
+            gamma, beta = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda")
+            mm, mv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+            out = torch.empty_like(z)
+            mask = torch.empty(m, c // 8, dtype=torch.uint8, device="cuda")
+            mean, invstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+            res_t = {}
+            for mode in ("cold", "warm-z"):
+                ts = []
+                for _ in range(5):
+                    if mode == "cold":
+                        flush.add_(1.0)
+                    else:
+                        flush.add_(1.0)
+                        z.copy_(zsrc)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops.bn_train_apply(z, stats, 16, m, gamma, beta, mm, mv, 0.99, 1.001e-5, out, mean, invstd, m, c, res=res, relu=True,
+                                       relu_mask=mask)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) * 1e3)
+                res_t[mode] = sorted(ts)[len(ts) // 2]
+            mb = (m * c * 2 * (3 if with_res else 2) + m * c // 8) / 1e6
+            print("var %s  %-18s %6.1f MB  cold %6.1f us (%.2f TB/s)   warm-z %6.1f us (%.2f TB/s)" % (
+                var, name, mb, res_t["cold"], mb / res_t["cold"], res_t["warm-z"], mb / res_t["warm-z"]), flush=True)
 
 
 if __name__ == "__main__":
