@@ -24,6 +24,11 @@ if os.environ.get("FRCNN_SWEEP"):
 if os.environ.get("FRCNN_STAMPS"):
     FLAGS.append("-DFRCNN_STAMPS")
     VARIANT += "_stamps"
+# one-off A/B builds: FRCNN_DEFINES="NAME[,NAME...]" adds -DNAME and FRCNN_TAG=xyz names the result lib2dod_hip_xyz.so (tools/ab_lib.sh)
+for name in filter(None, os.environ.get("FRCNN_DEFINES", "").split(",")):
+    FLAGS.append("-D" + name)
+if os.environ.get("FRCNN_TAG"):
+    VARIANT += "_" + os.environ["FRCNN_TAG"]
 if VARIANT:
     LIB = os.path.join(PKG, "lib2dod_hip%s.so" % VARIANT)
 

@@ -62,15 +62,20 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     const int lane = tid & 63;
 #ifdef FRCNN_STAMPS
     // kernel-development build (tools/conv_stamps.py): wave 0 records shader-clock stamps of the workgroup's phases
-    // dbg[blockIdx.x][8] = {entry, K loop start, K loop end (last tile), epilogue stores issued (last tile), exit, HW_ID, realtime, -}
-#define FRCNN_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    // dbg[blockIdx.x][24] = {entry, K loop start, K loop end (last tile), epilogue stores issued (last tile), exit, HW_ID, realtime, XCC,
+    //   slices 4 and 5 of the K loop, 5 stamps each: top of the step, after the vmcnt wait, after the barrier, after the DMA issue, after
+    //   the last MFMA was issued -- kept in registers until the kernel's end (a store inside the loop would count in vmcnt)}
+    unsigned long long ks[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define FRCNN_KSTAMP(slice, j) do { if (p.dbg && ((slice) == 4 || (slice) == 5)) ks[((slice) - 4) * 5 + (j)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FRCNN_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 24 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     if (p.dbg && tid == 0) {
-        p.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, 32 bits
-        p.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-        p.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+        p.dbg[(size_t)blockIdx.x * 24 + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, 32 bits
+        p.dbg[(size_t)blockIdx.x * 24 + 6] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[(size_t)blockIdx.x * 24 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
     }
 #else
 #define FRCNN_STAMP(i) do { } while (0)
+#define FRCNN_KSTAMP(slice, j) do { } while (0)
 #endif
     FRCNN_STAMP(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -373,12 +378,17 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
             int sl = 0, bslot = 0;
             auto kws_step = [&](auto kw_c, const int abuf) {
                 constexpr int kw = decltype(kw_c)::value;
+                FRCNN_KSTAMP(sl, 0);
                 if (sl + 1 < nk) FRCNN_WAIT_IMM(kw == 2 ? LCB + AK_IT : LCB);
                 else FRCNN_WAIT_IMM(0);
+                FRCNN_KSTAMP(sl, 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                FRCNN_KSTAMP(sl, 2);
                 if (sl + 2 < nk) issue_slice_kws(bslot == 0 ? 2 : bslot - 1);
+                FRCNN_KSTAMP(sl, 3);
                 mfma_slice_kws(bslot, abuf, kw_c);
+                FRCNN_KSTAMP(sl, 4);
                 bslot = bslot == 2 ? 0 : bslot + 1;
                 ++sl;
             };
@@ -396,11 +406,16 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
                 // whole trips around the ring: compile-time slots, ring stays full
 #pragma unroll
                 for (int c = 0; c < S; ++c) {
+                    FRCNN_KSTAMP(nk - left + c, 0);
                     FRCNN_WAIT_IMM((S - 2) * LC);
+                    FRCNN_KSTAMP(nk - left + c, 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's fragment reads of the slot refilled next have completed
                     __builtin_amdgcn_s_barrier();        // slice landed for everyone; everyone finished reading the slot refilled next
+                    FRCNN_KSTAMP(nk - left + c, 2);
                     issue_slice((c + S - 1) % S);
+                    FRCNN_KSTAMP(nk - left + c, 3);
                     mfma_slice(c);
+                    FRCNN_KSTAMP(nk - left + c, 4);
                 }
                 to_issue -= S;
                 left -= S;
@@ -685,7 +700,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
         }
     }
     FRCNN_STAMP(4);
+#ifdef FRCNN_STAMPS
+    if (p.dbg && tid == 0) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) p.dbg[(size_t)blockIdx.x * 24 + 8 + j] = ks[j];
+    }
+#endif
 #undef FRCNN_STAMP
+#undef FRCNN_KSTAMP
 #endif
 }
 

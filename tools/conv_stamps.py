@@ -85,7 +85,7 @@ def main():
         inst = ops.last_conv_instantiation()
         grid = int(inst.split("grid=")[1].split("x")[0])
         for cold in (True, False):
-            dbg = torch.zeros(grid * 8, dtype=torch.int64, device="cuda")
+            dbg = torch.zeros(grid * 24, dtype=torch.int64, device="cuda")
             if cold:
                 flush.add_(1.0)
             lib.frcnn_debug_set_stamp_buffer(ctypes.c_void_p(dbg.data_ptr()))
@@ -95,15 +95,23 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             lib.frcnn_debug_set_stamp_buffer(None)
-            t = dbg.view(grid, 8).cpu()
+            t = dbg.view(grid, 24).cpu()
             RAW["%s|%s" % (name, "cold" if cold else "warm")] = t.clone()
+            if os.environ.get("STAMPS_DEBUG"):
+                print(t[:3].tolist())
             base = t[:, 0].min()                                             # (64-bit counters: subtract in integers first)
             t0, t1, t2, t3, t4 = ((t[:, i] - base).double() for i in range(5))
             rt = (t[:, 6] - t[:, 6].min()).double()
-            span_ticks = float(t4.max() - t0.min())
-            span_rt = float(rt.max() - rt.min())                          # 100 MHz ticks between the first and the last workgroup START
-            start_span = float(t0.max() - t0.min())
+            xcc = t[:, 7] & 0xF
+            span_ticks = max(float(t4[xcc == x].max() - t0[xcc == x].min()) for x in xcc.unique().tolist())   # (per XCD: own counter)
+            # shader clock from ONE XCD's workgroups (s_memtime counters of different XCDs are offset against each other): ticks
+            # between its first and last workgroup start over the same interval in 100 MHz realtime ticks
+            x0 = (t[:, 7] & 0xF) == (t[0, 7] & 0xF)
+            span_rt = float(rt[x0].max() - rt[x0].min())
+            start_span = float(t[x0, 0].max() - t[x0, 0].min())
             clock_ghz = start_span / span_rt * 0.1 if span_rt > 0 else float("nan")
+            if not (1.0 < clock_ghz < 3.0):
+                clock_ghz = 2.1
             us = lambda ticks: ticks / (clock_ghz * 1e3) if clock_ghz == clock_ghz else float("nan")
             hw = t[:, 5]
             cu = ((t[:, 7] & 0xF) << 12) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF)
@@ -115,6 +123,20 @@ def main():
             print("%-38s %-5s event %.1f us | span %.1f us, %d WGs on %d CUs, %.2f resident/CU, clock %.2f GHz | med/p90 us: %s | %s" % (
                 name, "cold" if cold else "warm", e0.elapsed_time(e1) * 1e3, us(span_ticks), grid, ncu, resident, clock_ghz, line,
                 inst.split(">")[0].replace("conv_tile<", "") if cold else "%.0f TF/s" % (fl / (e0.elapsed_time(e1) * 1e-3) / 1e12)), flush=True)
+            # K-loop slices 4 and 5 of wave 0 (shader-clock cycles; s_memtime ticks at 100 MHz x 1 on this part? -> reported as ticks
+            # converted with the same clock): wait for the slice's DMA | barrier | DMA issue | fragment reads + MFMA issue | whole step
+            ks = t[:, 8:18]
+            ok = (ks > 0).all(1)
+            if int(ok.sum()) > 0:
+                kz = ks[ok].double()
+                parts = []
+                for sl in range(2):
+                    b = kz[:, sl * 5:sl * 5 + 5]
+                    dl = [b[:, j + 1] - b[:, j] for j in range(4)] + [b[:, 4] - b[:, 0]]
+                    parts.append("slice %d: " % (4 + sl) + " ".join("%s %.0f/%.0f" % (nm, us(pct(v.tolist(), 0.5)) * 1e3, us(pct(v.tolist(), 0.9)) * 1e3)
+                                                                    for nm, v in zip(("wait", "barrier", "issue", "mfma", "step"), dl)))
+                gap = kz[:, 5] - kz[:, 4]
+                print("      ns med/p90, %d WGs | %s | %s | between %.0f" % (int(ok.sum()), parts[0], parts[1], us(pct(gap.tolist(), 0.5)) * 1e3), flush=True)
 
 
 if __name__ == "__main__":
