@@ -16,7 +16,7 @@ class ConvDesc(Structure):
     """frcnn_conv_desc"""
     _fields_ = [(n, c_int) for n in (
         "n", "hi", "wi", "in_pix_stride", "cin", "kh", "kw", "stride", "pad_h", "pad_w",
-        "ho", "wo", "cout", "out_h", "out_w", "out_scatter", "flags", "split_k")]
+        "ho", "wo", "cout", "out_h", "out_w", "out_scatter", "flags", "split_k")] + [("workspace", c_void_p), ("workspace_bytes", ctypes.c_size_t)]
 
 
 class WgradItem(Structure):
@@ -38,6 +38,7 @@ _SIGNATURES = {
     "frcnn_abi_version": (c_int, []),
     "frcnn_last_error": (c_char_p, []),
     "frcnn_last_conv_instantiation": (c_char_p, []),
+    "frcnn_conv2d_workspace_bytes": (ctypes.c_size_t, [P]),
     "frcnn_conv2d_describe": (c_char_p, [POINTER(ConvDesc), c_int]),
     "frcnn_conv2d_wgrad_describe": (c_char_p, [POINTER(ConvDesc), c_int, P]),
     "frcnn_conv2d_stat_tiles": (c_int, [POINTER(ConvDesc)]),

@@ -33,6 +33,8 @@ struct ConvParams {
     const unsigned char* res_mask;          // ADD_RES: bit mask applied to the residual (the ReLU mask of the block output whose
                                             // gradient the residual is) or NULL
     long long in_row_stride, in_img_stride;
+    float* fix_partial;                     // split-K fix-up form (conv_tile.hip, FIX): [tiles][2][128*64] fp32 partial tiles and
+    unsigned* fix_counter;                  // [tiles] arrival counters (zero between launches) in the caller's workspace
     int dry_run;                            // host only: stop before the launch (frcnn_conv2d_describe)
     unsigned long long* dbg;                // FRCNN_STAMPS builds: per-workgroup phase stamps (NULL otherwise)
 };

@@ -16,7 +16,7 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, bool KWS>
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, bool KWS, bool FIX>
 __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // SMODE 0: plain, 1: BatchNorm statistics of the output (forward), 2: BatchNorm-backward reduce of the consumer layer
@@ -47,6 +47,12 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     // registers; vertical validity is a property of the staged source row (per-kh bit mask, zero-filled by the range check).
     static_assert(!KWS || (!LIN && !MULTI && !F32 && BM == 128 && BK == 64 && S == 3), "kw-sharing mode: 128-row tiles, 3-slot B ring");
     constexpr int AK_IT = 3, AK_BYTES = AK_IT * NW * 1024;          // shared A image: 192 rows x 128 B (130 used), two of them
+    // FIX (layers with fewer tiles than CUs and a very long K: the RPN's 3x3 1024->256 at M = 7,488): the K range of a tile is split
+    // over TWO workgroups placed on one XCD, so every CU holds two workgroups.  Each writes its fp32 partial tile to the
+    // caller's workspace; the SECOND to arrive (one relaxed atomic per tile, no waiting) adds its partner's partial and runs the
+    // ordinary epilogue -- bias / residual / statistics / fused reduce see the complete sums.  a + b == b + a: the result does not
+    // depend on who arrives last.
+    static_assert(!FIX || (!MULTI && !F32 && !KWS), "split-K fix-up: one-tile kernel only");
     constexpr int B_BASE = KWS ? 2 * AK_BYTES : S * A_BYTES;
     constexpr int RING = KWS ? 2 * AK_BYTES + S * B_BYTES : S * (A_BYTES + B_BYTES), STG = BM * ROWB;
     // one tile per workgroup: the staging tile aliases the drained ring.  Tile runs (MULTI): the ring keeps prefetching the
@@ -87,11 +93,20 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     // run on one XCD: each XCD takes a contiguous chunk of the unit list (n fastest), so the workgroups that share an L2
     // read neighbouring pixel rows and the same weight panels.
     int tm_begin, tn, tile_count;
+    int fix_pair = 0, fix_split = 0;
     {
         const int nb = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, local = bid >> 3;
         const int q = nb >> 3, r = nb & 7;
-        const int unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        int unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        if (FIX) {
+            // gridDim.x is a multiple of 16: every XCD's chunk starts at an even unit and has an even length, so the two halves
+            // (units 2t, 2t+1) of tile t run on the same XCD, eight workgroup ids apart
+            fix_pair = unit >> 1;
+            fix_split = unit & 1;
+            if (fix_pair >= p.items) return;
+            unit = fix_pair;
+        }
         const int run = unit / p.tiles_n;
         tn = unit - run * p.tiles_n;
         tm_begin = MULTI ? run * p.tiles_per_block : run;
@@ -182,11 +197,18 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
         b_voff[i] = (n < p.Cout && r < BN) ? (unsigned)n * (unsigned)(p.Ktot * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
     }
     // F32: blockIdx.y selects a K range of k_tiles_per_split slices (split-K, 1x1 filters only)
-    const int kt0 = F32 ? blockIdx.y * p.k_tiles_per_split : 0;
-    const int nk = F32 ? min(p.k_tiles, kt0 + p.k_tiles_per_split) - kt0 : p.k_tiles;
+    const int kt0 = F32 ? blockIdx.y * p.k_tiles_per_split : FIX ? fix_split * p.k_tiles_per_split : 0;
+    const int nk = (F32 || FIX) ? min(p.k_tiles, kt0 + p.k_tiles_per_split) - kt0 : p.k_tiles;
     int ld_c0 = kt0 * BK, ld_tap = 0, ld_kh = 0, ld_kw = 0;
     int ld_k = 0, ld_m0 = tm_begin * BM;         // loader position: K slice inside its tile, first row of its tile
     unsigned ld_soff_a = (unsigned)(kt0 * BK * 2), ld_soff_b = (unsigned)(kt0 * BK * 2);
+    if (FIX && !LIN) {                           // the second half starts inside the filter: slice kt0 = (tap, channel chunk)
+        ld_tap = (kt0 * BK) / p.Cin;
+        ld_c0 = kt0 * BK - ld_tap * p.Cin;
+        ld_kh = ld_tap / p.KW;
+        ld_kw = ld_tap - ld_kh * p.KW;
+        ld_soff_a = (unsigned)((ld_kh * p.in_row_stride32 + ld_kw * p.in_pix_stride + ld_c0) * 2);
+    }
 
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     auto issue_slice = [&](const int slot) {     // DMA the loader's next K slice into ring slot
@@ -441,6 +463,34 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
         }
 
         FRCNN_STAMP(2);
+        if (FIX) {
+            // fragment-major partial tile: store (i, j, e) of all 512 threads is one run of 512 floats.  Agent-scope relaxed
+            // atomics = write-through stores / cache-bypassing loads: no L2 write-back or invalidate, only the wait for this
+            // wave's stores before the workgroup announces itself.
+            __shared__ unsigned fix_order;
+            float* mine = p.fix_partial + ((size_t)fix_pair * 2 + fix_split) * (BM * BN);
+            const float* other = p.fix_partial + ((size_t)fix_pair * 2 + (fix_split ^ 1)) * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        __hip_atomic_store(mine + ((i * NI + j) * 4 + e) * T + tid, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) fix_order = __hip_atomic_fetch_add(p.fix_counter + fix_pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (fix_order == 0u) return;             // first to arrive: the partner completes the tile
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][j][e] += __hip_atomic_load(other + ((i * NI + j) * 4 + e) * T + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(p.fix_counter + fix_pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        }
         // -------------------------------------------------------------- epilogue of tile t
         // lane holds, for fragment (i,j): pixel = wm*WTM + i*16 + (lane&15); couts = wn*WTN + j*16 + (lane>>4)*4 + 0..3
         if (F32) {
@@ -716,36 +766,40 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
 thread_local char g_last_inst[192] = "";
 unsigned long long* g_stamp_buffer = nullptr;    // FRCNN_STAMPS builds: set through frcnn_debug_set_stamp_buffer (tools/conv_stamps.py)
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false>
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false, bool FIX = false>
 int launch_tile(const ConvParams& p, hipStream_t s) {
     constexpr int ring = KWS ? 2 * 3 * 8 * 1024 + S * BN * BK * 2 : S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
     constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4;
     static_assert(smem <= 163840, "LDS budget");
     static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
-    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS>), smem) != 0) {
+    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
-    snprintf(g_last_inst, sizeof(g_last_inst), "conv_tile<BM=%d,BN=%d,BK=%d,S=%d,LIN=%d,SMODE=%d,OCC=%d,MULTI=%d,F32=%d,KWS=%d> grid=%dx%d tpb=%d",
-             BM, BN, BK, S, (int)LIN, SMODE, OCC, (int)MULTI, (int)F32, (int)KWS, p.items, F32 ? p.split : 1, p.tiles_per_block);
+    const int grid_x = FIX ? ((2 * p.items + 15) / 16) * 16 : p.items;      // FIX: two halves per tile, whole pairs per XCD
+    snprintf(g_last_inst, sizeof(g_last_inst), "conv_tile<BM=%d,BN=%d,BK=%d,S=%d,LIN=%d,SMODE=%d,OCC=%d,MULTI=%d,F32=%d,KWS=%d%s> grid=%dx%d tpb=%d",
+             BM, BN, BK, S, (int)LIN, SMODE, OCC, (int)MULTI, (int)F32, (int)KWS, FIX ? ",FIX=1" : "", grid_x, F32 ? p.split : 1, p.tiles_per_block);
     if (p.dry_run) return FRCNN_OK;              // frcnn_conv2d_describe: the dispatch decision only
-    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS>), dim3(p.items, F32 ? p.split : 1), dim3(512), smem, s, p);
+    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX>), dim3(grid_x, F32 ? p.split : 1), dim3(512), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
     return FRCNN_OK;
 }
 
-template <int BM, int BN, int BK, int S, int OCC, bool MULTI>
+template <int BM, int BN, int BK, int S, int OCC, bool MULTI, bool FIX = false>
 int launch_tile_flags(const ConvParams& p, hipStream_t s) {
     const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
     if (smode == 2)
-        return p.linear_a ? launch_tile<BM, BN, BK, S, true, 2, OCC, MULTI>(p, s) : launch_tile<BM, BN, BK, S, false, 2, OCC, MULTI>(p, s);
+        return p.linear_a ? launch_tile<BM, BN, BK, S, true, 2, OCC, MULTI, false, false, FIX>(p, s)
+                          : launch_tile<BM, BN, BK, S, false, 2, OCC, MULTI, false, false, FIX>(p, s);
     if (p.linear_a) {
-        if (smode == 1) return launch_tile<BM, BN, BK, S, true, 1, OCC, MULTI>(p, s);
-        return launch_tile<BM, BN, BK, S, true, 0, OCC, MULTI>(p, s);
+        if (smode == 1) return launch_tile<BM, BN, BK, S, true, 1, OCC, MULTI, false, false, FIX>(p, s);
+        return launch_tile<BM, BN, BK, S, true, 0, OCC, MULTI, false, false, FIX>(p, s);
     }
-    if (smode == 1) return launch_tile<BM, BN, BK, S, false, 1, OCC, MULTI>(p, s);
-    return launch_tile<BM, BN, BK, S, false, 0, OCC, MULTI>(p, s);
+    if (smode == 1) return launch_tile<BM, BN, BK, S, false, 1, OCC, MULTI, false, false, FIX>(p, s);
+    return launch_tile<BM, BN, BK, S, false, 0, OCC, MULTI, false, false, FIX>(p, s);
 }
+
+thread_local size_t g_last_ws_bytes = 0;          // workspace the last dispatch decision would use (frcnn_conv2d_workspace_bytes)
 
 #ifdef FRCNN_SWEEP
 // kernel-development builds only (FRCNN_SWEEP=1 python .../build.py --force; tools/tile_sweep.py): tile shape / kw-sharing
@@ -837,6 +891,31 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
             return launch_tile<128, 64, 64, 3, false, 0, 2, false, false, true>(p, s);
         }
     }
+    g_last_ws_bytes = 0;
+    {
+        // fewer tiles than CUs and a very long K: split-K fix-up form (conv_tile_kernel, FIX) when the caller provides the workspace.
+        // Measured per layer at M = 7,488 (tools/fix_bench.py, warm, us): 3x3 1024->256 (144 slices) 59.7 -> 52.8; 3x3 256->256
+        // (36 slices) 23.4 -> 26.9; 1x1 1024->256 (16 slices) 14.6 -> 16.7 -- the exchange (partial tile written through, one atomic
+        // round trip, partner's tile read back: 4-6 us in which the pair computes nothing) is paid back only from ~64 slices on,
+        // because two workgroups on a CU do NOT halve the K loop: the CU's LDS-DMA path delivers ~37 GB/s whether one workgroup
+        // or two feed it.
+        const bool want = tpb == 1 && bm == 128 && bn == 64 && bk == 64 && stages == 3 && p.items <= num_cus() && p.k_tiles >= 64;
+        const size_t need = (size_t)p.items * 2 * 128 * 64 * sizeof(float) + (size_t)p.items * sizeof(unsigned);
+        bool fix = want && d->workspace != nullptr;
+#ifdef FRCNN_SWEEP
+        if (const char* e = getenv("FRCNN_FIX")) fix = fix && e[0] != '0';
+#endif
+        if (want) g_last_ws_bytes = need;
+        if (fix) {
+            FRCNN_CHECK_ARG(d->workspace_bytes >= need, "conv2d_fprop: workspace of %zu bytes given, %zu needed (frcnn_conv2d_workspace_bytes)",
+                            (size_t)d->workspace_bytes, need);
+            FRCNN_CHECK_ARG((reinterpret_cast<size_t>(d->workspace) & 15) == 0, "conv2d_fprop: workspace must be 16-byte aligned");
+            p.fix_partial = reinterpret_cast<float*>(d->workspace);
+            p.fix_counter = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(d->workspace) + (size_t)p.items * 2 * 128 * 64 * sizeof(float));
+            p.k_tiles_per_split = (p.k_tiles + 1) / 2;
+            return launch_tile_flags<128, 64, 64, 3, 2, false, true>(p, s);
+        }
+    }
     int rc = FRCNN_ENOTSUP;
 #define FRCNN_TILE(BM_, BN_, BK_, S_, OCC_) \
     if (rc == FRCNN_ENOTSUP && tpb == 1 && bm == BM_ && bn == BN_ && bk == BK_ && stages == S_) rc = launch_tile_flags<BM_, BN_, BK_, S_, OCC_, false>(p, s);
@@ -916,6 +995,8 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     p.res_mask = res_mask;
     p.dry_run = dry_run ? 1 : 0;
     p.dbg = g_stamp_buffer;
+    p.fix_partial = nullptr;
+    p.fix_counter = nullptr;
     p.Hi = d->hi; p.Wi = d->wi; p.in_pix_stride = d->in_pix_stride; p.Cin = d->cin; p.KW = d->kw;
     p.stride = d->stride; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
     p.Ho = d->ho; p.Wo = d->wo; p.Cout = d->cout; p.out_h = d->out_h; p.out_w = d->out_w; p.out_scatter = d->out_scatter;
@@ -971,6 +1052,12 @@ extern "C" const char* frcnn_conv2d_describe(const frcnn_conv_desc* d, int with_
                                      reinterpret_cast<const frcnn_bf16*>(q), nullptr, const_cast<void*>(q),
                                      const_cast<double*>(reinterpret_cast<const double*>(q)), with_bn_reduce ? &red : nullptr, nullptr, true);
     return rc == FRCNN_OK ? g_last_inst : nullptr;
+}
+
+extern "C" size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d) {
+    g_last_ws_bytes = 0;
+    if (!d || !frcnn_conv2d_describe(d, 0)) return 0;
+    return g_last_ws_bytes;
 }
 
 extern "C" int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d) {

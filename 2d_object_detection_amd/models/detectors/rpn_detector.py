@@ -112,6 +112,7 @@ class RPNDetector:
         p = self.ws // 2
         self.d_inter = ops.conv_desc(batch, gh, gw, cf, self.ws, self.ws, 1, p, p, gh, gw, 256, flags=ops.CONV_BIAS | ops.CONV_RELU)
         self.d_heads = ops.conv_desc(batch, gh, gw, 256, 1, 1, 1, 0, 0, gh, gw, HEAD_LD, flags=ops.CONV_BIAS | ops.CONV_OUT_F32)
+        self._conv_ws = [ops.conv_attach_workspace(self.d_inter, dev)]      # (K = 9 * 1024 on fewer tiles than CUs: split-K fix-up form)
         self.f = torch.empty(m, 256, dtype=BF16, device=dev)
         self.head = torch.empty(m, HEAD_LD, device=dev)
         self.n = int(self._keep.numel()) if training else self.num_anchors
@@ -126,6 +127,7 @@ class RPNDetector:
             self.dz_f = torch.empty(m, 256, dtype=BF16, device=dev)
             self.d_heads_bwd = ops.conv_desc(batch, gh, gw, HEAD_LD, 1, 1, 1, 0, 0, gh, gw, 256)
             self.d_inter_bwd = ops.conv_desc(batch, gh, gw, 256, self.ws, self.ws, 1, p, p, gh, gw, cf, flags=ops.CONV_ADD_RES)
+            self._conv_ws.append(ops.conv_attach_workspace(self.d_inter_bwd, dev))
 
     def refresh_weights(self, plan):
         st = self.store

@@ -63,6 +63,9 @@ class _ConvBN:
             self.desc = ops.conv_desc(n, hi, wi, self.cin, k, k, s, p, p, self.ho, self.wo, self.cout,
                                       flags=ops.CONV_BIAS | (ops.CONV_STATS if training else 0))
             self.w_t = torch.zeros(self.cin, k, k, self.cout, dtype=BF16, device=device)   # data-gradient weights
+            # fewer output tiles than CUs and a long K (conv4 at 375x1242): scratch for the split-K fix-up form of the conv kernel
+            self.conv_ws = ops.conv_attach_workspace(self.desc, device)
+        self._device = device
         self.m = n * self.ho * self.wo
         c = self.cout
         f32 = dict(dtype=torch.float32, device=device)
@@ -165,6 +168,7 @@ class _ConvBN:
             d = ops.conv_desc(self.n, self.ho, self.wo, self.cout, 1, 1, 1, 0, 0, self.ho, self.wo, self.cin, out_h=self.hi,
                               out_w=self.wi, out_scatter=s, flags=ops.CONV_ADD_RES if res is not None else 0)
         plan.hold(d)
+        plan.hold(ops.conv_attach_workspace(d, self._device))
         if consumer is not None:
             red = consumer.reduce_args(relu=True)
             plan.hold(red)

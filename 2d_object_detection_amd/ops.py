@@ -40,6 +40,24 @@ def conv_desc(n, hi, wi, cin, kh, kw, stride, pad_h, pad_w, ho, wo, cout, in_pix
                     ho if out_h is None else out_h, wo if out_w is None else out_w, out_scatter, flags, split_k)
 
 
+def conv_workspace_bytes(d):
+    """Scratch bytes with which conv2d_fprop / conv2d_dgrad_bnreduce run descriptor d in the split-K fix-up form (0: not used)."""
+    return int(_lib.load().frcnn_conv2d_workspace_bytes(byref(d)))
+
+
+def conv_attach_workspace(d, device):
+    """Give descriptor d its own zeroed workspace when the dispatcher can use one (fewer tiles than CUs, long K).  Returns the
+    tensor (the caller keeps it alive) or None."""
+    n = conv_workspace_bytes(d)
+    if n == 0:
+        return None
+    ws = torch.zeros(n, dtype=torch.uint8, device=device)      # (a CPU tensor serves the dispatcher's dry runs: tests/test_conv_dispatch.py)
+    d.workspace = c_void_p(ws.data_ptr())
+    d.workspace_bytes = n
+    d._ws_tensor = ws                                          # the descriptor keeps its scratch alive
+    return ws
+
+
 STAT_SLOTS = 16          # FRCNN_STAT_SLOTS of include/frcnn_hip.h (checked against the library in tests/test_abi.py)
 
 

@@ -63,6 +63,12 @@ typedef struct {
     int ho, wo, cout;
     int out_h, out_w, out_scatter;
     int flags, split_k;
+    /* Optional scratch for layers with fewer output tiles than CUs and a long K (frcnn_conv2d_workspace_bytes(d) > 0): the K range of
+     * a tile is then split over two workgroups that meet in this buffer (fp32 partial tiles + one arrival counter per tile).
+     * Device memory, 16-byte aligned, ZEROED once by the caller (the kernel leaves the counters zero); a descriptor in flight on two
+     * streams at once needs two workspaces.  NULL: the one-workgroup-per-tile form. */
+    void* workspace;
+    size_t workspace_bytes;
 } frcnn_conv_desc;
 /* Data gradient fused with the BatchNorm-backward REDUCE of the layer that consumes it: gx = conv(dz, w_t) [+ res] is the
  * gradient g arriving at a BatchNorm layer whose raw input was z; while storing gx the kernel accumulates that layer's
@@ -91,6 +97,9 @@ const char* frcnn_conv2d_describe(const frcnn_conv_desc* d, int with_bn_reduce);
 /* likewise for frcnn_conv2d_wgrad (group_table_host == NULL) or for frcnn_conv2d_wgrad_grouped on a planned host table */
 const char* frcnn_conv2d_wgrad_describe(const frcnn_conv_desc* d, int with_row_index, const void* group_table_host);
 /* rows of the stats_partial buffer [rows][2][cout] (== FRCNN_STAT_SLOTS) */
+/* Bytes of frcnn_conv_desc.workspace with which frcnn_conv2d_fprop / frcnn_conv2d_dgrad_bnreduce run this descriptor in the split-K
+ * fix-up form; 0 when the dispatcher would not use it (the answer does not depend on d->workspace).  No device needed. */
+size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d);
 int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
                        const frcnn_bf16* res, void* y, double* stats_partial, frcnn_stream_t stream);

@@ -31,6 +31,12 @@ FPROP = [
     dict(id="small_run_512", n=4, h=64, w=64, cin=64, cout=512, k=1, s=1, p=0, bias=True, relu=False, stats=True),
     dict(id="small_3x3_128_stats", n=1, h=9, w=11, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     dict(id="c4_3x3_256_256_b2", n=2, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+    # split-K fix-up form (ws: the descriptor carries a workspace): fewer tiles than CUs, >= 64 K slices
+    dict(id="rpn_3x3_1024_256_relu_fix_b4", n=4, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),   # the plan's launch: 236 tiles
+    dict(id="rpn_3x3_1024_256_relu_fix", n=1, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),
+    dict(id="k4096_1x1_stats_fix", n=1, h=24, w=78, cin=4096, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True, ws=True),
+    dict(id="k4096_1x1_relu_fix", n=1, h=12, w=10, cin=4096, cout=64, k=1, s=1, p=0, bias=True, relu=True, stats=False, ws=True),
+    dict(id="small_3x3_576_oddk_stats_fix", n=1, h=12, w=10, cin=576, cout=64, k=3, s=1, p=1, bias=True, relu=False, stats=True, ws=True),   # 81 slices: 41 + 40, one tile, 14 idle workgroups
 ]
 
 # ---- data gradients: dz grid n x h x w with cin channels -> gx with cout channels; k = 1 or 3 (stride 1, pad k//2);
@@ -60,6 +66,12 @@ DGRAD = [
     dict(id="small_dg_3x3", n=2, h=13, w=17, cin=128, cout=128, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
     dict(id="small_dg_nomask", n=1, h=24, w=78, cin=1024, cout=256, k=1, res=False, res_mask=False, red=True, mask=False, scatter=1),
     dict(id="small_dg_scatter", n=2, h=12, w=39, cin=512, cout=256, k=1, res=True, res_mask=False, red=True, mask=True, scatter=2),
+    # split-K fix-up form (>= 64 K slices on fewer tiles than CUs)
+    dict(id="k4096_dg_red_fix", n=1, h=24, w=78, cin=4096, cout=256, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1, ws=True),
+    dict(id="k4096_dg_res_mask_red_fix", n=1, h=12, w=39, cin=4096, cout=64, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1, ws=True),
+    dict(id="k4096_dg_scatter_fix", n=1, h=12, w=39, cin=4096, cout=64, k=1, res=True, res_mask=False, red=True, mask=True, scatter=2, ws=True),
+    dict(id="dg_3x3_512_red_fix", n=1, h=13, w=17, cin=512, cout=64, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1, ws=True),
+    dict(id="dg_3x3_512_plain_fix", n=1, h=13, w=17, cin=512, cout=64, k=3, res=False, res_mask=False, red=False, mask=False, scatter=1, ws=True),
 ]
 
 # ---- fp32-output / split-K GEMMs (RPN heads, Dense heads)
@@ -96,17 +108,25 @@ def conv_desc(ops, c, **kw):
     return ops.conv_desc(c["n"], c["h"], c["w"], c["cin"], c["k"], c["k"], c["s"], c["p"], c["p"], ho, wo, c["cout"], **kw)
 
 
-def fprop_desc(ops, c):
+def _with_workspace(ops, c, d, device):
+    if c.get("ws"):
+        assert ops.conv_attach_workspace(d, device) is not None, "case %s: the dispatcher does not take a workspace here" % c["id"]
+    return d
+
+
+def fprop_desc(ops, c, device="cpu"):
     flags = (ops.CONV_BIAS if c["bias"] else 0) | (ops.CONV_RELU if c["relu"] else 0) | (ops.CONV_STATS if c["stats"] else 0)
-    return conv_desc(ops, c, flags=flags)
+    return _with_workspace(ops, c, conv_desc(ops, c, flags=flags), device)
 
 
-def dgrad_desc(ops, c):
+def dgrad_desc(ops, c, device="cpu"):
     n, h, w, k, sc = c["n"], c["h"], c["w"], c["k"], c["scatter"]
     flags = ops.CONV_ADD_RES if c["res"] else 0
     if sc == 1:
-        return ops.conv_desc(n, h, w, c["cin"], k, k, 1, k // 2, k // 2, h, w, c["cout"], flags=flags)
-    return ops.conv_desc(n, h, w, c["cin"], 1, 1, 1, 0, 0, h, w, c["cout"], out_h=sc * h, out_w=sc * w - 1, out_scatter=sc, flags=flags)     # (odd width, as 311 -> 156)
+        d = ops.conv_desc(n, h, w, c["cin"], k, k, 1, k // 2, k // 2, h, w, c["cout"], flags=flags)
+    else:
+        d = ops.conv_desc(n, h, w, c["cin"], 1, 1, 1, 0, 0, h, w, c["cout"], out_h=sc * h, out_w=sc * w - 1, out_scatter=sc, flags=flags)   # (odd width, as 311 -> 156)
+    return _with_workspace(ops, c, d, device)
 
 
 def f32_desc(ops, c):

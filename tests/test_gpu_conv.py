@@ -59,7 +59,7 @@ def test_conv_fprop(ops, case):
         ref = F.relu(ref)
     ref = ref.permute(0, 2, 3, 1).contiguous()
     ho, wo = ref.shape[1], ref.shape[2]
-    d = fprop_desc(ops, case)
+    d = fprop_desc(ops, case, "cuda")
     assert (d.ho, d.wo) == (ho, wo)
     xd, wd, bd = x.to(BF).cuda(), _ohwi(wt).to(BF).cuda(), bias.cuda()
     y = torch.full((n, ho, wo, cout), float("nan"), dtype=BF, device="cuda")
@@ -85,7 +85,7 @@ def test_conv_dgrad(ops, case):
     torch-CPU fp32; the partial sums against an fp64 evaluation of their definition on the kernel's own (bf16) gx."""
     g = torch.Generator().manual_seed(11)
     n, h, w, cin, cout, k, sc = (case[x] for x in ("n", "h", "w", "cin", "cout", "k", "scatter"))
-    d = dgrad_desc(ops, case)
+    d = dgrad_desc(ops, case, "cuda")
     oh, ow = d.out_h, d.out_w
     m, mo = n * h * w, n * oh * ow
     dz = _rt(torch.randn(n, h, w, cin, generator=g))
