@@ -339,6 +339,116 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
     }
 }
 
+// BatchNorm (batch statistics) + ReLU + 3x3 / stride-2 / pad-1 max pool in one pass (the ResNet stem: reference
+// models/feature_extractor.py:8-10, conv1_bn -> conv1_relu -> pool1_pad -> pool1_pool): the activation between them -- 60 MB at
+// 375x1242, batch 4, written once and read once -- never exists.  Same statistics prologue, same arithmetic and the same bf16
+// rounding of the activation as bn_train_apply_kernel followed by maxpool_fwd_kernel (zero padding takes part in the max; the
+// first maximum in window order wins): bit-identical pooled values, arg-max bytes and ReLU bit mask (which the backward pass
+// needs: the gradient of the activation is still materialised by maxpool_bwd_kernel -- gathering it through the pool inside the
+// BatchNorm backward kernels was built and measured: 82 + 80 us against 34 + 25 + 31).  Grid as the strip kernels; a workgroup
+// owns 64 channels of a run of pooled cells, 8 channel vectors x 32 cell lanes.
+__global__ __launch_bounds__(256) void bn_train_apply_pool_kernel(const bf16_t* __restrict__ z, const double* __restrict__ part, int slots,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
+                                                                  float inv_count, float unbias, bf16_t* __restrict__ pool,
+                                                                  uint8_t* __restrict__ amax, uint8_t* __restrict__ relu_mask,
+                                                                  float* __restrict__ mean_o,
+                                                                  float* __restrict__ invstd_o, int N, int H, int W, int C, int Ho, int Wo,
+                                                                  int cells_per_block, int strips, int chunks) {
+    __shared__ double red[2][4][64];
+    __shared__ float s_scale[64], s_shift[64];
+    int strip, chunk;
+    strip_chunk(strips, strip, chunk);
+    if (chunk >= chunks) return;
+    const int c0 = strip * 64;
+    {
+        const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        const int c = c0 + cl;
+        float ga = 0.f, be = 0.f;
+        if (sl == 0 && c < C) { ga = gamma[c]; be = beta[c]; }
+        double s = 0.0, ss = 0.0;
+        if (c < C)
+            for (int t = sl; t < slots; t += 4) {
+                s += (double)part[((int64_t)t * 2) * C + c];
+                ss += (double)part[((int64_t)t * 2 + 1) * C + c];
+            }
+        red[0][sl][cl] = s;
+        red[1][sl][cl] = ss;
+        __syncthreads();
+        if (sl == 0 && c < C) {
+            s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+            ss = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+            const double mean = s * inv_count;
+            double var = ss * inv_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = ga * invstd;
+            s_scale[cl] = sc;
+            s_shift[cl] = be - (float)mean * sc;
+            if (chunk == 0) {
+                mean_o[c] = (float)mean;
+                invstd_o[c] = invstd;
+                mm[c] = mm[c] * momentum + (float)mean * (1.f - momentum);
+                mv[c] = mv[c] * momentum + (float)(var * unbias) * (1.f - momentum);
+            }
+        }
+        __syncthreads();
+    }
+    const int v = threadIdx.x & 7, cell_lane = threadIdx.x >> 3;
+    const int C8 = C / 8, cv = c0 / 8 + v;
+    if (cv >= C8) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = s_scale[v * 8 + e]; sh[e] = s_shift[v * 8 + e]; }
+    const int64_t cells = (int64_t)N * Ho * Wo;
+    const int64_t cell_begin = (int64_t)chunk * cells_per_block;
+    const int64_t cell_end = min(cells, cell_begin + (int64_t)cells_per_block);
+    for (int64_t cell = cell_begin + cell_lane; cell < cell_end; cell += 32) {
+        const int ox = (int)(cell % Wo);
+        const int64_t t = cell / Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        u32x4 raw[9];
+        bool in[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {                               // all nine loads in flight
+            const int iy = oy * 2 - 1 + k / 3, ix = ox * 2 - 1 + k % 3;
+            in[k] = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int64_t src = ((((int64_t)n * H + (in[k] ? iy : 0)) * W + (in[k] ? ix : 0)) * C8 + cv) * 8;
+            raw[k] = *reinterpret_cast<const u32x4*>(z + src);
+        }
+        float best[8];
+        unsigned char arg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -1.f; arg[e] = 0; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float x[8];
+            unpack8(raw[k], x);
+            unsigned mbits = 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                // the activation as bn_train_apply_kernel stores it (bf16), or the zero padding
+                const float a = in[k] ? bf16_round(fmaxf(x[e] * sc[e] + sh[e], 0.f)) : 0.f;
+                if (a > best[e]) { best[e] = a; arg[e] = (unsigned char)k; }
+                mbits |= a > 0.f ? (1u << e) : 0u;
+            }
+            // the ReLU bit mask of the activation (read by the BatchNorm backward kernels): every pixel is written by the one cell
+            // that owns it -- window positions 4, 5, 7, 8 = pixels (2oy, 2ox), (2oy, 2ox+1), (2oy+1, 2ox), (2oy+1, 2ox+1)
+            if (relu_mask && (k == 4 || k == 5 || k == 7 || k == 8) && in[k]) {
+                const int iy = oy * 2 - 1 + k / 3, ix = ox * 2 - 1 + k % 3;
+                relu_mask[(((int64_t)n * H + iy) * W + ix) * C8 + cv] = (uint8_t)mbits;
+            }
+        }
+        const int64_t o = cell * C8 + cv;
+        *reinterpret_cast<u32x4*>(pool + o * 8) = pack8(best);
+        u32x2 a;
+        a[0] = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
+        a[1] = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
+        *reinterpret_cast<u32x2*>(amax + o * 8) = a;
+    }
+}
+
 // fused BN backward finalize + apply: c1 = sum(g)/m, c2 = sum(g*xhat)/m of the workgroup's 64 channels from the reduce
 // kernel's slot partials; the row-chunk-0 workgroups publish dgamma / dbeta.
 template <int MASK, int LEGACY = 0>          // LEGACY 1: round-1 placement and cached loads (FRCNN_SWEEP A/B runs only)
@@ -817,6 +927,25 @@ extern "C" int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act
     else FRCNN_LAUNCH(0, nullptr);
 #undef FRCNN_LAUNCH
     FRCNN_CHECK_LAUNCH("bn_bwd_reduce");
+    return FRCNN_OK;
+}
+
+// ---- the stem's BatchNorm + ReLU + max pool without the activation tensor
+extern "C" int frcnn_bn_train_apply_maxpool(const frcnn_bf16* z, const double* stats_partial, int slots, int64_t count, const float* gamma,
+                                            const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
+                                            frcnn_bf16* pooled, uint8_t* argmax, uint8_t* relu_mask, float* mean, float* invstd, int n,
+                                            int h, int w, int c, int ho, int wo, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(z && stats_partial && gamma && beta && moving_mean && moving_var && pooled && argmax && mean && invstd && count > 0 &&
+                        slots > 0 && c % 8 == 0 && n > 0 && ho == (h + 2 - 3) / 2 + 1 && wo == (w + 2 - 3) / 2 + 1,
+                    "bn_train_apply_maxpool: bad arguments");
+    const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
+    const int64_t cells = (int64_t)n * ho * wo;
+    const int per = strip_rows_per_block(cells, c);
+    const int strips = (c + 63) / 64, chunks = (int)((cells + per - 1) / per);
+    hipLaunchKernelGGL(bn_train_apply_pool_kernel, dim3((unsigned)(strips * 8 * ((chunks + 7) / 8))), dim3(256), 0, S_(stream), CBF(z),
+                       stats_partial, slots, gamma, beta, moving_mean, moving_var, momentum, eps, (float)(1.0 / (double)count), unbias,
+                       BF(pooled), argmax, relu_mask, mean, invstd, n, h, w, c, ho, wo, per, strips, chunks);
+    FRCNN_CHECK_LAUNCH("bn_train_apply_maxpool");
     return FRCNN_OK;
 }
 

@@ -306,7 +306,7 @@ class FeatureExtractor:
         npad = batch * st.hp * st.wp * 4
         self.xpad_flat = torch.zeros(npad + 256, dtype=BF16, device=dev)        # slack for the 8-wide tap reads
         self.xpad = self.xpad_flat[:npad].view(batch, st.hp, st.wp, 4)
-        self.a_stem = torch.empty(st.m, 64, dtype=BF16, device=dev)
+        self.a_stem = None if training else torch.empty(st.m, 64, dtype=BF16, device=dev)   # (training: fused into the pool kernel)
         self.hp1, self.wp1 = (st.ho + 2 - 3) // 2 + 1, (st.wo + 2 - 3) // 2 + 1
         self.pool = torch.empty(batch * self.hp1 * self.wp1, 64, dtype=BF16, device=dev)
         self.pool_arg = torch.empty(batch * self.hp1 * self.wp1, 64, dtype=torch.uint8, device=dev)
@@ -343,8 +343,15 @@ class FeatureExtractor:
             plan.zero(self.acc_flat)
         plan.add(ops.preprocess, self.images, self.xpad, 3)
         st.forward(plan, self.xpad_flat, training)
-        st.apply(plan, self.a_stem, relu=True)
-        plan.add(ops.maxpool_fwd, self.a_stem, self.pool, self.pool_arg, self.batch, st.ho, st.wo, 64, self.hp1, self.wp1)
+        if training:
+            # conv1_bn + conv1_relu + pool1 in one pass over z: the 60 MB activation between them (375x1242, batch 4) is neither
+            # written nor read back; the kernel also leaves the ReLU bit mask the backward pass reads
+            plan.add(ops.bn_train_apply_maxpool, st.z, st.stats, st.tiles, st.m * st.sync_world, self.store.weight(st.name + "_bn/gamma"),
+                     self.store.weight(st.name + "_bn/beta"), st.mm, st.mv, BN_MOMENTUM, BN_EPS, self.pool, self.pool_arg, st.relu_mask,
+                     st.mean, st.invstd, self.batch, st.ho, st.wo, 64, self.hp1, self.wp1)
+        else:
+            st.apply(plan, self.a_stem, relu=True)
+            plan.add(ops.maxpool_fwd, self.a_stem, self.pool, self.pool_arg, self.batch, st.ho, st.wo, 64, self.hp1, self.wp1)
         x = self.pool
         for (n, ci, f, s, first) in self.specs:
             u, a = self.units[n], self.acts[n]
@@ -431,7 +438,7 @@ class FeatureExtractor:
         flush_deferred()
         st = self.stem
         plan.add(ops.maxpool_bwd, gout, self.pool_arg, self.g_stem, self.batch, st.ho, st.wo, 64, self.hp1, self.wp1)
-        st.backward_bn(plan, self.g_stem, self.a_stem)
+        st.backward_bn(plan, self.g_stem, st.z)            # (second argument: only "this layer ends in a ReLU")
         st.backward_weights(plan, self.xpad_flat)
 
     # ------------------------------------------------------------------ Keras-model-like call

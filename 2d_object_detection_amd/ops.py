@@ -217,6 +217,13 @@ def bn_train_apply(z, stats, slots, count, gamma, beta, mm, mv, momentum, eps, o
          1 if relu else 0, _p(out), _p(relu_mask), _p(mean), _p(invstd), m, c, _stream())
 
 
+def bn_train_apply_maxpool(z, stats, slots, count, gamma, beta, mm, mv, momentum, eps, pooled, argmax, relu_mask, mean, invstd, n, h, w, c,
+                           ho, wo):
+    """bn_train_apply (ReLU, bit mask) + maxpool_fwd in one pass: the activation between them is never written."""
+    call("frcnn_bn_train_apply_maxpool", _p(z), _p(stats), slots, count, _p(gamma), _p(beta), _p(mm), _p(mv), momentum, eps, _p(pooled),
+         _p(argmax), _p(relu_mask), _p(mean), _p(invstd), n, h, w, c, ho, wo, _stream())
+
+
 def bn_bwd_apply_fused(gout, act, z, mean, invstd, gamma, partial, slots, dgamma, dbeta, dz, gpre, m, c, relu_mask=None, count=0,
                        param_grad_scale=1.0):
     call("frcnn_bn_bwd_apply_fused", _p(gout), _p(act), _p(relu_mask), _p(z), _p(mean), _p(invstd), _p(gamma), _p(partial), slots,

@@ -90,7 +90,7 @@ def classify(ops, fn, args, kwargs):
     if fn is ops.conv2d_wgrad_grouped:
         return FAM_WGRAD, sum(conv_flops(d, *_true_dims(d)) for (d, _x, _dz, _dw) in args[0].items), 0.0
     name = getattr(fn, "__name__", str(fn))
-    if name in ("bn_train_apply", "bn_apply", "bn_bwd_apply_fused", "bn_bwd_reduce"):
+    if name in ("bn_train_apply", "bn_apply", "bn_bwd_apply_fused", "bn_bwd_reduce", "bn_train_apply_maxpool"):
         return "batchnorm apply / reduce (bn_*_kernel)", 0.0, _tensor_bytes(args, kwargs)
     if name == "roi_crop_pool_fwd":
         return "RoI crop+pool forward (roi_fwd_kernel)", 0.0, _tensor_bytes(args, kwargs)
@@ -99,8 +99,8 @@ def classify(ops, fn, args, kwargs):
     if name == "nms_combined":
         # boxes [B,N,q,4] + scores [B,N,*] in, padded outputs out (the workspace is scratch)
         return "combined NMS (nms_class_kernel + nms_merge_kernel)", 0.0, float(sum(t.numel() * t.element_size() for t in (args[0], args[1], args[12], args[13], args[14])))
-    if name in ("assign_targets", "sample_indices", "losses", "rpn_head_grad", "rcnn_head_grad", "rpn_head_post", "rcnn_head_post", "decode_boxes",
-                "boxes_scale"):
+    if name in ("assign_targets", "sample_indices", "losses", "losses_head_grad", "losses_rpn_head_grad", "rpn_head_grad", "rcnn_head_grad",
+                "rpn_head_post", "rpn_head_post_decode", "rcnn_head_post", "decode_boxes", "boxes_scale"):
         return "targets / sampling / losses / head post", 0.0, _tensor_bytes(args, kwargs)
     if name in ("sgd_momentum",):
         return "SGD-momentum update (sgd_kernel)", 0.0, float(args[4]) * (4 + 4 + 4 + 4 + 4 + 2)

@@ -210,6 +210,15 @@ int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, 
  * the flat gradient buffer is zeroed at the start of a step) */
 int frcnn_colsum_bf16(const frcnn_bf16* x, int64_t m, int c, int ld, float* out, frcnn_stream_t stream);
 
+/* The ResNet stem's BatchNorm (batch statistics, as frcnn_bn_train_apply) + ReLU + 3x3 / stride-2 / pad-1 max pool
+ * (reference models/feature_extractor.py:8-10: conv1_bn, conv1_relu, pool1_pad, pool1_pool) in one pass over z [n,h,w,c]:
+ * pooled [n,ho,wo,c], argmax and relu_mask ([n*h*w, c/8] bits of (activation > 0), may be NULL) are bit-identical to
+ * frcnn_bn_train_apply followed by frcnn_maxpool3x3s2_fwd, but the activation between them is never written.  mean / invstd /
+ * moving statistics as frcnn_bn_train_apply. */
+int frcnn_bn_train_apply_maxpool(const frcnn_bf16* z, const double* stats_partial, int slots, int64_t count, const float* gamma,
+                                 const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
+                                 frcnn_bf16* pooled, uint8_t* argmax, uint8_t* relu_mask, float* mean, float* invstd, int n, int h,
+                                 int w, int c, int ho, int wo, frcnn_stream_t stream);
 /* ZeroPadding2D(1) + MaxPool 3x3/2 valid of Keras ResNet50 (pool1_pad/pool1_pool); input >= 0.
  * argmax (uint8, 0..8 window position, first max wins) feeds the backward gather. */
 int frcnn_maxpool3x3s2_fwd(const frcnn_bf16* x, frcnn_bf16* y, uint8_t* argmax, int n, int h, int w, int c,

@@ -69,11 +69,16 @@ def test_backbone_teacher_forced(training, geom):
     z_hip = nchw(st.z, B, st.ho, st.wo)
     worst.append(("stem z", rel(z_hip, z_ref), mism(z_hip, z_ref)))
     a_ref = Q(F.relu(R._bn(z_hip, p, "conv1", training, ns)))
-    a_hip = nchw(m.a_stem, B, st.ho, st.wo)
-    worst.append(("stem act", rel(a_hip, a_ref), mism(a_hip, a_ref)))
-    pool_ref = F.max_pool2d(F.pad(a_hip, (1, 1, 1, 1)), 3, 2)
     pool_hip = nchw(m.pool, B, m.hp1, m.wp1)
-    assert mism(pool_hip, pool_ref) == 0.0
+    if m.a_stem is not None:
+        a_hip = nchw(m.a_stem, B, st.ho, st.wo)
+        worst.append(("stem act", rel(a_hip, a_ref), mism(a_hip, a_ref)))
+        assert mism(pool_hip, F.max_pool2d(F.pad(a_hip, (1, 1, 1, 1)), 3, 2)) == 0.0
+    else:
+        # training mode: conv1_bn + ReLU + pool1 are ONE kernel and the activation is never stored (its bit-identity with the
+        # two-kernel form is tests/test_gpu_kernels.py::test_stem_bn_relu_maxpool_fused): the pooled map against the oracle's
+        pool_ref = F.max_pool2d(F.pad(a_ref, (1, 1, 1, 1)), 3, 2)
+        worst.append(("stem pool", rel(pool_hip, pool_ref), mism(pool_hip, pool_ref)))
     xin = pool_hip
     for (n, ci, f, s, first) in m.specs:
         u, a = m.units[n], m.acts[n]
@@ -217,11 +222,16 @@ def test_backbone_backward_teacher_forced(geom):
         cmp(n + " gin", nchw(a["gin"], hi, wi), exp_gin, 0.015)
         gout = a["gin"]
     # max-pool backward + stem
+    # the stem's activation is not stored (BatchNorm + ReLU + pool are one kernel): the pool's routing is checked on the oracle's
+    # bf16 activation of the HIP path's own z, at the pixels where both sides agree that it is positive
     stem = fe.stem
-    a_stem = nchw(fe.a_stem, stem.ho, stem.wo).requires_grad_(True)
+    bits = ((stem.relu_mask[:, :, None] >> torch.arange(8, dtype=torch.uint8, device=gout.device)) & 1).reshape(-1, 64).bool()
+    a_stem = Q(F.relu(F.batch_norm(nchw(stem.z, stem.ho, stem.wo), None, None, params["conv1_bn/gamma"], params["conv1_bn/beta"],
+                                   training=True, eps=R.BN_EPS))).requires_grad_(True)
     F.max_pool2d(F.pad(a_stem, (1, 1, 1, 1)), 3, 2).backward(nchw(gout, fe.hp1, fe.wp1))
-    mask = a_stem.detach() > 0                          # ties among zeros may route differently; they are ReLU-masked anyway
-    cmp("pool bwd", nchw(fe.g_stem, stem.ho, stem.wo)[mask], a_stem.grad[mask], 0.01)
+    mask = (a_stem.detach() > 0) & nchw(bits, stem.ho, stem.wo).bool()
+    assert float(mask.float().mean()) > 0.2 and float(((a_stem.detach() > 0) != nchw(bits, stem.ho, stem.wo).bool()).float().mean()) < 5e-3
+    cmp("pool bwd", nchw(fe.g_stem, stem.ho, stem.wo)[mask], a_stem.grad[mask], 0.02)
     _, gw, gg, gbt, _ = _unit_backward(params, "conv1", Q(R.preprocess(images)), 2, 3, nchw(fe.g_stem, stem.ho, stem.wo))
     check_params("conv1", gw, gg, gbt)
     bad = [r for r in report if not r[1] <= r[2]]

@@ -167,6 +167,46 @@ def test_maxpool(ops):
     _close(gx.float().cpu()[mask], ref[mask], 2 ** -7, 1e-2, "maxpool bwd")
 
 
+@pytest.mark.parametrize("n,h,w,c", [(2, 21, 30, 64), (1, 8, 9, 64), (3, 13, 16, 128), (1, 7, 5, 8)])
+def test_stem_bn_relu_maxpool_fused(ops, n, h, w, c):
+    """frcnn_bn_train_apply_maxpool == bn_train_apply(ReLU, bit mask) + maxpool_fwd bit for bit: pooled values, arg-max bytes, ReLU
+    bit mask, mean / invstd / moving statistics -- without the activation tensor."""
+    g = torch.Generator().manual_seed(31 + h)
+    dev = "cuda"
+    m = n * h * w
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    z = (torch.randn(m, c, generator=g) * 1.5 + 0.3).to(BF).to(dev)
+    zf = z.double()
+    stats = torch.zeros(16, 2, c, dtype=torch.float64, device=dev)
+    stats[3, 0], stats[3, 1] = zf.sum(0), (zf * zf).sum(0)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(dev), (torch.randn(c, generator=g) * 0.2).to(dev)
+
+    def fresh():
+        return torch.full((c,), 0.25, device=dev), torch.full((c,), 0.75, device=dev)
+
+    mm_a, mv_a = fresh()
+    act = torch.empty(m, c, dtype=BF, device=dev)
+    mask_a = torch.empty(m, c // 8, dtype=torch.uint8, device=dev)
+    mean_a, inv_a = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    ops.bn_train_apply(z, stats, 16, m, gamma, beta, mm_a, mv_a, 0.99, 1.001e-5, act, mean_a, inv_a, m, c, relu=True, relu_mask=mask_a)
+    pool_a = torch.empty(n * ho * wo, c, dtype=BF, device=dev)
+    arg_a = torch.empty(n * ho * wo, c, dtype=torch.uint8, device=dev)
+    ops.maxpool_fwd(act, pool_a, arg_a, n, h, w, c, ho, wo)
+    mm_b, mv_b = fresh()
+    pool_b = torch.full((n * ho * wo, c), 7.0, dtype=BF, device=dev)
+    arg_b = torch.full((n * ho * wo, c), 77, dtype=torch.uint8, device=dev)
+    mask_b = torch.full((m, c // 8), 0xA5, dtype=torch.uint8, device=dev)
+    mean_b, inv_b = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    ops.bn_train_apply_maxpool(z, stats, 16, m, gamma, beta, mm_b, mv_b, 0.99, 1.001e-5, pool_b, arg_b, mask_b, mean_b, inv_b, n, h, w, c, ho, wo)
+    torch.cuda.synchronize()
+    assert torch.equal(pool_a.view(torch.int16), pool_b.view(torch.int16)), "pooled values"
+    assert torch.equal(arg_a, arg_b), "arg-max bytes"
+    assert torch.equal(mask_a, mask_b), "ReLU bit mask (every pixel written once, by the cell that owns it)"
+    for x, y in ((mean_a, mean_b), (inv_a, inv_b), (mm_a, mm_b), (mv_a, mv_b)):
+        assert torch.equal(x, y)
+    assert 0.2 < float((act > 0).float().mean()) < 0.9
+
+
 def test_sgd_and_lr_schedule(ops):
     g = torch.Generator().manual_seed(3)
     n = 10007
