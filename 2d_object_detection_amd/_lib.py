@@ -68,6 +68,7 @@ _SIGNATURES = {
     "frcnn_bn_bwd_apply": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int64, c_int, P]),
     "frcnn_relu_bwd": (c_int, [P, P, P, c_int64, P]),
     "frcnn_colsum_bf16": (c_int, [P, c_int64, c_int, c_int, P, P]),
+    "frcnn_bn_train_apply_dual": (c_int, [P] * 16 + [c_int, c_int64, c_float, c_float, c_int, P, P, c_int64, c_int, P]),
     "frcnn_bn_train_apply_maxpool": (c_int, [P, P, c_int, c_int64, P, P, P, P, c_float, c_float, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                              c_int, c_int, P]),
     "frcnn_maxpool3x3s2_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

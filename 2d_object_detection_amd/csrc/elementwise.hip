@@ -229,16 +229,26 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int block
 // thread's 8 channels in registers for all its rows, so the streaming loop issues one 16-byte load per stream and one
 // 16-byte store, no parameter loads.  The row-chunk-0 workgroups also publish mean / invstd (for the backward pass) and
 // update the moving statistics.
-template <int VAR>   // 0: production; 4: round-1 form (2-D placement, cached loads) for FRCNN_SWEEP A/B runs (tools/ab_lib.sh)
+// The second BatchNorm of the DUAL form (the shortcut branch of a stage's first bottleneck block): its conv output, statistics and
+// parameters.  out = ReLU(BN(z) + BN2(z2)) in one pass: the shortcut's normalised output -- 60 MB at conv2, written by one kernel
+// and read back by the next -- is never stored (the backward pass needs z2, not BN2(z2)).  BN2(z2) is rounded to bf16 before the
+// addition, as it was when it went through memory: bit-identical results.
+struct Bn2 {
+    const bf16_t* z; const double* part; const float* gamma; const float* beta;
+    float* mm; float* mv; float* mean_o; float* invstd_o;
+};
+
+template <int VAR, bool DUAL = false>   // VAR 0: production; 4: round-1 form (2-D placement, cached loads) for FRCNN_SWEEP A/B runs (tools/ab_lib.sh)
 __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __restrict__ z, const double* __restrict__ part, int slots,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
                                                              float inv_count, float unbias, const bf16_t* __restrict__ res, int relu,
                                                              bf16_t* __restrict__ out, uint8_t* __restrict__ relu_mask,
                                                              float* __restrict__ mean_o, float* __restrict__ invstd_o, int64_t M, int C,
-                                                             int rows_per_block, int strips, int chunks) {
+                                                             int rows_per_block, int strips, int chunks, const Bn2 b2) {
     __shared__ double red[2][4][64];
     __shared__ float s_scale[64], s_shift[64];
+    __shared__ float s_scale2[DUAL ? 64 : 1], s_shift2[DUAL ? 64 : 1];
     int strip, chunk;
     if (VAR == 4) { strip = blockIdx.x % strips; chunk = blockIdx.x / strips; }      // (the round-1 placement, for A/B runs)
     else strip_chunk(strips, strip, chunk);
@@ -286,17 +296,58 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
             }
         }
         __syncthreads();
+        if (DUAL) {                              // the same for the second BatchNorm (its loads overlap the first one's arithmetic)
+            float ga2 = 0.f, be2 = 0.f;
+            if (sl == 0 && c < C) { ga2 = b2.gamma[c]; be2 = b2.beta[c]; }
+            s = ss = 0.0;
+            if (c < C)
+                for (int t = sl; t < slots; t += 4) {
+                    s += (double)b2.part[((int64_t)t * 2) * C + c];
+                    ss += (double)b2.part[((int64_t)t * 2 + 1) * C + c];
+                }
+            red[0][sl][cl] = s;
+            red[1][sl][cl] = ss;
+            __syncthreads();
+            if (sl == 0 && c < C) {
+                s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+                ss = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+                const double mean = s * inv_count;
+                double var = ss * inv_count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+                const float sc2 = ga2 * invstd;
+                s_scale2[cl] = sc2;
+                s_shift2[cl] = be2 - (float)mean * sc2;
+                if (chunk == 0) {
+                    b2.mean_o[c] = (float)mean;
+                    b2.invstd_o[c] = invstd;
+                    b2.mm[c] = b2.mm[c] * momentum + (float)mean * (1.f - momentum);
+                    b2.mv[c] = b2.mv[c] * momentum + (float)(var * unbias) * (1.f - momentum);
+                }
+            }
+            __syncthreads();
+        }
     }
     if (!live) return;
-    float sc[8], sh[8];
+    float sc[8], sh[8], sc2[DUAL ? 8 : 1], sh2[DUAL ? 8 : 1];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = s_scale[v * 8 + e]; sh[e] = s_shift[v * 8 + e]; }
+    if (DUAL) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc2[e] = s_scale2[v * 8 + e]; sh2[e] = s_shift2[v * 8 + e]; }
+    }
+    const bf16_t* second = DUAL ? b2.z : res;
     auto finish = [&](const int64_t i, const u32x4 zraw, const u32x4 qraw) {
         float x[8];
         unpack8(zraw, x);
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = x[e] * sc[e] + sh[e];
-        if (res) {
+        if (DUAL) {
+            float q[8];
+            unpack8(qraw, q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += bf16_round(q[e] * sc2[e] + sh2[e]);
+        } else if (res) {
             float q[8];
             unpack8(qraw, q);
 #pragma unroll
@@ -334,7 +385,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
         const int64_t i = r * C8 + cv;
         const u32x4 zraw = NT ? load_stream(z + i * 8) : *reinterpret_cast<const u32x4*>(z + i * 8);
         u32x4 qraw = {0u, 0u, 0u, 0u};
-        if (res) qraw = NT ? load_stream(res + i * 8) : *reinterpret_cast<const u32x4*>(res + i * 8);
+        if (second) qraw = NT ? load_stream(second + i * 8) : *reinterpret_cast<const u32x4*>(second + i * 8);
         finish(i, zraw, qraw);
     }
 }
@@ -868,7 +919,7 @@ extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_par
 #define FRCNN_BN_LAUNCH(V)                                                                                                          \
     hipLaunchKernelGGL(bn_train_apply_kernel<V>, grid, dim3(256), 0, S_(stream), CBF(z), stats_partial, slots, gamma, beta, moving_mean, \
                        moving_var, momentum, eps, (float)(1.0 / (double)count), unbias, CBF(res), relu, BF(out), relu_mask, mean, invstd, \
-                       m, c, rows, strips, chunks)
+                       m, c, rows, strips, chunks, Bn2{})
 #ifdef FRCNN_SWEEP
     const char* ev = getenv("FRCNN_BN_VAR");
     const int var = ev ? atoi(ev) : 0;
@@ -927,6 +978,27 @@ extern "C" int frcnn_bn_bwd_reduce(const frcnn_bf16* gout, const frcnn_bf16* act
     else FRCNN_LAUNCH(0, nullptr);
 #undef FRCNN_LAUNCH
     FRCNN_CHECK_LAUNCH("bn_bwd_reduce");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_bn_train_apply_dual(const frcnn_bf16* z, const double* stats_partial, const float* gamma, const float* beta,
+                                         float* moving_mean, float* moving_var, float* mean, float* invstd, const frcnn_bf16* z2,
+                                         const double* stats_partial2, const float* gamma2, const float* beta2, float* moving_mean2,
+                                         float* moving_var2, float* mean2, float* invstd2, int slots, int64_t count, float momentum,
+                                         float eps, int relu, frcnn_bf16* out, uint8_t* relu_mask, int64_t m, int c, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(z && stats_partial && gamma && beta && moving_mean && moving_var && mean && invstd && z2 && stats_partial2 && gamma2 &&
+                        beta2 && moving_mean2 && moving_var2 && mean2 && invstd2 && out && count > 0 && slots > 0 && c % 8 == 0,
+                    "bn_train_apply_dual: bad arguments");
+    const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
+    const int rows = strip_rows_per_block(m, c);
+    const int strips = (c + 63) / 64, chunks = (int)((m + rows - 1) / rows);
+    Bn2 b2;
+    b2.z = CBF(z2); b2.part = stats_partial2; b2.gamma = gamma2; b2.beta = beta2; b2.mm = moving_mean2; b2.mv = moving_var2;
+    b2.mean_o = mean2; b2.invstd_o = invstd2;
+    hipLaunchKernelGGL((bn_train_apply_kernel<0, true>), dim3((unsigned)(strips * 8 * ((chunks + 7) / 8))), dim3(256), 0, S_(stream), CBF(z),
+                       stats_partial, slots, gamma, beta, moving_mean, moving_var, momentum, eps, (float)(1.0 / (double)count), unbias,
+                       (const bf16_t*)nullptr, relu, BF(out), relu_mask, mean, invstd, m, c, rows, strips, chunks, b2);
+    FRCNN_CHECK_LAUNCH("bn_train_apply_dual");
     return FRCNN_OK;
 }
 

@@ -109,7 +109,17 @@ class _ConvBN:
             g, b = st.weight(self.name + "_bn/gamma"), st.weight(self.name + "_bn/beta")
             plan.add(ops.bn_finalize_eval, self.cout, g, b, self.mm, self.mv, BN_EPS, self.scale, self.shift)
 
-    def apply(self, plan, out, res=None, relu=True):
+    def apply(self, plan, out, res=None, relu=True, dual=None):
+        """dual: a second conv unit of the same output shape whose BatchNorm (no ReLU) is added before the ReLU -- the shortcut
+        branch of a stage's first block: out = ReLU(BN(z) + BN_dual(z_dual)) in one kernel, the shortcut's output never stored."""
+        if self._training and dual is not None:
+            st = self.store
+            assert res is None and dual.m == self.m and dual.cout == self.cout and dual.tiles == self.tiles
+            plan.add(ops.bn_train_apply_dual, self.z, self.stats, st.weight(self.name + "_bn/gamma"), st.weight(self.name + "_bn/beta"),
+                     self.mm, self.mv, self.mean, self.invstd, dual.z, dual.stats, st.weight(dual.name + "_bn/gamma"),
+                     st.weight(dual.name + "_bn/beta"), dual.mm, dual.mv, dual.mean, dual.invstd, self.tiles, self.m * self.sync_world,
+                     BN_MOMENTUM, BN_EPS, out, self.m, self.cout, relu=relu, relu_mask=self.relu_mask if relu else None)
+            return
         if self._training:
             # batch statistics -> scale/shift inside the apply kernel (every workgroup reduces its own 64 channels)
             st = self.store
@@ -323,8 +333,10 @@ class FeatureExtractor:
             m = batch * ho * wo
             a = {"a1": torch.empty(m, f, dtype=BF16, device=dev), "a2": torch.empty(m, f, dtype=BF16, device=dev),
                  "out": torch.empty(m, 4 * f, dtype=BF16, device=dev)}
-            if first:
+            if first and not training:
                 a["sc"] = torch.empty(m, 4 * f, dtype=BF16, device=dev)
+            elif first:
+                a["sc"] = None                    # (training: the shortcut BatchNorm is fused into the block-final one)
             if training:
                 a["g1"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a1
                 a["g2"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a2
@@ -355,9 +367,11 @@ class FeatureExtractor:
         x = self.pool
         for (n, ci, f, s, first) in self.specs:
             u, a = self.units[n], self.acts[n]
+            fused_shortcut = first and training      # shortcut BatchNorm applied inside the block-final BatchNorm kernel (no a["sc"])
             if first:
                 u[0].forward(plan, x, training)
-                u[0].apply(plan, a["sc"], relu=False)
+                if not fused_shortcut:
+                    u[0].apply(plan, a["sc"], relu=False)
                 res = a["sc"]
             else:
                 res = x
@@ -366,7 +380,10 @@ class FeatureExtractor:
             u[2].forward(plan, a["a1"], training)
             u[2].apply(plan, a["a2"])
             u[3].forward(plan, a["a2"], training)
-            u[3].apply(plan, a["out"], res=res, relu=True)
+            if fused_shortcut:
+                u[3].apply(plan, a["out"], relu=True, dual=u[0])
+            else:
+                u[3].apply(plan, a["out"], res=res, relu=True)
             x = a["out"]
         return self.feature_maps
 

@@ -217,6 +217,14 @@ def bn_train_apply(z, stats, slots, count, gamma, beta, mm, mv, momentum, eps, o
          1 if relu else 0, _p(out), _p(relu_mask), _p(mean), _p(invstd), m, c, _stream())
 
 
+def bn_train_apply_dual(z, stats, gamma, beta, mm, mv, mean, invstd, z2, stats2, gamma2, beta2, mm2, mv2, mean2, invstd2, slots, count,
+                        momentum, eps, out, m, c, relu=True, relu_mask=None):
+    """out = [ReLU](BN(z) + BN2(z2)), both with batch statistics, in one pass (block-final + shortcut BatchNorm of a first block)."""
+    call("frcnn_bn_train_apply_dual", _p(z), _p(stats), _p(gamma), _p(beta), _p(mm), _p(mv), _p(mean), _p(invstd), _p(z2), _p(stats2),
+         _p(gamma2), _p(beta2), _p(mm2), _p(mv2), _p(mean2), _p(invstd2), slots, count, momentum, eps, 1 if relu else 0, _p(out),
+         _p(relu_mask), m, c, _stream())
+
+
 def bn_train_apply_maxpool(z, stats, slots, count, gamma, beta, mm, mv, momentum, eps, pooled, argmax, relu_mask, mean, invstd, n, h, w, c,
                            ho, wo):
     """bn_train_apply (ReLU, bit mask) + maxpool_fwd in one pass: the activation between them is never written."""

@@ -90,7 +90,7 @@ def classify(ops, fn, args, kwargs):
     if fn is ops.conv2d_wgrad_grouped:
         return FAM_WGRAD, sum(conv_flops(d, *_true_dims(d)) for (d, _x, _dz, _dw) in args[0].items), 0.0
     name = getattr(fn, "__name__", str(fn))
-    if name in ("bn_train_apply", "bn_apply", "bn_bwd_apply_fused", "bn_bwd_reduce", "bn_train_apply_maxpool"):
+    if name in ("bn_train_apply", "bn_apply", "bn_bwd_apply_fused", "bn_bwd_reduce", "bn_train_apply_maxpool", "bn_train_apply_dual"):
         return "batchnorm apply / reduce (bn_*_kernel)", 0.0, _tensor_bytes(args, kwargs)
     if name == "roi_crop_pool_fwd":
         return "RoI crop+pool forward (roi_fwd_kernel)", 0.0, _tensor_bytes(args, kwargs)

@@ -210,6 +210,15 @@ int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, 
  * the flat gradient buffer is zeroed at the start of a step) */
 int frcnn_colsum_bf16(const frcnn_bf16* x, int64_t m, int c, int ld, float* out, frcnn_stream_t stream);
 
+/* out = [ReLU](BN(z) + BN2(z2)) with batch statistics for both BatchNorm layers in one pass (the block-final BatchNorm of a
+ * stage's first bottleneck block and the BatchNorm of its shortcut convolution, reference Keras ResNet50 conv*_block1_0_bn /
+ * _3_bn / _add / _out): what frcnn_bn_train_apply(z2 -> tmp) followed by frcnn_bn_train_apply(z, res = tmp) computes, bit for
+ * bit, without tmp.  Both layers share slots, count, momentum, eps; each publishes its own mean / invstd / moving statistics. */
+int frcnn_bn_train_apply_dual(const frcnn_bf16* z, const double* stats_partial, const float* gamma, const float* beta,
+                              float* moving_mean, float* moving_var, float* mean, float* invstd, const frcnn_bf16* z2,
+                              const double* stats_partial2, const float* gamma2, const float* beta2, float* moving_mean2,
+                              float* moving_var2, float* mean2, float* invstd2, int slots, int64_t count, float momentum, float eps,
+                              int relu, frcnn_bf16* out, uint8_t* relu_mask, int64_t m, int c, frcnn_stream_t stream);
 /* The ResNet stem's BatchNorm (batch statistics, as frcnn_bn_train_apply) + ReLU + 3x3 / stride-2 / pad-1 max pool
  * (reference models/feature_extractor.py:8-10: conv1_bn, conv1_relu, pool1_pad, pool1_pool) in one pass over z [n,h,w,c]:
  * pooled [n,ho,wo,c], argmax and relu_mask ([n*h*w, c/8] bits of (activation > 0), may be NULL) are bit-identical to

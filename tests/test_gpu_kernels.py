@@ -207,6 +207,49 @@ def test_stem_bn_relu_maxpool_fused(ops, n, h, w, c):
     assert 0.2 < float((act > 0).float().mean()) < 0.9
 
 
+@pytest.mark.parametrize("m,c,relu", [(1500, 256, True), (333, 64, True), (700, 1024, False), (64, 8, True)])
+def test_bn_dual_equals_two_launches(ops, m, c, relu):
+    """frcnn_bn_train_apply_dual == bn_train_apply(z2 -> tmp, no ReLU) followed by bn_train_apply(z, res = tmp): output, ReLU mask and
+    both layers' mean / invstd / moving statistics bit for bit -- without tmp."""
+    g = torch.Generator().manual_seed(51 + c)
+    dev = "cuda"
+    z1 = (torch.randn(m, c, generator=g) * 1.2 + 0.1).to(BF).to(dev)
+    z2 = (torch.randn(m, c, generator=g) * 0.7 - 0.2).to(BF).to(dev)
+
+    def stats_of(z):
+        st = torch.zeros(16, 2, c, dtype=torch.float64, device=dev)
+        st[5, 0], st[5, 1] = z.double().sum(0), (z.double() ** 2).sum(0)
+        return st
+
+    s1, s2 = stats_of(z1), stats_of(z2)
+    prm = [(torch.rand(c, generator=g) + 0.5).to(dev) for _ in range(2)] + [(torch.randn(c, generator=g) * 0.2).to(dev) for _ in range(2)]
+    ga1, ga2, be1, be2 = prm
+
+    def state():
+        return [torch.full((c,), v, device=dev) for v in (0.1, 0.9, 0.2, 0.8)] + [torch.empty(c, device=dev) for _ in range(4)]
+
+    mm1a, mv1a, mm2a, mv2a, me1a, iv1a, me2a, iv2a = state()
+    tmp = torch.empty(m, c, dtype=BF, device=dev)
+    out_a = torch.empty(m, c, dtype=BF, device=dev)
+    mask_a = torch.zeros(m, c // 8, dtype=torch.uint8, device=dev)
+    ops.bn_train_apply(z2, s2, 16, m, ga2, be2, mm2a, mv2a, 0.99, 1.001e-5, tmp, me2a, iv2a, m, c, relu=False)
+    ops.bn_train_apply(z1, s1, 16, m, ga1, be1, mm1a, mv1a, 0.99, 1.001e-5, out_a, me1a, iv1a, m, c, res=tmp, relu=relu,
+                       relu_mask=mask_a if relu else None)
+    mm1b, mv1b, mm2b, mv2b, me1b, iv1b, me2b, iv2b = state()
+    out_b = torch.full((m, c), 3.0, dtype=BF, device=dev)
+    mask_b = torch.zeros(m, c // 8, dtype=torch.uint8, device=dev)
+    ops.bn_train_apply_dual(z1, s1, ga1, be1, mm1b, mv1b, me1b, iv1b, z2, s2, ga2, be2, mm2b, mv2b, me2b, iv2b, 16, m, 0.99, 1.001e-5,
+                            out_b, m, c, relu=relu, relu_mask=mask_b if relu else None)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a.view(torch.int16), out_b.view(torch.int16)), "output"
+    assert torch.equal(mask_a, mask_b), "ReLU bit mask"
+    for x, y in ((mm1a, mm1b), (mv1a, mv1b), (mm2a, mm2b), (mv2a, mv2b), (me1a, me1b), (iv1a, iv1b), (me2a, me2b), (iv2a, iv2b)):
+        assert torch.equal(x, y)
+    ref = torch.nn.functional.batch_norm(z1.float().cpu(), None, None, ga1.cpu(), be1.cpu(), training=True, eps=1.001e-5) + \
+        torch.nn.functional.batch_norm(z2.float().cpu(), None, None, ga2.cpu(), be2.cpu(), training=True, eps=1.001e-5)
+    _close(out_b, torch.relu(ref) if relu else ref, 2 ** -7, 2e-2, "dual BatchNorm against torch")
+
+
 def test_sgd_and_lr_schedule(ops):
     g = torch.Generator().manual_seed(3)
     n = 10007
