@@ -30,6 +30,8 @@ class BnReduce(Structure):
     _fields_ = [("z", c_void_p), ("relu_mask", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("partial", c_void_p)]
 
 
+ABI_VERSION = 3          # FRCNN_ABI_VERSION of include/frcnn_hip.h this table was written against (load() refuses any other library)
+
 CONV_BIAS, CONV_RELU, CONV_OUT_F32, CONV_ADD_RES, CONV_STATS, CONV_SPLITK_ATOMIC = 1, 2, 4, 8, 16, 32
 
 P = c_void_p
@@ -39,6 +41,7 @@ _SIGNATURES = {
     "frcnn_last_error": (c_char_p, []),
     "frcnn_last_conv_instantiation": (c_char_p, []),
     "frcnn_conv2d_workspace_bytes": (ctypes.c_size_t, [P]),
+    "frcnn_conv2d_workspace_counter_bytes": (ctypes.c_size_t, [P]),
     "frcnn_conv2d_describe": (c_char_p, [POINTER(ConvDesc), c_int]),
     "frcnn_conv2d_wgrad_describe": (c_char_p, [POINTER(ConvDesc), c_int, P]),
     "frcnn_conv2d_stat_tiles": (c_int, [POINTER(ConvDesc)]),
@@ -124,6 +127,14 @@ def load():
     except ImportError:
         pass
     lib = ctypes.CDLL(LIB_PATH)
+    try:
+        lib.frcnn_abi_version.restype = c_int
+        found = int(lib.frcnn_abi_version())
+    except AttributeError as e:
+        raise HipLibraryError("symbol frcnn_abi_version missing from %s" % LIB_PATH) from e
+    if found != ABI_VERSION:
+        raise HipLibraryError("%s implements ABI version %d, this binding needs %d (struct layouts / signatures differ): rebuild it with "
+                              "`python 2d_object_detection_amd/csrc/build.py`" % (LIB_PATH, found, ABI_VERSION))
     for name, (res, args) in _SIGNATURES.items():
         try:
             fn = getattr(lib, name)

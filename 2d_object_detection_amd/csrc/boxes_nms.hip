@@ -4,16 +4,20 @@
 // Box arithmetic is compiled with -ffp-contract=off so that IoU comparisons are bit-identical
 // to the C oracle (no FMA contraction).
 //
-// NMS design (wavefront primitives, one 1024-thread workgroup per (image, class)):
-//   1. keys = (score bits << 32 | ~index) for score > threshold, else 0; bitonic sort descending
-//      in LDS (n_pad <= 16384) or in a global scratch slab (larger N);
-//   2. greedy selection in chunks of 64 sorted candidates: every candidate is tested against the
-//      kept list (16 threads per candidate striding the list, reduced with a 16-lane OR), then the
-//      64x64 intra-chunk suppression matrix is built with one __ballot per row and resolved by a
-//      64-step scalar scan in wave 0; survivors are appended to the kept list in LDS.
-//      The loop ends when max_per_class boxes are kept or candidates run out -- no host sync.
-//   3. one workgroup per image merges the classes: bitonic sort of the <= C*max_per_class kept
-//      (score, class, slot) keys, top max_total written clipped to [0,1], remainder zero.
+// NMS design (wavefront primitives, one 1024-thread workgroup per (image, class); details at nms_class_kernel):
+//   1. composite keys (score bits << 32 | ~index) for score > threshold; the candidates are NOT sorted as a whole -- greedy
+//      NMS stops long before the list ends.  In rounds, the next 1024 best unvisited keys are SELECTED (MSB-first radix
+//      select, one per-wave LDS histogram pass per byte, ending as soon as the boundary does not split a digit; 32-bit score
+//      keys staged in LDS, or re-read from global when they do not fit beside the kept list), compacted with one returning
+//      atomic per wave and sorted by an in-LDS bitonic network whose stages with pair distance <= 64 are wave-local;
+//   2. the sorted round is resolved in 256-candidate chunks: every candidate is tested against the kept list (4 threads
+//      per candidate), the survivors' upper-triangular suppression rows are built with wave ballots (column candidates in
+//      registers) and wave 0 walks them in score order, appending whole runs of non-suppressing survivors to the kept list.
+//      Visit order = exact descending composite order, so the result is bit-identical to a full sort.  The loop ends when
+//      max_per_class boxes are kept or candidates run out -- no host sync;
+//   3. one class: the workgroup writes the final padded outputs itself; several classes: one workgroup per image merges the
+//      per-class kept lists (nms_merge_kernel: bitonic sort of <= C*max_per_class (score, class, slot) keys), top max_total
+//      written clipped to [0,1], remainder zero.
 #include "common.h"
 
 #pragma clang fp contract(off)

@@ -465,8 +465,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
         FRCNN_STAMP(2);
         if (FIX) {
             // fragment-major partial tile: store (i, j, e) of all 512 threads is one run of 512 floats.  Agent-scope relaxed
-            // atomics = write-through stores / cache-bypassing loads: no L2 write-back or invalidate, only the wait for this
-            // wave's stores before the workgroup announces itself.
+            // atomics = write-through (sc1) stores / L1-bypassing (sc1) loads: no L2 write-back or invalidate, only the wait for
+            // this wave's stores before the workgroup announces itself.  This is the hand-off form MI355X_MICROARCH.md lists as
+            // measured-valid on gfx950 (every payload store sc1 and drained by its wave's vmcnt(0), a workgroup barrier, ONE lane's
+            // agent-scope counter add; the last arriver -- told by the value its add returned -- loads every payload byte sc1 behind
+            // a workgroup barrier): it relies on that lowering, not on the HIP memory model's release / acquire, which would cost a
+            // write-back + invalidate (~3.5 us) per tile against the 7 us the split saves.  The counters are zeroed by the caller's
+            // per-step fill (frcnn_conv2d_workspace_counter_bytes), so an aborted launch cannot poison the next one.
             __shared__ unsigned fix_order;
             float* mine = p.fix_partial + ((size_t)fix_pair * 2 + fix_split) * (BM * BN);
             const float* other = p.fix_partial + ((size_t)fix_pair * 2 + (fix_split ^ 1)) * (BM * BN);
@@ -800,6 +805,7 @@ int launch_tile_flags(const ConvParams& p, hipStream_t s) {
 }
 
 thread_local size_t g_last_ws_bytes = 0;          // workspace the last dispatch decision would use (frcnn_conv2d_workspace_bytes)
+thread_local size_t g_last_ws_counter_bytes = 0;  // ... and the size of its arrival-counter tail
 
 #ifdef FRCNN_SWEEP
 // kernel-development builds only (FRCNN_SWEEP=1 python .../build.py --force; tools/tile_sweep.py): tile shape / kw-sharing
@@ -891,7 +897,7 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
             return launch_tile<128, 64, 64, 3, false, 0, 2, false, false, true>(p, s);
         }
     }
-    g_last_ws_bytes = 0;
+    g_last_ws_bytes = g_last_ws_counter_bytes = 0;
     {
         // fewer tiles than CUs and a very long K: split-K fix-up form (conv_tile_kernel, FIX) when the caller provides the workspace.
         // Measured per layer at M = 7,488 (tools/fix_bench.py, warm, us): 3x3 1024->256 (144 slices) 59.7 -> 52.8; 3x3 256->256
@@ -900,12 +906,13 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
         // because two workgroups on a CU do NOT halve the K loop: the CU's LDS-DMA path delivers ~37 GB/s whether one workgroup
         // or two feed it.
         const bool want = tpb == 1 && bm == 128 && bn == 64 && bk == 64 && stages == 3 && p.items <= num_cus() && p.k_tiles >= 64;
-        const size_t need = (size_t)p.items * 2 * 128 * 64 * sizeof(float) + (size_t)p.items * sizeof(unsigned);
+        const size_t ctr_bytes = (((size_t)p.items * sizeof(unsigned)) + 15) & ~(size_t)15;      // counter tail: whole 16-byte units
+        const size_t need = (size_t)p.items * 2 * 128 * 64 * sizeof(float) + ctr_bytes;
         bool fix = want && d->workspace != nullptr;
 #ifdef FRCNN_SWEEP
         if (const char* e = getenv("FRCNN_FIX")) fix = fix && e[0] != '0';
 #endif
-        if (want) g_last_ws_bytes = need;
+        if (want) { g_last_ws_bytes = need; g_last_ws_counter_bytes = ctr_bytes; }
         if (fix) {
             FRCNN_CHECK_ARG(d->workspace_bytes >= need, "conv2d_fprop: workspace of %zu bytes given, %zu needed (frcnn_conv2d_workspace_bytes)",
                             (size_t)d->workspace_bytes, need);
@@ -1055,9 +1062,15 @@ extern "C" const char* frcnn_conv2d_describe(const frcnn_conv_desc* d, int with_
 }
 
 extern "C" size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d) {
-    g_last_ws_bytes = 0;
+    g_last_ws_bytes = g_last_ws_counter_bytes = 0;
     if (!d || !frcnn_conv2d_describe(d, 0)) return 0;
     return g_last_ws_bytes;
+}
+
+extern "C" size_t frcnn_conv2d_workspace_counter_bytes(const frcnn_conv_desc* d) {
+    g_last_ws_bytes = g_last_ws_counter_bytes = 0;
+    if (!d || !frcnn_conv2d_describe(d, 0)) return 0;
+    return g_last_ws_counter_bytes;
 }
 
 extern "C" int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d) {

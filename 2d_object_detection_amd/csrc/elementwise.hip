@@ -14,7 +14,7 @@ void frcnn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* frcnn_last_error(void) { return g_err; }
-extern "C" int frcnn_abi_version(void) { return 1; }
+extern "C" int frcnn_abi_version(void) { return FRCNN_ABI_VERSION; }
 
 namespace {
 

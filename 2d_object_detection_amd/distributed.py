@@ -20,8 +20,15 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialise the default process group from torchrun's environment.  Returns (rank, world, local_rank)."""
+def init_from_env(backend=None, timeout_s=None):
+    """Initialise the default process group from torchrun's environment.  Returns (rank, world, local_rank).
+    timeout_s: time-out of every collective of the group, barriers included (default: FRCNN_DIST_TIMEOUT_S or 7200).  The
+    backend's own default (10 minutes for nccl/RCCL) is shorter than a validation pass of the chief rank can be: the other
+    ranks wait in a barrier for it, and a barrier is a collective under the same watchdog."""
+    import datetime
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("FRCNN_DIST_TIMEOUT_S", "7200"))
+    timeout = datetime.timedelta(seconds=float(timeout_s))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -33,9 +40,9 @@ def init_from_env(backend=None):
             backend = os.environ.get("FRCNN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local_rank
 
 

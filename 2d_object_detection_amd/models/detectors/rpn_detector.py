@@ -147,6 +147,7 @@ class RPNDetector:
     def forward_plan(self, plan, feature_maps, training, decoded=None):
         """decoded [B,n,1,4]: also receives the decoded proposals (first launch of post-processing) from the head-post kernel."""
         st = self.store
+        ops.conv_zero_counters(plan, self.d_inter)
         plan.add(ops.conv2d_fprop, self.d_inter, feature_maps, st.weight_bf16("rpn_intermediate_layer/kernel"), self.f,
                  bias=st.weight("rpn_intermediate_layer/bias"))
         plan.add(ops.conv2d_fprop, self.d_heads, self.f, st.weight_bf16("rpn_heads/kernel"), self.head, bias=st.weight("rpn_heads/bias"))
@@ -191,6 +192,7 @@ class RPNDetector:
     def backward_data_plan(self, plan, g_feat, consumer=None):
         """consumer: the backbone's last conv unit -- g_feat is complete after this kernel, so it also runs that unit's
         BatchNorm-backward reduce."""
+        ops.conv_zero_counters(plan, self.d_inter_bwd)
         if consumer is not None:
             red = consumer.reduce_args(relu=True)
             plan.hold(red)

@@ -268,6 +268,9 @@ class FasterRCNN:
     def _feed(self, built, images, gt_labels, gt_boxes):
         io = built["io"]
         pairs = ((images, io["images"]), (gt_labels, io["gt_labels"]), (gt_boxes, io["gt_boxes"]))
+        for s, d in pairs:
+            if tuple(s.shape) != tuple(d.shape):      # (copy_ would broadcast a smaller input silently)
+                raise ValueError("input of shape %s where the step expects %s" % (tuple(s.shape), tuple(d.shape)))
         if all(s.is_cuda and s.dtype == d.dtype and s.shape == d.shape and s.is_contiguous() and s.data_ptr() % 16 == 0 for s, d in pairs):
             # device-resident inputs of the right types: ONE copy launch into the plan's static buffers (three launches of the
             # runtime's blit kernel were 22 us at the head of every step; its 5.6 MB image copy alone took 24 us in round 1)
@@ -370,10 +373,14 @@ class FasterRCNN:
                 self._fwd_plan = self._build_forward(self._fwd_train, b)
             built = self._fwd_plan
             self._sync_derived_weights(self._fwd_train)
-            if images.is_cuda and images.dtype == built["io"]["images"].dtype and images.is_contiguous() and images.data_ptr() % 16 == 0:
-                ops.copy_bytes(images, built["io"]["images"])
+            dst = built["io"]["images"]
+            if tuple(images.shape) != tuple(dst.shape):
+                raise ValueError("images of shape %s do not match the model's input [%d, %d, %d, 3] (config image_shape)" % (
+                    tuple(images.shape), b, dst.shape[1], dst.shape[2]))
+            if images.is_cuda and images.dtype == dst.dtype and images.is_contiguous() and images.data_ptr() % 16 == 0:
+                ops.copy_bytes(images, dst)
             else:
-                built["io"]["images"].copy_(images, non_blocking=True)
+                dst.copy_(images, non_blocking=True)
             self._run_with_collectives(built["plan"])
             return built["aux"]["rpn_out"], built["aux"]["rcnn_out"]
         z = torch.zeros

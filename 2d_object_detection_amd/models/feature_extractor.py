@@ -100,6 +100,7 @@ class _ConvBN:
     # -- forward: x -> z (raw conv output) -> scale/shift
     def forward(self, plan, x, training):
         st = self.store
+        ops.conv_zero_counters(plan, self.desc)
         plan.add(ops.conv2d_fprop, self.desc, x, self.w_fwd(), self.z, bias=st.weight(self.name + "_conv/bias"),
                  stats=self.stats if training else None)
         self._training = training
@@ -179,6 +180,7 @@ class _ConvBN:
                               out_w=self.wi, out_scatter=s, flags=ops.CONV_ADD_RES if res is not None else 0)
         plan.hold(d)
         plan.hold(ops.conv_attach_workspace(d, self._device))
+        ops.conv_zero_counters(plan, d)
         if consumer is not None:
             red = consumer.reduce_args(relu=True)
             plan.hold(red)

@@ -55,7 +55,17 @@ def conv_attach_workspace(d, device):
     d.workspace = c_void_p(ws.data_ptr())
     d.workspace_bytes = n
     d._ws_tensor = ws                                          # the descriptor keeps its scratch alive
+    cb = int(_lib.load().frcnn_conv2d_workspace_counter_bytes(byref(d)))
+    d._ws_counters = ws[n - cb:] if cb else None               # arrival counters: plans re-zero them every step (conv_zero_counters)
     return ws
+
+
+def conv_zero_counters(plan, d):
+    """Register the arrival counters of descriptor d's split-K workspace (if it has one) with the plan's per-step zero fill: a
+    counter left non-zero by an aborted launch must not outlive the step."""
+    c = getattr(d, "_ws_counters", None)
+    if c is not None:
+        plan.zero(c)
 
 
 STAT_SLOTS = 16          # FRCNN_STAT_SLOTS of include/frcnn_hip.h (checked against the library in tests/test_abi.py)
@@ -148,7 +158,11 @@ def weights_transpose_flip_batched(table, total):
 
 def copy_bytes(src, dst):
     """dst <- src (same dtype / shape, contiguous, 16-byte aligned): a full-width copy kernel instead of the runtime's blit."""
-    call("frcnn_copy_bytes", _p(src), _p(dst), src.numel() * src.element_size(), _stream())
+    nbytes = src.numel() * src.element_size()
+    if nbytes != dst.numel() * dst.element_size() or not (src.is_contiguous() and dst.is_contiguous()):
+        raise ValueError("copy_bytes: source of %d bytes, destination of %d bytes (contiguous tensors of equal size expected)" % (
+            nbytes, dst.numel() * dst.element_size()))
+    call("frcnn_copy_bytes", _p(src), _p(dst), nbytes, _stream())
 
 
 def copy_bytes_multi(pairs):
@@ -158,7 +172,8 @@ def copy_bytes_multi(pairs):
     dsts = (c_void_p * n)(*[d.data_ptr() for _, d in pairs])
     sizes = (ctypes.c_int64 * n)(*[s.numel() * s.element_size() for s, _ in pairs])
     for s_, d_ in pairs:
-        assert s_.numel() * s_.element_size() == d_.numel() * d_.element_size() and s_.is_contiguous() and d_.is_contiguous()
+        if s_.numel() * s_.element_size() != d_.numel() * d_.element_size() or not (s_.is_contiguous() and d_.is_contiguous()):
+            raise ValueError("copy_bytes_multi: every pair must be contiguous and of equal byte size")
     call("frcnn_copy_bytes_multi", srcs, dsts, sizes, n, _stream())
 
 

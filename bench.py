@@ -31,6 +31,7 @@ import torch
 
 METRIC = "images/sec training, ResNet-50 Faster-RCNN KITTI 1242x375, 1/2/4/8 GPU"
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0           # dense fp8 (block-scaled f8f6f4 MFMA at K = 128), same guide
 PEAK_HBM_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable, same guide)
 FAM_CONV = "conv fprop/dgrad (conv_tile_kernel)"
 FAM_WGRAD = "conv wgrad (wgrad_kernel, wgrad_group_kernel)"
@@ -240,16 +241,23 @@ def cpu_baseline(cfg, budget_s=150.0):
             "legs": legs}
 
 
-def offline_profile(family):
+def offline_profile(family, variant=""):
     """rocprofv3 numbers for `family` committed under profiles/ (kernel-trace summary + PMC HBM traffic of this same command),
-    valid only for the kernel sources they were taken from."""
-    path = os.path.join(ROOT, "profiles", "r02_offline.json")
-    if not os.path.exists(path):
-        return None, "no profiles/r02_offline.json"
-    off = json.load(open(path))
-    if off.get("kernel_source_hash") != kernel_source_hash():
-        return None, "stale: profiles/r02_offline.json was taken from kernel sources %s, this tree is %s" % (off.get("kernel_source_hash"), kernel_source_hash())
-    return off.get("families", {}).get(family), "offline: profiles/r02_offline.json (%s) @ kernel sources %s" % (off.get("from", "?"), off.get("kernel_source_hash"))
+    valid only for the kernel sources they were taken from: the newest profiles/r*_offline<variant>.json whose source hash is
+    this tree's.  Returns (family record or None, provenance / reason string)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_offline%s.json" % variant)), reverse=True)
+    if not cands:
+        return None, "no profiles/r*_offline%s.json" % variant
+    mine = kernel_source_hash()
+    stale = []
+    for path in cands:
+        off = json.load(open(path))
+        if off.get("kernel_source_hash") == mine:
+            return off.get("families", {}).get(family), "offline: profiles/%s (%s) @ kernel sources %s" % (
+                os.path.basename(path), off.get("from", "?"), mine)
+        stale.append("%s@%s" % (os.path.basename(path), off.get("kernel_source_hash")))
+    return None, "stale: %s were taken from other kernel sources, this tree is %s" % (", ".join(stale), mine)
 
 
 def main():
@@ -261,8 +269,10 @@ def main():
     ap.add_argument("--windows", type=int, default=5, help="time the K-step region this many times back to back (the first is `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-segmented", action="store_true", help="skip the segmented-replay leg (config.segmented_ms_per_step)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--lr-scale", type=float, default=0.01)
+    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) MFMA conv path where a layer supports it (BASELINE.json configs[4]'s precision)")
     ap.add_argument("--depth", type=int, default=50, help="ResNet depth (101 with --proposals 1000 --batch-per-gpu 2 = BASELINE.json configs[3])")
     ap.add_argument("--proposals", type=int, default=0, help="RPN NMS max_total_size / max_output_size_per_class (0: config.json's 300)")
     args = ap.parse_args()
@@ -308,7 +318,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = model.train_step(images, gl, gb, opt, sync_fn=hook)
+            out = model.train_step(images, gl, gb, opt, sync_fn=hook)     # (`hook` is read at call time: the segmented leg swaps it)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -319,14 +329,34 @@ def main():
 
     for _ in range(args.warmup):
         losses, preds = model.train_step(images, gl, gb, opt, sync_fn=hook)
-    dt, (losses, preds) = timed_window()                       # the contract's region: EXACTLY K steps, barrier + synchronize both sides
+    # every timed window starts from the SAME weights, momentum, moving statistics and step counter (the state after the warm-up):
+    # window 5 times what window 1 timed, and the synthetic run cannot drift towards non-finite boxes while it is being measured
+    barrier()
+    state0 = model._snapshot(opt)
+
+    def window():
+        model._restore(state0, opt)
+        return timed_window()
+
+    dt, (losses, preds) = window()                             # the contract's region: EXACTLY K steps, barrier + synchronize both sides
     loss_vals = {k: float(v) for k, v in losses.items()}
     window_ms = [dt / args.steps * 1e3]
     for _ in range(max(0, args.windows - 1)):                  # more evidence than one 0.1 s region: the same region again
-        window_ms.append(timed_window()[0] / args.steps * 1e3)
+        window_ms.append(window()[0] / args.steps * 1e3)
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt
     srt = sorted(window_ms)
+    # what data parallelism costs before any byte moves: the same step as its backward-segment graphs with a (no-op) hook between
+    # them -- the form every rank runs when a GradientSynchronizer interleaves bucket all-reduces -- against the one-graph replay
+    segmented_ms = None
+    if world == 1 and model.use_graphs and not args.no_segmented:
+        hook_calls = []
+        keep_hook, hook = hook, (lambda i, n: hook_calls.append(i))
+        try:
+            segmented_ms = sorted(window()[0] / args.steps * 1e3 for _ in range(3))[1]
+        finally:
+            hook = keep_hook
+        assert len(hook_calls) >= 3 * args.steps, "the segmented run did not call the hook"
 
     out = {
         "metric": METRIC, "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -336,7 +366,9 @@ def main():
                                "%d proposals, 7 classes (BASELINE.json configs[%d])" % (
                                    args.depth, B, args.proposals or 300, 3 if args.depth == 101 else 1 if world == 1 else 2),
                    "global_batch": world * B, "image_shape": cfg["image_shape"], "parallelism": "dp%d" % world,
-                   "hip_graphs": model.use_graphs, "kernel_launches_per_step": model._train_plan["plan"].num_launches},
+                   "hip_graphs": model.use_graphs, "kernel_launches_per_step": model._train_plan["plan"].num_launches,
+                   "segmented_ms_per_step": None if segmented_ms is None else round(segmented_ms, 4),
+                   "segments": len(model._train_plan["plan"].segments)},
         "windows": {"steps_each": args.steps, "ms_per_step": [round(x, 4) for x in window_ms], "min": round(srt[0], 4),
                     "median": round(srt[len(srt) // 2], 4), "max": round(srt[-1], 4),
                     "images_per_s_median": round(world * B / (srt[len(srt) // 2] * 1e-3), 2)},
@@ -347,40 +379,65 @@ def main():
         if fam:
             dom = FAM_CONV if FAM_CONV in fam else max(fam, key=lambda k: fam[k]["seconds"])
             f = fam[dom]
-            achieved = f["flops"] / f["seconds"] / 1e12
-            off, source = offline_profile(dom)
+            peak = PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS
+            gflop_per_launch = f["flops"] / f["launches"] / 1e9
+            # HEADLINE = the figure a reader can reproduce from profiles/: algorithmic FLOP per launch (counted live from this run's
+            # plan) / the family's average launch duration in the committed rocprofv3 kernel trace of this same command -- valid only
+            # while the kernel sources are the ones that trace was taken from.  The live HIP-event timing of the same launches is
+            # reported beside it (`events`): raw pairs over-state a launch by the cost of the pair itself, pairs minus the calibrated
+            # empty-pair cost under-state it; when the committed trace is stale the RAW (conservative) event figure is the headline.
+            off, source = offline_profile(dom, "_fp8" if args.fp8 else "")
+            ev_raw_us = (f["seconds"] + f["launches"] * f["event_pair_overhead_us"] * 1e-6) / f["launches"] * 1e6
+            ev_net_us = f["seconds"] / f["launches"] * 1e6
+            if off and off.get("avg_launch_us"):
+                head_us, head_src = float(off["avg_launch_us"]), "rocprofv3 kernel trace, " + source
+            else:
+                head_us, head_src = ev_raw_us, "live HIP events, raw pairs (no committed trace for these kernel sources: %s)" % source
+            achieved = gflop_per_launch / head_us / 1e3
+            off_all = {}
+            for k in fam:
+                off_all[k] = offline_profile(k, "_fp8" if args.fp8 else "")[0]
             families = {}
             for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["seconds"]):
-                e = {"launches_per_step": v["launches"], "ms_per_step": round(v["seconds"] * 1e3, 4)}
+                o = off_all.get(k)
+                # durations: the committed trace where it is current (same source as the headline), else raw event pairs
+                sec = o["ms_per_step"] * 1e-3 if (o and o.get("ms_per_step")) else v["seconds"] + v["launches"] * v["event_pair_overhead_us"] * 1e-6
+                e = {"launches_per_step": v["launches"], "ms_per_step": round(sec * 1e3, 4), "timing": "rocprof" if (o and o.get("ms_per_step")) else "events_raw",
+                     "events_net_ms_per_step": round(v["seconds"] * 1e3, 4)}
                 if v["flops"] > 0:
-                    e["tflops"] = round(v["flops"] / v["seconds"] / 1e12, 2)
-                    e["frac_of_mfma_peak"] = round(v["flops"] / v["seconds"] / 1e12 / PEAK_BF16_TFLOPS, 4)
-                elif v["bytes"] > 0 and v["seconds"] > 0:
+                    e["tflops"] = round(v["flops"] / sec / 1e12, 2)
+                    e["frac_of_mfma_peak"] = round(v["flops"] / sec / 1e12 / peak, 4)
+                elif v["bytes"] > 0 and sec > 0:
                     e["algorithmic_MB_per_step"] = round(v["bytes"] / 1e6, 2)
-                    e["algorithmic_GBs"] = round(v["bytes"] / v["seconds"] / 1e9, 1)
-                    e["frac_of_hbm_peak"] = round(v["bytes"] / v["seconds"] / 1e9 / PEAK_HBM_GBS, 4)
+                    e["algorithmic_GBs"] = round(v["bytes"] / sec / 1e9, 1)
+                    e["frac_of_hbm_peak"] = round(v["bytes"] / sec / 1e9 / PEAK_HBM_GBS, 4)
+                if o and o.get("hbm_bytes_per_launch"):
+                    e["hbm_MB_per_step_pmc"] = round((o.get("hbm_read_bytes_per_step", 0) + o.get("hbm_write_bytes_per_step", 0)) / 1e6, 1)
                 families[k] = e
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 5),
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
+                               "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
                                "traffic": None if not off else off.get("hbm_bytes_per_launch"),
                                "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
-                               "traffic_source": source,
-                               "launches_per_step": f["launches"], "avg_launch_us": round(f["seconds"] / f["launches"] * 1e6, 2),
-                               "algorithmic_gflop_per_launch": round(f["flops"] / f["launches"] / 1e9, 4),
-                               "event_pair_overhead_us": round(f["event_pair_overhead_us"], 2),
-                               "rocprof": None if not off else {"avg_launch_us": off.get("avg_launch_us"), "launches_per_step": off.get("launches_per_step"),
-                                                                "achieved": None if not off.get("avg_launch_us") else round(
-                                                                    f["flops"] / f["launches"] / (off["avg_launch_us"] * 1e-6) / 1e12, 2),
-                                                                "frac": None if not off.get("avg_launch_us") else round(
-                                                                    f["flops"] / f["launches"] / (off["avg_launch_us"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 5)},
+                               "source": head_src,
+                               "launches_per_step": f["launches"], "avg_launch_us": round(head_us, 2),
+                               "algorithmic_gflop_per_launch": round(gflop_per_launch, 4),
+                               "events": {"avg_launch_us_raw": round(ev_raw_us, 2), "avg_launch_us_minus_empty_pair": round(ev_net_us, 2),
+                                          "empty_pair_us": round(f["event_pair_overhead_us"], 2),
+                                          "frac_raw": round(gflop_per_launch / ev_raw_us / 1e3 / peak, 5),
+                                          "frac_minus_empty_pair": round(gflop_per_launch / ev_net_us / 1e3 / peak, 5)},
                                "whole_step_tflops": round(sum(v["flops"] for v in fam.values()) / (ms * 1e-3) / 1e12, 1),
                                "families": families}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
+        bad = [k for k, v in loss_vals.items() if not (v == v and abs(v) != float("inf"))]
+        if bad:
+            out["error"] = "non-finite losses after the timed window: %s -- the timed workload is degenerate, the number is void" % bad
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not all(v == v and abs(v) != float("inf") for v in loss_vals.values()):
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -31,6 +31,11 @@ typedef uint16_t frcnn_bf16;
 #define FRCNN_EINVAL (-1)      /* bad argument / unsupported shape */
 #define FRCNN_ELAUNCH (-2)     /* kernel launch failed */
 
+/* Version of this header's structs and signatures.  Bumped whenever a struct grows or a signature changes (2: frcnn_conv_desc
+ * gained workspace / workspace_bytes, frcnn_bn_bwd_apply_fused gained count / param_grad_scale; 3: the fp8 entry points).  A
+ * binding must compare frcnn_abi_version() with the FRCNN_ABI_VERSION it was written against and refuse any other library:
+ * an older build would read the descriptor past the caller's struct. */
+#define FRCNN_ABI_VERSION 3
 int frcnn_abi_version(void);
 const char* frcnn_last_error(void);
 
@@ -65,7 +70,8 @@ typedef struct {
     int flags, split_k;
     /* Optional scratch for layers with fewer output tiles than CUs and a long K (frcnn_conv2d_workspace_bytes(d) > 0): the K range of
      * a tile is then split over two workgroups that meet in this buffer (fp32 partial tiles + one arrival counter per tile).
-     * Device memory, 16-byte aligned, ZEROED once by the caller (the kernel leaves the counters zero); a descriptor in flight on two
+     * Device memory, 16-byte aligned, ZEROED once by the caller (the kernel leaves the counters zero; see
+     * frcnn_conv2d_workspace_counter_bytes for callers that re-zero them per launch); a descriptor in flight on two
      * streams at once needs two workspaces.  NULL: the one-workgroup-per-tile form. */
     void* workspace;
     size_t workspace_bytes;
@@ -100,6 +106,11 @@ const char* frcnn_conv2d_wgrad_describe(const frcnn_conv_desc* d, int with_row_i
 /* Bytes of frcnn_conv_desc.workspace with which frcnn_conv2d_fprop / frcnn_conv2d_dgrad_bnreduce run this descriptor in the split-K
  * fix-up form; 0 when the dispatcher would not use it (the answer does not depend on d->workspace).  No device needed. */
 size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d);
+/* The arrival counters are the LAST frcnn_conv2d_workspace_counter_bytes(d) bytes of that workspace (a multiple of 16).  The kernel
+ * leaves them zero after a completed launch; a caller that may abort launches (or replays captured graphs after an error) zeroes
+ * this tail before every launch -- cheaply, together with its other accumulation targets (frcnn_fill_zero_multi) -- so that a
+ * counter left at 1 cannot make both halves of a later launch believe they arrived first. */
+size_t frcnn_conv2d_workspace_counter_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d);
 int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
                        const frcnn_bf16* res, void* y, double* stats_partial, frcnn_stream_t stream);

@@ -1,7 +1,7 @@
 """Reduce the rocprofv3 outputs of ONE bench command into the tracked files bench.py and DESIGN.md cite:
 
   profiles/<tag>_hbm_per_kernel.csv   per kernel: launches, FETCH_SIZE (raw KiB and corrected bytes), WRITE_SIZE, bytes / launch
-  profiles/r02_offline.json           per kernel family: launches / step, average launch duration (kernel trace), HBM bytes per
+  profiles/rNN_offline<variant>.json  (rNN = the tag's round prefix, variant = $OFFLINE_VARIANT, e.g. "_fp8") per kernel family: launches / step, average launch duration (kernel trace), HBM bytes per
                                       launch (PMC), stamped with the hash of the kernel sources they were measured on
 
 Counters are collected and corrected as /opt/skills/guides/MI355X_MICROARCH.md 'HBM' prescribes for gfx950: FETCH_SIZE and
@@ -88,7 +88,8 @@ def main():
             "ms_per_step": round(f["ns"] / 1e6 / steps, 4),
             "hbm_read_bytes_per_step": round(f["rd"] / steps), "hbm_write_bytes_per_step": round(f["wr"] / steps),
             "hbm_bytes_per_launch": round((f["rd"] + f["wr"]) / f["launches"]) if f["launches"] else None}
-    json.dump(off, open(os.path.join(ROOT, "profiles", "r02_offline.json"), "w"), indent=1)
+    name = "%s_offline%s.json" % (tag[:3], os.environ.get("OFFLINE_VARIANT", ""))
+    json.dump(off, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
     print(json.dumps(off["families"], indent=1))
 
 

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_bound():
     for sym in declared:
         assert hasattr(handle, sym), "header declares %s but the library does not export it" % sym
     assert sorted(lib_mod.EXPORTED_SYMBOLS) == declared, "ctypes table and header differ"
-    assert handle.frcnn_abi_version() == 1
+    assert handle.frcnn_abi_version() == lib_mod.ABI_VERSION == 3
 
 
 def test_argument_validation_without_gpu():
@@ -59,3 +59,15 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
         assert False, "expected HipLibraryError"
     except lib_mod.HipLibraryError as e:
         assert "no CPU fallback" in str(e)
+
+
+def test_library_of_another_abi_version_is_refused(monkeypatch):
+    """A same-named build with other struct layouts / signatures must not be bound (FRCNN_LIB points at development builds)."""
+    lib_mod = importlib.import_module("2d_object_detection_amd._lib")
+    monkeypatch.setattr(lib_mod, "_lib", None)
+    monkeypatch.setattr(lib_mod, "ABI_VERSION", lib_mod.ABI_VERSION + 1)
+    try:
+        lib_mod.load()
+        assert False, "expected HipLibraryError"
+    except lib_mod.HipLibraryError as e:
+        assert "ABI version" in str(e)

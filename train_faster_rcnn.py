@@ -44,6 +44,9 @@ def parse_args(argv=None):
     parser.add_argument("--metrics-every", default=1, type=int, help="update the AP / mAP metrics every k-th training step (reference: 1)")
     parser.add_argument("--init-weights", default=None, type=str, help="weight file (FasterRCNN.save_weights format) to start from")
     parser.add_argument("--seed", default=0, type=int)
+    parser.add_argument("--collective-timeout-minutes", default=120.0, type=float,
+                        help="time-out of the process group's collectives (several ranks): must exceed the chief's validation pass, "
+                             "during which the other ranks wait in a barrier")
     args = parser.parse_args(argv)
     if not args.synthetic and not (args.train_data_path and args.valid_data_path):
         parser.error("--train-data-path and --valid-data-path are required (or use --synthetic N)")
@@ -144,7 +147,7 @@ def main(argv=None):
     MET = importlib.import_module(PKG + ".utils.metrics")
     IP = importlib.import_module(PKG + ".data.input_pipeline")
 
-    rank, world, local_rank = D.init_from_env()
+    rank, world, local_rank = D.init_from_env(timeout_s=60.0 * args.collective_timeout_minutes)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     chief = rank == 0
@@ -207,8 +210,10 @@ def main(argv=None):
                            ("Losses/RPN/regression_loss", rpn_train_reg), ("Metrics/RPN/AP@IoU=.50", rpn_train_ap)):
                 train_writer.scalar(tag, m.result(), step)
 
-            # validation: one ordered pass on rank 0 (the reference is single-device).  The other ranks wait at an explicit
-            # barrier instead of inside the next step's first all-reduce (whose time-out a long validation set could hit)
+            # validation: one ordered pass on rank 0 (the reference is single-device).  The other ranks wait in the barrier
+            # behind it; a barrier is a collective under the process group's watchdog like the all-reduce it stands in front
+            # of, so the group is created with a time-out sized for this pass (--collective-timeout-minutes, default 2 h; the
+            # backend default of 10 minutes would abort the waiting ranks on a long validation set)
             if world > 1:
                 torch.distributed.barrier()
             if chief:
