@@ -25,6 +25,11 @@ class WgradItem(Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+class Fp8Out(Structure):
+    """frcnn_fp8_out: optional fp8 twin of a BatchNorm kernel's output"""
+    _fields_ = [("out8", c_void_p), ("qscale", c_void_p), ("amax", c_void_p)]
+
+
 class BnReduce(Structure):
     """frcnn_bn_reduce"""
     _fields_ = [("z", c_void_p), ("relu_mask", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("partial", c_void_p)]
@@ -46,6 +51,11 @@ _SIGNATURES = {
     "frcnn_conv2d_wgrad_describe": (c_char_p, [POINTER(ConvDesc), c_int, P]),
     "frcnn_conv2d_stat_tiles": (c_int, [POINTER(ConvDesc)]),
     "frcnn_conv2d_fprop": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
+    "frcnn_conv2d_fprop_fp8": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P]),
+    "frcnn_conv2d_describe_fp8": (c_char_p, [POINTER(ConvDesc)]),
+    "frcnn_quantize_fp8": (c_int, [P, c_int64, P, P, P, P]),
+    "frcnn_quantize_weights_fp8_batched": (c_int, [P, c_int, c_int64, P]),
+    "frcnn_fp8_update_scales": (c_int, [P, P, P, c_int, c_float, P]),
     "frcnn_conv2d_dgrad_bnreduce": (c_int, [POINTER(ConvDesc), P, P, P, P, P, POINTER(BnReduce), P]),
     "frcnn_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
     "frcnn_wgrad_group_bytes": (c_size_t, []),
@@ -63,7 +73,7 @@ _SIGNATURES = {
     "frcnn_bn_finalize_train": (c_int, [P, c_int, c_int, c_int64, P, P, P, P, c_float, c_float, P, P, P, P, P]),
     "frcnn_bn_finalize_eval": (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
     "frcnn_bn_apply": (c_int, [P, P, P, P, c_int, P, c_int64, c_int, P]),
-    "frcnn_bn_train_apply": (c_int, [P, P, c_int, c_int64, P, P, P, P, c_float, c_float, P, c_int, P, P, P, P, c_int64, c_int, P]),
+    "frcnn_bn_train_apply": (c_int, [P, P, c_int, c_int64, P, P, P, P, c_float, c_float, P, c_int, P, P, P, P, c_int64, c_int, POINTER(Fp8Out), P]),
     "frcnn_bn_bwd_apply_fused": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int64, c_float, P]),
     "frcnn_bn_bwd_blocks": (c_int, [c_int64]),
     "frcnn_bn_bwd_reduce": (c_int, [P, P, P, P, P, P, P, c_int64, c_int, P]),
@@ -71,7 +81,7 @@ _SIGNATURES = {
     "frcnn_bn_bwd_apply": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int64, c_int, P]),
     "frcnn_relu_bwd": (c_int, [P, P, P, c_int64, P]),
     "frcnn_colsum_bf16": (c_int, [P, c_int64, c_int, c_int, P, P]),
-    "frcnn_bn_train_apply_dual": (c_int, [P] * 16 + [c_int, c_int64, c_float, c_float, c_int, P, P, c_int64, c_int, P]),
+    "frcnn_bn_train_apply_dual": (c_int, [P] * 16 + [c_int, c_int64, c_float, c_float, c_int, P, P, c_int64, c_int, POINTER(Fp8Out), P]),
     "frcnn_bn_train_apply_maxpool": (c_int, [P, P, c_int, c_int64, P, P, P, P, c_float, c_float, P, P, P, P, P, c_int, c_int, c_int, c_int,
                                              c_int, c_int, P]),
     "frcnn_maxpool3x3s2_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -96,7 +106,7 @@ _SIGNATURES = {
     "frcnn_boxes_scale": (c_int, [P, P, c_int64, c_float, c_float, P]),
     "frcnn_assign_targets": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
                                      c_float, c_float, c_float, P, P, P]),
-    "frcnn_sample_indices": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_uint64, P, c_int, P, P, P, P]),
+    "frcnn_sample_indices": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_uint64, P, c_int, P, P, P, c_int, P]),
     "frcnn_losses": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P]),
     "frcnn_losses_rpn_head_grad": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_int, c_int, P, c_int, P]),
     "frcnn_losses_head_grad": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_int, P, P]),

@@ -71,6 +71,28 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
     return v;
 }
 
+// 8 floats -> 8 OCP e4m3 bytes (RNE; gfx950's v_cvt_pk_fp8_f32 converts to the OCP format).  Inputs are clamped to the finite
+// range first: e4m3fn has no infinity and an out-of-range value would otherwise become NaN.
+__device__ __forceinline__ u32x2 pack8_fp8(const float* f, const float qs) {
+    u32x2 r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int w = 0;
+        const float a = __builtin_amdgcn_fmed3f(f[4 * h] * qs, -448.f, 448.f), b = __builtin_amdgcn_fmed3f(f[4 * h + 1] * qs, -448.f, 448.f);
+        const float c = __builtin_amdgcn_fmed3f(f[4 * h + 2] * qs, -448.f, 448.f), d = __builtin_amdgcn_fmed3f(f[4 * h + 3] * qs, -448.f, 448.f);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+        r[h] = (unsigned)w;
+    }
+    return r;
+}
+// wave-wide max of non-negative floats folded into *dst (device float compared as its bit pattern: order-preserving for x >= 0)
+__device__ __forceinline__ void atomic_amax(float* dst, float v) {
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) v = fmaxf(v, __shfl_xor(v, sh));
+    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
+}
+
 // Philox4x32-10 (shared by the sampler; oracle/philox.py is the numpy twin)
 __device__ __forceinline__ unsigned int philox_first(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
                                                      unsigned int k0, unsigned int k1) {

@@ -35,6 +35,8 @@ struct ConvParams {
     long long in_row_stride, in_img_stride;
     float* fix_partial;                     // split-K fix-up form (conv_tile.hip, FIX): [tiles][2][128*64] fp32 partial tiles and
     unsigned* fix_counter;                  // [tiles] arrival counters (zero between launches) in the caller's workspace
+    const float* f8_x_scale;                // fp8 operands (conv_tile.hip, F8): dequantisation scale of x (device scalar) and of every
+    const float* f8_w_scale;                //   output channel's weight row (device [Cout]); NULL: bf16 operands
     int dry_run;                            // host only: stop before the launch (frcnn_conv2d_describe)
     unsigned long long* dbg;                // FRCNN_STAMPS builds: per-workgroup phase stamps (NULL otherwise)
 };

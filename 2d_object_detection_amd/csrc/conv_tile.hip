@@ -16,7 +16,7 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, bool KWS, bool FIX>
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, bool KWS, bool FIX, bool F8>
 __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // SMODE 0: plain, 1: BatchNorm statistics of the output (forward), 2: BatchNorm-backward reduce of the consumer layer
@@ -53,6 +53,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     // ordinary epilogue -- bias / residual / statistics / fused reduce see the complete sums.  a + b == b + a: the result does not
     // depend on who arrives last.
     static_assert(!FIX || (!MULTI && !F32 && !KWS), "split-K fix-up: one-tile kernel only");
+    // F8: both operands are OCP e4m3 bytes.  The host passes every element count HALVED (Cin, pixel stride, K: two fp8 values take the
+    // place of one bf16), so tiles, DMA, swizzle and fragment reads are byte for byte those of the bf16 kernel: a 128-byte staged row
+    // is 128 K values instead of 64.  The two 16-byte fragment reads of a slice (kk = 0, 1) are the 32 bytes ONE
+    // v_mfma_scale_f32_16x16x128_f8f6f4 takes per lane (lane group g contracts bytes [16g, 16g+16) and [64+16g, 64+16g+16) of the row
+    // for BOTH operands -- a consistent permutation of K, which a dot product does not see), issued with unit block scales: the same
+    // matrix-pipe cycles per slice as the two bf16 MFMAs it replaces, at twice the K.  Dequantisation (activation scale x weight
+    // scale of the output channel) is one multiply in the epilogue.
+    static_assert(!F8 || (BK == 64 && !F32), "fp8 operands: 128-byte slices, bf16 output");
     constexpr int B_BASE = KWS ? 2 * AK_BYTES : S * A_BYTES;
     constexpr int RING = KWS ? 2 * AK_BYTES + S * B_BYTES : S * (A_BYTES + B_BYTES), STG = BM * ROWB;
     // one tile per workgroup: the staging tile aliases the drained ring.  Tile runs (MULTI): the ring keeps prefetching the
@@ -123,6 +131,19 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
         if ((flags & FRCNN_CONV_BIAS) && c < p.Cout) b = *reinterpret_cast<const f32x4*>(p.bias + c);   // Cout % 8 == 0
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[j][e] = b[e];
+    }
+
+    float dq[F8 ? NI : 1][4];                     // F8: x_scale * w_scale[cout] of this lane's channels
+    if (F8) {
+        const float xs = *p.f8_x_scale;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int c = n0 + wn * WTN + j * 16 + fchunk * 4;
+            f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < p.Cout) w = *reinterpret_cast<const f32x4*>(p.f8_w_scale + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dq[F8 ? j : 0][e] = w[e] * xs;
+        }
     }
 
     // ------------------------------------------------------------------ loader (LDS-DMA) state
@@ -280,10 +301,34 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
         a_foff[kk] = (unsigned)((wm * WTM + frow) * (BK * 2) + swz<BK>(kk * 4 + fchunk, frow) * 16);
         b_foff[kk] = (unsigned)((wn * WTN + frow) * (BK * 2) + swz<BK>(kk * 4 + fchunk, frow) * 16);
     }
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    auto cat8 = [](const bf16x8 lo, const bf16x8 hi) {           // the 32 fp8 bytes of a lane: its kk = 0 and kk = 1 fragments
+        const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+        return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+    };
     auto mfma_slice = [&](const int slot) {      // acc += A(slot) * B(slot)^T, fragments of step kk+1 fetched under the MFMAs of kk
         const unsigned char* cA = ring + slot * A_BYTES;
         const unsigned char* cB = ring + B_BASE + slot * B_BYTES;
         bf16x8 af[2][MI], bfr[2][NI];
+        if (F8) {
+            static_assert(!F8 || KK == 2, "fp8: one 128-deep MFMA per 128-byte slice");
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bfr[kk][j] = *reinterpret_cast<const bf16x8*>(cB + j * 16 * (BK * 2) + b_foff[kk]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[kk][i] = *reinterpret_cast<const bf16x8*>(cA + i * 16 * (BK * 2) + a_foff[kk]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const i32x8 a8 = cat8(af[0][i], af[1][i]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat8(bfr[0][j], bfr[1][j]), a8, acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0,
+                                                                                  0x7F7F7F7F);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(cA + i * 16 * (BK * 2) + a_foff[0]);
 #pragma unroll
@@ -318,6 +363,34 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
         const unsigned char* cB = ring + B_BASE + slot * B_BYTES;
         u32x4 af[2][MI];
         bf16x8 bfr[2][NI];
+        if (F8) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bfr[kk][j] = *reinterpret_cast<const bf16x8*>(cB + j * 16 * (BK * 2) + b_foff[kk]);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    af[kk][i] = *reinterpret_cast<const u32x4*>(cA + i * 16 * (BK * 2) + ak_foff[kw][kk]);
+                    if (kw == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) af[kk][i][q] &= edge_l[i];
+                    }
+                    if (kw == 2) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) af[kk][i][q] &= edge_r[i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const i32x8 a8 = cat8(__builtin_bit_cast(bf16x8, af[0][i]), __builtin_bit_cast(bf16x8, af[1][i]));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat8(bfr[0][j], bfr[1][j]), a8, acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0,
+                                                                                  0x7F7F7F7F);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const u32x4*>(cA + i * 16 * (BK * 2) + ak_foff[kw][0]);
 #pragma unroll
@@ -575,8 +648,13 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         f32x2 v;
-                        v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] + bv[j][2 * h], lo, __builtin_inff());
-                        v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
+                        if (F8) {
+                            v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] * dq[F8 ? j : 0][2 * h] + bv[j][2 * h], lo, __builtin_inff());
+                            v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] * dq[F8 ? j : 0][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
+                        } else {
+                            v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] + bv[j][2 * h], lo, __builtin_inff());
+                            v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
+                        }
                         const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
                         pk[h] = bits;
                         if (STATS) {             // sums of the ROUNDED outputs (what the next layer reads)
@@ -771,21 +849,22 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
 thread_local char g_last_inst[192] = "";
 unsigned long long* g_stamp_buffer = nullptr;    // FRCNN_STAMPS builds: set through frcnn_debug_set_stamp_buffer (tools/conv_stamps.py)
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false, bool FIX = false>
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false, bool FIX = false, bool F8 = false>
 int launch_tile(const ConvParams& p, hipStream_t s) {
     constexpr int ring = KWS ? 2 * 3 * 8 * 1024 + S * BN * BK * 2 : S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
     constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4;
     static_assert(smem <= 163840, "LDS budget");
     static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
-    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX>), smem) != 0) {
+    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
     const int grid_x = FIX ? ((2 * p.items + 15) / 16) * 16 : p.items;      // FIX: two halves per tile, whole pairs per XCD
-    snprintf(g_last_inst, sizeof(g_last_inst), "conv_tile<BM=%d,BN=%d,BK=%d,S=%d,LIN=%d,SMODE=%d,OCC=%d,MULTI=%d,F32=%d,KWS=%d%s> grid=%dx%d tpb=%d",
-             BM, BN, BK, S, (int)LIN, SMODE, OCC, (int)MULTI, (int)F32, (int)KWS, FIX ? ",FIX=1" : "", grid_x, F32 ? p.split : 1, p.tiles_per_block);
+    snprintf(g_last_inst, sizeof(g_last_inst), "conv_tile<BM=%d,BN=%d,BK=%d,S=%d,LIN=%d,SMODE=%d,OCC=%d,MULTI=%d,F32=%d,KWS=%d%s%s> grid=%dx%d tpb=%d",
+             BM, BN, BK, S, (int)LIN, SMODE, OCC, (int)MULTI, (int)F32, (int)KWS, FIX ? ",FIX=1" : "", F8 ? ",F8=1" : "", grid_x, F32 ? p.split : 1,
+             p.tiles_per_block);
     if (p.dry_run) return FRCNN_OK;              // frcnn_conv2d_describe: the dispatch decision only
-    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX>), dim3(grid_x, F32 ? p.split : 1), dim3(512), smem, s, p);
+    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8>), dim3(grid_x, F32 ? p.split : 1), dim3(512), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
     return FRCNN_OK;
 }
@@ -793,6 +872,23 @@ int launch_tile(const ConvParams& p, hipStream_t s) {
 template <int BM, int BN, int BK, int S, int OCC, bool MULTI, bool FIX = false>
 int launch_tile_flags(const ConvParams& p, hipStream_t s) {
     const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
+    if (p.f8_x_scale) {                          // fp8 operands (frcnn_conv2d_fprop_fp8): forward convolutions, with or without statistics
+        if constexpr (BK == 64) {
+            if (smode == 2) {
+                frcnn_set_error("conv2d fp8: the fused BatchNorm-backward reduce has no fp8 instantiation");
+                return FRCNN_EINVAL;
+            }
+            if (p.linear_a) {
+                if (smode == 1) return launch_tile<BM, BN, BK, S, true, 1, OCC, MULTI, false, false, FIX, true>(p, s);
+                return launch_tile<BM, BN, BK, S, true, 0, OCC, MULTI, false, false, FIX, true>(p, s);
+            }
+            if (smode == 1) return launch_tile<BM, BN, BK, S, false, 1, OCC, MULTI, false, false, FIX, true>(p, s);
+            return launch_tile<BM, BN, BK, S, false, 0, OCC, MULTI, false, false, FIX, true>(p, s);
+        } else {
+            frcnn_set_error("conv2d fp8: needs 128-byte K slices (cin %% 128 == 0)");
+            return FRCNN_EINVAL;
+        }
+    }
     if (smode == 2)
         return p.linear_a ? launch_tile<BM, BN, BK, S, true, 2, OCC, MULTI, false, false, FIX>(p, s)
                           : launch_tile<BM, BN, BK, S, false, 2, OCC, MULTI, false, false, FIX>(p, s);
@@ -829,6 +925,8 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
         frcnn_set_error("conv2d_fprop: filters with more than 32 taps are not supported (per-row tap validity masks are 32 bits)");
         return FRCNN_EINVAL;
     }
+    FRCNN_CHECK_ARG(!(p.f8_x_scale && (p.flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC | FRCNN_CONV_ADD_RES))),
+                    "conv2d fp8: bf16 output without residual only");
     if (p.flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC)) {
         // fp32 output / split-K partial sums: 1x1 filters whose output rows are the GEMM rows, K a multiple of 64
         FRCNN_CHECK_ARG(p.taps == 1 && p.linear_a && d->cin % 64 == 0 && !(p.flags & (FRCNN_CONV_STATS | FRCNN_CONV_ADD_RES)),
@@ -892,6 +990,14 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
             p.tiles_per_block = 1;
             p.items = p.tiles_m * p.tiles_n;
             const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
+            if (p.f8_x_scale) {
+                if (smode == 2) {
+                    frcnn_set_error("conv2d fp8: the fused BatchNorm-backward reduce has no fp8 instantiation");
+                    return FRCNN_EINVAL;
+                }
+                if (smode == 1) return launch_tile<128, 64, 64, 3, false, 1, 2, false, false, true, false, true>(p, s);
+                return launch_tile<128, 64, 64, 3, false, 0, 2, false, false, true, false, true>(p, s);
+            }
             if (smode == 2) return launch_tile<128, 64, 64, 3, false, 2, 2, false, false, true>(p, s);
             if (smode == 1) return launch_tile<128, 64, 64, 3, false, 1, 2, false, false, true>(p, s);
             return launch_tile<128, 64, 64, 3, false, 0, 2, false, false, true>(p, s);
@@ -962,7 +1068,7 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
 
 int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias, const frcnn_bf16* res,
                       const uint8_t* res_mask, void* y, double* stats_partial, const frcnn_bn_reduce* red, frcnn_stream_t stream,
-                      const bool dry_run = false) {
+                      const bool dry_run = false, const float* f8_x_scale = nullptr, const float* f8_w_scale = nullptr) {
     FRCNN_CHECK_ARG(d && x && w && y, "conv2d_fprop: null pointer");
     FRCNN_CHECK_ARG(d->cin > 0 && d->cin % 32 == 0, "conv2d_fprop: cin=%d must be a multiple of 32", d->cin);
     FRCNN_CHECK_ARG(d->cout > 0 && d->cout % 8 == 0, "conv2d_fprop: cout=%d must be a multiple of 8", d->cout);
@@ -1001,6 +1107,8 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     p.red_part = red ? red->partial : nullptr;
     p.res_mask = res_mask;
     p.dry_run = dry_run ? 1 : 0;
+    p.f8_x_scale = f8_x_scale;
+    p.f8_w_scale = f8_w_scale;
     p.dbg = g_stamp_buffer;
     p.fix_partial = nullptr;
     p.fix_counter = nullptr;
@@ -1081,6 +1189,41 @@ extern "C" int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d) {
 extern "C" int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
                                   const frcnn_bf16* res, void* y, double* stats_partial, frcnn_stream_t stream) {
     return conv2d_fprop_impl(d, x, w, bias, res, nullptr, y, stats_partial, nullptr, stream);
+}
+
+// fp8 (OCP e4m3) operands: the geometry with every element count halved IS the bf16 kernel's geometry in bytes (conv_tile_kernel, F8)
+static int fp8_halved_desc(const frcnn_conv_desc* d, frcnn_conv_desc* h, const char* who) {
+    FRCNN_CHECK_ARG(d, "%s: null descriptor", who);
+    FRCNN_CHECK_ARG(d->cin % 128 == 0 && d->in_pix_stride % 128 == 0, "%s: cin=%d / in_pix_stride=%d must be multiples of 128 (128-deep fp8 MFMA steps)",
+                    who, d->cin, d->in_pix_stride);
+    FRCNN_CHECK_ARG(!(d->flags & (FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC | FRCNN_CONV_ADD_RES)) && d->split_k <= 1,
+                    "%s: bf16 output without residual / split-K only", who);
+    *h = *d;
+    h->cin = d->cin / 2;
+    h->in_pix_stride = d->in_pix_stride / 2;
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_conv2d_fprop_fp8(const frcnn_conv_desc* d, const frcnn_fp8* x8, const frcnn_fp8* w8, const float* x_scale,
+                                      const float* w_scale, const float* bias, frcnn_bf16* y, double* stats_partial, frcnn_stream_t stream) {
+    frcnn_conv_desc h;
+    const int rc = fp8_halved_desc(d, &h, "conv2d_fprop_fp8");
+    if (rc != FRCNN_OK) return rc;
+    FRCNN_CHECK_ARG(x_scale && w_scale, "conv2d_fprop_fp8: null scale pointer");
+    return conv2d_fprop_impl(&h, reinterpret_cast<const frcnn_bf16*>(x8), reinterpret_cast<const frcnn_bf16*>(w8), bias, nullptr, nullptr, y,
+                             stats_partial, nullptr, stream, false, x_scale, w_scale);
+}
+
+extern "C" const char* frcnn_conv2d_describe_fp8(const frcnn_conv_desc* d) {
+    static const uint8_t dummy[16] = {0};
+    frcnn_conv_desc h;
+    g_last_inst[0] = 0;
+    if (fp8_halved_desc(d, &h, "conv2d_describe_fp8") != FRCNN_OK) return nullptr;
+    const void* q = dummy;
+    const int rc = conv2d_fprop_impl(&h, reinterpret_cast<const frcnn_bf16*>(q), reinterpret_cast<const frcnn_bf16*>(q), reinterpret_cast<const float*>(q),
+                                     nullptr, nullptr, const_cast<void*>(q), const_cast<double*>(reinterpret_cast<const double*>(q)), nullptr, nullptr,
+                                     true, reinterpret_cast<const float*>(q), reinterpret_cast<const float*>(q));
+    return rc == FRCNN_OK ? g_last_inst : nullptr;
 }
 
 extern "C" int frcnn_conv2d_dgrad_bnreduce(const frcnn_conv_desc* d, const frcnn_bf16* dz, const frcnn_bf16* w_t, const frcnn_bf16* res,

@@ -236,6 +236,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int block
 struct Bn2 {
     const bf16_t* z; const double* part; const float* gamma; const float* beta;
     float* mm; float* mv; float* mean_o; float* invstd_o;
+    // optional fp8 twin of the output (frcnn_fp8_out): e4m3 bytes of the bf16-rounded activation times *qscale, max |value| into *amax
+    uint8_t* out8; const float* qscale; float* amax;
 };
 
 template <int VAR, bool DUAL = false>   // VAR 0: production; 4: round-1 form (2-D placement, cached loads) for FRCNN_SWEEP A/B runs (tools/ab_lib.sh)
@@ -337,6 +339,8 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
         for (int e = 0; e < 8; ++e) { sc2[e] = s_scale2[v * 8 + e]; sh2[e] = s_shift2[v * 8 + e]; }
     }
     const bf16_t* second = DUAL ? b2.z : res;
+    const float f8_qs = b2.out8 ? *b2.qscale : 0.f;
+    float f8_max = 0.f;
     auto finish = [&](const int64_t i, const u32x4 zraw, const u32x4 qraw) {
         float x[8];
         unpack8(zraw, x);
@@ -359,6 +363,13 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
         }
         const u32x4 pk = pack8(x);
         *reinterpret_cast<u32x4*>(out + i * 8) = pk;
+        if (b2.out8) {                           // fp8 twin of the STORED (bf16-rounded) activation
+            float xr[8];
+            unpack8(pk, xr);
+            *reinterpret_cast<u32x2*>(b2.out8 + i * 8) = pack8_fp8(xr, f8_qs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f8_max = fmaxf(f8_max, fabsf(xr[e]));
+        }
         if (relu_mask) {
             // one bit per element: (stored bf16 activation > 0), i.e. exactly what the backward pass would derive from the
             // activation itself -- it reads this byte instead of the 16-byte activation vector (twice)
@@ -388,6 +399,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
         if (second) qraw = NT ? load_stream(second + i * 8) : *reinterpret_cast<const u32x4*>(second + i * 8);
         finish(i, zraw, qraw);
     }
+    if (b2.out8 && b2.amax) atomic_amax(b2.amax, f8_max);
 }
 
 // BatchNorm (batch statistics) + ReLU + 3x3 / stride-2 / pad-1 max pool in one pass (the ResNet stem: reference
@@ -908,7 +920,10 @@ static int strip_rows_per_block(int64_t m, int c) {
 extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_partial, int slots, int64_t count, const float* gamma,
                                     const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
                                     const frcnn_bf16* res, int relu, frcnn_bf16* out, uint8_t* relu_mask, float* mean, float* invstd,
-                                    int64_t m, int c, frcnn_stream_t stream) {
+                                    int64_t m, int c, const frcnn_fp8_out* f8, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(!f8 || (f8->out8 && f8->qscale), "bn_train_apply: fp8 output without buffer / scale");
+    Bn2 extra{};
+    if (f8) { extra.out8 = f8->out8; extra.qscale = f8->qscale; extra.amax = f8->amax; }
     FRCNN_CHECK_ARG(z && stats_partial && gamma && beta && moving_mean && moving_var && out && mean && invstd && count > 0 &&
                         slots > 0 && c % 8 == 0,
                     "bn_train_apply: bad arguments");
@@ -919,7 +934,7 @@ extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_par
 #define FRCNN_BN_LAUNCH(V)                                                                                                          \
     hipLaunchKernelGGL(bn_train_apply_kernel<V>, grid, dim3(256), 0, S_(stream), CBF(z), stats_partial, slots, gamma, beta, moving_mean, \
                        moving_var, momentum, eps, (float)(1.0 / (double)count), unbias, CBF(res), relu, BF(out), relu_mask, mean, invstd, \
-                       m, c, rows, strips, chunks, Bn2{})
+                       m, c, rows, strips, chunks, extra)
 #ifdef FRCNN_SWEEP
     const char* ev = getenv("FRCNN_BN_VAR");
     const int var = ev ? atoi(ev) : 0;
@@ -985,14 +1000,17 @@ extern "C" int frcnn_bn_train_apply_dual(const frcnn_bf16* z, const double* stat
                                          float* moving_mean, float* moving_var, float* mean, float* invstd, const frcnn_bf16* z2,
                                          const double* stats_partial2, const float* gamma2, const float* beta2, float* moving_mean2,
                                          float* moving_var2, float* mean2, float* invstd2, int slots, int64_t count, float momentum,
-                                         float eps, int relu, frcnn_bf16* out, uint8_t* relu_mask, int64_t m, int c, frcnn_stream_t stream) {
+                                         float eps, int relu, frcnn_bf16* out, uint8_t* relu_mask, int64_t m, int c, const frcnn_fp8_out* f8,
+                                         frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(!f8 || (f8->out8 && f8->qscale), "bn_train_apply_dual: fp8 output without buffer / scale");
     FRCNN_CHECK_ARG(z && stats_partial && gamma && beta && moving_mean && moving_var && mean && invstd && z2 && stats_partial2 && gamma2 &&
                         beta2 && moving_mean2 && moving_var2 && mean2 && invstd2 && out && count > 0 && slots > 0 && c % 8 == 0,
                     "bn_train_apply_dual: bad arguments");
     const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
     const int rows = strip_rows_per_block(m, c);
     const int strips = (c + 63) / 64, chunks = (int)((m + rows - 1) / rows);
-    Bn2 b2;
+    Bn2 b2{};
+    if (f8) { b2.out8 = f8->out8; b2.qscale = f8->qscale; b2.amax = f8->amax; }
     b2.z = CBF(z2); b2.part = stats_partial2; b2.gamma = gamma2; b2.beta = beta2; b2.mm = moving_mean2; b2.mv = moving_var2;
     b2.mean_o = mean2; b2.invstd_o = invstd2;
     hipLaunchKernelGGL((bn_train_apply_kernel<0, true>), dim3((unsigned)(strips * 8 * ((chunks + 7) / 8))), dim3(256), 0, S_(stream), CBF(z),

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams
 // ---------------------------------------------------------------- sampling
 struct SampleParams {
     const float* tl; int R, C1, S, max_fg;
-    unsigned int k0, k1; const int64_t* step; int stream_base;
+    unsigned int k0, k1; const int64_t* step; int stream_base, image_base;
     int* out; int* ws; int* status;
 };
 constexpr int kFgLds = 8192;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     // fg: partial Fisher-Yates (== shuffle then take).  The swap chain is sequential by construction, its random partners are
     // not: all threads draw them first (Philox + the modulo were 3/4 of this kernel's time on the one lane walking the chain)
     for (int i = threadIdx.x; i < n_fg; i += blockDim.x) {
-        const unsigned int rnd = philox_first((unsigned)i, (unsigned)b, step, (unsigned)(p.stream_base + 0), p.k0, p.k1);
+        const unsigned int rnd = philox_first((unsigned)i, (unsigned)(b + p.image_base), step, (unsigned)(p.stream_base + 0), p.k0, p.k1);
         swap_j[i] = i + (int)(rnd % (unsigned)(nfg - i));
     }
     __syncthreads();                       // (also publishes fg_list / fg_lds / bg_list inside the workgroup)
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     for (int i = threadIdx.x; i < n_bg; i += blockDim.x) {
         int v = 0;
         if (nbg > 0) {
-            const unsigned int rnd = philox_first((unsigned)i, (unsigned)b, step, (unsigned)(p.stream_base + 1), p.k0, p.k1);
+            const unsigned int rnd = philox_first((unsigned)i, (unsigned)(b + p.image_base), step, (unsigned)(p.stream_base + 1), p.k0, p.k1);
             v = bg_list[rnd % (unsigned)nbg];
         }
         out[n_fg + i] = v;
@@ -487,14 +487,14 @@ extern "C" int frcnn_assign_targets(const float* regions, int regions_per_image,
 
 extern "C" int frcnn_sample_indices(const float* target_labels, int b, int r, int c1, int num_samples, float fg_proportion, uint64_t seed,
                                     const int64_t* step, int stream_base, int32_t* indices, int32_t* workspace, int32_t* status,
-                                    frcnn_stream_t stream) {
+                                    int image_base, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(target_labels && step && indices && workspace && status && b > 0 && r > 0 && num_samples > 0, "sample_indices: bad arguments");
     FRCNN_CHECK_ARG(num_samples <= 1024, "sample_indices: num_samples=%d > 1024 unsupported", num_samples);
     SampleParams p;
     p.tl = target_labels; p.R = r; p.C1 = c1; p.S = num_samples;
     p.max_fg = (int)nearbyint((double)num_samples * (double)fg_proportion);   // tf.math.round: half to even
     p.k0 = (unsigned int)(seed & 0xFFFFFFFFull); p.k1 = (unsigned int)(seed >> 32);
-    p.step = step; p.stream_base = stream_base; p.out = indices; p.ws = workspace; p.status = status;
+    p.step = step; p.stream_base = stream_base; p.image_base = image_base; p.out = indices; p.ws = workspace; p.status = status;
     hipLaunchKernelGGL(sample_kernel, dim3(b), dim3(256), 0, S_(stream), p);
     FRCNN_CHECK_LAUNCH("sample_indices");
     return FRCNN_OK;

@@ -51,7 +51,8 @@ def _feature_shape(image_shape, depth):
 
 
 class FasterRCNN:
-    def __init__(self, config, name="faster_rcnn", depth=50, device="cuda", seed=0, sampling_seed=0, world_size=1, sync_bn=False):
+    def __init__(self, config, name="faster_rcnn", depth=50, device="cuda", seed=0, sampling_seed=0, world_size=1, sync_bn=False,
+                 sampling_image_base=0):
         """reference faster_rcnn.py:11-37.  `config`: dict with the reference's config.json schema.
         world_size: data-parallel ranks (classification losses are means over the GLOBAL batch).  sync_bn: BatchNorm batch
         statistics and their backward sums are all-reduced over the ranks, so world_size x b images behave like the reference's
@@ -64,6 +65,10 @@ class FasterRCNN:
         self.depth = depth
         self.device = torch.device(device)
         self.sampling_seed = int(sampling_seed)
+        # index of this replica's first image in the global batch: with one sampling_seed for all ranks and image_base = rank * b,
+        # N ranks x b images draw exactly the fg / bg samples one device draws for N*b images (the sampler's Philox counter
+        # carries the global image index)
+        self.sampling_image_base = int(sampling_image_base)
         self.world_size = int(world_size)
         self.sync_bn = bool(sync_bn)
         self.store = ParamStore(self.device)
@@ -171,7 +176,7 @@ class FasterRCNN:
             plan.add(ops.assign_targets, regions, io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
                      rs["foreground_iou_interval"], rs["background_iou_interval"], t["rpn_tl"], t["rpn_tb"])
             plan.add(ops.sample_indices, t["rpn_tl"], batch, n, 2, S_rpn, rs["foreground_proportion"], self.sampling_seed, step, 0,
-                     t["rpn_idx"], t["rpn_ws"], self.status)
+                     t["rpn_idx"], t["rpn_ws"], self.status, image_base=self.sampling_image_base)
 
         def rpn_losses():
             if training:
@@ -186,7 +191,7 @@ class FasterRCNN:
             plan.add(ops.assign_targets, regions, io["gt_labels"], io["gt_boxes"], batch, P, G, nc1, False, W, H,
                      cs["foreground_iou_interval"], cs["background_iou_interval"], t["rcnn_tl"], t["rcnn_tb"])
             plan.add(ops.sample_indices, t["rcnn_tl"], batch, P, nc1, S_rcnn, cs["foreground_proportion"], self.sampling_seed, step, 2,
-                     t["rcnn_idx"], t["rcnn_ws"], self.status)
+                     t["rcnn_idx"], t["rcnn_ws"], self.status, image_base=self.sampling_image_base)
 
         def rcnn_losses():
             if training:

@@ -10,7 +10,7 @@ from ctypes import byref, c_float, c_void_p
 import torch
 
 from . import _lib
-from ._lib import (CONV_ADD_RES, CONV_BIAS, CONV_OUT_F32, CONV_RELU, CONV_SPLITK_ATOMIC, CONV_STATS, BnReduce, ConvDesc, call)
+from ._lib import (CONV_ADD_RES, CONV_BIAS, CONV_OUT_F32, CONV_RELU, CONV_SPLITK_ATOMIC, CONV_STATS, BnReduce, ConvDesc, Fp8Out, call)
 
 BF16 = torch.bfloat16
 
@@ -99,6 +99,51 @@ def conv_stat_tiles(d):
 
 def conv2d_fprop(d, x, w, y, bias=None, res=None, stats=None):
     call("frcnn_conv2d_fprop", byref(d), _p(x), _p(w), _p(bias), _p(res), _p(y), _p(stats), _stream())
+
+
+# ---------------------------------------------------------------- fp8 (e4m3) convolution path
+FP8 = torch.uint8            # storage type of OCP e4m3 bytes (torch.float8_e4m3fn views of these tensors are used by the tests only)
+
+
+def conv2d_fprop_fp8(d, x8, w8, x_scale, w_scale, y, bias=None, stats=None):
+    """y = bf16(x_scale * w_scale[co] * conv(x8, w8) + bias): both operands e4m3 bytes, x_scale a device scalar, w_scale [cout]."""
+    call("frcnn_conv2d_fprop_fp8", byref(d), _p(x8), _p(w8), _p(x_scale), _p(w_scale), _p(bias), _p(y), _p(stats), _stream())
+
+
+def conv2d_describe_fp8(d):
+    r = _lib.load().frcnn_conv2d_describe_fp8(byref(d))
+    if r is None:
+        raise RuntimeError("frcnn_conv2d_describe_fp8: " + _lib.load().frcnn_last_error().decode())
+    return r.decode()
+
+
+def quantize_fp8(x, qscale, out8, amax=None):
+    call("frcnn_quantize_fp8", _p(x), x.numel(), _p(qscale), _p(out8), _p(amax), _stream())
+
+
+def make_weight_quant_table(entries, device):
+    """entries: list of (fp32 master [rows, K] view, fp8 destination, float scale[rows]) -> (int64 table on device, total rows)."""
+    rows, begin = [], 0
+    for (w, w8, scale) in entries:
+        r = int(w.shape[0])
+        k = w.numel() // r
+        assert k % 8 == 0 and w.is_contiguous() and w8.numel() == w.numel() and scale.numel() == r
+        rows.append([w.data_ptr(), w8.data_ptr(), scale.data_ptr(), r, k, begin])
+        begin += r
+    return torch.tensor(rows, dtype=torch.int64, device=device), begin
+
+
+def quantize_weights_fp8_batched(table, total_rows):
+    call("frcnn_quantize_weights_fp8_batched", _p(table), table.shape[0], total_rows, _stream())
+
+
+def fp8_update_scales(amax, scale, qscale, n, margin=1.0):
+    call("frcnn_fp8_update_scales", _p(amax), _p(scale), _p(qscale), n, float(margin), _stream())
+
+
+def fp8_out(out8, qscale, amax=None):
+    """frcnn_fp8_out for bn_train_apply / bn_train_apply_dual (keep the struct alive as long as a plan refers to it)."""
+    return Fp8Out(out8.data_ptr(), qscale.data_ptr(), amax.data_ptr() if amax is not None else None)
 
 
 def bn_reduce_args(z, relu_mask, mean, invstd, partial):
@@ -227,17 +272,17 @@ def bn_apply(z, scale, shift, out, m, c, res=None, relu=True):
 
 
 def bn_train_apply(z, stats, slots, count, gamma, beta, mm, mv, momentum, eps, out, mean, invstd, m, c, res=None, relu=True,
-                   relu_mask=None):
+                   relu_mask=None, f8=None):
     call("frcnn_bn_train_apply", _p(z), _p(stats), slots, count, _p(gamma), _p(beta), _p(mm), _p(mv), momentum, eps, _p(res),
-         1 if relu else 0, _p(out), _p(relu_mask), _p(mean), _p(invstd), m, c, _stream())
+         1 if relu else 0, _p(out), _p(relu_mask), _p(mean), _p(invstd), m, c, byref(f8) if f8 is not None else None, _stream())
 
 
 def bn_train_apply_dual(z, stats, gamma, beta, mm, mv, mean, invstd, z2, stats2, gamma2, beta2, mm2, mv2, mean2, invstd2, slots, count,
-                        momentum, eps, out, m, c, relu=True, relu_mask=None):
+                        momentum, eps, out, m, c, relu=True, relu_mask=None, f8=None):
     """out = [ReLU](BN(z) + BN2(z2)), both with batch statistics, in one pass (block-final + shortcut BatchNorm of a first block)."""
     call("frcnn_bn_train_apply_dual", _p(z), _p(stats), _p(gamma), _p(beta), _p(mm), _p(mv), _p(mean), _p(invstd), _p(z2), _p(stats2),
          _p(gamma2), _p(beta2), _p(mm2), _p(mv2), _p(mean2), _p(invstd2), slots, count, momentum, eps, 1 if relu else 0, _p(out),
-         _p(relu_mask), m, c, _stream())
+         _p(relu_mask), m, c, byref(f8) if f8 is not None else None, _stream())
 
 
 def bn_train_apply_maxpool(z, stats, slots, count, gamma, beta, mm, mv, momentum, eps, pooled, argmax, relu_mask, mean, invstd, n, h, w, c,
@@ -367,9 +412,9 @@ def assign_targets(regions, gt_labels, gt_boxes, b, r, g, c1g, objectness, img_w
          float(bg_interval[1]), _p(target_labels), _p(target_boxes), _stream())
 
 
-def sample_indices(target_labels, b, r, c1, num_samples, fg_proportion, seed, step, stream_base, indices, workspace, status):
+def sample_indices(target_labels, b, r, c1, num_samples, fg_proportion, seed, step, stream_base, indices, workspace, status, image_base=0):
     call("frcnn_sample_indices", _p(target_labels), b, r, c1, num_samples, float(fg_proportion), ctypes.c_uint64(seed), _p(step),
-         stream_base, _p(indices), _p(workspace), _p(status), _stream())
+         stream_base, _p(indices), _p(workspace), _p(status), int(image_base), _stream())
 
 
 def losses(scores, deltas, target_labels, target_boxes, indices, b, r, c1, s, cls_scale, reg_scale, out_losses, dlogits_s=None,

@@ -393,7 +393,7 @@ def main():
                 head_us, head_src = float(off["avg_launch_us"]), "rocprofv3 kernel trace, " + source
             else:
                 head_us, head_src = ev_raw_us, "live HIP events, raw pairs (no committed trace for these kernel sources: %s)" % source
-            achieved = gflop_per_launch / head_us / 1e3
+            achieved = gflop_per_launch / head_us * 1e3       # GFLOP / us = PFLOP/s
             off_all = {}
             for k in fam:
                 off_all[k] = offline_profile(k, "_fp8" if args.fp8 else "")[0]
@@ -423,8 +423,8 @@ def main():
                                "algorithmic_gflop_per_launch": round(gflop_per_launch, 4),
                                "events": {"avg_launch_us_raw": round(ev_raw_us, 2), "avg_launch_us_minus_empty_pair": round(ev_net_us, 2),
                                           "empty_pair_us": round(f["event_pair_overhead_us"], 2),
-                                          "frac_raw": round(gflop_per_launch / ev_raw_us / 1e3 / peak, 5),
-                                          "frac_minus_empty_pair": round(gflop_per_launch / ev_net_us / 1e3 / peak, 5)},
+                                          "frac_raw": round(gflop_per_launch / ev_raw_us * 1e3 / peak, 5),
+                                          "frac_minus_empty_pair": round(gflop_per_launch / ev_net_us * 1e3 / peak, 5)},
                                "whole_step_tflops": round(sum(v["flops"] for v in fam.values()) / (ms * 1e-3) / 1e12, 1),
                                "families": families}
         if not args.no_cpu_baseline:

@@ -26,6 +26,7 @@ extern "C" {
 
 typedef void* frcnn_stream_t;
 typedef uint16_t frcnn_bf16;
+typedef uint8_t frcnn_fp8;     /* OCP e4m3fn (gfx950's fp8: 4 exponent bits, bias 7, max 448, no infinities) */
 
 #define FRCNN_OK 0
 #define FRCNN_EINVAL (-1)      /* bad argument / unsupported shape */
@@ -114,6 +115,40 @@ size_t frcnn_conv2d_workspace_counter_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d);
 int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
                        const frcnn_bf16* res, void* y, double* stats_partial, frcnn_stream_t stream);
+
+/* ------------------------------------------------------------------ fp8 (e4m3) MFMA convolution path
+ * BASELINE.json configs[4] ("fp8 weights ... CDNA4 fp8 MFMA conv path").  The reference is fp32 throughout
+ * (models/feature_extractor.py:5-9); this is the same Conv2D contraction with both operands stored as OCP e4m3 bytes and
+ * multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulation, unit block scales), twice the bf16 matrix rate and half
+ * the operand bytes per FLOP:
+ *   x ~= x8 * x_scale[0]   (per tensor; device scalar, so that a captured graph follows a scale that changes from step to step)
+ *   w[co] ~= w8[co] * w_scale[co]   (per output channel)
+ *   y[(n,oy,ox), co] = bf16( x_scale * w_scale[co] * sum_k x8 * w8  + bias[co] )        (+ FRCNN_CONV_STATS as the bf16 form)
+ * Same descriptor as frcnn_conv2d_fprop with cin and in_pix_stride multiples of 128; flags BIAS / RELU / STATS; bf16 output.  The
+ * sum is EXACT in fp32 terms (products of two e4m3 values are exact, accumulation is fp32): against an fp32 convolution of the
+ * dequantised operands only the accumulation order and the bf16 rounding of y differ. */
+int frcnn_conv2d_fprop_fp8(const frcnn_conv_desc* d, const frcnn_fp8* x8, const frcnn_fp8* w8, const float* x_scale,
+                           const float* w_scale, const float* bias, frcnn_bf16* y, double* stats_partial, frcnn_stream_t stream);
+/* the instantiation frcnn_conv2d_fprop_fp8 would launch (host logic, as frcnn_conv2d_describe) */
+const char* frcnn_conv2d_describe_fp8(const frcnn_conv_desc* d);
+/* Quantisers.  out8[i] = e4m3_rne(clamp(x[i] * qscale[0], -448, 448)); amax (optional, device scalar, pre-zeroed per step):
+ * atomic max of |x[i]| as fp32 -- the input of the delayed scaling rule below.  n a multiple of 8. */
+int frcnn_quantize_fp8(const frcnn_bf16* x, int64_t n, const float* qscale, frcnn_fp8* out8, float* amax, frcnn_stream_t stream);
+/* Weights, several layers in one launch: table int64 [n][6] = {fp32 master (rows of K values, row-major), fp8 destination, float
+ * scale[rows] destination, rows, K, first workgroup}; one workgroup per row: scale = max|w| / 448 (1 for an all-zero row),
+ * w8 = e4m3_rne(w * (1 / scale)), all in fp32.  Serves the forward weights [cout][kh*kw*cin] and, given transposed masters, any other row layout. */
+int frcnn_quantize_weights_fp8_batched(const int64_t* table, int n, int64_t total_rows, frcnn_stream_t stream);
+/* Delayed scaling (one amax of history): for i < n: a = amax[i] (this step's maximum); if a > 0: scale[i] = margin * a / 448,
+ * qscale[i] = 1 / scale[i]; a == 0 (tensor not produced this step) leaves both unchanged. */
+int frcnn_fp8_update_scales(const float* amax, float* scale, float* qscale, int n, float margin, frcnn_stream_t stream);
+/* Optional fp8 twin of a BatchNorm kernel's output (frcnn_bn_train_apply / _dual): the kernel that writes the bf16 activation also
+ * writes out8 = e4m3(clamp(bf16 value * qscale[0])) and folds max|value| into amax[0] -- the next convolution reads 1 byte per
+ * element instead of 2 and no separate quantise pass exists. */
+typedef struct frcnn_fp8_out {
+    frcnn_fp8* out8;        /* [M][C] */
+    const float* qscale;    /* device scalar: 1 / dequantisation scale */
+    float* amax;            /* device scalar or NULL */
+} frcnn_fp8_out;
 
 /* Weight gradient: dw[co,kh,kw,ci] (fp32, accumulated with atomics into a pre-zeroed buffer) =
  * sum_pixels dz[(n,oy,ox), co] * x[n, oy*stride-pad_h+kh, ox*stride-pad_w+kw, ci].
@@ -210,7 +245,7 @@ int frcnn_bn_bwd_apply(const frcnn_bf16* gout, const frcnn_bf16* act, const frcn
 int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_partial, int slots, int64_t count, const float* gamma,
                          const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
                          const frcnn_bf16* res, int relu, frcnn_bf16* out, uint8_t* relu_mask, float* mean, float* invstd,
-                         int64_t m, int c, frcnn_stream_t stream);
+                         int64_t m, int c, const struct frcnn_fp8_out* f8 /* NULL: no fp8 twin */, frcnn_stream_t stream);
 int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z,
                              const float* mean, const float* invstd, const float* gamma, const float* partial, int slots,
                              float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, int64_t count,
@@ -229,7 +264,8 @@ int frcnn_bn_train_apply_dual(const frcnn_bf16* z, const double* stats_partial, 
                               float* moving_mean, float* moving_var, float* mean, float* invstd, const frcnn_bf16* z2,
                               const double* stats_partial2, const float* gamma2, const float* beta2, float* moving_mean2,
                               float* moving_var2, float* mean2, float* invstd2, int slots, int64_t count, float momentum, float eps,
-                              int relu, frcnn_bf16* out, uint8_t* relu_mask, int64_t m, int c, frcnn_stream_t stream);
+                              int relu, frcnn_bf16* out, uint8_t* relu_mask, int64_t m, int c, const struct frcnn_fp8_out* f8,
+                              frcnn_stream_t stream);
 /* The ResNet stem's BatchNorm (batch statistics, as frcnn_bn_train_apply) + ReLU + 3x3 / stride-2 / pad-1 max pool
  * (reference models/feature_extractor.py:8-10: conv1_bn, conv1_relu, pool1_pad, pool1_pool) in one pass over z [n,h,w,c]:
  * pooled [n,ho,wo,c], argmax and relu_mask ([n*h*w, c/8] bits of (activation > 0), may be NULL) are bit-identical to
@@ -330,12 +366,14 @@ int frcnn_assign_targets(const float* regions, int regions_per_image, const floa
                          int b, int r, int g, int c1g, int objectness, float img_w, float img_h, float fg_lo,
                          float fg_hi, float bg_lo, float bg_hi, float* target_labels, float* target_boxes,
                          frcnn_stream_t stream);
-/* utils/training.py:80-120 with a counter-based RNG (Philox4x32-10; counter = (i, image, step,
+/* utils/training.py:80-120 with a counter-based RNG (Philox4x32-10; counter = (i, image_base + image, step,
  * stream_base + {0 fg, 1 bg}), key = seed).  indices int32 [B,S].  status[0] |= 1 on an empty
- * background set (the reference raises there).  workspace: int32 [B, 2*R]. */
+ * background set (the reference raises there).  workspace: int32 [B, 2*R].  image_base: index of this call's first image in
+ * the GLOBAL batch (data parallelism: rank * per-rank batch), so that N ranks x b images draw exactly the samples one device
+ * draws for N*b images. */
 int frcnn_sample_indices(const float* target_labels, int b, int r, int c1, int num_samples, float fg_proportion,
                          uint64_t seed, const int64_t* step, int stream_base, int32_t* indices, int32_t* workspace,
-                         int32_t* status, frcnn_stream_t stream);
+                         int32_t* status, int image_base, frcnn_stream_t stream);
 /* utils/losses.py + gathers of get_training_samples (rpn_detector.py:156-159,
  * fast_rcnn_detector.py:126-129) + their gradients.
  * scores [B,R,C1] (probabilities), deltas [B,R,C,4], targets as written by frcnn_assign_targets,

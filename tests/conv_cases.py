@@ -39,6 +39,26 @@ FPROP = [
     dict(id="small_3x3_576_oddk_stats_fix", n=1, h=12, w=10, cin=576, cout=64, k=3, s=1, p=1, bias=True, relu=False, stats=True, ws=True),   # 81 slices: 41 + 40, one tile, 14 idle workgroups
 ]
 
+# ---- fp8 (e4m3) forward convolutions (frcnn_conv2d_fprop_fp8): the layers of the same network whose cin is a multiple of 128
+FPROP_FP8 = [
+    dict(id="f8_c4_1x1_256_1024_stats", n=4, h=24, w=78, cin=256, cout=1024, k=1, s=1, p=0, bias=True, relu=False, stats=True),       # 128 x 128 tiles, 2 slices
+    dict(id="f8_c4_s2_512_1024_stats", n=4, h=47, w=156, cin=512, cout=1024, k=1, s=2, p=0, bias=True, relu=False, stats=True),
+    dict(id="f8_c3_3x3_128_128_stats", n=3, h=47, w=156, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),       # kw-sharing
+    dict(id="f8_c3_1x1_128_512_stats_run", n=4, h=47, w=156, cin=128, cout=512, k=1, s=1, p=0, bias=True, relu=False, stats=True),   # ONE slice per tile
+    dict(id="f8_c3_1x1_512_128_stats", n=4, h=47, w=156, cin=512, cout=128, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    dict(id="f8_c3_s2_256_512_stats_run", n=4, h=94, w=311, cin=256, cout=512, k=1, s=2, p=0, bias=True, relu=False, stats=True),
+    dict(id="f8_c3_s2_256_128_stats", n=4, h=94, w=311, cin=256, cout=128, k=1, s=2, p=0, bias=True, relu=False, stats=True),
+    dict(id="f8_c2_1x1_256_64_stats", n=4, h=94, w=311, cin=256, cout=64, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    dict(id="f8_c4_1x1_1024_256_stats", n=4, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    dict(id="f8_c4_s2_512_256_stats", n=4, h=47, w=156, cin=512, cout=256, k=1, s=2, p=0, bias=True, relu=False, stats=True),
+    dict(id="f8_c4_3x3_256_256_stats", n=4, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+    dict(id="f8_rpn_3x3_1024_256_relu", n=1, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),
+    dict(id="f8_rpn_3x3_1024_256_relu_fix_b4", n=4, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),
+    dict(id="f8_small_s2_stats", n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0, bias=False, relu=False, stats=True),
+    dict(id="f8_small_3x3_128_stats", n=1, h=9, w=11, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+    dict(id="f8_small_1x1_relu", n=2, h=13, w=17, cin=384, cout=72, k=1, s=1, p=0, bias=True, relu=True, stats=False),
+]
+
 # ---- data gradients: dz grid n x h x w with cin channels -> gx with cout channels; k = 1 or 3 (stride 1, pad k//2);
 # scatter 2: the gradient of a stride-2 1x1 convolution, written to every second pixel of a 2h x 2w (-1) grid.
 # res: residual added (ADD_RES); res_mask: bit mask on the residual; red: fused BatchNorm-backward reduce (mask: with ReLU bits)

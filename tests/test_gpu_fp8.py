@@ -1,0 +1,176 @@
+"""GPU parity of the fp8 (OCP e4m3) convolution path (BASELINE.json configs[4]: "fp8 weights ... CDNA4 fp8 MFMA conv path";
+reference contraction: the Conv2D layers of models/feature_extractor.py:8-10 and models/detectors/rpn_detector.py:26-34).
+
+The fp8 kernel is compared with torch-CPU fp32 on the DEQUANTISED operands: products of two e4m3 values are exact in fp32 and
+the MFMA accumulates in fp32, so only the accumulation order and the bf16 rounding of the output differ -- the tolerance is the
+bf16 kernels' (2^-7 relative + the absolute term of cancelling sums), not an fp8 tolerance.  The quantisers are compared bit for
+bit with torch's float8_e4m3fn conversion (round to nearest even) of the same fp32 product."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conv_cases import FPROP_FP8, fprop_desc
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+E4M3 = torch.float8_e4m3fn
+
+
+def _close(a, b, rtol, atol, what):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    bad = int((err > atol + rtol * b.abs()).sum())
+    assert bad == 0, "%s: %d/%d mismatches, max err %g (ref max %g)" % (what, bad, a.numel(), float(err.max()), float(b.abs().max()))
+
+
+def _rand_fp8(shape, g, spread=1.0):
+    """random e4m3 bytes with a wide spread of exponents (and exact zeros), as uint8 + their fp32 values"""
+    v = torch.randn(shape, generator=g) * spread * torch.exp2(torch.randint(-6, 4, shape, generator=g).float())
+    v = torch.where(torch.rand(shape, generator=g) < 0.1, torch.zeros(()), v).clamp(-448, 448)
+    q = v.to(E4M3)
+    return q.view(torch.uint8), q.float()
+
+
+def test_fp8_mfma_operand_layout_with_exact_integers(ops):
+    """K-permutation check of the 128-deep MFMA step: integer-valued operands (exact in e4m3 and in fp32 sums) whose every K
+    position carries a different weight -- a lane map that does not pair the SAME k of both operands gives wrong integers."""
+    g = torch.Generator().manual_seed(1)
+    n, h, w, cin, cout = 1, 8, 16, 256, 64
+    x = torch.randint(-3, 4, (n, h, w, cin), generator=g).float()
+    wt = torch.zeros(cout, cin)
+    for co in range(cout):                                       # row co: +-1 / +-2 at positions that depend on co and k (asymmetric)
+        wt[co] = ((torch.arange(cin) * 7 + co * 13) % 5 - 2).float()
+    ref = (x.reshape(-1, cin) @ wt.t())
+    d = ops.conv_desc(n, h, w, cin, 1, 1, 1, 0, 0, h, w, cout)
+    x8, w8 = x.to(E4M3).view(torch.uint8).cuda(), wt.to(E4M3).view(torch.uint8).cuda()
+    one = torch.ones(1, device="cuda")
+    y = torch.empty(n * h * w, cout, dtype=BF, device="cuda")
+    ops.conv2d_fprop_fp8(d, x8, w8, one, torch.ones(cout, device="cuda"), y)
+    torch.cuda.synchronize()
+    assert float(ref.abs().max()) < 256                          # integers below 2^8: exact in bf16
+    assert torch.equal(y.float().cpu(), ref), "fp8 MFMA: wrong K pairing (max err %g)" % float((y.float().cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize("case", FPROP_FP8, ids=[c["id"] for c in FPROP_FP8])
+def test_conv_fprop_fp8_vs_fp32_on_dequantised_operands(ops, case):
+    g = torch.Generator().manual_seed(0)
+    n, h, w, cin, cout, k, s, p = (case[x] for x in ("n", "h", "w", "cin", "cout", "k", "s", "p"))
+    x8, xf = _rand_fp8((n, h, w, cin), g)
+    w8, wf = _rand_fp8((cout, k, k, cin), g, spread=0.5)        # OHWI
+    x_scale = torch.tensor([0.0371])
+    w_scale = torch.rand(cout, generator=g) * 0.02 + 0.001
+    bias = torch.randn(cout, generator=g)
+    xd = xf * x_scale
+    wd = wf * w_scale.view(-1, 1, 1, 1)
+    ref = F.conv2d(xd.permute(0, 3, 1, 2), wd.permute(0, 3, 1, 2), bias if case["bias"] else None, stride=s, padding=p)
+    if case["relu"]:
+        ref = F.relu(ref)
+    ref = ref.permute(0, 2, 3, 1).contiguous()
+    ho, wo = ref.shape[1], ref.shape[2]
+    d = fprop_desc(ops, case, "cuda")
+    y = torch.full((n, ho, wo, cout), float("nan"), dtype=BF, device="cuda")
+    stats = torch.zeros(ops.conv_stat_tiles(d), 2, cout, dtype=torch.float64, device="cuda")
+    ops.conv2d_fprop_fp8(d, x8.cuda(), w8.cuda(), x_scale.cuda(), w_scale.cuda(), y, bias=bias.cuda(), stats=stats if case["stats"] else None)
+    got = ops.last_conv_instantiation().split(" grid")[0]
+    assert got == ops.conv2d_describe_fp8(d).split(" grid")[0] and "F8=1" in got, (got, ops.conv2d_describe_fp8(d))
+    torch.cuda.synchronize()
+    yc, rc = y.float().cpu().reshape(-1, cout), ref.reshape(-1, cout)
+    # the sums cancel (random signs over K up to 9216): absolute term scaled to the typical magnitude of a term-sum
+    atol = 2e-3 * float(rc.abs().max())
+    _close(yc, rc, 2 ** -7, atol, "fp8 conv output")
+    rel = float((yc - rc).norm() / rc.norm())
+    assert rel < 3e-3, "fp8 conv: relative L2 error %g beyond bf16 output rounding" % rel
+    if case["stats"]:
+        _close(stats[:, 0].sum(0), yc.double().sum(0), 1e-4, 1e-2 * float(rc.abs().max()), "stats sum")
+        _close(stats[:, 1].sum(0), (yc.double() * yc.double()).sum(0), 1e-4, 1e-2 * float(rc.abs().max()) ** 2, "stats sumsq")
+
+
+def test_quantize_fp8_bit_exact_and_amax(ops):
+    g = torch.Generator().manual_seed(3)
+    n = 8 * 1000 + 8 * 37
+    x = (torch.randn(n, generator=g) * torch.exp2(torch.randint(-10, 10, (n,), generator=g).float())).to(BF)
+    x[:8] = torch.tensor([0.0, -0.0, 1e30, -1e30, 448.0, 464.0, 2.0 ** -9, 2.0 ** -11]).to(BF)    # zeros, saturation, subnormals
+    qs = torch.tensor([3.17])
+    out8 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    amax = torch.zeros(1, device="cuda")
+    ops.quantize_fp8(x.cuda(), qs.cuda(), out8, amax)
+    torch.cuda.synchronize()
+    exp = (x.float() * qs).clamp(-448, 448).to(E4M3).view(torch.uint8)
+    got = out8.cpu()
+    same = (got == exp) | ((got & 0x7F) == 0) & ((exp & 0x7F) == 0)       # (+0 / -0 both mean zero)
+    assert bool(same.all()), "quantize_fp8: %d of %d bytes differ from torch's e4m3fn conversion" % (int((~same).sum()), n)
+    assert float(amax) == float(x.float().abs().max())
+
+
+def test_weight_quantiser_per_row_scales(ops):
+    g = torch.Generator().manual_seed(4)
+    shapes = [(64, 3, 3, 128), (256, 1, 1, 1024), (24, 1, 1, 256)]
+    entries, masters = [], []
+    for (co, kh, kw, ci) in shapes:
+        wm = (torch.randn(co, kh, kw, ci, generator=g) * 0.05).cuda()
+        wm[1] = 0                                                 # an all-zero row: scale 1, bytes 0
+        w8 = torch.full((co, kh, kw, ci), 0xFF, dtype=torch.uint8, device="cuda")
+        sc = torch.zeros(co, device="cuda")
+        entries.append((wm.view(co, -1), w8, sc))
+        masters.append(wm)
+    table, total = ops.make_weight_quant_table(entries, "cuda")
+    ops.quantize_weights_fp8_batched(table, total)
+    torch.cuda.synchronize()
+    for (wm2, w8, sc), wm in zip(entries, masters):
+        wc = wm2.cpu()
+        mx = wc.abs().amax(1)
+        exp_sc = torch.where(mx > 0, mx * torch.tensor(1.0 / 448.0, dtype=torch.float32), torch.ones(()))
+        assert torch.equal(sc.cpu(), exp_sc)
+        exp8 = (wc * (1.0 / exp_sc).view(-1, 1)).clamp(-448, 448).to(E4M3).view(torch.uint8)
+        got = w8.cpu().view(wc.shape)
+        same = (got == exp8) | ((got & 0x7F) == 0) & ((exp8 & 0x7F) == 0)
+        assert bool(same.all()), "weight bytes differ"
+        # the largest entry of every row maps to +-448
+        assert bool(((got.view(torch.float8_e4m3fn).float().abs().amax(1) == 448) | (mx == 0)).all())
+
+
+def test_bn_train_apply_writes_the_fp8_twin(ops):
+    g = torch.Generator().manual_seed(5)
+    m, c = 777, 192
+    z = (torch.randn(m, c, generator=g) * 2 + 0.5).to(BF)
+    z2 = (torch.randn(m, c, generator=g)).to(BF)
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    dev = "cuda"
+    parts = torch.zeros(16, 2, c, dtype=torch.float64, device=dev)
+    parts[0, 0], parts[0, 1] = z.double().sum(0).to(dev), (z.double() ** 2).sum(0).to(dev)
+    parts2 = torch.zeros(16, 2, c, dtype=torch.float64, device=dev)
+    parts2[0, 0], parts2[0, 1] = z2.double().sum(0).to(dev), (z2.double() ** 2).sum(0).to(dev)
+    new = lambda: (torch.zeros(c, device=dev), torch.ones(c, device=dev), torch.empty(c, device=dev), torch.empty(c, device=dev))
+    qs = torch.tensor([37.5], device=dev)
+    for dual in (False, True):
+        outs = []
+        for with_f8 in (False, True):
+            mm, mv, mean, invstd = new()
+            out = torch.empty(m, c, dtype=BF, device=dev)
+            out8 = torch.zeros(m, c, dtype=torch.uint8, device=dev)
+            amax = torch.zeros(1, device=dev)
+            f8 = ops.fp8_out(out8, qs, amax) if with_f8 else None
+            if dual:
+                mm2, mv2, mean2, invstd2 = new()
+                ops.bn_train_apply_dual(z.to(dev), parts, gamma.to(dev), beta.to(dev), mm, mv, mean, invstd, z2.to(dev), parts2, beta.to(dev) + 1,
+                                        gamma.to(dev) - 1, mm2, mv2, mean2, invstd2, 16, m, 0.99, 1.001e-5, out, m, c, relu=True, f8=f8)
+            else:
+                ops.bn_train_apply(z.to(dev), parts, 16, m, gamma.to(dev), beta.to(dev), mm, mv, 0.99, 1.001e-5, out, mean, invstd, m, c,
+                                   res=z2.to(dev), relu=True, f8=f8)
+            torch.cuda.synchronize()
+            outs.append(out.clone())
+        assert torch.equal(outs[0], outs[1]), "the fp8 twin must not change the bf16 output"
+        exp = (outs[1].float().cpu() * 37.5).clamp(-448, 448).to(E4M3).view(torch.uint8)
+        got = out8.cpu()
+        same = (got == exp) | ((got & 0x7F) == 0) & ((exp & 0x7F) == 0)
+        assert bool(same.all()), "fp8 twin (dual=%s): %d bytes differ" % (dual, int((~same).sum()))
+        assert float(amax) == float(outs[1].float().abs().max())
+
+
+def test_fp8_delayed_scaling_update(ops):
+    amax = torch.tensor([4.48, 0.0, 896.0], device="cuda")
+    scale = torch.tensor([7.0, 7.0, 7.0], device="cuda")
+    qscale = torch.tensor([9.0, 9.0, 9.0], device="cuda")
+    ops.fp8_update_scales(amax, scale, qscale, 3, margin=1.0)
+    torch.cuda.synchronize()
+    assert torch.allclose(scale.cpu(), torch.tensor([0.01, 7.0, 2.0])) and torch.allclose(qscale.cpu(), torch.tensor([100.0, 9.0, 0.5]))
