@@ -18,9 +18,12 @@ HEAD_LD = 128
 
 
 class RPNDetector:
-    def __init__(self, image_shape, feature_maps_shape, config, name="region_proposal_network_detector", store=None, device="cuda"):
-        """reference rpn_detector.py:8-58 (same positional arguments)."""
+    def __init__(self, image_shape, feature_maps_shape, config, name="region_proposal_network_detector", store=None, device="cuda",
+                 precision="bf16"):
+        """reference rpn_detector.py:8-58 (same positional arguments).  precision "fp8": the 3x3 convolution's training forward
+        pass on e4m3 operands (frcnn_conv2d_fprop_fp8)."""
         self.name = name
+        self.precision = precision
         self._image_shape = tuple(image_shape)
         _, gh, gw, cf = feature_maps_shape
         self.gh, self.gw, self.cf = gh, gw, cf
@@ -120,6 +123,12 @@ class RPNDetector:
         self.deltas = torch.empty(batch, self.n, 1, 4, device=dev)
         self.w_inter_t = torch.zeros(cf, self.ws, self.ws, 256, dtype=BF16, device=dev)
         self.w_heads_t = torch.zeros(256, 1, 1, HEAD_LD, dtype=BF16, device=dev)
+        self.w_inter8 = None
+        self._quant_table = None
+        if training and getattr(self, "precision", "bf16") == "fp8" and cf % 128 == 0:
+            # fp8 forward of the 3x3 intermediate convolution (K = 9 * 1024: the largest single layer of the step)
+            self.w_inter8 = torch.zeros(256, self.ws, self.ws, cf, dtype=ops.FP8, device=dev)
+            self.w_inter8_scale = torch.ones(256, dtype=torch.float32, device=dev)
         if training:
             self.dhead32 = torch.zeros(m, HEAD_LD, device=dev)
             self.dhead = torch.empty(m, HEAD_LD, dtype=BF16, device=dev)
@@ -133,6 +142,16 @@ class RPNDetector:
         st = self.store
         plan.add(ops.weights_transpose_flip, st.weight("rpn_intermediate_layer/kernel"), self.w_inter_t, 256, self.ws, self.ws, self.cf)
         plan.add(ops.weights_transpose_flip, st.weight("rpn_heads/kernel"), self.w_heads_t, HEAD_LD, 1, 1, 256)
+        if self.quant_entries():
+            if getattr(self, "_quant_table", None) is None:
+                self._quant_table = ops.make_weight_quant_table(self.quant_entries(), self.device)
+            plan.add(ops.quantize_weights_fp8_batched, *self._quant_table)
+
+    def quant_entries(self):
+        """fp8 mode: (fp32 master rows, e4m3 destination, per-row scale) of the 3x3 intermediate convolution's weights."""
+        if getattr(self, "w_inter8", None) is None:
+            return []
+        return [(self.store.weight("rpn_intermediate_layer/kernel").view(256, -1), self.w_inter8, self.w_inter8_scale)]
 
     def flip_entries(self):
         st = self.store
@@ -144,12 +163,17 @@ class RPNDetector:
         all anchors clipped to the image otherwise."""
         return self._anchors_inside if training else self._anchors_clipped
 
-    def forward_plan(self, plan, feature_maps, training, decoded=None):
-        """decoded [B,n,1,4]: also receives the decoded proposals (first launch of post-processing) from the head-post kernel."""
+    def forward_plan(self, plan, feature_maps, training, decoded=None, feature_maps8=None):
+        """decoded [B,n,1,4]: also receives the decoded proposals (first launch of post-processing) from the head-post kernel.
+        feature_maps8: Fp8Twin of the feature maps (fp8 training): the 3x3 convolution reads e4m3 operands."""
         st = self.store
         ops.conv_zero_counters(plan, self.d_inter)
-        plan.add(ops.conv2d_fprop, self.d_inter, feature_maps, st.weight_bf16("rpn_intermediate_layer/kernel"), self.f,
-                 bias=st.weight("rpn_intermediate_layer/bias"))
+        if feature_maps8 is not None and self.w_inter8 is not None:
+            plan.add(ops.conv2d_fprop_fp8, self.d_inter, feature_maps8.data, self.w_inter8, feature_maps8.scale, self.w_inter8_scale, self.f,
+                     bias=st.weight("rpn_intermediate_layer/bias"))
+        else:
+            plan.add(ops.conv2d_fprop, self.d_inter, feature_maps, st.weight_bf16("rpn_intermediate_layer/kernel"), self.f,
+                     bias=st.weight("rpn_intermediate_layer/bias"))
         plan.add(ops.conv2d_fprop, self.d_heads, self.f, st.weight_bf16("rpn_heads/kernel"), self.head, bias=st.weight("rpn_heads/bias"))
         keep = self._keep if training else None
         regions = self.regions(training)

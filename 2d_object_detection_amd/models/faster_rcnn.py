@@ -28,17 +28,18 @@ LOSS_NAMES = ("rpn_cls", "rpn_reg", "rcnn_cls", "rcnn_reg")
 class _Modules:
     """One set of module instances (= one set of activation buffers) attached to the shared store."""
 
-    def __init__(self, config, depth, store, device, first, sync_bn_world=1):
+    def __init__(self, config, depth, store, device, first, sync_bn_world=1, precision="bf16"):
         image_shape = config["image_shape"]
         # registration order = gradient-bucket order: regularised kernels, head biases, then backbone
         fe_shape = _feature_shape(image_shape, depth)
         self.rcnn = FastRCNNDetector(image_shape, config["num_classes"], config["rcnn"], feature_channels=fe_shape[3], store=store,
                                      device=device)
-        self.rpn = RPNDetector(image_shape, fe_shape, config["rpn"], store=store, device=device)
+        self.rpn = RPNDetector(image_shape, fe_shape, config["rpn"], store=store, device=device, precision=precision)
         self.rcnn.register_biases()
         self.rpn.register_biases()
         store.end_bucket("heads")
-        self.fe = get_feature_extractor_model(image_shape, depth=depth, store=store, device=device, sync_bn_world=sync_bn_world)
+        self.fe = get_feature_extractor_model(image_shape, depth=depth, store=store, device=device, sync_bn_world=sync_bn_world,
+                                              precision=precision)
         assert tuple(self.fe.output_shape) == tuple(fe_shape)
 
 
@@ -52,7 +53,7 @@ def _feature_shape(image_shape, depth):
 
 class FasterRCNN:
     def __init__(self, config, name="faster_rcnn", depth=50, device="cuda", seed=0, sampling_seed=0, world_size=1, sync_bn=False,
-                 sampling_image_base=0):
+                 sampling_image_base=0, precision="bf16"):
         """reference faster_rcnn.py:11-37.  `config`: dict with the reference's config.json schema.
         world_size: data-parallel ranks (classification losses are means over the GLOBAL batch).  sync_bn: BatchNorm batch
         statistics and their backward sums are all-reduced over the ranks, so world_size x b images behave like the reference's
@@ -71,8 +72,11 @@ class FasterRCNN:
         self.sampling_image_base = int(sampling_image_base)
         self.world_size = int(world_size)
         self.sync_bn = bool(sync_bn)
+        # precision "fp8" (BASELINE.json configs[4]): the training step's forward convolutions with cin % 128 == 0 (backbone from
+        # conv2_block2 on, RPN 3x3) multiply e4m3 operands on the fp8 MFMA path; everything else as in "bf16"
+        self.precision = precision
         self.store = ParamStore(self.device)
-        self._train = _Modules(config, depth, self.store, self.device, True, self.world_size if self.sync_bn else 1)
+        self._train = _Modules(config, depth, self.store, self.device, True, self.world_size if self.sync_bn else 1, precision)
         self.store.finalize()
         self._eval = None
         self.feature_extractor, self.rpn_detector, self.rcnn_detector = self._train.fe, self._train.rpn, self._train.rcnn
@@ -206,7 +210,7 @@ class FasterRCNN:
         feat2d = feat.view(batch * gh * gw, cf)
         nms_cfg = self._rpn_config["nms"]
         rpn_nms = NmsBuffers(batch, mods.rpn.n, 1, nms_cfg["max_output_size_per_class"], nms_cfg["max_total_size"], dev)
-        rpn_out = mods.rpn.forward_plan(plan, feat2d, training, decoded=rpn_nms.decoded)
+        rpn_out = mods.rpn.forward_plan(plan, feat2d, training, decoded=rpn_nms.decoded, feature_maps8=mods.fe.feature_maps8 if training else None)
         assert n == rpn_out["pred_scores"].shape[1]
         if training:
             g_feat = torch.empty(batch * gh * gw, cf, dtype=BF16, device=dev)
@@ -246,6 +250,11 @@ class FasterRCNN:
             mods.fe.backward_plan(plan, g_feat, g_feat_reduced=True)
             plan.cut("update")
             optimizer.apply_plan(plan)
+            if mods.fe.f8 is not None:
+                # fp8 mode: next step's e4m3 weights from the updated masters (one launch), next step's activation scales from this
+                # step's amax row
+                mods.fe.quantize_weights_plan(plan, extra=mods.rpn.quant_entries())
+                mods.fe.f8.plan_update(plan)
             mods.fe.stem.refresh_weights(plan)
             plan.add(ops.step_increment, optimizer.iterations)
         else:
@@ -265,7 +274,9 @@ class FasterRCNN:
         P = int(self._rpn_config["nms"]["max_total_size"])
         mods.rcnn.setup(batch, P, gh, gw, False)
         feat = mods.fe.forward_plan(plan, True)
-        rpn_out = mods.rpn.forward_plan(plan, feat.view(batch * gh * gw, cf), True)
+        rpn_out = mods.rpn.forward_plan(plan, feat.view(batch * gh * gw, cf), True, feature_maps8=mods.fe.feature_maps8)
+        if mods.fe.f8 is not None:
+            mods.fe.f8.plan_update(plan)
         nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"])
         rcnn_out = mods.rcnn.forward_plan(plan, feat, nms_rpn["pred_boxes"])
         return {"plan": plan, "io": io, "batch": batch, "aux": {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn, "feature_maps": feat}}
@@ -373,7 +384,8 @@ class FasterRCNN:
             # its own module instances (activation buffers): the captured train plan's buffers stay untouched
             b = int(images.shape[0])
             if self._fwd_train is None:
-                self._fwd_train = _Modules(self.config, self.depth, self.store, self.device, False, self.world_size if self.sync_bn else 1)
+                self._fwd_train = _Modules(self.config, self.depth, self.store, self.device, False, self.world_size if self.sync_bn else 1,
+                                           self.precision)
             if self._fwd_plan is None or self._fwd_plan["batch"] != b:
                 self._fwd_plan = self._build_forward(self._fwd_train, b)
             built = self._fwd_plan

@@ -32,11 +32,62 @@ def _out_hw(h, w):
     return f1(h), f1(w), f2(f1(h)), f2(f1(w))
 
 
+FP8_MARGIN = 2.0           # delayed scaling: next step's scale = margin * this step's amax / 448 (e4m3 is a float format: head-room costs no precision)
+
+
+class Fp8Scales:
+    """Per-tensor scales of the fp8 (e4m3) activation twins, device resident so that captured graphs follow them: rows
+    [amax of this step | dequantisation scale | 1 / scale] x one column per tensor.  The amax row is an accumulation target of the
+    step (atomic max, zeroed by the plan's fill); `update` -- once per step, after the last producer -- turns it into the NEXT
+    step's scales (delayed scaling with one step of history; the first step runs on scale 1)."""
+
+    def __init__(self, device, capacity=256):
+        self.buf = torch.zeros(3, capacity, dtype=torch.float32, device=device)
+        self.buf[1:].fill_(1.0)
+        self.n = 0
+
+    def new(self):
+        assert self.n < self.buf.shape[1]
+        self.n += 1
+        return self.n - 1
+
+    def amax(self, i):
+        return self.buf[0, i:i + 1]
+
+    def scale(self, i):
+        return self.buf[1, i:i + 1]
+
+    def qscale(self, i):
+        return self.buf[2, i:i + 1]
+
+    def plan_zero(self, plan):
+        plan.zero(self.buf[0])
+
+    def plan_update(self, plan):
+        if self.n:
+            plan.add(ops.fp8_update_scales, self.buf[0], self.buf[1], self.buf[2], self.n, FP8_MARGIN)
+
+
+class Fp8Twin:
+    """fp8 copy of an activation tensor: bytes, its column in the scale table, and the frcnn_fp8_out the producing kernel takes."""
+
+    def __init__(self, scales, shape, device):
+        self.scales, self.idx = scales, scales.new()
+        self.data = torch.zeros(shape, dtype=ops.FP8, device=device)
+        self.out = ops.fp8_out(self.data, scales.qscale(self.idx), scales.amax(self.idx))
+
+    @property
+    def scale(self):
+        return self.scales.scale(self.idx)
+
+
 class _ConvBN:
     """One conv + BatchNorm unit (Keras names <name>_conv / <name>_bn)."""
 
-    def __init__(self, store, name, cin, cout, k, stride, pad, sync_world=1):
+    def __init__(self, store, name, cin, cout, k, stride, pad, sync_world=1, fp8=False):
         self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
+        # fp8 forward convolution (e4m3 operands, 128-deep MFMA steps): every layer whose cin is a multiple of 128
+        self.fp8 = bool(fp8) and k != 7 and cin % 128 == 0
         self.store = store
         self.sync_world = int(sync_world)            # > 1: BatchNorm statistics are summed over this many data-parallel ranks
         store.register(name + "_conv/kernel", (cout, k, k, cin))          # OHWI (Keras: HWIO)
@@ -63,6 +114,9 @@ class _ConvBN:
             self.desc = ops.conv_desc(n, hi, wi, self.cin, k, k, s, p, p, self.ho, self.wo, self.cout,
                                       flags=ops.CONV_BIAS | (ops.CONV_STATS if training else 0))
             self.w_t = torch.zeros(self.cin, k, k, self.cout, dtype=BF16, device=device)   # data-gradient weights
+            if self.fp8 and training:
+                self.w8 = torch.zeros(self.cout, k, k, self.cin, dtype=ops.FP8, device=device)
+                self.w8_scale = torch.ones(self.cout, dtype=torch.float32, device=device)
             # fewer output tiles than CUs and a long K (conv4 at 375x1242): scratch for the split-K fix-up form of the conv kernel
             self.conv_ws = ops.conv_attach_workspace(self.desc, device)
         self._device = device
@@ -98,11 +152,22 @@ class _ConvBN:
         return self.w_packed if self.is_stem else self.store.weight_bf16(self.name + "_conv/kernel")
 
     # -- forward: x -> z (raw conv output) -> scale/shift
-    def forward(self, plan, x, training):
+    def quant_entry(self):
+        """(fp32 master rows, fp8 destination, per-row scale) of this layer's forward weights, or None (bf16 layer)."""
+        if not (self.fp8 and hasattr(self, "w8")):
+            return None
+        return (self.store.weight(self.name + "_conv/kernel").view(self.cout, -1), self.w8, self.w8_scale)
+
+    def forward(self, plan, x, training, x8=None):
+        """x8: Fp8Twin of x (training, fp8 layers): the convolution reads the e4m3 bytes instead of the bf16 tensor."""
         st = self.store
         ops.conv_zero_counters(plan, self.desc)
-        plan.add(ops.conv2d_fprop, self.desc, x, self.w_fwd(), self.z, bias=st.weight(self.name + "_conv/bias"),
-                 stats=self.stats if training else None)
+        if x8 is not None and self.fp8 and training:
+            plan.add(ops.conv2d_fprop_fp8, self.desc, x8.data, self.w8, x8.scale, self.w8_scale, self.z, bias=st.weight(self.name + "_conv/bias"),
+                     stats=self.stats)
+        else:
+            plan.add(ops.conv2d_fprop, self.desc, x, self.w_fwd(), self.z, bias=st.weight(self.name + "_conv/bias"),
+                     stats=self.stats if training else None)
         self._training = training
         if training and self.sync_world > 1:
             plan.sync_point(self.name + "_bn_stats", [self.stats])       # f64 slot sums of every rank -> sums of the global batch
@@ -110,7 +175,7 @@ class _ConvBN:
             g, b = st.weight(self.name + "_bn/gamma"), st.weight(self.name + "_bn/beta")
             plan.add(ops.bn_finalize_eval, self.cout, g, b, self.mm, self.mv, BN_EPS, self.scale, self.shift)
 
-    def apply(self, plan, out, res=None, relu=True, dual=None):
+    def apply(self, plan, out, res=None, relu=True, dual=None, out8=None):
         """dual: a second conv unit of the same output shape whose BatchNorm (no ReLU) is added before the ReLU -- the shortcut
         branch of a stage's first block: out = ReLU(BN(z) + BN_dual(z_dual)) in one kernel, the shortcut's output never stored."""
         if self._training and dual is not None:
@@ -119,14 +184,15 @@ class _ConvBN:
             plan.add(ops.bn_train_apply_dual, self.z, self.stats, st.weight(self.name + "_bn/gamma"), st.weight(self.name + "_bn/beta"),
                      self.mm, self.mv, self.mean, self.invstd, dual.z, dual.stats, st.weight(dual.name + "_bn/gamma"),
                      st.weight(dual.name + "_bn/beta"), dual.mm, dual.mv, dual.mean, dual.invstd, self.tiles, self.m * self.sync_world,
-                     BN_MOMENTUM, BN_EPS, out, self.m, self.cout, relu=relu, relu_mask=self.relu_mask if relu else None)
+                     BN_MOMENTUM, BN_EPS, out, self.m, self.cout, relu=relu, relu_mask=self.relu_mask if relu else None,
+                     f8=out8.out if out8 is not None else None)
             return
         if self._training:
             # batch statistics -> scale/shift inside the apply kernel (every workgroup reduces its own 64 channels)
             st = self.store
             plan.add(ops.bn_train_apply, self.z, self.stats, self.tiles, self.m * self.sync_world, st.weight(self.name + "_bn/gamma"),
                      st.weight(self.name + "_bn/beta"), self.mm, self.mv, BN_MOMENTUM, BN_EPS, out, self.mean, self.invstd, self.m,
-                     self.cout, res=res, relu=relu, relu_mask=self.relu_mask if relu else None)
+                     self.cout, res=res, relu=relu, relu_mask=self.relu_mask if relu else None, f8=out8.out if out8 is not None else None)
         else:
             plan.add(ops.bn_apply, self.z, self.scale, self.shift, out, self.m, self.cout, res=res, relu=relu)
 
@@ -193,7 +259,7 @@ class _ConvBN:
 class FeatureExtractor:
     """ResNet-50/101 C4 backbone (callable like the Keras model returned by the reference)."""
 
-    def __init__(self, image_shape, depth=50, store=None, device="cuda", sync_bn_world=1):
+    def __init__(self, image_shape, depth=50, store=None, device="cuda", sync_bn_world=1, precision="bf16"):
         """sync_bn_world > 1: synchronised BatchNorm over that many data-parallel ranks -- the plan gets a sync point (an
         all-reduce of the layer's partial sums, runtime.Plan.sync_point) between every statistics-producing kernel and the
         kernel that consumes them, so that N ranks x b images reproduce the reference's single device with N*b images
@@ -201,6 +267,11 @@ class FeatureExtractor:
         depend on layer k's normalised output, so they cannot be batched across layers."""
         self.image_shape = tuple(image_shape)
         self.sync_bn_world = int(sync_bn_world)
+        assert precision in ("bf16", "fp8")
+        # "fp8": training-mode forward convolutions with cin % 128 == 0 run on e4m3 operands (BASELINE.json configs[4]'s precision;
+        # weights quantised per output channel from the fp32 masters, activations per tensor by the BatchNorm kernel that writes
+        # them); backward pass, statistics and every stored tensor stay as in "bf16"
+        self.precision = precision
         self.depth = depth
         self.device = torch.device(device)
         self.own_store = store is None
@@ -216,6 +287,7 @@ class FeatureExtractor:
                 specs.append(("conv%d_block%d" % (si + 2, b), cin, f, s1 if b == 1 else 1, b == 1))
                 cin = 4 * f
         units = {}
+        fp8 = precision == "fp8"
         stage_of = lambda n: int(n[4])
         last_stage = None
         for (n, ci, f, s, first) in reversed(specs):
@@ -224,10 +296,10 @@ class FeatureExtractor:
             last_stage = stage_of(n)
             u = {}
             if first:
-                u[0] = _ConvBN(self.store, n + "_0", ci, 4 * f, 1, s, 0, self.sync_bn_world)
-            u[1] = _ConvBN(self.store, n + "_1", ci, f, 1, s, 0, self.sync_bn_world)
-            u[2] = _ConvBN(self.store, n + "_2", f, f, 3, 1, 1, self.sync_bn_world)
-            u[3] = _ConvBN(self.store, n + "_3", f, 4 * f, 1, 1, 0, self.sync_bn_world)
+                u[0] = _ConvBN(self.store, n + "_0", ci, 4 * f, 1, s, 0, self.sync_bn_world, fp8)
+            u[1] = _ConvBN(self.store, n + "_1", ci, f, 1, s, 0, self.sync_bn_world, fp8)
+            u[2] = _ConvBN(self.store, n + "_2", f, f, 3, 1, 1, self.sync_bn_world, fp8)
+            u[3] = _ConvBN(self.store, n + "_3", f, 4 * f, 1, 1, 0, self.sync_bn_world, fp8)
             units[n] = u
         self.stem = _ConvBN(self.store, "conv1", 3, 64, 7, 2, 3, self.sync_bn_world)
         self.store.end_bucket("conv2+stem")
@@ -288,6 +360,21 @@ class FeatureExtractor:
     def refresh_weights(self, plan):
         for u in self.conv_units():
             u.refresh_weights(plan)
+        self.quantize_weights_plan(plan)
+
+    def quant_entries(self):
+        return [e for e in (u.quant_entry() for u in self.conv_units()) if e is not None]
+
+    def quantize_weights_plan(self, plan, extra=()):
+        """fp8 forward weights of every fp8 layer (+ extra entries, e.g. the RPN's) from the fp32 masters: ONE launch."""
+        entries = self.quant_entries() + list(extra)
+        if entries:
+            key = tuple(e[1].data_ptr() for e in entries)
+            cache = self.__dict__.setdefault("_quant_tables", {})
+            if key not in cache:
+                cache[key] = ops.make_weight_quant_table(entries, self.device)
+            table, total = cache[key]
+            plan.add(ops.quantize_weights_fp8_batched, table, total)
 
     def flip_entries(self):
         """(fp32 master, data-gradient weight buffer, cout, kh, kw, cin) of every conv except the stem (batched refresh)."""
@@ -324,6 +411,7 @@ class FeatureExtractor:
         self.pool_arg = torch.empty(batch * self.hp1 * self.wp1, 64, dtype=torch.uint8, device=dev)
         hi, wi = self.hp1, self.wp1
         self.acts = {}
+        self.f8 = Fp8Scales(dev) if (training and self.precision == "fp8") else None
         for (n, ci, f, s, first) in self.specs:
             u = self.units[n]
             if first:
@@ -339,6 +427,11 @@ class FeatureExtractor:
                 a["sc"] = torch.empty(m, 4 * f, dtype=BF16, device=dev)
             elif first:
                 a["sc"] = None                    # (training: the shortcut BatchNorm is fused into the block-final one)
+            if self.f8 is not None:
+                # fp8 twins of the activations that feed fp8 convolutions: a1 -> 3x3, a2 -> 1x1 expansion, out -> the next block / RPN
+                a["a1_8"] = Fp8Twin(self.f8, (m, f), dev) if u[2].fp8 else None
+                a["a2_8"] = Fp8Twin(self.f8, (m, f), dev) if u[3].fp8 else None
+                a["out_8"] = Fp8Twin(self.f8, (m, 4 * f), dev)
             if training:
                 a["g1"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a1
                 a["g2"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a2
@@ -348,6 +441,7 @@ class FeatureExtractor:
         if training:
             self.g_stem = torch.empty(st.m, 64, dtype=BF16, device=dev)
         self.feature_maps = self.acts[self.specs[-1][0]]["out"].view(batch, hi, wi, self.out_channels)
+        self.feature_maps8 = self.acts[self.specs[-1][0]].get("out_8")           # Fp8Twin of the feature maps (fp8 training) or None
         return self.images
 
     def forward_plan(self, plan, training):
@@ -366,27 +460,31 @@ class FeatureExtractor:
         else:
             st.apply(plan, self.a_stem, relu=True)
             plan.add(ops.maxpool_fwd, self.a_stem, self.pool, self.pool_arg, self.batch, st.ho, st.wo, 64, self.hp1, self.wp1)
-        x = self.pool
+        x, x8 = self.pool, None
+        f8 = self.f8 if training else None
+        if f8 is not None:
+            f8.plan_zero(plan)                        # this step's amax row
         for (n, ci, f, s, first) in self.specs:
             u, a = self.units[n], self.acts[n]
             fused_shortcut = first and training      # shortcut BatchNorm applied inside the block-final BatchNorm kernel (no a["sc"])
             if first:
-                u[0].forward(plan, x, training)
+                u[0].forward(plan, x, training, x8)
                 if not fused_shortcut:
                     u[0].apply(plan, a["sc"], relu=False)
                 res = a["sc"]
             else:
                 res = x
-            u[1].forward(plan, x, training)
-            u[1].apply(plan, a["a1"])
-            u[2].forward(plan, a["a1"], training)
-            u[2].apply(plan, a["a2"])
-            u[3].forward(plan, a["a2"], training)
+            u[1].forward(plan, x, training, x8)
+            u[1].apply(plan, a["a1"], out8=a.get("a1_8") if f8 is not None else None)
+            u[2].forward(plan, a["a1"], training, a.get("a1_8") if f8 is not None else None)
+            u[2].apply(plan, a["a2"], out8=a.get("a2_8") if f8 is not None else None)
+            u[3].forward(plan, a["a2"], training, a.get("a2_8") if f8 is not None else None)
+            o8 = a.get("out_8") if f8 is not None else None
             if fused_shortcut:
-                u[3].apply(plan, a["out"], relu=True, dual=u[0])
+                u[3].apply(plan, a["out"], relu=True, dual=u[0], out8=o8)
             else:
-                u[3].apply(plan, a["out"], res=res, relu=True)
-            x = a["out"]
+                u[3].apply(plan, a["out"], res=res, relu=True, out8=o8)
+            x, x8 = a["out"], o8
         return self.feature_maps
 
     def last_unit(self):
@@ -475,6 +573,6 @@ class FeatureExtractor:
         return self.feature_maps
 
 
-def get_feature_extractor_model(image_shape, depth=50, store=None, device="cuda", sync_bn_world=1):
+def get_feature_extractor_model(image_shape, depth=50, store=None, device="cuda", sync_bn_world=1, precision="bf16"):
     """reference models/feature_extractor.py:4 (weights: seeded synthetic init; load real ones with set_weights)."""
-    return FeatureExtractor(image_shape, depth=depth, store=store, device=device, sync_bn_world=sync_bn_world)
+    return FeatureExtractor(image_shape, depth=depth, store=store, device=device, sync_bn_world=sync_bn_world, precision=precision)

@@ -54,6 +54,7 @@ FPROP_FP8 = [
     dict(id="f8_c4_3x3_256_256_stats", n=4, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     dict(id="f8_rpn_3x3_1024_256_relu", n=1, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),
     dict(id="f8_rpn_3x3_1024_256_relu_fix_b4", n=4, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),
+    dict(id="f8_rpn_3x3_1024_256_relu_b8", n=8, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),    # configs[4]'s batch: 128 x 128 tiles
     dict(id="f8_small_s2_stats", n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0, bias=False, relu=False, stats=True),
     dict(id="f8_small_3x3_128_stats", n=1, h=9, w=11, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     dict(id="f8_small_1x1_relu", n=2, h=13, w=17, cin=384, cout=72, k=1, s=1, p=0, bias=True, relu=True, stats=False),
@@ -169,6 +170,8 @@ def covered_instantiations(ops):
 
     for c in FPROP:
         note(ops.conv2d_describe(fprop_desc(ops, c), False), c["id"])
+    for c in FPROP_FP8:
+        note(ops.conv2d_describe_fp8(fprop_desc(ops, c)), c["id"])
     for c in DGRAD:
         note(ops.conv2d_describe(dgrad_desc(ops, c), c["red"]), c["id"])
     for c in F32:

@@ -16,7 +16,7 @@ import torch
 import conv_cases
 
 
-def _plan_instantiations(monkeypatch, depth, batch, proposals=None):
+def _plan_instantiations(monkeypatch, depth, batch, proposals=None, precision="bf16"):
     ops = importlib.import_module("2d_object_detection_amd.ops")
     # the two init-time kernels of the RPN detector (anchor table, clip) need a device; their values do not matter here
     monkeypatch.setattr(ops, "anchors_generate", lambda out, *a, **k: out.zero_())
@@ -27,7 +27,7 @@ def _plan_instantiations(monkeypatch, depth, batch, proposals=None):
     cfg = copy.deepcopy(C.default_config())
     if proposals:
         cfg["rpn"]["nms"]["max_total_size"] = cfg["rpn"]["nms"]["max_output_size_per_class"] = proposals
-    model = M.FasterRCNN(cfg, depth=depth, device="cpu")
+    model = M.FasterRCNN(cfg, depth=depth, device="cpu", precision=precision)
     opt = OPT.SGD(learning_rate=1e-3, momentum=0.9)
     opt.bind(model.store)
     plan = model._build(model._train, batch, True, opt)["plan"]
@@ -37,6 +37,8 @@ def _plan_instantiations(monkeypatch, depth, batch, proposals=None):
             found = []
             if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce:
                 found = [ops.conv2d_describe(args[0], fn is ops.conv2d_dgrad_bnreduce)]
+            elif fn is ops.conv2d_fprop_fp8:
+                found = [ops.conv2d_describe_fp8(args[0])]
             elif fn is ops.conv2d_wgrad:
                 found = [ops.conv2d_wgrad_describe(args[0], with_row_index=kwargs.get("row_index") is not None)]
             elif fn is ops.conv2d_wgrad_grouped:
@@ -54,6 +56,17 @@ def test_every_plan_instantiation_has_a_parity_case(monkeypatch, ops, depth, bat
     assert len(used) >= 20 and launches >= 200
     missing = sorted(k for k in used if k not in covered)
     assert not missing, "conv kernels of the R%d batch-%d train plan without an oracle-compared GPU case:\n  %s" % (depth, batch, "\n  ".join(missing))
+
+
+def test_every_fp8_plan_instantiation_has_a_parity_case(monkeypatch, ops):
+    """BASELINE.json configs[4]'s precision (fp8 forward convolutions) at its batch of 8, and at the bench's batch 4."""
+    covered = conv_cases.covered_instantiations(ops)
+    for batch in (8, 4):
+        used, launches = _plan_instantiations(monkeypatch, 50, batch, precision="fp8")
+        f8 = sorted(k for k in used if "F8=1" in k)
+        assert len(f8) >= 5, f8
+        missing = sorted(k for k in used if k not in covered)
+        assert not missing, "conv kernels of the fp8 R50 batch-%d train plan without an oracle-compared GPU case:\n  %s" % (batch, "\n  ".join(missing))
 
 
 def test_describe_reports_errors(ops):
