@@ -86,11 +86,16 @@ __device__ __forceinline__ u32x2 pack8_fp8(const float* f, const float qs) {
     }
     return r;
 }
-// wave-wide max of non-negative floats folded into *dst (device float compared as its bit pattern: order-preserving for x >= 0)
+// wave-wide max of non-negative floats folded into one of the FRCNN_FP8_AMAX_SLOTS slots of dst (device floats compared as their bit
+// patterns: order-preserving for x >= 0).  Slots, because atomics on ONE address serialise at the memory side (~90 per us:
+// the 4096 waves of a BatchNorm launch on one word cost ~40 us, measured; spread over 64 words they cost < 1 us).
 __device__ __forceinline__ void atomic_amax(float* dst, float v) {
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) v = fmaxf(v, __shfl_xor(v, sh));
-    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
+    if ((threadIdx.x & 63) == 0 && v > 0.f) {
+        const unsigned slot = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (FRCNN_FP8_AMAX_SLOTS - 1);
+        atomicMax(reinterpret_cast<unsigned*>(dst) + slot, __float_as_uint(v));
+    }
 }
 
 // Philox4x32-10 (shared by the sampler; oracle/philox.py is the numpy twin)

@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void quantize_weights_fp8_kernel(const long lo
 __global__ void fp8_update_scales_kernel(const float* __restrict__ amax, float* __restrict__ scale, float* __restrict__ qscale, int n, float margin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float a = amax[i];
+    float a = 0.f;
+#pragma unroll 8
+    for (int sl = 0; sl < FRCNN_FP8_AMAX_SLOTS; ++sl) a = fmaxf(a, amax[(long long)i * FRCNN_FP8_AMAX_SLOTS + sl]);
     if (a > 0.f) {
         const float sc = margin * a * (1.f / 448.f);
         scale[i] = sc;

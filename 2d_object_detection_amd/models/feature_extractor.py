@@ -37,13 +37,14 @@ FP8_MARGIN = 2.0           # delayed scaling: next step's scale = margin * this 
 
 class Fp8Scales:
     """Per-tensor scales of the fp8 (e4m3) activation twins, device resident so that captured graphs follow them: rows
-    [amax of this step | dequantisation scale | 1 / scale] x one column per tensor.  The amax row is an accumulation target of the
-    step (atomic max, zeroed by the plan's fill); `update` -- once per step, after the last producer -- turns it into the NEXT
+    [dequantisation scale | 1 / scale] x one column per tensor, plus the amax slots of this step [tensor][64].  The amax slots are an
+    accumulation target of the step (atomic max, zeroed by the plan's fill); `update` -- once per step, after the last producer -- turns it into the NEXT
     step's scales (delayed scaling with one step of history; the first step runs on scale 1)."""
 
     def __init__(self, device, capacity=256):
-        self.buf = torch.zeros(3, capacity, dtype=torch.float32, device=device)
-        self.buf[1:].fill_(1.0)
+        self.buf = torch.zeros(2, capacity, dtype=torch.float32, device=device)             # [scale | 1 / scale]
+        self.buf.fill_(1.0)
+        self.amax_buf = torch.zeros(capacity, ops.FP8_AMAX_SLOTS, dtype=torch.float32, device=device)   # slots per tensor (one word would serialise the atomics)
         self.n = 0
 
     def new(self):
@@ -52,20 +53,20 @@ class Fp8Scales:
         return self.n - 1
 
     def amax(self, i):
-        return self.buf[0, i:i + 1]
+        return self.amax_buf[i]
 
     def scale(self, i):
-        return self.buf[1, i:i + 1]
+        return self.buf[0, i:i + 1]
 
     def qscale(self, i):
-        return self.buf[2, i:i + 1]
+        return self.buf[1, i:i + 1]
 
     def plan_zero(self, plan):
-        plan.zero(self.buf[0])
+        plan.zero(self.amax_buf)
 
     def plan_update(self, plan):
         if self.n:
-            plan.add(ops.fp8_update_scales, self.buf[0], self.buf[1], self.buf[2], self.n, FP8_MARGIN)
+            plan.add(ops.fp8_update_scales, self.amax_buf, self.buf[0], self.buf[1], self.n, FP8_MARGIN)
 
 
 class Fp8Twin:

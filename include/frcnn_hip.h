@@ -131,23 +131,25 @@ int frcnn_conv2d_fprop_fp8(const frcnn_conv_desc* d, const frcnn_fp8* x8, const 
                            const float* w_scale, const float* bias, frcnn_bf16* y, double* stats_partial, frcnn_stream_t stream);
 /* the instantiation frcnn_conv2d_fprop_fp8 would launch (host logic, as frcnn_conv2d_describe) */
 const char* frcnn_conv2d_describe_fp8(const frcnn_conv_desc* d);
-/* Quantisers.  out8[i] = e4m3_rne(clamp(x[i] * qscale[0], -448, 448)); amax (optional, device scalar, pre-zeroed per step):
- * atomic max of |x[i]| as fp32 -- the input of the delayed scaling rule below.  n a multiple of 8. */
+/* Quantisers.  out8[i] = e4m3_rne(clamp(x[i] * qscale[0], -448, 448)); amax (optional, FRCNN_FP8_AMAX_SLOTS device floats,
+ * pre-zeroed per step): max |x[i]| as fp32, folded with atomics into one of the slots per wave (atomics on a single word would
+ * serialise) -- the maximum over the slots is the input of the delayed scaling rule below.  n a multiple of 8. */
+#define FRCNN_FP8_AMAX_SLOTS 64
 int frcnn_quantize_fp8(const frcnn_bf16* x, int64_t n, const float* qscale, frcnn_fp8* out8, float* amax, frcnn_stream_t stream);
 /* Weights, several layers in one launch: table int64 [n][6] = {fp32 master (rows of K values, row-major), fp8 destination, float
  * scale[rows] destination, rows, K, first workgroup}; one workgroup per row: scale = max|w| / 448 (1 for an all-zero row),
  * w8 = e4m3_rne(w * (1 / scale)), all in fp32.  Serves the forward weights [cout][kh*kw*cin] and, given transposed masters, any other row layout. */
 int frcnn_quantize_weights_fp8_batched(const int64_t* table, int n, int64_t total_rows, frcnn_stream_t stream);
-/* Delayed scaling (one amax of history): for i < n: a = amax[i] (this step's maximum); if a > 0: scale[i] = margin * a / 448,
- * qscale[i] = 1 / scale[i]; a == 0 (tensor not produced this step) leaves both unchanged. */
+/* Delayed scaling (one amax of history): for i < n: a = max over amax[i][0..FRCNN_FP8_AMAX_SLOTS) (this step's maximum); if a > 0:
+ * scale[i] = margin * a / 448, qscale[i] = 1 / scale[i]; a == 0 (tensor not produced this step) leaves both unchanged. */
 int frcnn_fp8_update_scales(const float* amax, float* scale, float* qscale, int n, float margin, frcnn_stream_t stream);
 /* Optional fp8 twin of a BatchNorm kernel's output (frcnn_bn_train_apply / _dual): the kernel that writes the bf16 activation also
- * writes out8 = e4m3(clamp(bf16 value * qscale[0])) and folds max|value| into amax[0] -- the next convolution reads 1 byte per
+ * writes out8 = e4m3(clamp(bf16 value * qscale[0])) and folds max|value| into the amax slots -- the next convolution reads 1 byte per
  * element instead of 2 and no separate quantise pass exists. */
 typedef struct frcnn_fp8_out {
     frcnn_fp8* out8;        /* [M][C] */
     const float* qscale;    /* device scalar: 1 / dequantisation scale */
-    float* amax;            /* device scalar or NULL */
+    float* amax;            /* FRCNN_FP8_AMAX_SLOTS device floats or NULL */
 } frcnn_fp8_out;
 
 /* Weight gradient: dw[co,kh,kw,ci] (fp32, accumulated with atomics into a pre-zeroed buffer) =
