@@ -53,7 +53,9 @@ _SIGNATURES = {
     "frcnn_conv2d_fprop": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P]),
     "frcnn_conv2d_fprop_fp8": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, P]),
     "frcnn_conv2d_describe_fp8": (c_char_p, [POINTER(ConvDesc)]),
-    "frcnn_quantize_fp8": (c_int, [P, c_int64, P, P, P, P]),
+    "frcnn_quantize_fp8": (c_int, [P, c_int64, P, P, P, c_int, P]),
+    "frcnn_conv2d_dgrad_fp8": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, POINTER(BnReduce), P]),
+    "frcnn_conv2d_describe_dgrad_fp8": (c_char_p, [POINTER(ConvDesc), c_int]),
     "frcnn_quantize_weights_fp8_batched": (c_int, [P, c_int, c_int64, P]),
     "frcnn_fp8_update_scales": (c_int, [P, P, P, c_int, c_float, P]),
     "frcnn_conv2d_dgrad_bnreduce": (c_int, [POINTER(ConvDesc), P, P, P, P, P, POINTER(BnReduce), P]),
@@ -74,7 +76,7 @@ _SIGNATURES = {
     "frcnn_bn_finalize_eval": (c_int, [c_int, P, P, P, P, c_float, P, P, P]),
     "frcnn_bn_apply": (c_int, [P, P, P, P, c_int, P, c_int64, c_int, P]),
     "frcnn_bn_train_apply": (c_int, [P, P, c_int, c_int64, P, P, P, P, c_float, c_float, P, c_int, P, P, P, P, c_int64, c_int, POINTER(Fp8Out), P]),
-    "frcnn_bn_bwd_apply_fused": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int64, c_float, P]),
+    "frcnn_bn_bwd_apply_fused": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int64, c_float, POINTER(Fp8Out), P]),
     "frcnn_bn_bwd_blocks": (c_int, [c_int64]),
     "frcnn_bn_bwd_reduce": (c_int, [P, P, P, P, P, P, P, c_int64, c_int, P]),
     "frcnn_bn_bwd_finalize": (c_int, [P, c_int, c_int, c_int64, P, P, P, P, P]),

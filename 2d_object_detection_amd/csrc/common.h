@@ -86,6 +86,20 @@ __device__ __forceinline__ u32x2 pack8_fp8(const float* f, const float qs) {
     }
     return r;
 }
+// 8 floats -> 8 OCP e5m2 bytes ("bf8": the gradient format -- 5 exponent bits, max 57344), clamped to the finite range
+__device__ __forceinline__ u32x2 pack8_bf8(const float* f, const float qs) {
+    u32x2 r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int w = 0;
+        const float a = __builtin_amdgcn_fmed3f(f[4 * h] * qs, -57344.f, 57344.f), b = __builtin_amdgcn_fmed3f(f[4 * h + 1] * qs, -57344.f, 57344.f);
+        const float c = __builtin_amdgcn_fmed3f(f[4 * h + 2] * qs, -57344.f, 57344.f), d = __builtin_amdgcn_fmed3f(f[4 * h + 3] * qs, -57344.f, 57344.f);
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+        r[h] = (unsigned)w;
+    }
+    return r;
+}
 // wave-wide max of non-negative floats folded into one of the FRCNN_FP8_AMAX_SLOTS slots of dst (device floats compared as their bit
 // patterns: order-preserving for x >= 0).  Slots, because atomics on ONE address serialise at the memory side (~90 per us:
 // the 4096 waves of a BatchNorm launch on one word cost ~40 us, measured; spread over 64 words they cost < 1 us).

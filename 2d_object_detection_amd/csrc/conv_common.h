@@ -37,6 +37,7 @@ struct ConvParams {
     unsigned* fix_counter;                  // [tiles] arrival counters (zero between launches) in the caller's workspace
     const float* f8_x_scale;                // fp8 operands (conv_tile.hip, F8): dequantisation scale of x (device scalar) and of every
     const float* f8_w_scale;                //   output channel's weight row (device [Cout]); NULL: bf16 operands
+    int f8_fmt;                             // 1: x is e4m3 (activations), 2: x is e5m2 (gradients); the weights are always e4m3
     int dry_run;                            // host only: stop before the launch (frcnn_conv2d_describe)
     unsigned long long* dbg;                // FRCNN_STAMPS builds: per-workgroup phase stamps (NULL otherwise)
 };

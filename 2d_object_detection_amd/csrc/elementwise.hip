@@ -233,6 +233,21 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int block
 // parameters.  out = ReLU(BN(z) + BN2(z2)) in one pass: the shortcut's normalised output -- 60 MB at conv2, written by one kernel
 // and read back by the next -- is never stored (the backward pass needs z2, not BN2(z2)).  BN2(z2) is rounded to bf16 before the
 // addition, as it was when it went through memory: bit-identical results.
+// The 8 fp8 bytes of a thread's channel vector, stored 16 bytes at a time: neighbouring lanes (channel vectors v, v ^ 1 of one row: same
+// control flow) pool their halves and the even lane stores both -- as many store instructions per wave, but full 16-byte lanes
+// (the strip kernels are bound by memory instructions in flight, not bytes: 8-byte stores of the twin cost as much as the
+// 16-byte stores of the bf16 tensor)
+__device__ __forceinline__ void store_fp8_pair(uint8_t* dst, const u32x2 q, const int v, const bool pair_ok) {
+#ifndef FRCNN_FP8_STORE8
+    if (pair_ok) {
+        const unsigned p0 = __shfl_xor(q[0], 1), p1 = __shfl_xor(q[1], 1);
+        if (!(v & 1)) *reinterpret_cast<u32x4*>(dst) = u32x4{q[0], q[1], p0, p1};
+        return;
+    }
+#endif
+    *reinterpret_cast<u32x2*>(dst) = q;
+}
+
 struct Bn2 {
     const bf16_t* z; const double* part; const float* gamma; const float* beta;
     float* mm; float* mv; float* mean_o; float* invstd_o;
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
         if (b2.out8) {                           // fp8 twin of the STORED (bf16-rounded) activation
             float xr[8];
             unpack8(pk, xr);
-            *reinterpret_cast<u32x2*>(b2.out8 + i * 8) = pack8_fp8(xr, f8_qs);
+            store_fp8_pair(b2.out8 + i * 8, pack8_fp8(xr, f8_qs), v, (C & 15) == 0);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f8_max = fmaxf(f8_max, fabsf(xr[e]));
         }
@@ -521,7 +536,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
                                                                  const float* __restrict__ part, int slots, float inv_m, float pscale,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                  bf16_t* __restrict__ dz, bf16_t* __restrict__ gpre, int64_t M, int C,
-                                                                 int rows_per_block, int strips, int chunks) {
+                                                                 int rows_per_block, int strips, int chunks, uint8_t* __restrict__ dz8,
+                                                                 const float* __restrict__ dz8_qscale, float* __restrict__ dz8_amax) {
     __shared__ double red[2][4][64];
     __shared__ float s_par[4][64];                // gamma*invstd, mean, invstd (xhat), c1, c2 folded: a, mu, is, k1, k2
     __shared__ float s_c2[64];
@@ -581,6 +597,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
     float carry[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) carry[e] = 0.f;
+    // optional fp8 twin of dz for the fp8 data-gradient convolution: e5m2 bytes of the STORED bf16 value times *dz8_qscale
+    const float f8_qs = dz8 ? *dz8_qscale : 0.f;
+    float f8_max = 0.f;
 #pragma unroll 2
     for (int64_t r = row_begin + rl; r < row_end; r += 32) {
         const int64_t i = r * C8 + cv;
@@ -606,7 +625,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
         }
         *reinterpret_cast<u32x4*>(dz + i * 8) = pack8(o);
         if (gpre) *reinterpret_cast<u32x4*>(gpre + i * 8) = pack8(g);
+        if (dz8) {
+            store_fp8_pair(dz8 + i * 8, pack8_bf8(o, f8_qs), v, (C & 15) == 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f8_max = fmaxf(f8_max, fabsf(o[e]));
+        }
     }
+    if (dz8 && dz8_amax) atomic_amax(dz8_amax, f8_max);
 }
 
 template <bool MASK>
@@ -950,17 +975,19 @@ extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_par
 extern "C" int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z,
                                         const float* mean, const float* invstd, const float* gamma, const float* partial, int slots,
                                         float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, int64_t count,
-                                        float param_grad_scale, frcnn_stream_t stream) {
+                                        float param_grad_scale, const frcnn_fp8_out* f8, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(gout && z && mean && invstd && gamma && partial && dgamma && dbeta && dz && m > 0 && slots > 0 && c % 8 == 0 &&
                         !(act && relu_mask),
                     "bn_bwd_apply_fused: bad arguments");
+    FRCNN_CHECK_ARG(!f8 || (f8->out8 && f8->qscale), "bn_bwd_apply_fused: fp8 output without buffer / scale");
     const int rows = strip_rows_per_block(m, c);
     const int strips = (c + 63) / 64, chunks = (int)((m + rows - 1) / rows);
     const dim3 grid((unsigned)(strips * 8 * ((chunks + 7) / 8)));
     const float inv_m = (float)(1.0 / (double)(count > 0 ? count : m));
 #define FRCNN_LAUNCH(MODE, PTR, LEG)                                                                                                      \
     hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<MODE, LEG>), grid, dim3(256), 0, S_(stream), CBF(gout), (const void*)(PTR), CBF(z), mean, \
-                       invstd, gamma, partial, slots, inv_m, param_grad_scale, dgamma, dbeta, BF(dz), BF(gpre), m, c, rows, strips, chunks)
+                       invstd, gamma, partial, slots, inv_m, param_grad_scale, dgamma, dbeta, BF(dz), BF(gpre), m, c, rows, strips, chunks,   \
+                       f8 ? f8->out8 : (uint8_t*)nullptr, f8 ? f8->qscale : (const float*)nullptr, f8 ? f8->amax : (float*)nullptr)
 #ifdef FRCNN_SWEEP
     const char* ev = getenv("FRCNN_BN_VAR");
     if (ev && atoi(ev) == 4) {

@@ -8,6 +8,7 @@ namespace {
 #define S_(s) reinterpret_cast<hipStream_t>(s)
 
 // out8 = e4m3(clamp(x * qscale)), |x| max folded into *amax
+template <bool E5M2>
 __global__ __launch_bounds__(256) void quantize_fp8_kernel(const bf16_t* __restrict__ x, int64_t nvec, const float* __restrict__ qscale,
                                                            uint8_t* __restrict__ out8, float* __restrict__ amax) {
     const float qs = *qscale;
@@ -15,7 +16,7 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const bf16_t* __restr
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
         float f[8];
         unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), f);
-        *reinterpret_cast<u32x2*>(out8 + i * 8) = pack8_fp8(f, qs);
+        *reinterpret_cast<u32x2*>(out8 + i * 8) = E5M2 ? pack8_bf8(f, qs) : pack8_fp8(f, qs);
 #pragma unroll
         for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(f[e]));
     }
@@ -30,19 +31,30 @@ __global__ __launch_bounds__(256) void quantize_weights_fp8_kernel(const long lo
     int lo = 0, hi = n - 1;                       // layer by prefix search over the table's "first workgroup" column
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (table[mid * 6 + 5] <= row_id) lo = mid; else hi = mid - 1;
+        if (table[mid * 8 + 5] <= row_id) lo = mid; else hi = mid - 1;
     }
-    const long long* t = table + lo * 6;
-    const float* w = reinterpret_cast<const float*>(t[0]);
+    const long long* t = table + lo * 8;
     uint8_t* w8 = reinterpret_cast<uint8_t*>(t[1]);
     float* scale = reinterpret_cast<float*>(t[2]);
     const long long K = t[4];
     const long long r = row_id - t[5];
-    const float* src = w + r * K;
+    const bool src_bf16 = t[6] != 0;
+    const float* src = reinterpret_cast<const float*>(t[0]) + r * K;
+    const bf16_t* srcb = reinterpret_cast<const bf16_t*>(t[0]) + r * K;
+    auto load8 = [&](const long long k, float* f) {
+        if (src_bf16) {
+            unpack8(*reinterpret_cast<const u32x4*>(srcb + k), f);
+        } else {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + k), b = *reinterpret_cast<const f32x4*>(src + k + 4);
+            f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+        }
+    };
     float mx = 0.f;
-    for (long long k = (long long)threadIdx.x * 4; k < K; k += 256 * 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + k);
-        mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), mx));
+    for (long long k = (long long)threadIdx.x * 8; k < K; k += 256 * 8) {
+        float f[8];
+        load8(k, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(f[e]));
     }
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
@@ -53,8 +65,8 @@ __global__ __launch_bounds__(256) void quantize_weights_fp8_kernel(const long lo
     const float qs = 1.f / sc;
     if (threadIdx.x == 0) scale[r] = sc;
     for (long long k = (long long)threadIdx.x * 8; k < K; k += 256 * 8) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(src + k), b = *reinterpret_cast<const f32x4*>(src + k + 4);
-        const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        float f[8];
+        load8(k, f);
         *reinterpret_cast<u32x2*>(w8 + r * K + k) = pack8_fp8(f, qs);
     }
 }
@@ -74,11 +86,12 @@ __global__ void fp8_update_scales_kernel(const float* __restrict__ amax, float* 
 
 }  // namespace
 
-extern "C" int frcnn_quantize_fp8(const frcnn_bf16* x, int64_t n, const float* qscale, frcnn_fp8* out8, float* amax, frcnn_stream_t stream) {
+extern "C" int frcnn_quantize_fp8(const frcnn_bf16* x, int64_t n, const float* qscale, frcnn_fp8* out8, float* amax, int e5m2, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(x && qscale && out8 && n > 0 && n % 8 == 0, "quantize_fp8: bad arguments (n must be a multiple of 8)");
     const int64_t nvec = n / 8;
     const int blocks = (int)((nvec + 255) / 256 < 2048 ? (nvec + 255) / 256 : 2048);
-    hipLaunchKernelGGL(quantize_fp8_kernel, dim3(blocks), dim3(256), 0, S_(stream), reinterpret_cast<const bf16_t*>(x), nvec, qscale, out8, amax);
+    if (e5m2) hipLaunchKernelGGL(quantize_fp8_kernel<true>, dim3(blocks), dim3(256), 0, S_(stream), reinterpret_cast<const bf16_t*>(x), nvec, qscale, out8, amax);
+    else hipLaunchKernelGGL(quantize_fp8_kernel<false>, dim3(blocks), dim3(256), 0, S_(stream), reinterpret_cast<const bf16_t*>(x), nvec, qscale, out8, amax);
     FRCNN_CHECK_LAUNCH("quantize_fp8");
     return FRCNN_OK;
 }

@@ -107,7 +107,9 @@ class RPNDetector:
         }
 
     # ------------------------------------------------------------------ plans
-    def setup(self, batch, training):
+    def setup(self, batch, training, f8_scales=None):
+        """f8_scales: the backbone's Fp8Scales table (fp8 training): the e5m2 twin of the 3x3 convolution's incoming gradient gets
+        its column there, so one update launch per step serves every fp8 tensor."""
         dev, gh, gw, cf = self.device, self.gh, self.gw, self.cf
         self.batch = batch
         m = batch * gh * gw
@@ -129,6 +131,7 @@ class RPNDetector:
             # fp8 forward of the 3x3 intermediate convolution (K = 9 * 1024: the largest single layer of the step)
             self.w_inter8 = torch.zeros(256, self.ws, self.ws, cf, dtype=ops.FP8, device=dev)
             self.w_inter8_scale = torch.ones(256, dtype=torch.float32, device=dev)
+        self.dz_f8 = None
         if training:
             self.dhead32 = torch.zeros(m, HEAD_LD, device=dev)
             self.dhead = torch.empty(m, HEAD_LD, dtype=BF16, device=dev)
@@ -137,6 +140,13 @@ class RPNDetector:
             self.d_heads_bwd = ops.conv_desc(batch, gh, gw, HEAD_LD, 1, 1, 1, 0, 0, gh, gw, 256)
             self.d_inter_bwd = ops.conv_desc(batch, gh, gw, 256, self.ws, self.ws, 1, p, p, gh, gw, cf, flags=ops.CONV_ADD_RES)
             self._conv_ws.append(ops.conv_attach_workspace(self.d_inter_bwd, dev))
+            if self.w_inter8 is not None and f8_scales is not None:
+                # fp8 data gradient of the 3x3 convolution: e5m2 twin of dz_f (written by a quantise pass behind the ReLU backward),
+                # e4m3 twin of the tap-flipped transposed weights, one scale per row (= per feature-map channel)
+                from ..feature_extractor import Fp8Twin
+                self.dz_f8 = Fp8Twin(f8_scales, (m, 256), dev)
+                self.w_inter_t8 = torch.zeros(cf, self.ws, self.ws, 256, dtype=ops.FP8, device=dev)
+                self.w_inter_t8_scale = torch.ones(cf, dtype=torch.float32, device=dev)
 
     def refresh_weights(self, plan):
         st = self.store
@@ -144,8 +154,13 @@ class RPNDetector:
         plan.add(ops.weights_transpose_flip, st.weight("rpn_heads/kernel"), self.w_heads_t, HEAD_LD, 1, 1, 256)
         if self.quant_entries():
             if getattr(self, "_quant_table", None) is None:
-                self._quant_table = ops.make_weight_quant_table(self.quant_entries(), self.device)
+                self._quant_table = ops.make_weight_quant_table(self.quant_entries() + self.quant_entries_bwd(), self.device)
             plan.add(ops.quantize_weights_fp8_batched, *self._quant_table)
+
+    def quant_entries_bwd(self):
+        if getattr(self, "dz_f8", None) is None:
+            return []
+        return [(self.w_inter_t.view(self.cf, -1), self.w_inter_t8, self.w_inter_t8_scale)]
 
     def quant_entries(self):
         """fp8 mode: (fp32 master rows, e4m3 destination, per-row scale) of the 3x3 intermediate convolution's weights."""
@@ -210,6 +225,9 @@ class RPNDetector:
         plan.add(ops.conv2d_wgrad, self.d_heads, self.f, self.dhead, st.grad("rpn_heads/kernel"))
         plan.add(ops.conv2d_fprop, self.d_heads_bwd, self.dhead, self.w_heads_t, self.g_f)
         plan.add(ops.relu_bwd, self.g_f, self.f, self.dz_f)
+        if self.dz_f8 is not None:
+            sc = self.dz_f8.scales
+            plan.add(ops.quantize_fp8, self.dz_f, sc.qscale(self.dz_f8.idx), self.dz_f8.data, sc.amax(self.dz_f8.idx), e5m2=True)
         plan.add(ops.colsum_bf16, self.dz_f, self.m, 256, 256, st.grad("rpn_intermediate_layer/bias"))
         plan.add(ops.conv2d_wgrad, self.d_inter, feature_maps, self.dz_f, st.grad("rpn_intermediate_layer/kernel"))
 
@@ -217,9 +235,14 @@ class RPNDetector:
         """consumer: the backbone's last conv unit -- g_feat is complete after this kernel, so it also runs that unit's
         BatchNorm-backward reduce."""
         ops.conv_zero_counters(plan, self.d_inter_bwd)
+        red = None
         if consumer is not None:
             red = consumer.reduce_args(relu=True)
             plan.hold(red)
+        if self.dz_f8 is not None:
+            plan.add(ops.conv2d_dgrad_fp8, self.d_inter_bwd, self.dz_f8.data, self.w_inter_t8, self.dz_f8.scale, self.w_inter_t8_scale, g_feat,
+                     red=red, res=g_feat)
+        elif consumer is not None:
             plan.add(ops.conv2d_dgrad_bnreduce, self.d_inter_bwd, self.dz_f, self.w_inter_t, g_feat, red, res=g_feat)
         else:
             plan.add(ops.conv2d_fprop, self.d_inter_bwd, self.dz_f, self.w_inter_t, g_feat, res=g_feat)

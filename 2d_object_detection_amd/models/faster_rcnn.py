@@ -141,7 +141,7 @@ class FasterRCNN:
         G = 100
         io["gt_labels"] = torch.zeros(batch, G, nc1, device=dev)
         io["gt_boxes"] = torch.zeros(batch, G, 4, device=dev)
-        mods.rpn.setup(batch, training)
+        mods.rpn.setup(batch, training, f8_scales=mods.fe.f8)
         P = int(self._rpn_config["nms"]["max_total_size"])
         rs, cs = self._rpn_config["sampling"], self._rcnn_config["sampling"]
         S_rpn, S_rcnn = int(rs["num_samples"]), int(cs["num_samples"])
@@ -156,6 +156,8 @@ class FasterRCNN:
             plan.hold(table)
             with plan.branch("weight_flips"):
                 plan.add(ops.weights_transpose_flip_batched, table, total)
+                if mods.fe.f8 is not None:           # fp8 mode: e4m3 twins of the transposes, for the fp8 data gradients
+                    mods.fe.quantize_bwd_weights_plan(plan, extra=mods.rpn.quant_entries_bwd())
         # ---- targets, sampling, losses (+ per-sample gradients)
         n = mods.rpn.n
         f32 = dict(dtype=torch.float32, device=dev)
@@ -270,7 +272,7 @@ class FasterRCNN:
         plan = Plan("call_training")
         io = {"images": mods.fe.setup(batch, True)}
         _, gh, gw, cf = mods.fe.output_shape
-        mods.rpn.setup(batch, True)
+        mods.rpn.setup(batch, True, f8_scales=None)
         P = int(self._rpn_config["nms"]["max_total_size"])
         mods.rcnn.setup(batch, P, gh, gw, False)
         feat = mods.fe.forward_plan(plan, True)

@@ -89,6 +89,8 @@ class _ConvBN:
         self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
         # fp8 forward convolution (e4m3 operands, 128-deep MFMA steps): every layer whose cin is a multiple of 128
         self.fp8 = bool(fp8) and k != 7 and cin % 128 == 0
+        # fp8 data gradient (e5m2 gradient x e4m3 transposed weights): its contraction runs over this layer's OUTPUT channels
+        self.fp8_bwd = bool(fp8) and k != 7 and cout % 128 == 0
         self.store = store
         self.sync_world = int(sync_world)            # > 1: BatchNorm statistics are summed over this many data-parallel ranks
         store.register(name + "_conv/kernel", (cout, k, k, cin))          # OHWI (Keras: HWIO)
@@ -118,6 +120,9 @@ class _ConvBN:
             if self.fp8 and training:
                 self.w8 = torch.zeros(self.cout, k, k, self.cin, dtype=ops.FP8, device=device)
                 self.w8_scale = torch.ones(self.cout, dtype=torch.float32, device=device)
+            if self.fp8_bwd and training:
+                self.w_t8 = torch.zeros(self.cin, k, k, self.cout, dtype=ops.FP8, device=device)
+                self.w_t8_scale = torch.ones(self.cin, dtype=torch.float32, device=device)
             # fewer output tiles than CUs and a long K (conv4 at 375x1242): scratch for the split-K fix-up form of the conv kernel
             self.conv_ws = ops.conv_attach_workspace(self.desc, device)
         self._device = device
@@ -138,6 +143,7 @@ class _ConvBN:
                                 else torch.zeros(self.bwd_blocks, 2, c, **f32))
             self.c1, self.c2 = torch.empty(c, **f32), torch.empty(c, **f32)
             self.dz = torch.empty(self.m, c, dtype=BF16, device=device)
+            self.dz8 = None                          # Fp8Twin (e5m2) of dz, attached by FeatureExtractor.setup in fp8 mode
             # ReLU bit mask written by the forward BN kernel: the backward kernels read 1 bit instead of 16 per element
             self.relu_mask = torch.empty(self.m, c // 8, dtype=torch.uint8, device=device)
 
@@ -158,6 +164,12 @@ class _ConvBN:
         if not (self.fp8 and hasattr(self, "w8")):
             return None
         return (self.store.weight(self.name + "_conv/kernel").view(self.cout, -1), self.w8, self.w8_scale)
+
+    def quant_entry_bwd(self):
+        """(bf16 tap-flipped transposed weights as rows per input channel, e4m3 destination, per-row scale) or None."""
+        if not (self.fp8_bwd and hasattr(self, "w_t8")):
+            return None
+        return (self.w_t.view(self.cin, -1), self.w_t8, self.w_t8_scale)
 
     def forward(self, plan, x, training, x8=None):
         """x8: Fp8Twin of x (training, fp8 layers): the convolution reads the e4m3 bytes instead of the bf16 tensor."""
@@ -217,7 +229,8 @@ class _ConvBN:
             plan.sync_point(self.name + "_bn_bwd", [self.bwd_partial])
         plan.add(ops.bn_bwd_apply_fused, gout, None, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"),
                  self.bwd_partial, self.bwd_blocks, st.grad(self.name + "_bn/gamma"), st.grad(self.name + "_bn/beta"), self.dz, gpre,
-                 self.m, self.cout, relu_mask=mask, count=self.m * self.sync_world, param_grad_scale=1.0 / self.sync_world)
+                 self.m, self.cout, relu_mask=mask, count=self.m * self.sync_world, param_grad_scale=1.0 / self.sync_world,
+                 f8=self.dz8.out if self.dz8 is not None else None)
         # the conv bias feeds a training-mode BN: its gradient is identically zero (flat grad buffer is pre-zeroed)
 
     def backward_weights(self, plan, x, defer=None):
@@ -248,12 +261,17 @@ class _ConvBN:
         plan.hold(d)
         plan.hold(ops.conv_attach_workspace(d, self._device))
         ops.conv_zero_counters(plan, d)
+        red = None
         if consumer is not None:
             red = consumer.reduce_args(relu=True)
             plan.hold(red)
-            plan.add(ops.conv2d_dgrad_bnreduce, d, self.dz, self.w_t, gx, red, res=res, res_mask=res_mask)
         else:
             assert res_mask is None
+        if self.dz8 is not None:
+            plan.add(ops.conv2d_dgrad_fp8, d, self.dz8.data, self.w_t8, self.dz8.scale, self.w_t8_scale, gx, red=red, res=res, res_mask=res_mask)
+        elif consumer is not None:
+            plan.add(ops.conv2d_dgrad_bnreduce, d, self.dz, self.w_t, gx, red, res=res, res_mask=res_mask)
+        else:
             plan.add(ops.conv2d_fprop, d, self.dz, self.w_t, gx, res=res)
 
 
@@ -362,9 +380,23 @@ class FeatureExtractor:
         for u in self.conv_units():
             u.refresh_weights(plan)
         self.quantize_weights_plan(plan)
+        self.quantize_bwd_weights_plan(plan)
 
     def quant_entries(self):
         return [e for e in (u.quant_entry() for u in self.conv_units()) if e is not None]
+
+    def quant_entries_bwd(self):
+        return [e for e in (u.quant_entry_bwd() for u in self.conv_units()) if e is not None]
+
+    def quantize_bwd_weights_plan(self, plan, extra=()):
+        """e4m3 twins of the tap-flipped transposed weights (after the transposes that produce them): ONE launch."""
+        entries = self.quant_entries_bwd() + list(extra)
+        if entries:
+            key = tuple(e[1].data_ptr() for e in entries)
+            cache = self.__dict__.setdefault("_quant_tables", {})
+            if key not in cache:
+                cache[key] = ops.make_weight_quant_table(entries, self.device)
+            plan.add(ops.quantize_weights_fp8_batched, *cache[key])
 
     def quantize_weights_plan(self, plan, extra=()):
         """fp8 forward weights of every fp8 layer (+ extra entries, e.g. the RPN's) from the fp32 masters: ONE launch."""
@@ -429,6 +461,9 @@ class FeatureExtractor:
             elif first:
                 a["sc"] = None                    # (training: the shortcut BatchNorm is fused into the block-final one)
             if self.f8 is not None:
+                for k_ in sorted(u):                     # e5m2 twins of the BatchNorm-backward outputs that feed fp8 data gradients
+                    if u[k_].fp8_bwd:
+                        u[k_].dz8 = Fp8Twin(self.f8, (u[k_].m, u[k_].cout), dev)
                 # fp8 twins of the activations that feed fp8 convolutions: a1 -> 3x3, a2 -> 1x1 expansion, out -> the next block / RPN
                 a["a1_8"] = Fp8Twin(self.f8, (m, f), dev) if u[2].fp8 else None
                 a["a2_8"] = Fp8Twin(self.f8, (m, f), dev) if u[3].fp8 else None

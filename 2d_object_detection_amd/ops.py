@@ -118,18 +118,32 @@ def conv2d_describe_fp8(d):
     return r.decode()
 
 
-def quantize_fp8(x, qscale, out8, amax=None):
-    call("frcnn_quantize_fp8", _p(x), x.numel(), _p(qscale), _p(out8), _p(amax), _stream())
+def conv2d_dgrad_fp8(d, dz8, w_t8, dz_scale, w_scale, gx, red=None, res=None, res_mask=None):
+    """gx = bf16(dz_scale * w_scale[ci] * conv(dz8 (e5m2), w_t8 (e4m3))) [+ res (* res_mask bits)] [+ fused BatchNorm-backward reduce]."""
+    call("frcnn_conv2d_dgrad_fp8", byref(d), _p(dz8), _p(w_t8), _p(dz_scale), _p(w_scale), _p(res), _p(res_mask), _p(gx),
+         byref(red) if red is not None else None, _stream())
+
+
+def conv2d_describe_dgrad_fp8(d, with_bn_reduce=False):
+    r = _lib.load().frcnn_conv2d_describe_dgrad_fp8(byref(d), 1 if with_bn_reduce else 0)
+    if r is None:
+        raise RuntimeError("frcnn_conv2d_describe_dgrad_fp8: " + _lib.load().frcnn_last_error().decode())
+    return r.decode()
+
+
+def quantize_fp8(x, qscale, out8, amax=None, e5m2=False):
+    call("frcnn_quantize_fp8", _p(x), x.numel(), _p(qscale), _p(out8), _p(amax), 1 if e5m2 else 0, _stream())
 
 
 def make_weight_quant_table(entries, device):
-    """entries: list of (fp32 master [rows, K] view, fp8 destination, float scale[rows]) -> (int64 table on device, total rows)."""
+    """entries: list of (source [rows, K] view -- fp32 masters or bf16 derived weights --, fp8 destination, float scale[rows])
+    -> (int64 table on device, total rows)."""
     rows, begin = [], 0
     for (w, w8, scale) in entries:
         r = int(w.shape[0])
         k = w.numel() // r
-        assert k % 8 == 0 and w.is_contiguous() and w8.numel() == w.numel() and scale.numel() == r
-        rows.append([w.data_ptr(), w8.data_ptr(), scale.data_ptr(), r, k, begin])
+        assert k % 8 == 0 and w.is_contiguous() and w8.numel() == w.numel() and scale.numel() == r and w.dtype in (torch.float32, BF16)
+        rows.append([w.data_ptr(), w8.data_ptr(), scale.data_ptr(), r, k, begin, 1 if w.dtype == BF16 else 0, 0])
         begin += r
     return torch.tensor(rows, dtype=torch.int64, device=device), begin
 
@@ -294,9 +308,9 @@ def bn_train_apply_maxpool(z, stats, slots, count, gamma, beta, mm, mv, momentum
 
 
 def bn_bwd_apply_fused(gout, act, z, mean, invstd, gamma, partial, slots, dgamma, dbeta, dz, gpre, m, c, relu_mask=None, count=0,
-                       param_grad_scale=1.0):
+                       param_grad_scale=1.0, f8=None):
     call("frcnn_bn_bwd_apply_fused", _p(gout), _p(act), _p(relu_mask), _p(z), _p(mean), _p(invstd), _p(gamma), _p(partial), slots,
-         _p(dgamma), _p(dbeta), _p(dz), _p(gpre), m, c, count, float(param_grad_scale), _stream())
+         _p(dgamma), _p(dbeta), _p(dz), _p(gpre), m, c, count, float(param_grad_scale), byref(f8) if f8 is not None else None, _stream())
 
 
 def bn_bwd_blocks(m):

@@ -131,13 +131,26 @@ int frcnn_conv2d_fprop_fp8(const frcnn_conv_desc* d, const frcnn_fp8* x8, const 
                            const float* w_scale, const float* bias, frcnn_bf16* y, double* stats_partial, frcnn_stream_t stream);
 /* the instantiation frcnn_conv2d_fprop_fp8 would launch (host logic, as frcnn_conv2d_describe) */
 const char* frcnn_conv2d_describe_fp8(const frcnn_conv_desc* d);
+/* Data gradient on fp8 operands (the backward of the layers above: tf.GradientTape over Conv2D, models/faster_rcnn.py:103):
+ * gx = bf16(dz_scale * w_scale[ci] * conv(dz8, w_t8)) [+ res (* res_mask bits)], optionally fused with the BatchNorm-backward
+ * reduce of the layer that consumes gx (red != NULL; semantics of frcnn_conv2d_dgrad_bnreduce).  dz8: the incoming gradient as
+ * OCP e5m2 bytes (5 exponent bits: the gradient format of Micikevicius et al., "FP8 formats for deep learning", 2022) with a
+ * per-tensor scale; w_t8: the tap-flipped transposed weights [cin][kh][kw][cout] as e4m3 bytes with one scale per row (per input
+ * channel of the forward layer).  Descriptor as for frcnn_conv2d_dgrad_bnreduce with its cin (the forward layer's cout) a
+ * multiple of 128. */
+int frcnn_conv2d_dgrad_fp8(const frcnn_conv_desc* d, const frcnn_fp8* dz8, const frcnn_fp8* w_t8, const float* dz_scale,
+                           const float* w_scale, const frcnn_bf16* res, const uint8_t* res_mask, frcnn_bf16* gx,
+                           const struct frcnn_bn_reduce* red, frcnn_stream_t stream);
+const char* frcnn_conv2d_describe_dgrad_fp8(const frcnn_conv_desc* d, int with_bn_reduce);
 /* Quantisers.  out8[i] = e4m3_rne(clamp(x[i] * qscale[0], -448, 448)); amax (optional, FRCNN_FP8_AMAX_SLOTS device floats,
  * pre-zeroed per step): max |x[i]| as fp32, folded with atomics into one of the slots per wave (atomics on a single word would
  * serialise) -- the maximum over the slots is the input of the delayed scaling rule below.  n a multiple of 8. */
 #define FRCNN_FP8_AMAX_SLOTS 64
-int frcnn_quantize_fp8(const frcnn_bf16* x, int64_t n, const float* qscale, frcnn_fp8* out8, float* amax, frcnn_stream_t stream);
-/* Weights, several layers in one launch: table int64 [n][6] = {fp32 master (rows of K values, row-major), fp8 destination, float
- * scale[rows] destination, rows, K, first workgroup}; one workgroup per row: scale = max|w| / 448 (1 for an all-zero row),
+int frcnn_quantize_fp8(const frcnn_bf16* x, int64_t n, const float* qscale, frcnn_fp8* out8, float* amax, int e5m2 /* 0: e4m3, 1: e5m2 (clamp 57344) */,
+                       frcnn_stream_t stream);
+/* Weights, several layers in one launch: table int64 [n][8] = {source (rows of K values, row-major), fp8 destination, float
+ * scale[rows] destination, rows, K, first workgroup, source type (0: fp32 masters, 1: bf16 -- the tap-flipped transposes the
+ * data gradients read), 0}; one workgroup per row: scale = max|w| / 448 (1 for an all-zero row),
  * w8 = e4m3_rne(w * (1 / scale)), all in fp32.  Serves the forward weights [cout][kh*kw*cin] and, given transposed masters, any other row layout. */
 int frcnn_quantize_weights_fp8_batched(const int64_t* table, int n, int64_t total_rows, frcnn_stream_t stream);
 /* Delayed scaling (one amax of history): for i < n: a = max over amax[i][0..FRCNN_FP8_AMAX_SLOTS) (this step's maximum); if a > 0:
@@ -251,7 +264,7 @@ int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_partial, int s
 int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z,
                              const float* mean, const float* invstd, const float* gamma, const float* partial, int slots,
                              float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, int64_t count,
-                             float param_grad_scale, frcnn_stream_t stream);
+                             float param_grad_scale, const struct frcnn_fp8_out* f8 /* NULL, or the e5m2 twin of dz */, frcnn_stream_t stream);
 /* g_out = g * (act > 0): ReLU backward without BN (RPN intermediate layer) */
 int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, int64_t n, frcnn_stream_t stream);
 /* per-channel column sum of a bf16 [m,c] matrix ADDED (float atomics) to fp32 out[c] (bias gradients;

@@ -60,6 +60,24 @@ FPROP_FP8 = [
     dict(id="f8_small_1x1_relu", n=2, h=13, w=17, cin=384, cout=72, k=1, s=1, p=0, bias=True, relu=True, stats=False),
 ]
 
+# ---- fp8 data gradients (frcnn_conv2d_dgrad_fp8: e5m2 gradient x e4m3 transposed weights); fields as DGRAD below
+DGRAD_FP8 = [
+    dict(id="f8_rpn_dg_3x3_256_1024_res_red", n=4, h=24, w=78, cin=256, cout=1024, k=3, res=True, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="f8_c4_dg_1024_256_red", n=4, h=24, w=78, cin=1024, cout=256, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="f8_c4_dg_3x3_256_256_red", n=4, h=24, w=78, cin=256, cout=256, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="f8_c4_dg_256_1024_res_mask_red", n=4, h=24, w=78, cin=256, cout=1024, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
+    dict(id="f8_c4_dg_s2_256_512_scatter_plain", n=4, h=24, w=78, cin=256, cout=512, k=1, res=False, res_mask=False, red=False, mask=False, scatter=2),
+    dict(id="f8_c3_dg_3x3_128_128_red", n=3, h=47, w=156, cin=128, cout=128, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),      # kw-sharing
+    dict(id="f8_c3_dg_128_512_res_mask_red_run", n=4, h=47, w=156, cin=128, cout=512, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
+    dict(id="f8_c2_dg_256_64_red", n=4, h=94, w=311, cin=256, cout=64, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="f8_c2_dg_256_64_res_plain", n=4, h=94, w=311, cin=256, cout=64, k=1, res=True, res_mask=False, red=False, mask=False, scatter=1),
+    dict(id="f8_c4_dg_1024_256_red_b8", n=8, h=24, w=78, cin=1024, cout=256, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="f8_c4_dg_256_1024_res_mask_red_b8_run", n=8, h=24, w=78, cin=256, cout=1024, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
+    dict(id="f8_c3_dg_s2_128_256_scatter_plain_b8_run", n=8, h=47, w=156, cin=128, cout=256, k=1, res=False, res_mask=False, red=False, mask=False, scatter=2),
+    dict(id="f8_small_dg_scatter_res_red", n=2, h=12, w=39, cin=512, cout=256, k=1, res=True, res_mask=False, red=True, mask=True, scatter=2),
+    dict(id="f8_small_dg_3x3_nomask", n=2, h=13, w=17, cin=128, cout=128, k=3, res=False, res_mask=False, red=True, mask=False, scatter=1),
+]
+
 # ---- data gradients: dz grid n x h x w with cin channels -> gx with cout channels; k = 1 or 3 (stride 1, pad k//2);
 # scatter 2: the gradient of a stride-2 1x1 convolution, written to every second pixel of a 2h x 2w (-1) grid.
 # res: residual added (ADD_RES); res_mask: bit mask on the residual; red: fused BatchNorm-backward reduce (mask: with ReLU bits)
@@ -172,6 +190,8 @@ def covered_instantiations(ops):
         note(ops.conv2d_describe(fprop_desc(ops, c), False), c["id"])
     for c in FPROP_FP8:
         note(ops.conv2d_describe_fp8(fprop_desc(ops, c)), c["id"])
+    for c in DGRAD_FP8:
+        note(ops.conv2d_describe_dgrad_fp8(dgrad_desc(ops, c), c["red"]), c["id"])
     for c in DGRAD:
         note(ops.conv2d_describe(dgrad_desc(ops, c), c["red"]), c["id"])
     for c in F32:

@@ -39,6 +39,8 @@ def _plan_instantiations(monkeypatch, depth, batch, proposals=None, precision="b
                 found = [ops.conv2d_describe(args[0], fn is ops.conv2d_dgrad_bnreduce)]
             elif fn is ops.conv2d_fprop_fp8:
                 found = [ops.conv2d_describe_fp8(args[0])]
+            elif fn is ops.conv2d_dgrad_fp8:
+                found = [ops.conv2d_describe_dgrad_fp8(args[0], kwargs.get("red") is not None)]
             elif fn is ops.conv2d_wgrad:
                 found = [ops.conv2d_wgrad_describe(args[0], with_row_index=kwargs.get("row_index") is not None)]
             elif fn is ops.conv2d_wgrad_grouped:

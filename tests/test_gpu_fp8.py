@@ -9,11 +9,12 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conv_cases import FPROP_FP8, fprop_desc
+from conv_cases import DGRAD_FP8, FPROP_FP8, dgrad_desc, fprop_desc
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 E4M3 = torch.float8_e4m3fn
+E5M2 = torch.float8_e5m2
 
 
 def _close(a, b, rtol, atol, what):
@@ -85,6 +86,145 @@ def test_conv_fprop_fp8_vs_fp32_on_dequantised_operands(ops, case):
         _close(stats[:, 1].sum(0), (yc.double() * yc.double()).sum(0), 1e-4, 1e-2 * float(rc.abs().max()) ** 2, "stats sumsq")
 
 
+def test_fp8_mfma_mixed_formats_with_exact_integers(ops):
+    """Data-gradient form: the x operand in e5m2, the weights in e4m3 (format selectors of the scaled MFMA).  Integers up to 4 are
+    exact in e5m2; a swapped format selector decodes the bytes of one operand in the other's format and misses by far."""
+    g = torch.Generator().manual_seed(2)
+    n, h, w, cin, cout = 1, 8, 16, 256, 64
+    x = torch.randint(-4, 5, (n, h, w, cin), generator=g).float()
+    wt = torch.zeros(cout, cin)
+    for co in range(cout):
+        wt[co] = ((torch.arange(cin) * 5 + co * 11) % 7 - 3).float()
+    ref = x.reshape(-1, cin) @ wt.t()
+    d = ops.conv_desc(n, h, w, cin, 1, 1, 1, 0, 0, h, w, cout)
+    y = torch.empty(n * h * w, cout, dtype=BF, device="cuda")
+    ops.conv2d_dgrad_fp8(d, x.to(E5M2).view(torch.uint8).cuda(), wt.to(E4M3).view(torch.uint8).cuda(), torch.ones(1, device="cuda"),
+                         torch.ones(cout, device="cuda"), y)
+    torch.cuda.synchronize()
+    assert float(ref.abs().max()) < 256 * 8
+    err = float((y.float().cpu() - ref).abs().max())
+    assert err <= 2 ** -8 * float(ref.abs().max()), "mixed-format MFMA: max err %g" % err
+
+
+@pytest.mark.parametrize("case", DGRAD_FP8, ids=[c["id"] for c in DGRAD_FP8])
+def test_conv_dgrad_fp8_vs_fp32_on_dequantised_operands(ops, case):
+    """As tests/test_gpu_conv.py::test_conv_dgrad, with the gradient in e5m2 and the transposed weights in e4m3: gx against an fp32
+    convolution of the dequantised operands (+ residual, masks, scatter), the fused BatchNorm-backward sums against an fp64
+    evaluation of their definition on the kernel's own bf16 gx."""
+    g = torch.Generator().manual_seed(11)
+    n, h, w, cin, cout, k, sc = (case[x] for x in ("n", "h", "w", "cin", "cout", "k", "scatter"))
+    d = dgrad_desc(ops, case, "cuda")
+    oh, ow = d.out_h, d.out_w
+    m, mo = n * h * w, n * oh * ow
+    v = torch.randn(n, h, w, cin, generator=g) * torch.exp2(torch.randint(-8, 6, (n, h, w, cin), generator=g).float())
+    dz8q = v.clamp(-57344, 57344).to(E5M2)
+    w8q = (torch.randn(cout, k, k, cin, generator=g) * 0.5 * torch.exp2(torch.randint(-5, 3, (cout, k, k, cin), generator=g).float())).clamp(-448, 448).to(E4M3)
+    dz_scale = torch.tensor([2.3e-3])
+    w_scale = torch.rand(cout, generator=g) * 0.02 + 0.001
+    dzf = dz8q.float() * dz_scale
+    wf = w8q.float() * w_scale.view(-1, 1, 1, 1)                       # the kernel's "w_t" operand, OHWI
+    conv = F.conv2d(dzf.permute(0, 3, 1, 2), wf.permute(0, 3, 1, 2), None, stride=1, padding=k // 2).permute(0, 2, 3, 1).contiguous()
+    amp = float(conv.abs().max())
+    base = (torch.randn(n, oh, ow, cout, generator=g) * 0.3 * amp).to(BF).float() if (case["res"] or sc > 1) else None
+    rmask = torch.randint(0, 256, (mo, cout // 8), generator=g, dtype=torch.uint8) if case["res_mask"] else None
+    res_eff = base
+    if rmask is not None:
+        bits = ((rmask[:, :, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(n, oh, ow, cout).bool()
+        res_eff = torch.where(bits, base, torch.zeros_like(base))
+    if sc == 1:
+        ref = conv + (res_eff if case["res"] else 0)
+        touched = torch.ones(mo, dtype=torch.bool)
+    else:
+        ref = base.clone() if case["res"] else torch.zeros(n, oh, ow, cout)
+        ref[:, ::sc, ::sc][:, :h, :w] = conv + (res_eff[:, ::sc, ::sc][:, :h, :w] if case["res"] else 0)
+        t2 = torch.zeros(n, oh, ow, dtype=torch.bool)
+        t2[:, ::sc, ::sc][:, :h, :w] = True
+        touched = t2.reshape(-1)
+    z = (torch.randn(mo, cout, generator=g) * 2 + 0.5).to(BF).float()
+    zmask = torch.randint(0, 256, (mo, cout // 8), generator=g, dtype=torch.uint8) if case["mask"] else None
+    mean = z.mean(0).contiguous()
+    invstd = (1.0 / (z.var(0, unbiased=False) + 1e-5).sqrt()).contiguous()
+    if case["res"]:
+        out = base.to(BF).cuda()
+        res_d = out
+    else:
+        out = torch.zeros(n, oh, ow, cout, dtype=BF, device="cuda") if sc > 1 else torch.full((n, oh, ow, cout), float("nan"), dtype=BF, device="cuda")
+        res_d = None
+    part = torch.zeros(ops.STAT_SLOTS, 2, cout, device="cuda")
+    z_d = z.to(BF).cuda()
+    zmask_d, rmask_d = (zmask.cuda() if zmask is not None else None), (rmask.cuda() if rmask is not None else None)
+    mean_d, invstd_d = mean.cuda(), invstd.cuda()
+    red = ops.bn_reduce_args(z_d, zmask_d, mean_d, invstd_d, part) if case["red"] else None
+    ops.conv2d_dgrad_fp8(d, dz8q.view(torch.uint8).cuda(), w8q.view(torch.uint8).cuda(), dz_scale.cuda(), w_scale.cuda(), out, red=red, res=res_d,
+                         res_mask=rmask_d)
+    got = ops.last_conv_instantiation().split(" grid")[0]
+    assert got == ops.conv2d_describe_dgrad_fp8(d, case["red"]).split(" grid")[0] and "F8=2" in got, got
+    torch.cuda.synchronize()
+    oc, rc = out.float().cpu().reshape(mo, cout), ref.reshape(mo, cout)
+    _close(oc, rc, 2 ** -7, 2e-3 * amp, "fp8 data gradient")
+    assert float((oc - rc).norm() / rc.norm()) < 3e-3
+    if case["red"]:
+        gm = oc.double()[touched]
+        if zmask is not None:
+            zb = ((zmask[:, :, None] >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(mo, cout).bool()[touched]
+            gm = torch.where(zb, gm, torch.zeros_like(gm))
+        zt = z.double()[touched]
+        sg = gm.sum(0)
+        sgz = invstd.double() * ((gm * zt).sum(0) - mean.double() * sg)
+        got_p = part.sum(0).double().cpu()
+        for name, a, b in (("sum g*m", got_p[0], sg), ("sum g*m*xhat", got_p[1], sgz)):
+            scale = float(b.abs().max()) + 1e-6
+            err = float((a - b).abs().max()) / scale
+            assert err < 2e-4, "%s: fused reduce %s off by %.3g of its scale" % (case["id"], name, err)
+
+
+def test_bn_bwd_apply_writes_the_e5m2_twin(ops):
+    g = torch.Generator().manual_seed(6)
+    m, c = 911, 128
+    dev = "cuda"
+    z = (torch.randn(m, c, generator=g) * 2 + 0.5).to(BF)
+    gout = (torch.randn(m, c, generator=g) * 1e-3).to(BF)
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(dev)
+    mean, invstd = z.float().mean(0).to(dev), (1.0 / (z.float().var(0, unbiased=False) + 1e-5).sqrt()).to(dev)
+    mask = torch.randint(0, 256, (m, c // 8), generator=g, dtype=torch.uint8).to(dev)
+    nb = ops.bn_bwd_blocks(m)
+    partial = torch.zeros(nb, 2, c, device=dev)
+    ops.bn_bwd_reduce(gout.to(dev), None, z.to(dev), mean, invstd, partial, m, c, relu_mask=mask)
+    outs = []
+    qs = torch.tensor([3.0e5], device=dev)
+    for with_f8 in (False, True):
+        dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        dz = torch.empty(m, c, dtype=BF, device=dev)
+        dz8 = torch.zeros(m, c, dtype=torch.uint8, device=dev)
+        amax = torch.zeros(ops.FP8_AMAX_SLOTS, device=dev)
+        ops.bn_bwd_apply_fused(gout.to(dev), None, z.to(dev), mean, invstd, gamma, partial, nb, dg, db, dz, None, m, c, relu_mask=mask,
+                               f8=ops.fp8_out(dz8, qs, amax) if with_f8 else None)
+        torch.cuda.synchronize()
+        outs.append(dz.clone())
+    assert torch.equal(outs[0], outs[1]), "the e5m2 twin must not change dz"
+    exp = (outs[1].float().cpu() * 3.0e5).clamp(-57344, 57344).to(E5M2).view(torch.uint8)
+    got = dz8.cpu()
+    same = (got == exp) | ((got & 0x7F) == 0) & ((exp & 0x7F) == 0)
+    assert bool(same.all()), "e5m2 twin: %d bytes differ" % int((~same).sum())
+    assert float(amax.max()) == float(outs[1].float().abs().max())
+
+
+def test_weight_quantiser_bf16_source(ops):
+    g = torch.Generator().manual_seed(8)
+    wt = (torch.randn(256, 3 * 3 * 128, generator=g) * 0.03).to(BF).cuda()
+    w8 = torch.zeros(256, 3 * 3 * 128, dtype=torch.uint8, device="cuda")
+    sc = torch.zeros(256, device="cuda")
+    table, total = ops.make_weight_quant_table([(wt, w8, sc)], "cuda")
+    ops.quantize_weights_fp8_batched(table, total)
+    torch.cuda.synchronize()
+    wc = wt.float().cpu()
+    exp_sc = wc.abs().amax(1) * torch.tensor(1.0 / 448.0, dtype=torch.float32)
+    assert torch.equal(sc.cpu(), exp_sc)
+    exp8 = (wc * (1.0 / exp_sc).view(-1, 1)).clamp(-448, 448).to(E4M3).view(torch.uint8)
+    got = w8.cpu()
+    assert bool(((got == exp8) | ((got & 0x7F) == 0) & ((exp8 & 0x7F) == 0)).all())
+
+
 def test_quantize_fp8_bit_exact_and_amax(ops):
     g = torch.Generator().manual_seed(3)
     n = 8 * 1000 + 8 * 37
@@ -100,6 +240,12 @@ def test_quantize_fp8_bit_exact_and_amax(ops):
     same = (got == exp) | ((got & 0x7F) == 0) & ((exp & 0x7F) == 0)       # (+0 / -0 both mean zero)
     assert bool(same.all()), "quantize_fp8: %d of %d bytes differ from torch's e4m3fn conversion" % (int((~same).sum()), n)
     assert float(amax.max()) == float(x.float().abs().max())
+    ops.quantize_fp8(x.cuda(), qs.cuda(), out8, None, e5m2=True)
+    torch.cuda.synchronize()
+    exp = (x.float() * qs).clamp(-57344, 57344).to(E5M2).view(torch.uint8)
+    got = out8.cpu()
+    same = (got == exp) | ((got & 0x7F) == 0) & ((exp & 0x7F) == 0)
+    assert bool(same.all()), "quantize_fp8 (e5m2): %d of %d bytes differ" % (int((~same).sum()), n)
 
 
 def test_weight_quantiser_per_row_scales(ops):

@@ -34,6 +34,11 @@ def main():
             out = torch.empty_like(z)
             mask = torch.empty(m, c // 8, dtype=torch.uint8, device="cuda")
             mean, invstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+            f8 = None
+            if os.environ.get("BN_F8"):                      # with the fp8 twin of the output (frcnn_fp8_out)
+                out8 = torch.empty(m, c, dtype=torch.uint8, device="cuda")
+                qs, amax = torch.ones(1, device="cuda"), torch.zeros(ops.FP8_AMAX_SLOTS, device="cuda")
+                f8 = ops.fp8_out(out8, qs, amax if os.environ["BN_F8"] != "noamax" else None)
             res_t = {}
             for mode in ("cold", "warm-z"):
                 ts = []
@@ -46,12 +51,12 @@ def main():
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     ops.bn_train_apply(z, stats, 16, m, gamma, beta, mm, mv, 0.99, 1.001e-5, out, mean, invstd, m, c, res=res, relu=True,
-                                       relu_mask=mask)
+                                       relu_mask=mask, f8=f8)
                     e1.record()
                     torch.cuda.synchronize()
                     ts.append(e0.elapsed_time(e1) * 1e3)
                 res_t[mode] = sorted(ts)[len(ts) // 2]
-            mb = (m * c * 2 * (3 if with_res else 2) + m * c // 8) / 1e6
+            mb = (m * c * 2 * (3 if with_res else 2) + m * c // 8 + (m * c if f8 is not None else 0)) / 1e6
             print("var %s  %-18s %6.1f MB  cold %6.1f us (%.2f TB/s)   warm-z %6.1f us (%.2f TB/s)" % (
                 var, name, mb, res_t["cold"], mb / res_t["cold"], res_t["warm-z"], mb / res_t["warm-z"]), flush=True)
 
