@@ -101,8 +101,9 @@ __device__ __forceinline__ u32x2 pack8_bf8(const float* f, const float qs) {
     return r;
 }
 // wave-wide max of non-negative floats folded into one of the FRCNN_FP8_AMAX_SLOTS slots of dst (device floats compared as their bit
-// patterns: order-preserving for x >= 0).  Slots, because atomics on ONE address serialise at the memory side (~90 per us:
-// the 4096 waves of a BatchNorm launch on one word cost ~40 us, measured; spread over 64 words they cost < 1 us).
+// patterns: order-preserving for x >= 0).  One slot per wave of a launch (8192 slots: more than the waves of any launch here),
+// because atomics on ONE address serialise (~0.1 us each: the 4096 waves of a BatchNorm launch on one word cost ~40 us, on 64
+// words still 9 us of an 18 us launch -- tools/bn_bench.py, BN_F8=1 against BN_F8=noamax).
 __device__ __forceinline__ void atomic_amax(float* dst, float v) {
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) v = fmaxf(v, __shfl_xor(v, sh));

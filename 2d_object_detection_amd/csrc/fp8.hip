@@ -71,13 +71,22 @@ __global__ __launch_bounds__(256) void quantize_weights_fp8_kernel(const long lo
     }
 }
 
-__global__ void fp8_update_scales_kernel(const float* __restrict__ amax, float* __restrict__ scale, float* __restrict__ qscale, int n, float margin) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// one workgroup per tensor: maximum over its amax slots, then the next step's scales
+__global__ __launch_bounds__(256) void fp8_update_scales_kernel(const float* __restrict__ amax, float* __restrict__ scale, float* __restrict__ qscale, int n, float margin) {
+    __shared__ float red[4];
+    const int i = blockIdx.x;
+    const f32x4* src = reinterpret_cast<const f32x4*>(amax + (long long)i * FRCNN_FP8_AMAX_SLOTS);
     float a = 0.f;
-#pragma unroll 8
-    for (int sl = 0; sl < FRCNN_FP8_AMAX_SLOTS; ++sl) a = fmaxf(a, amax[(long long)i * FRCNN_FP8_AMAX_SLOTS + sl]);
-    if (a > 0.f) {
+    for (int k = threadIdx.x; k < FRCNN_FP8_AMAX_SLOTS / 4; k += 256) {
+        const f32x4 v = src[k];
+        a = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), a);
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) a = fmaxf(a, __shfl_xor(a, sh));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    a = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0 && a > 0.f) {
         const float sc = margin * a * (1.f / 448.f);
         scale[i] = sc;
         qscale[i] = 1.f / sc;
@@ -106,7 +115,7 @@ extern "C" int frcnn_quantize_weights_fp8_batched(const int64_t* table, int n, i
 
 extern "C" int frcnn_fp8_update_scales(const float* amax, float* scale, float* qscale, int n, float margin, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(amax && scale && qscale && n > 0 && margin > 0.f, "fp8_update_scales: bad arguments");
-    hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n + 255) / 256), dim3(256), 0, S_(stream), amax, scale, qscale, n, margin);
+    hipLaunchKernelGGL(fp8_update_scales_kernel, dim3(n), dim3(256), 0, S_(stream), amax, scale, qscale, n, margin);
     FRCNN_CHECK_LAUNCH("fp8_update_scales");
     return FRCNN_OK;
 }

@@ -37,11 +37,11 @@ FP8_MARGIN = 2.0           # delayed scaling: next step's scale = margin * this 
 
 class Fp8Scales:
     """Per-tensor scales of the fp8 (e4m3) activation twins, device resident so that captured graphs follow them: rows
-    [dequantisation scale | 1 / scale] x one column per tensor, plus the amax slots of this step [tensor][64].  The amax slots are an
+    [dequantisation scale | 1 / scale] x one column per tensor, plus the amax slots of this step [tensor][8192].  The amax slots are an
     accumulation target of the step (atomic max, zeroed by the plan's fill); `update` -- once per step, after the last producer -- turns it into the NEXT
     step's scales (delayed scaling with one step of history; the first step runs on scale 1)."""
 
-    def __init__(self, device, capacity=256):
+    def __init__(self, device, capacity=128):
         self.buf = torch.zeros(2, capacity, dtype=torch.float32, device=device)             # [scale | 1 / scale]
         self.buf.fill_(1.0)
         self.amax_buf = torch.zeros(capacity, ops.FP8_AMAX_SLOTS, dtype=torch.float32, device=device)   # slots per tensor (one word would serialise the atomics)
@@ -62,7 +62,7 @@ class Fp8Scales:
         return self.buf[1, i:i + 1]
 
     def plan_zero(self, plan):
-        plan.zero(self.amax_buf)
+        plan.zero(self.amax_buf[:max(self.n, 1)])          # (called after every twin has taken its column)
 
     def plan_update(self, plan):
         if self.n:

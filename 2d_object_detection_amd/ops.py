@@ -102,7 +102,7 @@ def conv2d_fprop(d, x, w, y, bias=None, res=None, stats=None):
 
 
 # ---------------------------------------------------------------- fp8 (e4m3) convolution path
-FP8_AMAX_SLOTS = 64          # FRCNN_FP8_AMAX_SLOTS
+FP8_AMAX_SLOTS = 8192        # FRCNN_FP8_AMAX_SLOTS
 FP8 = torch.uint8            # storage type of OCP e4m3 bytes (torch.float8_e4m3fn views of these tensors are used by the tests only)
 
 

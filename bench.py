@@ -34,7 +34,7 @@ PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md
 PEAK_FP8_TFLOPS = 5000.0           # dense fp8 (block-scaled f8f6f4 MFMA at K = 128), same guide
 PEAK_HBM_GBS = 8000.0              # HBM3E spec (6.3 TB/s achievable, same guide)
 FAM_CONV = "conv fprop/dgrad (conv_tile_kernel)"
-FAM_CONV_F8 = "conv fprop fp8 (conv_tile_kernel<..., F8>)"
+FAM_CONV_F8 = "conv fprop/dgrad fp8 (conv_tile_kernel<..., F8>)"
 FAM_WGRAD = "conv wgrad (wgrad_kernel, wgrad_group_kernel)"
 
 
@@ -87,7 +87,7 @@ def classify(ops, fn, args, kwargs):
     """(family name, algorithmic FLOP, algorithmic bytes) of one plan launch."""
     if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce:
         return FAM_CONV, conv_flops(args[0], *_true_dims(args[0])), 0.0
-    if fn is ops.conv2d_fprop_fp8:
+    if fn is ops.conv2d_fprop_fp8 or fn is ops.conv2d_dgrad_fp8:
         return FAM_CONV_F8, conv_flops(args[0], *_true_dims(args[0])), 0.0
     if fn is ops.conv2d_wgrad:
         return FAM_WGRAD, conv_flops(args[0], *_true_dims(args[0])), 0.0
@@ -171,8 +171,10 @@ def profile_kernels(model, built, steps=3):
                     inst = ops.conv2d_describe(d, fn is ops.conv2d_dgrad_bnreduce)
                 if fn is ops.conv2d_fprop_fp8:
                     inst = ops.conv2d_describe_fp8(d)
+                if fn is ops.conv2d_dgrad_fp8:
+                    inst = ops.conv2d_describe_dgrad_fp8(d, kwargs.get("red") is not None)
                 fh.write("%-12s M=%7d cin=%5d cout=%5d k=%dx%d s=%d  %8.1f us %7.1f TF/s %7.0f GB/s(min traffic)  roof %6.1f us (%s) frac %.2f  %s\n" % (
-                    "wgrad" if name == FAM_WGRAD else "fprop fp8" if name == FAM_CONV_F8 else "fprop/dgrad", m, d.cin, d.cout, d.kh, d.kw, d.stride, us, fl / us / 1e6, byts / us / 1e3, roof,
+                    "wgrad" if name == FAM_WGRAD else "fp8" if name == FAM_CONV_F8 else "fprop/dgrad", m, d.cin, d.cout, d.kh, d.kw, d.stride, us, fl / us / 1e6, byts / us / 1e3, roof,
                     "mfma" if fl / pk > byts / 8e12 else "hbm", roof / us, inst))
     fam = {}
     for name, fl, by, e0, e1 in events:

@@ -143,9 +143,10 @@ int frcnn_conv2d_dgrad_fp8(const frcnn_conv_desc* d, const frcnn_fp8* dz8, const
                            const struct frcnn_bn_reduce* red, frcnn_stream_t stream);
 const char* frcnn_conv2d_describe_dgrad_fp8(const frcnn_conv_desc* d, int with_bn_reduce);
 /* Quantisers.  out8[i] = e4m3_rne(clamp(x[i] * qscale[0], -448, 448)); amax (optional, FRCNN_FP8_AMAX_SLOTS device floats,
- * pre-zeroed per step): max |x[i]| as fp32, folded with atomics into one of the slots per wave (atomics on a single word would
- * serialise) -- the maximum over the slots is the input of the delayed scaling rule below.  n a multiple of 8. */
-#define FRCNN_FP8_AMAX_SLOTS 64
+ * pre-zeroed per step): max |x[i]| as fp32, one slot per wave of the launch (slot = wave index mod FRCNN_FP8_AMAX_SLOTS; an atomic max,
+ * but practically uncontended: atomics of many waves on one word serialise at ~0.1 us each -- 64 slots still cost a BatchNorm
+ * launch 9 us, measured) -- the maximum over the slots is the input of the delayed scaling rule below.  n a multiple of 8. */
+#define FRCNN_FP8_AMAX_SLOTS 8192
 int frcnn_quantize_fp8(const frcnn_bf16* x, int64_t n, const float* qscale, frcnn_fp8* out8, float* amax, int e5m2 /* 0: e4m3, 1: e5m2 (clamp 57344) */,
                        frcnn_stream_t stream);
 /* Weights, several layers in one launch: table int64 [n][8] = {source (rows of K values, row-major), fp8 destination, float

@@ -24,8 +24,8 @@ def family(name):
     if "conv_tile_kernel" in name:
         # the last template argument is F8 (fp8 operands): conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8>
         args = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",") if "<" in name and ">" in name else []
-        if len(args) >= 12 and args[11] in ("true", "1"):
-            return "conv fprop fp8 (conv_tile_kernel<..., F8>)"
+        if len(args) >= 12 and args[11] in ("true", "1", "2"):
+            return "conv fprop/dgrad fp8 (conv_tile_kernel<..., F8>)"
         return "conv fprop/dgrad (conv_tile_kernel)"
     if "wgrad_kernel" in name or "wgrad_group_kernel" in name:
         return "conv wgrad (wgrad_kernel, wgrad_group_kernel)"
