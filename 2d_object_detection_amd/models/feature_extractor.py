@@ -32,6 +32,7 @@ def _out_hw(h, w):
     return f1(h), f1(w), f2(f1(h)), f2(f1(w))
 
 
+FP8_MIN_STAGE = int(os.environ.get("FRCNN_FP8_MIN_STAGE", "3"))      # first ResNet stage whose tensors get fp8 twins (measuring aid: 2 = all)
 FP8_MARGIN = 2.0           # delayed scaling: next step's scale = margin * this step's amax / 448 (e4m3 is a float format: head-room costs no precision)
 
 
@@ -85,12 +86,12 @@ class Fp8Twin:
 class _ConvBN:
     """One conv + BatchNorm unit (Keras names <name>_conv / <name>_bn)."""
 
-    def __init__(self, store, name, cin, cout, k, stride, pad, sync_world=1, fp8=False):
+    def __init__(self, store, name, cin, cout, k, stride, pad, sync_world=1, fp8=False, fp8_bwd=None):
         self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
-        # fp8 forward convolution (e4m3 operands, 128-deep MFMA steps): every layer whose cin is a multiple of 128
+        # fp8 forward convolution (e4m3 operands, 128-deep MFMA steps): a layer whose cin is a multiple of 128
         self.fp8 = bool(fp8) and k != 7 and cin % 128 == 0
         # fp8 data gradient (e5m2 gradient x e4m3 transposed weights): its contraction runs over this layer's OUTPUT channels
-        self.fp8_bwd = bool(fp8) and k != 7 and cout % 128 == 0
+        self.fp8_bwd = bool(fp8 if fp8_bwd is None else fp8_bwd) and k != 7 and cout % 128 == 0
         self.store = store
         self.sync_world = int(sync_world)            # > 1: BatchNorm statistics are summed over this many data-parallel ranks
         store.register(name + "_conv/kernel", (cout, k, k, cin))          # OHWI (Keras: HWIO)
@@ -314,11 +315,18 @@ class FeatureExtractor:
                 self.store.end_bucket("conv%d" % last_stage)
             last_stage = stage_of(n)
             u = {}
+            # fp8 from conv3 on.  At conv2's resolution (94 x 311) the convolutions are bound by HBM and their epilogues, not by
+            # operand fill: measured per block (375x1242, batch 4), the e4m3 twin costs the BatchNorm kernel that writes it +9 us
+            # (40 -> 49) and saves the 1x1 256 -> 64 convolution that reads it 5 us -- so conv2 stays bf16, and so do the two
+            # stride-2 convolutions of conv3_block1 that read conv2's output (they touch a quarter of its pixels).
+            stage = stage_of(n)
+            f_in = fp8 and (stage - (1 if first else 0)) >= FP8_MIN_STAGE          # units reading the block input
+            f_blk = fp8 and stage >= FP8_MIN_STAGE                                 # units reading this block's own activations
             if first:
-                u[0] = _ConvBN(self.store, n + "_0", ci, 4 * f, 1, s, 0, self.sync_bn_world, fp8)
-            u[1] = _ConvBN(self.store, n + "_1", ci, f, 1, s, 0, self.sync_bn_world, fp8)
-            u[2] = _ConvBN(self.store, n + "_2", f, f, 3, 1, 1, self.sync_bn_world, fp8)
-            u[3] = _ConvBN(self.store, n + "_3", f, 4 * f, 1, 1, 0, self.sync_bn_world, fp8)
+                u[0] = _ConvBN(self.store, n + "_0", ci, 4 * f, 1, s, 0, self.sync_bn_world, f_in, f_blk)
+            u[1] = _ConvBN(self.store, n + "_1", ci, f, 1, s, 0, self.sync_bn_world, f_in, f_blk)
+            u[2] = _ConvBN(self.store, n + "_2", f, f, 3, 1, 1, self.sync_bn_world, f_blk)
+            u[3] = _ConvBN(self.store, n + "_3", f, 4 * f, 1, 1, 0, self.sync_bn_world, f_blk)
             units[n] = u
         self.stem = _ConvBN(self.store, "conv1", 3, 64, 7, 2, 3, self.sync_bn_world)
         self.store.end_bucket("conv2+stem")
@@ -467,7 +475,7 @@ class FeatureExtractor:
                 # fp8 twins of the activations that feed fp8 convolutions: a1 -> 3x3, a2 -> 1x1 expansion, out -> the next block / RPN
                 a["a1_8"] = Fp8Twin(self.f8, (m, f), dev) if u[2].fp8 else None
                 a["a2_8"] = Fp8Twin(self.f8, (m, f), dev) if u[3].fp8 else None
-                a["out_8"] = Fp8Twin(self.f8, (m, 4 * f), dev)
+                a["out_8"] = Fp8Twin(self.f8, (m, 4 * f), dev) if u[3].fp8 or u[2].fp8 else None      # (this stage runs fp8: so do the readers of its output)
             if training:
                 a["g1"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a1
                 a["g2"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a2

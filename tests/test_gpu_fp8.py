@@ -358,7 +358,61 @@ def _small_step(precision, steps=3):
             "launches": model._train_plan["plan"].num_launches, "model": model}
 
 
-def test_fp8_train_step_deviation_from_bf16():
+def _backbone_fwd_bwd(precision):
+    """ResNet-50 backbone alone, forward + backward from a FIXED feature-map gradient (nothing discrete in between: the full step's
+    proposals and samples differ as soon as a score moves, which makes its head gradients incomparable).  Two runs: the first
+    calibrates the delayed scales."""
+    import importlib
+    FE = importlib.import_module("2d_object_detection_amd.models.feature_extractor")
+    RT = importlib.import_module("2d_object_detection_amd.runtime")
+    shape = (192, 256, 3)
+    fe = FE.FeatureExtractor(shape, depth=50, device="cuda", precision=precision)
+    g = torch.Generator().manual_seed(5)
+    for u in fe.conv_units():
+        fe.store.weight(u.name + "_bn/gamma").copy_((torch.rand(u.cout, generator=g) + 0.5) * (0.25 if u.name.endswith("_3") else 1.0))
+        fe.store.weight(u.name + "_bn/beta").copy_(torch.randn(u.cout, generator=g) * 0.1)
+    batch = 2
+    fe.setup(batch, True)
+    fe.images.copy_(torch.randint(0, 256, (batch,) + shape, generator=g, dtype=torch.uint8))
+    fe.store.refresh_bf16()
+    _, gh, gw, cf = fe.output_shape
+    g_feat = (torch.randn(batch * gh * gw, cf, generator=g) * 1e-2).to(BF).cuda()
+    plan = RT.Plan("backbone")
+    plan.zero(fe.store.g)
+    fe.refresh_weights(plan)
+    fe.forward_plan(plan, True)
+    fe.backward_plan(plan, g_feat, g_feat_reduced=False)
+    if fe.f8 is not None:
+        fe.f8.plan_update(plan)
+    for _ in range(2):
+        plan.run()
+        torch.cuda.synchronize()
+    first = fe.specs[0][0]
+    return {"feat": fe.feature_maps.float().cpu(), "gin": fe.acts[first]["gin"].float().cpu(), "g": fe.store.g.cpu().clone(),
+            "buckets": list(fe.store.buckets), "fe": fe}
+
+
+def test_fp8_backbone_deviation_from_bf16():
+    ref, f8 = _backbone_fwd_bwd("bf16"), _backbone_fwd_bwd("fp8")
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-20))
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm() + 1e-20))
+    fe = f8["fe"]
+    n_f8 = sum(1 for u in fe.conv_units() if u.fp8), sum(1 for u in fe.conv_units() if u.dz8 is not None)
+    cosines = {n: round(cos(f8["g"][b:e], ref["g"][b:e]), 4) for n, b, e in ref["buckets"]}
+    print("fp8 vs bf16 backbone (R50, 192x256, batch 2; %d fp8 forward convs, %d fp8 data gradients): feature maps rel L2 %.4f, "
+          "block-input gradient rel L2 %.4f, parameter-gradient cosine per bucket %s" % (n_f8[0], n_f8[1], rel(f8["feat"], ref["feat"]),
+                                                                                       rel(f8["gin"], ref["gin"]), cosines))
+    assert n_f8[0] >= 25 and n_f8[1] >= 25
+    sc = fe.f8.buf[0, :fe.f8.n].cpu()
+    assert bool((sc != 1.0).all()) and bool(torch.isfinite(sc).all()) and bool((sc > 0).all()), "delayed scaling did not calibrate every tensor"
+    # e4m3 / e5m2 operands: 2^-4 / 2^-3 relative per element, averaged down by the contractions; ReLU masks flip under the forward
+    # difference, which is what the gradient deviation mostly is
+    assert rel(f8["feat"], ref["feat"]) < 0.12
+    assert rel(f8["gin"], ref["gin"]) < 0.5
+    assert min(cosines.values()) > 0.85, cosines
+
+
+def test_fp8_train_step_runs_and_stays_close():
     ref = _small_step("bf16")
     f8 = _small_step("fp8")
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-20))
@@ -377,5 +431,5 @@ def test_fp8_train_step_deviation_from_bf16():
     assert e_feat < 0.25, e_feat                                      # (e4m3: ~2^-4 relative per element, partly averaged by the contraction)
     for k in ("rpn_cls", "rcnn_cls"):
         assert abs(f8["losses"][-1][k] - ref["losses"][-1][k]) < 0.1 * abs(ref["losses"][-1][k]) + 0.02
-    for n, b, e in ref["buckets"]:
-        assert cos(f8["g"][b:e], ref["g"][b:e]) > 0.5, n
+    # (no gradient comparison here: proposals and samples are discrete functions of the scores -- once one differs, the head gradients
+    # of the two runs belong to different samples; test_fp8_backbone_deviation_from_bf16 measures the backward path on a fixed gradient)
