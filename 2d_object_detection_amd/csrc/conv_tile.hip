@@ -975,6 +975,15 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
         while (tpb > 1 && ((tiles_m128 + tpb - 1) / tpb) * tn64 < 512) tpb >>= 1;
         if (tpb > 1) { bn = 64; stages = 2; }
     }
+#ifdef FRCNN_WIDE_N
+    // 256 output channels per tile for the short-K 1x1 layers that write 4x the channels they read (64 -> 256, 128 -> 512,
+    // 256 -> 1024 and the data gradients of their mirror images): a CU takes in ~37 GB/s through its load path whatever the
+    // tile, so time ~ bytes ingested + stored per CU; with all 256 columns in one workgroup the A rows are fetched once
+    // instead of 2-4 times.  One workgroup per CU (96 KB of LDS, ~150 VGPRs).
+    if (bk == 64 && p.taps == 1 && p.Ktot <= FRCNN_WIDE_N && d->cout % 256 == 0 && tiles_m128 * (d->cout / 256) >= 200) {
+        bn = 256; stages = 2; tpb = 1;
+    }
+#endif
     int force_kws = -1;
 #ifdef FRCNN_SWEEP
     if (sweep_env().bm) { bm = sweep_env().bm; bn = sweep_env().bn; bk = sweep_env().bk; stages = sweep_env().stages; tpb = sweep_env().tpb; force_kws = 0; }
@@ -1053,6 +1062,9 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
     // the instantiations the heuristics above can select
     FRCNN_RUN(128, 64, 64, 2)
     FRCNN_TILE(128, 128, 64, 2, 2)
+#ifdef FRCNN_WIDE_N
+    FRCNN_TILE(128, 256, 64, 2, 1)
+#endif
     FRCNN_TILE(128, 64, 64, 2, 3)          // (48 KB of LDS, <= 80 VGPRs: three workgroups per CU)
     FRCNN_TILE(128, 64, 64, 3, 2)
     FRCNN_TILE(128, 64, 32, 2, 2)

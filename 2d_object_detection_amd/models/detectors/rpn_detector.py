@@ -140,7 +140,8 @@ class RPNDetector:
             self.d_heads_bwd = ops.conv_desc(batch, gh, gw, HEAD_LD, 1, 1, 1, 0, 0, gh, gw, 256)
             self.d_inter_bwd = ops.conv_desc(batch, gh, gw, 256, self.ws, self.ws, 1, p, p, gh, gw, cf, flags=ops.CONV_ADD_RES)
             self._conv_ws.append(ops.conv_attach_workspace(self.d_inter_bwd, dev))
-            if self.w_inter8 is not None and f8_scales is not None:
+            from ..feature_extractor import FP8_BWD
+            if self.w_inter8 is not None and f8_scales is not None and FP8_BWD:
                 # fp8 data gradient of the 3x3 convolution: e5m2 twin of dz_f (written by a quantise pass behind the ReLU backward),
                 # e4m3 twin of the tap-flipped transposed weights, one scale per row (= per feature-map channel)
                 from ..feature_extractor import Fp8Twin

@@ -33,6 +33,7 @@ def _out_hw(h, w):
 
 
 FP8_MIN_STAGE = int(os.environ.get("FRCNN_FP8_MIN_STAGE", "3"))      # first ResNet stage whose tensors get fp8 twins (measuring aid: 2 = all)
+FP8_BWD = os.environ.get("FRCNN_FP8_BWD", "1") != "0"                # measuring aid: 0 keeps the data gradients in bf16 (fp8 forward only)
 FP8_MARGIN = 2.0           # delayed scaling: next step's scale = margin * this step's amax / 448 (e4m3 is a float format: head-room costs no precision)
 
 
@@ -89,9 +90,11 @@ class _ConvBN:
     def __init__(self, store, name, cin, cout, k, stride, pad, sync_world=1, fp8=False, fp8_bwd=None):
         self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
         # fp8 forward convolution (e4m3 operands, 128-deep MFMA steps): a layer whose cin is a multiple of 128
-        self.fp8 = bool(fp8) and k != 7 and cin % 128 == 0
+        # ... and whose contraction is at least two 128-deep steps long (a single step has no K loop to shorten: measured at
+        # 375x1242, batch 4, the 1x1 128 -> 512 layers of conv3 run 16.4 -> 15.3 us forward and 30.9 -> 35.0 us backward in fp8)
+        self.fp8 = bool(fp8) and k != 7 and cin % 128 == 0 and k * k * cin >= 256
         # fp8 data gradient (e5m2 gradient x e4m3 transposed weights): its contraction runs over this layer's OUTPUT channels
-        self.fp8_bwd = bool(fp8 if fp8_bwd is None else fp8_bwd) and k != 7 and cout % 128 == 0
+        self.fp8_bwd = FP8_BWD and bool(fp8 if fp8_bwd is None else fp8_bwd) and k != 7 and cout % 128 == 0 and k * k * cout >= 256
         self.store = store
         self.sync_world = int(sync_world)            # > 1: BatchNorm statistics are summed over this many data-parallel ranks
         store.register(name + "_conv/kernel", (cout, k, k, cin))          # OHWI (Keras: HWIO)
