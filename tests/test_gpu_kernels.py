@@ -462,6 +462,41 @@ def test_roi_crop_pool_fwd_bwd(ops):
     _close(gbf, fr.grad, 2 ** -6, 5e-2, "roi grad (gather) vs oracle")
 
 
+def test_roi_bwd_with_mostly_padding_rois(ops):
+    """Regression case of the gather-form backward: more than half of the sampled RoI rows are boxes of zero extent -- the zero
+    padding of an NMS output (all at pixel (0,0)) and degenerate boxes at fractional positions.  All ps*ps bins of such a box
+    hit the same <= 4 pixels; the kernel sums them in registers (one LDS atomic per tap) instead of ps*ps atomics on one
+    address in the one workgroup that owns the row (which made the launch time data-dependent: 48 -> 376 us in round 2)."""
+    g = torch.Generator().manual_seed(16)
+    B, P, Hf, Wf, C = 2, 64, 24, 78, 128
+    feat = _rt(torch.randn(B, Hf, Wf, C, generator=g))
+    x0, y0 = torch.rand(B, P, generator=g) * 0.7, torch.rand(B, P, generator=g) * 0.7
+    rois = torch.stack([x0, y0, x0 + torch.rand(B, P, generator=g) * 0.3 + 0.02, y0 + torch.rand(B, P, generator=g) * 0.3 + 0.02], -1)
+    rois[:, :36] = 0.0                                   # 56 % padding rows
+    rois[0, 36] = torch.tensor([0.31, 0.42, 0.31, 0.42])   # degenerate boxes off the pixel grid (4 taps) ...
+    rois[1, 37] = torch.tensor([0.5, 1.0, 0.5, 1.0])       # ... on the last feature row ...
+    rois[1, 38] = torch.tensor([1.2, 0.3, 1.2, 0.3])       # ... and outside the image (extrapolation: no gradient)
+    fr = feat.clone().requires_grad_(True)
+    exp = oroi.roi_pooling(fr, rois, 7, 2)
+    dev = "cuda"
+    pooled = torch.empty(B * P, 49 * C, dtype=BF, device=dev)
+    am = torch.empty(B * P, 49 * C, dtype=torch.uint8, device=dev)
+    ops.roi_crop_pool_fwd(feat.to(BF).to(dev), rois.to(dev), B, P, Hf, Wf, C, 7, 2, pooled, am)
+    torch.cuda.synchronize()
+    _close(pooled.view(B, P, -1), exp.detach(), 2 ** -7, 2e-2, "roi pooled")
+    rows = torch.cat([torch.arange(0, 40), torch.arange(64, 64 + 44)]).to(torch.int32)       # 40 + 44 sampled rows, 72 of them degenerate
+    gp = _rt(torch.randn(len(rows), 49 * C, generator=g))
+    gfull = torch.zeros(B * P, 49 * C)
+    gfull.index_add_(0, rows.long(), gp)
+    exp.backward(gfull.view(B, P, -1))
+    gbf = torch.full((B, Hf, Wf, C), 7.0, dtype=BF, device=dev)
+    ops.roi_crop_pool_bwd_bf16(gp.to(BF).to(dev), am, rois.to(dev), rows.to(dev), len(rows), B, P, Hf, Wf, C, 7, 2, gbf)
+    torch.cuda.synchronize()
+    # pixel (0,0) collects 36 boxes x 49 bins per image: a large sum, compared relative to its own size
+    _close(gbf, fr.grad, 2 ** -6, 2e-2 * float(fr.grad.abs().max()) / 8, "roi grad (gather) with padding rows")
+    assert float(fr.grad[0, 0, 0].abs().max()) > 20.0
+
+
 # ------------------------------------------------------------------ targets / sampling / losses
 def _targets_case(seed, B, R, rpn):
     g = torch.Generator().manual_seed(seed)
