@@ -114,6 +114,15 @@ _SIGNATURES = {
     "frcnn_losses_head_grad": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_int, P, P]),
     "frcnn_rpn_head_grad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
     "frcnn_rcnn_head_grad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P]),
+    "frcnn_upsample_add": (c_int, [P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "frcnn_upsample_add_bwd": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "frcnn_subsample2": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "frcnn_subsample2_bwd_add": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "frcnn_roi_assign_levels": (c_int, [P, c_int64, c_float, c_float, P, P]),
+    "frcnn_roi_crop_pool_fwd_level": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P]),
+    "frcnn_roi_crop_pool_bwd_bf16_level": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),
+    "frcnn_rpn_head_post_level": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_float, c_float, c_int, c_int, P]),
+    "frcnn_rpn_head_grad_level": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, P]),
     "frcnn_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, P, c_size_t]),
 }
 

@@ -52,10 +52,13 @@ __device__ __forceinline__ f32x4 decode_one(const f32x4 ref, const f32x4 d, cons
 // ---------------------------------------------------------------- RPN head post (+ optionally the decode of proposal NMS)
 __global__ void rpn_head_post_kernel(const float* __restrict__ head, int ld, int B, int A_total, int apl, const int* __restrict__ keep,
                                      int n, float* __restrict__ scores, float* __restrict__ deltas, const float* __restrict__ regions,
-                                     float* __restrict__ decoded, float W, float H) {
+                                     float* __restrict__ decoded, float W, float H, int out_stride, int out_off) {
+    // out_stride / out_off: the n rows of image b land at rows [b * out_stride + out_off, ... + n) of the outputs -- one pyramid
+    // level's window of the concatenated per-image anchor list (out_stride = n, out_off = 0: a single feature map)
     const int total = B * n;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int b = i / n, j = i - b * n;
+    for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += gridDim.x * blockDim.x) {
+        const int b = i0 / n, j = i0 - b * n;
+        const int64_t i = (int64_t)b * out_stride + out_off + j;
         const int a = keep ? keep[j] : j;
         const int loc = a / apl, k = a - loc * apl;
         const int locs = A_total / apl;
@@ -626,8 +629,20 @@ extern "C" int frcnn_rpn_head_post_decode(const float* head, int ld, int b, int 
     FRCNN_CHECK_ARG(head && scores && deltas && ld >= 6 * a_per_loc && num_anchors_total % a_per_loc == 0 && n > 0, "rpn_head_post: bad arguments");
     FRCNN_CHECK_ARG(!decoded || regions, "rpn_head_post_decode: decoded boxes need the regions");
     hipLaunchKernelGGL(rpn_head_post_kernel, dim3(cdiv((int64_t)b * n, 256)), dim3(256), 0, S_(stream), head, ld, b, num_anchors_total,
-                       a_per_loc, keep, n, scores, deltas, regions, decoded, img_w, img_h);
+                       a_per_loc, keep, n, scores, deltas, regions, decoded, img_w, img_h, n, 0);
     FRCNN_CHECK_LAUNCH("rpn_head_post");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_rpn_head_post_level(const float* head, int ld, int b, int num_anchors_level, int a_per_loc, const int32_t* keep, int n,
+                                         float* scores, float* deltas, const float* regions, float* decoded, float img_w, float img_h,
+                                         int n_total, int offset, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(head && scores && deltas && ld >= 6 * a_per_loc && num_anchors_level % a_per_loc == 0 && n > 0 && offset >= 0 && offset + n <= n_total,
+                    "rpn_head_post_level: bad arguments");
+    FRCNN_CHECK_ARG(!decoded || regions, "rpn_head_post_level: decoded boxes need the regions");
+    hipLaunchKernelGGL(rpn_head_post_kernel, dim3(cdiv((int64_t)b * n, 256)), dim3(256), 0, S_(stream), head, ld, b, num_anchors_level, a_per_loc, keep,
+                       n, scores, deltas, regions, decoded, img_w, img_h, n_total, offset);
+    FRCNN_CHECK_LAUNCH("rpn_head_post_level");
     return FRCNN_OK;
 }
 

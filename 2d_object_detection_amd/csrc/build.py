@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, "lib2dod_hip.so")
-SOURCES = ["elementwise.hip", "conv_tile.hip", "conv_wgrad.hip", "boxes_nms.hip", "roi.hip", "targets_losses.hip", "host_io.hip", "fp8.hip"]
+SOURCES = ["elementwise.hip", "conv_tile.hip", "conv_wgrad.hip", "boxes_nms.hip", "roi.hip", "targets_losses.hip", "host_io.hip", "fp8.hip", "fpn.hip"]
 HEADERS = ["common.h", "conv_common.h", os.path.join("..", "..", "include", "frcnn_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-DFRCNN_BUILD"]
 # kernel-development variants live in their own library file and object directory (FRCNN_LIB selects it at load time):

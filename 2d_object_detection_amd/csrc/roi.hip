@@ -38,7 +38,7 @@ constexpr int kMaxCrop = 64;
 template <int KS>
 __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ rois, int P, int Hf, int Wf,
                                                       int C8, int ps, int ks_rt, bf16_t* __restrict__ pooled, uint8_t* __restrict__ amax, int nsplit,
-                                                      int npairs) {
+                                                      int npairs, const int* __restrict__ levels, int level) {
     const int ks = KS > 0 ? KS : ks_rt;
     // workgroup -> (RoI, channel slice).  Workgroups b, b + 8, ... share an XCD (one L2 of 4 MiB): the grid is laid out so that an XCD
     // only ever sees ONE (image, channel slice) pair -- 1/8 of all feature maps, 1.9 MB at batch 4 -- instead of every XCD pulling all
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__
     }
     const int b = row / P;
     const int crop = ps * ks;
+    if (levels && levels[row] != level) return;                // feature pyramid: this launch pools another level's RoIs
     __shared__ int4 ys[kMaxCrop], xs[kMaxCrop];               // {first tap byte offset, second tap byte offset, weight bits, valid}
     if ((int)threadIdx.x < 2 * crop) {
         const RoiGeom g = roi_geom(rois + (int64_t)row * 4, Hf, Wf, crop);
@@ -211,7 +212,8 @@ __global__ __launch_bounds__(256) void roi_bwd_kernel(const bf16_t* __restrict__
 template <int CS>
 __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(const bf16_t* __restrict__ gpooled, const uint8_t* __restrict__ amax,
                                                            const float* __restrict__ rois, const int* __restrict__ rows, int nrows, int P,
-                                                           int Hf, int Wf, int C, int ps, int ks, bf16_t* __restrict__ gfeat) {
+                                                           int Hf, int Wf, int C, int ps, int ks, bf16_t* __restrict__ gfeat,
+                                                           const int* __restrict__ levels, int level) {
     extern __shared__ __attribute__((aligned(16))) float racc[];              // [Wf][CS]
     constexpr int LANES = CS / 2, GROUPS = 256 / LANES;                        // channel pairs per slab, RoI rows in flight
     const int slabs = C / CS;
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(const bf16_t* __restr
     for (int r = grp; r < nrows; r += GROUPS) {
         const int row = rows[r];
         if (row / P != b) continue;                                           // (uniform per group)
+        if (levels && levels[row] != level) continue;                         // feature pyramid: pooled from another level
         const RoiGeom g = roi_geom(rois + (int64_t)row * 4, Hf, Wf, crop);
         if (g.hs == 0.f && g.ws == 0.f) {
             // a box of zero extent (the zero padding of an NMS output with fewer detections than slots: all four coordinates
@@ -314,8 +317,8 @@ __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(const bf16_t* __restr
 
 }  // namespace
 
-extern "C" int frcnn_roi_crop_pool_fwd(const frcnn_bf16* feat, const float* rois, int b, int p, int hf, int wf, int c, int ps, int ks,
-                                       frcnn_bf16* pooled, uint8_t* argmax, frcnn_stream_t stream) {
+static int roi_fwd_impl(const frcnn_bf16* feat, const float* rois, int b, int p, int hf, int wf, int c, int ps, int ks,
+                        frcnn_bf16* pooled, uint8_t* argmax, const int32_t* levels, int level, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(feat && rois && pooled && argmax, "roi_crop_pool_fwd: null pointer");
     FRCNN_CHECK_ARG(b > 0 && p > 0 && c % 8 == 0 && ps >= 1 && ks >= 1 && ps * ks >= 2 && ks * ks <= 255 && hf > 1 && wf > 1,
                     "roi_crop_pool_fwd: bad sizes");
@@ -327,12 +330,23 @@ extern "C" int frcnn_roi_crop_pool_fwd(const frcnn_bf16* feat, const float* rois
     const dim3 grid((unsigned)(lanes_x * per_lane * p));
     if (ks == 2)
         hipLaunchKernelGGL(roi_fwd_kernel<2>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           reinterpret_cast<const bf16_t*>(feat), rois, p, hf, wf, c / 8, ps, ks, reinterpret_cast<bf16_t*>(pooled), argmax, nsplit, pairs);
+                           reinterpret_cast<const bf16_t*>(feat), rois, p, hf, wf, c / 8, ps, ks, reinterpret_cast<bf16_t*>(pooled), argmax, nsplit, pairs, levels, level);
     else
         hipLaunchKernelGGL(roi_fwd_kernel<0>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           reinterpret_cast<const bf16_t*>(feat), rois, p, hf, wf, c / 8, ps, ks, reinterpret_cast<bf16_t*>(pooled), argmax, nsplit, pairs);
+                           reinterpret_cast<const bf16_t*>(feat), rois, p, hf, wf, c / 8, ps, ks, reinterpret_cast<bf16_t*>(pooled), argmax, nsplit, pairs, levels, level);
     FRCNN_CHECK_LAUNCH("roi_crop_pool_fwd");
     return FRCNN_OK;
+}
+
+extern "C" int frcnn_roi_crop_pool_fwd(const frcnn_bf16* feat, const float* rois, int b, int p, int hf, int wf, int c, int ps, int ks,
+                                       frcnn_bf16* pooled, uint8_t* argmax, frcnn_stream_t stream) {
+    return roi_fwd_impl(feat, rois, b, p, hf, wf, c, ps, ks, pooled, argmax, nullptr, 0, stream);
+}
+
+extern "C" int frcnn_roi_crop_pool_fwd_level(const frcnn_bf16* feat, const float* rois, int b, int p, int hf, int wf, int c, int ps, int ks,
+                                             frcnn_bf16* pooled, uint8_t* argmax, const int32_t* levels, int level, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(levels, "roi_crop_pool_fwd_level: null level table");
+    return roi_fwd_impl(feat, rois, b, p, hf, wf, c, ps, ks, pooled, argmax, levels, level, stream);
 }
 
 extern "C" int frcnn_roi_crop_pool_bwd(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows, int nrows,
@@ -344,9 +358,9 @@ extern "C" int frcnn_roi_crop_pool_bwd(const frcnn_bf16* gpooled, const uint8_t*
     return FRCNN_OK;
 }
 
-extern "C" int frcnn_roi_crop_pool_bwd_bf16(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,
-                                            int nrows, int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat,
-                                            frcnn_stream_t stream) {
+static int roi_bwd_bf16_impl(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,
+                             int nrows, int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat, const int32_t* levels, int level,
+                             frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(gpooled && argmax && rois && rows && gfeat && nrows > 0 && b > 0, "roi_crop_pool_bwd_bf16: bad arguments");
     FRCNN_CHECK_ARG(c % 64 == 0 && ps >= 1 && ks >= 1 && ks * ks <= 255 && hf > 1 && wf > 1, "roi_crop_pool_bwd_bf16: bad sizes");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -354,7 +368,20 @@ extern "C" int frcnn_roi_crop_pool_bwd_bf16(const frcnn_bf16* gpooled, const uin
     const size_t smem = (size_t)wf * 64 * 4;
     FRCNN_CHECK_ARG(smem <= 64 * 1024, "roi_crop_pool_bwd_bf16: feature map too wide (wf=%d)", wf);
     hipLaunchKernelGGL(roi_bwd_rows_kernel<64>, dim3(b * hf * (c / 64)), dim3(256), smem, s, reinterpret_cast<const bf16_t*>(gpooled),
-                       argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat));
+                       argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat), levels, level);
     FRCNN_CHECK_LAUNCH("roi_crop_pool_bwd_bf16");
     return FRCNN_OK;
+}
+
+extern "C" int frcnn_roi_crop_pool_bwd_bf16(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,
+                                            int nrows, int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat,
+                                            frcnn_stream_t stream) {
+    return roi_bwd_bf16_impl(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, ps, ks, gfeat, nullptr, 0, stream);
+}
+
+extern "C" int frcnn_roi_crop_pool_bwd_bf16_level(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,
+                                                  int nrows, int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat,
+                                                  const int32_t* levels, int level, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(levels, "roi_crop_pool_bwd_bf16_level: null level table");
+    return roi_bwd_bf16_impl(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, ps, ks, gfeat, levels, level, stream);
 }

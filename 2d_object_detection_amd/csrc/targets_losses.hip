@@ -413,11 +413,16 @@ static void launch_losses(const LossParams& p, hipStream_t stream) {
 
 // RPN: scatter-add per-sample gradients into the dense fp32 head-gradient matrix
 __global__ void rpn_head_grad_kernel(const float* __restrict__ dlog, const float* __restrict__ ddel, const int* __restrict__ idx,
-                                     const int* __restrict__ keep, int B, int S, int locs, int apl, float* __restrict__ dhead, int ld) {
+                                     const int* __restrict__ keep, int B, int S, int locs, int apl, float* __restrict__ dhead, int ld, int win_off,
+                                     int win_n) {
+    // win_off / win_n: only the samples whose index lies in [win_off, win_off + win_n) belong to this head (one pyramid level's
+    // window of the concatenated anchor list); 0 / INT_MAX: a single feature map
     const int total = B * S;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int b = i / S;
-        const int j = idx[i];
+        int j = idx[i];
+        if (j < win_off || j - win_off >= win_n) continue;
+        j -= win_off;
         const int a = keep ? keep[j] : j;
         const int loc = a / apl, k = a - loc * apl;
         float* row = dhead + ((int64_t)b * locs + loc) * ld;
@@ -546,8 +551,17 @@ extern "C" int frcnn_rpn_head_grad(const float* dlogits_s, const float* ddeltas_
                                    int num_anchors_total, int a_per_loc, float* dhead, int ld, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(dlogits_s && ddeltas_s && indices && dhead && ld >= 6 * a_per_loc, "rpn_head_grad: bad arguments");
     hipLaunchKernelGGL(rpn_head_grad_kernel, dim3(cdiv((int64_t)b * s, 256)), dim3(256), 0, S_(stream), dlogits_s, ddeltas_s, indices, keep,
-                       b, s, num_anchors_total / a_per_loc, a_per_loc, dhead, ld);
+                       b, s, num_anchors_total / a_per_loc, a_per_loc, dhead, ld, 0, 0x7FFFFFFF);
     FRCNN_CHECK_LAUNCH("rpn_head_grad");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_rpn_head_grad_level(const float* dlogits_s, const float* ddeltas_s, const int32_t* indices, const int32_t* keep, int b, int s,
+                                         int num_anchors_level, int a_per_loc, float* dhead, int ld, int offset, int n, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(dlogits_s && ddeltas_s && indices && dhead && ld >= 6 * a_per_loc && offset >= 0 && n > 0, "rpn_head_grad_level: bad arguments");
+    hipLaunchKernelGGL(rpn_head_grad_kernel, dim3(cdiv((int64_t)b * s, 256)), dim3(256), 0, S_(stream), dlogits_s, ddeltas_s, indices, keep,
+                       b, s, num_anchors_level / a_per_loc, a_per_loc, dhead, ld, offset, n);
+    FRCNN_CHECK_LAUNCH("rpn_head_grad_level");
     return FRCNN_OK;
 }
 

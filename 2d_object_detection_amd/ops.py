@@ -416,6 +416,46 @@ def roi_crop_pool_bwd_bf16(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, 
     call("frcnn_roi_crop_pool_bwd_bf16", _p(gpooled), _p(argmax), _p(rois), _p(rows), nrows, b, p, hf, wf, c, ps, ks, _p(gfeat), _stream())
 
 
+# ---------------------------------------------------------------- feature pyramid (BASELINE.json configs[4])
+def upsample_add(top, ht, wt, lat, out, b, h, w, c):
+    call("frcnn_upsample_add", _p(top), ht, wt, _p(lat), _p(out), b, h, w, c, _stream())
+
+
+def upsample_add_bwd(g, h, w, gtop, b, ht, wt, c, accumulate=True):
+    call("frcnn_upsample_add_bwd", _p(g), h, w, _p(gtop), b, ht, wt, c, 1 if accumulate else 0, _stream())
+
+
+def subsample2(x, y, b, h, w, c):
+    call("frcnn_subsample2", _p(x), _p(y), b, h, w, c, _stream())
+
+
+def subsample2_bwd_add(gy, gx, b, h, w, c):
+    call("frcnn_subsample2_bwd_add", _p(gy), _p(gx), b, h, w, c, _stream())
+
+
+def roi_assign_levels(rois_rel, img_w, img_h, levels):
+    call("frcnn_roi_assign_levels", _p(rois_rel), rois_rel.numel() // 4, float(img_w), float(img_h), _p(levels), _stream())
+
+
+def roi_crop_pool_fwd_level(feat, rois, b, p, hf, wf, c, ps, ks, pooled, argmax, levels, level):
+    call("frcnn_roi_crop_pool_fwd_level", _p(feat), _p(rois), b, p, hf, wf, c, ps, ks, _p(pooled), _p(argmax), _p(levels), level, _stream())
+
+
+def roi_crop_pool_bwd_bf16_level(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, ps, ks, gfeat, levels, level):
+    call("frcnn_roi_crop_pool_bwd_bf16_level", _p(gpooled), _p(argmax), _p(rois), _p(rows), nrows, b, p, hf, wf, c, ps, ks, _p(gfeat), _p(levels),
+         level, _stream())
+
+
+def rpn_head_post_level(head, ld, b, num_anchors_level, a_per_loc, keep, n, scores, deltas, regions, decoded, img_w, img_h, n_total, offset):
+    call("frcnn_rpn_head_post_level", _p(head), ld, b, num_anchors_level, a_per_loc, _p(keep), n, _p(scores), _p(deltas), _p(regions), _p(decoded),
+         float(img_w), float(img_h), n_total, offset, _stream())
+
+
+def rpn_head_grad_level(dlogits_s, ddeltas_s, indices, keep, b, s, num_anchors_level, a_per_loc, dhead, ld, offset, n):
+    call("frcnn_rpn_head_grad_level", _p(dlogits_s), _p(ddeltas_s), _p(indices), _p(keep), b, s, num_anchors_level, a_per_loc, _p(dhead), ld, offset,
+         n, _stream())
+
+
 def rcnn_head_post(logits, ld, bias, r, nc1, scores, deltas):
     call("frcnn_rcnn_head_post", _p(logits), ld, _p(bias), r, nc1, _p(scores), _p(deltas), _stream())
 

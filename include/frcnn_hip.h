@@ -373,6 +373,36 @@ int frcnn_rcnn_head_post(const float* logits, int ld, const float* bias, int r, 
 /* rois_abs = rois_rel * [W,H,W,H]  (utils/boxes.py:76-83, fast_rcnn_detector.py:67) */
 int frcnn_boxes_scale(const float* in, float* out, int64_t n, float sx, float sy, frcnn_stream_t stream);
 
+/* ------------------------------------------------------------------ feature pyramid (BASELINE.json configs[4]) */
+/* The reference has no FPN (models/faster_rcnn.py:25-34 wires one conv4 map); these restate Lin et al., "Feature Pyramid Networks for
+ * Object Detection", CVPR 2017 (oracle/fpn.py).  The neck's convolutions are frcnn_conv2d_* launches.
+ * sec. 3, top-down merge: out[b,y,x,:] = lat[b,y,x,:] + top[b, (y*ht)/h, (x*wt)/w, :]   (nearest-neighbour upsampling; out may alias lat)
+ * and its gradient w.r.t. top: gtop[b,ys,xs,:] = (accumulate ? gtop : 0) + sum of g over the fine pixels that read (ys, xs). */
+int frcnn_upsample_add(const frcnn_bf16* top, int ht, int wt, const frcnn_bf16* lat, frcnn_bf16* out, int b, int h, int w, int c,
+                       frcnn_stream_t stream);
+int frcnn_upsample_add_bwd(const frcnn_bf16* g, int h, int w, frcnn_bf16* gtop, int b, int ht, int wt, int c, int accumulate,
+                           frcnn_stream_t stream);
+/* sec. 4.1, the extra RPN level: y[b,i,j,:] = x[b,2i,2j,:] (y is [b, ceil(h/2), ceil(w/2), c]); backward: gx[b,2i,2j,:] += gy[b,i,j,:]. */
+int frcnn_subsample2(const frcnn_bf16* x, frcnn_bf16* y, int b, int h, int w, int c, frcnn_stream_t stream);
+int frcnn_subsample2_bwd_add(const frcnn_bf16* gy, frcnn_bf16* gx, int b, int h, int w, int c, frcnn_stream_t stream);
+/* sec. 4.2, eq. (1): level of an RoI, k = floor(4 + log2(sqrt(w h) / 224)) clamped to [2, 4], evaluated as
+ * 2 + [w h >= 112^2] + [w h >= 224^2] (w, h in input pixels from the relative box [x1,y1,x2,y2]); levels int32 [n]. */
+int frcnn_roi_assign_levels(const float* rois_rel, int64_t n, float img_w, float img_h, int32_t* levels, frcnn_stream_t stream);
+/* frcnn_roi_crop_pool_fwd / _bwd_bf16 restricted to the RoIs whose level equals `level` (rows of other levels are neither read nor
+ * written by the forward launch; the backward launch writes the complete gradient of THIS level's map from this level's rows). */
+int frcnn_roi_crop_pool_fwd_level(const frcnn_bf16* feat, const float* rois, int b, int p, int hf, int wf, int c, int ps, int ks,
+                                  frcnn_bf16* pooled, uint8_t* argmax, const int32_t* levels, int level, frcnn_stream_t stream);
+int frcnn_roi_crop_pool_bwd_bf16_level(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows, int nrows,
+                                       int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat, const int32_t* levels,
+                                       int level, frcnn_stream_t stream);
+/* frcnn_rpn_head_post_decode / frcnn_rpn_head_grad for ONE level of a pyramid whose anchors are concatenated per image: the level's n
+ * kept anchors occupy rows [offset, offset + n) of the n_total rows of an image (regions: this level's [n,4] slice). */
+int frcnn_rpn_head_post_level(const float* head, int ld, int b, int num_anchors_level, int a_per_loc, const int32_t* keep, int n,
+                              float* scores, float* deltas, const float* regions, float* decoded, float img_w, float img_h, int n_total,
+                              int offset, frcnn_stream_t stream);
+int frcnn_rpn_head_grad_level(const float* dlogits_s, const float* ddeltas_s, const int32_t* indices, const int32_t* keep, int b, int s,
+                              int num_anchors_level, int a_per_loc, float* dhead, int ld, int offset, int n, frcnn_stream_t stream);
+
 /* ------------------------------------------------------------------ targets / sampling / losses */
 
 /* utils/training.py:7-77 (+ rpn_detector.py:141 objectness conversion when objectness != 0).
