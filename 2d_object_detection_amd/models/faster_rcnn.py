@@ -20,6 +20,8 @@ from ..utils.post_processing import NmsBuffers, postprocess_plan
 from .detectors.fast_rcnn_detector import FastRCNNDetector
 from .detectors.rpn_detector import RPNDetector
 from .feature_extractor import FeatureExtractor, get_feature_extractor_model
+from .fpn import LEVELS as FPN_LEVELS
+from .fpn import FastRCNNDetectorFPN, FPNNeck, RPNDetectorFPN
 
 BF16 = torch.bfloat16
 LOSS_NAMES = ("rpn_cls", "rpn_reg", "rcnn_cls", "rcnn_reg")
@@ -28,15 +30,25 @@ LOSS_NAMES = ("rpn_cls", "rpn_reg", "rcnn_cls", "rcnn_reg")
 class _Modules:
     """One set of module instances (= one set of activation buffers) attached to the shared store."""
 
-    def __init__(self, config, depth, store, device, first, sync_bn_world=1, precision="bf16"):
+    def __init__(self, config, depth, store, device, first, sync_bn_world=1, precision="bf16", topology="c4"):
         image_shape = config["image_shape"]
         # registration order = gradient-bucket order: regularised kernels, head biases, then backbone
         fe_shape = _feature_shape(image_shape, depth)
-        self.rcnn = FastRCNNDetector(image_shape, config["num_classes"], config["rcnn"], feature_channels=fe_shape[3], store=store,
-                                     device=device)
-        self.rpn = RPNDetector(image_shape, fe_shape, config["rpn"], store=store, device=device, precision=precision)
+        self.neck = None
+        if topology == "fpn":
+            # feature pyramid over C2..C4 (models/fpn.py; BASELINE.json configs[4]): heads and RPN read 256-channel pyramid levels
+            grids = _stage_grids(image_shape)
+            self.rcnn = FastRCNNDetectorFPN(image_shape, config["num_classes"], config["rcnn"], grids, store=store, device=device)
+            self.rpn = RPNDetectorFPN(image_shape, grids, config["rpn"], store=store, device=device)
+            self.neck = FPNNeck(store, {2: 256, 3: 512, 4: 1024}, float(config["rpn"]["weight_decay"]), device)
+        else:
+            self.rcnn = FastRCNNDetector(image_shape, config["num_classes"], config["rcnn"], feature_channels=fe_shape[3], store=store,
+                                         device=device)
+            self.rpn = RPNDetector(image_shape, fe_shape, config["rpn"], store=store, device=device, precision=precision)
         self.rcnn.register_biases()
         self.rpn.register_biases()
+        if self.neck is not None:
+            self.neck.register_biases()
         store.end_bucket("heads")
         self.fe = get_feature_extractor_model(image_shape, depth=depth, store=store, device=device, sync_bn_world=sync_bn_world,
                                               precision=precision)
@@ -51,9 +63,21 @@ def _feature_shape(image_shape, depth):
     return (None, f3(f3(f2(f1(h)))), f3(f3(f2(f1(w)))), 1024)
 
 
+def _stage_grids(image_shape):
+    """(h, w) of the backbone stage outputs C2, C3, C4 and of the subsampled pyramid level 5."""
+    h, w = image_shape[0], image_shape[1]
+    f1 = lambda n: (n + 6 - 7) // 2 + 1
+    f2 = lambda n: (n + 2 - 3) // 2 + 1
+    f3 = lambda n: (n - 1) // 2 + 1
+    g2 = (f2(f1(h)), f2(f1(w)))
+    g3 = (f3(g2[0]), f3(g2[1]))
+    g4 = (f3(g3[0]), f3(g3[1]))
+    return {2: g2, 3: g3, 4: g4, 5: ((g4[0] + 1) // 2, (g4[1] + 1) // 2)}
+
+
 class FasterRCNN:
     def __init__(self, config, name="faster_rcnn", depth=50, device="cuda", seed=0, sampling_seed=0, world_size=1, sync_bn=False,
-                 sampling_image_base=0, precision="bf16"):
+                 sampling_image_base=0, precision="bf16", topology="c4"):
         """reference faster_rcnn.py:11-37.  `config`: dict with the reference's config.json schema.
         world_size: data-parallel ranks (classification losses are means over the GLOBAL batch).  sync_bn: BatchNorm batch
         statistics and their backward sums are all-reduced over the ranks, so world_size x b images behave like the reference's
@@ -75,8 +99,12 @@ class FasterRCNN:
         # precision "fp8" (BASELINE.json configs[4]): the training step's forward convolutions with cin % 128 == 0 (backbone from
         # conv2_block2 on, RPN 3x3) multiply e4m3 operands on the fp8 MFMA path; everything else as in "bf16"
         self.precision = precision
+        # topology "fpn" (BASELINE.json configs[4]): feature pyramid over C2..C4, RPN on P2..P5 with shared weights, RoI heads on
+        # the level of each proposal (models/fpn.py, oracle/fpn.py); "c4": the reference's single conv4 map
+        assert topology in ("c4", "fpn")
+        self.topology = topology
         self.store = ParamStore(self.device)
-        self._train = _Modules(config, depth, self.store, self.device, True, self.world_size if self.sync_bn else 1, precision)
+        self._train = _Modules(config, depth, self.store, self.device, True, self.world_size if self.sync_bn else 1, precision, topology)
         self.store.finalize()
         self._eval = None
         self.feature_extractor, self.rpn_detector, self.rcnn_detector = self._train.fe, self._train.rpn, self._train.rcnn
@@ -93,6 +121,8 @@ class FasterRCNN:
         self.feature_extractor.init_weights(seed)
         self.rpn_detector.init_weights(seed + 1)
         self.rcnn_detector.init_weights(seed + 2)
+        if self._train.neck is not None:
+            self._train.neck.init_weights(seed + 3)
         self._weights_dirty = True
 
     def set_weights(self, weights):
@@ -100,12 +130,16 @@ class FasterRCNN:
         self.feature_extractor.set_weights(weights)
         self.rpn_detector.set_weights(weights)
         self.rcnn_detector.set_weights(weights)
+        if self._train.neck is not None:
+            self._train.neck.set_weights(weights)
         self._weights_dirty = True
 
     def get_weights(self):
         out = {}
         for m in (self.feature_extractor, self.rpn_detector, self.rcnn_detector):
             out.update(m.get_weights())
+        if self._train.neck is not None:
+            out.update(self._train.neck.get_weights())
         return out
 
     def save_weights(self, path):
@@ -126,10 +160,14 @@ class FasterRCNN:
         mods.fe.refresh_weights(p)
         mods.rpn.refresh_weights(p)
         mods.rcnn.refresh_weights(p)
+        if mods.neck is not None:
+            mods.neck.refresh_weights(p)
         p.run()
 
     # ------------------------------------------------------------------ plan builders
     def _build(self, mods, batch, training, optimizer):
+        if self.topology == "fpn":
+            return self._build_fpn(mods, batch, training, optimizer)
         cfg = self.config
         dev = self.device
         H, W = self._image_shape[0], self._image_shape[1]
@@ -266,6 +304,96 @@ class FasterRCNN:
         aux = {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn, "nms_rcnn": nms_rcnn, "targets": t, "feature_maps": feat}
         return {"plan": plan, "io": io, "losses": losses, "preds": preds, "aux": aux, "batch": batch}
 
+    def _build_fpn(self, mods, batch, training, optimizer):
+        """The step of _build on the feature pyramid (models/fpn.py): backbone -> neck -> RPN on P2..P5 -> ONE proposal NMS ->
+        per-level RoI pooling -> heads; backward through heads, RPN and neck into the backbone at C4, C3 and C2.  Everything on
+        the main stream (the side-stream branches of the C4 plan are a tuning step this topology has not had yet)."""
+        cfg, dev = self.config, self.device
+        H, W = self._image_shape[0], self._image_shape[1]
+        nc1 = cfg["num_classes"] + 1
+        plan = Plan("train_step_fpn" if training else "test_step_fpn")
+        io = {"images": mods.fe.setup(batch, training)}
+        G = 100
+        io["gt_labels"] = torch.zeros(batch, G, nc1, device=dev)
+        io["gt_boxes"] = torch.zeros(batch, G, 4, device=dev)
+        fe, neck, rpn, rcnn = mods.fe, mods.neck, mods.rpn, mods.rcnn
+        last = {2: "conv2_block3", 3: "conv3_block4", 4: fe.specs[-1][0]}
+        grids = {l: (fe.units[last[l]][1].ho, fe.units[last[l]][1].wo) for l in FPN_LEVELS}
+        neck.setup(batch, grids, training)
+        rpn.setup(batch, training)
+        P = int(self._rpn_config["nms"]["max_total_size"])
+        rs, cs = self._rpn_config["sampling"], self._rcnn_config["sampling"]
+        S_rpn, S_rcnn = int(rs["num_samples"]), int(cs["num_samples"])
+        rcnn.setup(batch, P, training, S_rcnn)
+        step = optimizer.iterations if training else self._eval_step
+        n = rpn.n
+        f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+        t = {"rpn_tl": torch.empty(batch, n, 2, **f32), "rpn_tb": torch.empty(batch, n, 1, 4, **f32),
+             "rpn_idx": torch.empty(batch, S_rpn, **i32), "rpn_ws": torch.empty(batch, 2 * n, **i32),
+             "rcnn_tl": torch.empty(batch, P, nc1, **f32), "rcnn_tb": torch.empty(batch, P, nc1 - 1, 4, **f32),
+             "rcnn_idx": torch.empty(batch, S_rcnn, **i32), "rcnn_ws": torch.empty(batch, 2 * P, **i32)}
+        losses = torch.zeros(4, **f32)
+        if training:
+            t["rpn_dl"], t["rpn_dd"] = torch.empty(batch, S_rpn, 2, **f32), torch.empty(batch, S_rpn, 1, 4, **f32)
+            t["rcnn_dl"], t["rcnn_dd"] = torch.empty(batch, S_rcnn, nc1, **f32), torch.empty(batch, S_rcnn, nc1 - 1, 4, **f32)
+        plan.hold(t)
+        cls_scale = 1.0 / self.world_size
+        if training:
+            plan.zero(self.store.g)
+            table, total = ops.make_transpose_flip_table(fe.flip_entries() + neck.flip_entries() + rpn.flip_entries() + rcnn.flip_entries(), dev)
+            plan.hold(table)
+            plan.add(ops.weights_transpose_flip_batched, table, total)
+        fe.forward_plan(plan, training)
+        stage_maps = {l: fe.acts[last[l]]["out"] for l in FPN_LEVELS}
+        pyramid = neck.forward_plan(plan, stage_maps)
+        nms_cfg = self._rpn_config["nms"]
+        rpn_nms = NmsBuffers(batch, n, 1, nms_cfg["max_output_size_per_class"], nms_cfg["max_total_size"], dev)
+        rpn_out = rpn.forward_plan(plan, pyramid, training, decoded=rpn_nms.decoded)
+        plan.add(ops.assign_targets, rpn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
+                 rs["foreground_iou_interval"], rs["background_iou_interval"], t["rpn_tl"], t["rpn_tb"])
+        plan.add(ops.sample_indices, t["rpn_tl"], batch, n, 2, S_rpn, rs["foreground_proportion"], self.sampling_seed, step, 0,
+                 t["rpn_idx"], t["rpn_ws"], self.status, image_base=self.sampling_image_base)
+        plan.add(ops.losses, rpn_out["pred_scores"], rpn_out["pred_boxes"], t["rpn_tl"], t["rpn_tb"], t["rpn_idx"], batch, n, 2, S_rpn, cls_scale,
+                 1.0, losses[0:2], t.get("rpn_dl"), t.get("rpn_dd"))
+        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"], buffers=rpn_nms, decoded_done=True)
+        rois = nms_rpn["pred_boxes"]
+        regions_abs = rcnn.regions_plan(plan, rois)
+        plan.add(ops.assign_targets, regions_abs, io["gt_labels"], io["gt_boxes"], batch, P, G, nc1, False, W, H,
+                 cs["foreground_iou_interval"], cs["background_iou_interval"], t["rcnn_tl"], t["rcnn_tb"])
+        plan.add(ops.sample_indices, t["rcnn_tl"], batch, P, nc1, S_rcnn, cs["foreground_proportion"], self.sampling_seed, step, 2,
+                 t["rcnn_idx"], t["rcnn_ws"], self.status, image_base=self.sampling_image_base)
+        rcnn_out = rcnn.forward_plan(plan, pyramid, rois, regions_done=True)
+        if training:
+            plan.add(ops.losses_head_grad, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"],
+                     batch, P, nc1, S_rcnn, cls_scale, 1.0, losses[2:4], t["rcnn_dl"], t["rcnn_dd"], *rcnn.head_grad_rows())
+        else:
+            plan.add(ops.losses, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"], batch, P, nc1,
+                     S_rcnn, cls_scale, 1.0, losses[2:4], None, None)
+        nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
+        if training:
+            rcnn.backward_plan(plan, rois, neck.gp)                                  # gp[2..4]: complete RoI-branch gradients
+            rpn.backward_plan(plan, t["rpn_dl"], t["rpn_dd"], t["rpn_idx"], S_rpn, pyramid, neck.gp, {2: True, 3: True, 4: True, 5: False})
+            _, gh, gw, cf = fe.output_shape
+            g_feat = torch.empty(batch * gh * gw, cf, dtype=BF16, device=dev)
+            plan.hold(g_feat)
+            t["g_feat"] = g_feat
+            first_of = {3: "conv3_block1", 4: "conv4_block1"}
+            targets = {4: g_feat, 3: fe.acts[first_of[4]]["gin"], 2: fe.acts[first_of[3]]["gin"]}
+            red4 = fe.last_unit().reduce_args(relu=True)
+            plan.hold(red4)
+            neck.backward_plan(plan, stage_maps, targets, red4=red4)
+            plan.cut("bwd_conv4")
+            fe.backward_plan(plan, g_feat, g_feat_reduced=True, injected=(first_of[4], first_of[3]))
+            plan.cut("update")
+            optimizer.apply_plan(plan)
+            fe.stem.refresh_weights(plan)
+            plan.add(ops.step_increment, optimizer.iterations)
+        preds = {"rpn_boxes": nms_rpn["pred_boxes"], "rpn_scores": nms_rpn["pred_scores"], "rcnn_boxes": nms_rcnn["pred_boxes"],
+                 "rcnn_scores": nms_rcnn["pred_scores"], "rcnn_classes": nms_rcnn["pred_classes"]}
+        aux = {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn, "nms_rcnn": nms_rcnn, "targets": t, "feature_maps": fe.feature_maps,
+               "pyramid": pyramid, "stage_maps": stage_maps, "roi_levels": rcnn.levels}
+        return {"plan": plan, "io": io, "losses": losses, "preds": preds, "aux": aux, "batch": batch}
+
     def _build_forward(self, mods, batch):
         """Training-mode forward only (reference faster_rcnn.py:39-57 with training=True): BatchNorm on batch statistics (its
         moving averages are updated, as Keras does), RPN on the in-image anchors, proposal NMS, Fast-RCNN heads."""
@@ -371,7 +499,7 @@ class FasterRCNN:
         """reference faster_rcnn.py:119-169 (BN in inference mode, all anchors clipped to the image)."""
         b = int(images.shape[0])
         if self._eval is None:
-            self._eval = _Modules(self.config, self.depth, self.store, self.device, False)
+            self._eval = _Modules(self.config, self.depth, self.store, self.device, False, topology=self.topology)
         if self._eval_plan is None or self._eval_plan["batch"] != b:
             self._eval_plan = self._build(self._eval, b, False, None)
         built = self._eval_plan

@@ -538,9 +538,12 @@ class FeatureExtractor:
         """The conv unit whose BatchNorm+ReLU produces feature_maps (consumer of the feature-map gradient)."""
         return self.units[self.specs[-1][0]][3]
 
-    def backward_plan(self, plan, g_feat, g_feat_reduced=False):
+    def backward_plan(self, plan, g_feat, g_feat_reduced=False, injected=()):
         """g_feat: bf16 gradient w.r.t. feature_maps [B*gh*gw, C].  Cuts the plan after each stage.
-        g_feat_reduced: the kernel that wrote g_feat already ran the BN-backward reduce of last_unit()."""
+        g_feat_reduced: the kernel that wrote g_feat already ran the BN-backward reduce of last_unit().
+        injected: names of stride-2 first blocks whose input-gradient buffer acts[name]["gin"] ALREADY holds a gradient w.r.t. the
+        previous stage's output (a second consumer of that output: the feature pyramid's lateral convolution, models/fpn.py);
+        the block's own data gradients are then added to it instead of being scattered into a zeroed buffer."""
         gout = g_feat
         gout_reduced = g_feat_reduced
         prev_of = {}
@@ -589,9 +592,12 @@ class FeatureExtractor:
             if first:
                 u[0].backward_bn(plan, gblock, None, mask=mblock)
                 u[0].backward_weights(plan, xin, defer)
-                if s != 1:
-                    plan.zero(a["gin"])             # (scatter target of the stride-2 data gradients)
-                u[1].backward_data(plan, a["gin"])
+                if s != 1 and n in injected:
+                    u[1].backward_data(plan, a["gin"], res=a["gin"])      # add to the gradient the other consumer left there
+                else:
+                    if s != 1:
+                        plan.zero(a["gin"])         # (scatter target of the stride-2 data gradients)
+                    u[1].backward_data(plan, a["gin"])
                 u[0].backward_data(plan, a["gin"], res=a["gin"], consumer=prev)   # gin is complete here (untouched pixels are zero)
             else:
                 u[1].backward_data(plan, a["gin"], res=gblock, consumer=prev, res_mask=mblock)

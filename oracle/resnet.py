@@ -131,4 +131,5 @@ def forward(p, images_u8, training, depth=50, taps=None, quant=None):
             x = Q(F.relu(sc + y))
             if taps is not None:
                 taps[n + "_out"] = x.permute(0, 2, 3, 1)
+                taps[n + "_out_nchw"] = x            # the node every consumer of the block output hangs on (total gradient w.r.t. it)
     return x.permute(0, 2, 3, 1).contiguous(), new_stats

@@ -1,0 +1,228 @@
+"""GPU: the feature-pyramid topology (FasterRCNN(topology="fpn"), BASELINE.json configs[4]) against oracle/fpn.py, stage by stage on
+the HIP path's own upstream tensors (every discrete decision -- anchors, proposals, RoI levels, targets, samples -- must match
+exactly; continuous outputs to bf16-scale tolerances), then the backward pass against the oracle's autograd, teacher-forced from
+the HIP path's stage outputs, and the gradient the pyramid injects into the backbone at C3 / C2.
+The reference has no FPN (models/faster_rcnn.py:25-34): the oracle restates Lin et al., CVPR 2017, and is unpinned (oracle/fpn.py)."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import faster_rcnn as O
+from oracle import fpn as OF
+from oracle import resnet as oresnet
+from oracle.losses import classification_loss, regression_loss
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+SHAPE = (256, 320, 3)
+
+
+def _rel(a, b):
+    a, b = a.float().cpu().reshape(-1), b.float().cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _cos(a, b):
+    a, b = a.float().cpu().reshape(-1), b.float().cpu().reshape(-1)
+    return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-20))
+
+
+def _cfg():
+    cfg = O.default_config(SHAPE)
+    cfg["rpn"]["anchors"]["base_anchor_shape"] = [64, 64]         # scales 0.25..2 -> 16..128 px anchors on P2..P5
+    cfg["rpn"]["nms"].update(max_total_size=48, max_output_size_per_class=48)
+    cfg["rpn"]["sampling"]["num_samples"] = 32
+    cfg["rcnn"]["sampling"]["num_samples"] = 16
+    cfg["rcnn"]["nms"].update(max_total_size=30, max_output_size_per_class=10)
+    return cfg
+
+
+@pytest.fixture(scope="module")
+def run():
+    M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
+    OPT = importlib.import_module("2d_object_detection_amd.optimizers")
+    cfg = _cfg()
+    params = OF.init_params(cfg, seed=3, randomize_affine=True)
+    for k in params:
+        if k.endswith("/kernel"):
+            params[k] = params[k].to(BF).float()
+        if k.endswith("_3_bn/gamma"):
+            params[k] = params[k] * 0.25            # (trained-net regime: rounding noise is not amplified 100x)
+    images, gl, gb = O.synthetic_batch(2, cfg["image_shape"], seed=5)
+    gb[0, 0] = torch.tensor([0.05, 0.05, 0.95, 0.95])            # one object large enough for pyramid level 4
+    model = M.FasterRCNN(cfg, sampling_seed=11, topology="fpn")
+    model.use_graphs = False
+    model.set_weights(params)
+    w = model.get_weights()
+    for k, v in params.items():
+        assert torch.equal(w[k], v), "weight round trip: " + k
+    opt = OPT.SGD(learning_rate=1e-3, momentum=0.9)
+    losses, preds = model.train_step(images.cuda(), gl.cuda(), gb.cuda(), opt)
+    torch.cuda.synchronize()
+    assert int(model.status[0].item()) == 0
+    return dict(cfg=cfg, params=params, images=images, gl=gl, gb=gb, model=model, losses={k: float(v) for k, v in losses.items()}, preds=preds,
+                M=M, OPT=OPT)
+
+
+def _hip_stage_maps(run):
+    aux = run["model"]._train_plan["aux"]
+    fe = run["model"]._train.fe
+    last = {2: "conv2_block3", 3: "conv3_block4", 4: fe.specs[-1][0]}
+    out = {}
+    for l in (2, 3, 4):
+        u = fe.units[last[l]][1]
+        out[l] = aux["stage_maps"][l].float().cpu().view(2, u.ho, u.wo, -1)
+    return out
+
+
+def test_fpn_forward_stagewise(run):
+    cfg, params, model = run["cfg"], run["params"], run["model"]
+    aux = model._train_plan["aux"]
+    t = aux["targets"]
+    ishape = cfg["image_shape"]
+    Q = oresnet.bf16_storage
+    # 1. neck on the HIP path's stage outputs
+    stage = _hip_stage_maps(run)
+    pyr = OF.neck(params, stage, quant=Q)
+    for l in (2, 3, 4, 5):
+        e = _rel(aux["pyramid"][l], pyr[l])
+        assert e < 6e-3, "pyramid level %d: %g" % (l, e)
+    assert torch.equal(aux["pyramid"][5].cpu(), aux["pyramid"][4].cpu()[:, ::2, ::2])
+    # 2. RPN on the HIP pyramid: anchors exact, scores / deltas close
+    hip_pyr = {l: aux["pyramid"][l].float().cpu() for l in (2, 3, 4, 5)}
+    rpn_ref = OF.rpn_forward(params, hip_pyr, cfg, ishape, True, quant=Q)
+    hip_rpn = {k: v.cpu() for k, v in aux["rpn_out"].items()}
+    assert torch.equal(hip_rpn["regions"], rpn_ref["regions"]), "pyramid anchors"
+    assert float((hip_rpn["pred_scores"] - rpn_ref["pred_scores"]).abs().max()) < 2e-3
+    assert _rel(hip_rpn["pred_boxes"], rpn_ref["pred_boxes"]) < 2e-2
+    # 3. proposal NMS over all levels: bit-exact on the HIP path's own scores / deltas
+    nms_ref = O.postprocess_output(ishape, **hip_rpn, **cfg["rpn"]["nms"])
+    assert torch.equal(aux["nms_rpn"]["pred_boxes"].cpu(), nms_ref["pred_boxes"]) and torch.equal(aux["nms_rpn"]["pred_scores"].cpu(), nms_ref["pred_scores"])
+    rois = aux["nms_rpn"]["pred_boxes"].cpu()
+    # 4. RoI levels exact; heads on the assigned levels
+    lv = OF.roi_levels(rois, ishape)
+    assert torch.equal(aux["roi_levels"].cpu().view(2, -1), lv)
+    rc_ref = OF.rcnn_forward(params, hip_pyr, rois, ishape, cfg, quant=Q)
+    rc = model._train.rcnn
+    assert _rel(rc.pooled.view(2, -1, rc.flat), rc_ref["pooled"]) < 6e-3
+    hip_rcnn = {k: v.cpu() for k, v in aux["rcnn_out"].items()}
+    assert float((hip_rcnn["pred_scores"] - rc_ref["pred_scores"]).abs().max()) < 2e-2
+    assert torch.equal(hip_rcnn["regions"], rc_ref["regions"])
+    # 5. targets, samples, losses on the HIP outputs
+    gl, gb = run["gl"], run["gb"]
+    gt_obj = F.one_hot(gl.sum(-1).long(), 2).float()
+    rs = O._training_samples(gt_obj, gb, **hip_rpn, image_shape=ishape, sampling=cfg["rpn"]["sampling"], step=0, seed=11, stream_base=0)
+    cs = O._training_samples(gl, gb, **hip_rcnn, image_shape=ishape, sampling=cfg["rcnn"]["sampling"], step=0, seed=11, stream_base=2)
+    assert torch.equal(t["rpn_tl"].cpu(), rs["all_target_labels"]) and torch.equal(t["rcnn_tl"].cpu(), cs["all_target_labels"])
+    assert torch.equal(t["rpn_idx"].cpu().long(), rs["sample_indices"]) and torch.equal(t["rcnn_idx"].cpu().long(), cs["sample_indices"])
+    exp = {"rpn_cls": classification_loss(rs["target_labels"], rs["pred_scores"]), "rpn_reg": regression_loss(rs["target_boxes"], rs["pred_boxes"]),
+           "rcnn_cls": classification_loss(cs["target_labels"], cs["pred_scores"]), "rcnn_reg": regression_loss(cs["target_boxes"], cs["pred_boxes"])}
+    for k, v in exp.items():
+        assert abs(run["losses"][k] - float(v)) <= 1e-4 * abs(float(v)) + 1e-5, (k, run["losses"][k], float(v))
+    # the samples reach more than one pyramid level on both sides of the model
+    n_lv = model._train.rpn.n_level
+    offs = torch.tensor([model._train.rpn.offset[l] for l in (2, 3, 4, 5)])
+    used = torch.bucketize(t["rpn_idx"].cpu().long().reshape(-1), offs, right=True).unique()
+    assert len(used) >= 2, (used, n_lv)
+    assert len(lv.unique()) >= 2, lv.unique()
+
+
+def test_fpn_backward_against_autograd(run):
+    """Teacher-forced from the HIP path's stage outputs, with the HIP path's proposals and sample indices injected: gradients of the
+    neck, RPN and head parameters, and the gradients the neck hands to the backbone."""
+    cfg, params, model = run["cfg"], run["params"], run["model"]
+    aux = model._train_plan["aux"]
+    t = aux["targets"]
+    ishape = cfg["image_shape"]
+    Q = oresnet.bf16_storage
+    names = [n for n in params if n.startswith(("fpn_", "rpn_", "fast_rcnn_"))]
+    p = {k: v.clone() for k, v in params.items()}
+    for n in names:
+        p[n].requires_grad_(True)
+    stage = {l: v.clone().requires_grad_(True) for l, v in _hip_stage_maps(run).items()}
+    pyr = OF.neck(p, stage, quant=Q)
+    rpn_out = OF.rpn_forward(p, pyr, cfg, ishape, True, quant=Q)
+    rois = aux["nms_rpn"]["pred_boxes"].cpu()
+    rc = OF.rcnn_forward(p, pyr, rois, ishape, cfg, quant=Q)
+    head = {k: rc[k] for k in ("regions", "pred_scores", "pred_boxes")}
+    gl, gb = run["gl"], run["gb"]
+    gt_obj = F.one_hot(gl.sum(-1).long(), 2).float()
+    rs = O._training_samples(gt_obj, gb, **rpn_out, image_shape=ishape, sampling=cfg["rpn"]["sampling"], step=0, seed=11, stream_base=0,
+                             sample_indices=t["rpn_idx"].cpu())
+    cs = O._training_samples(gl, gb, **head, image_shape=ishape, sampling=cfg["rcnn"]["sampling"], step=0, seed=11, stream_base=2,
+                             sample_indices=t["rcnn_idx"].cpu())
+    loss = (classification_loss(rs["target_labels"], rs["pred_scores"]) + regression_loss(rs["target_boxes"], rs["pred_boxes"]) +
+            classification_loss(cs["target_labels"], cs["pred_scores"]) + regression_loss(cs["target_boxes"], cs["pred_boxes"]))
+    grads = torch.autograd.grad(loss, [p[n] for n in names] + [stage[l] for l in (2, 3, 4)])
+    gpar = dict(zip(names, grads[:len(names)]))
+    gstage = dict(zip((2, 3, 4), grads[len(names):]))
+    st = model.store
+    A = model._train.rpn.apl
+    report = {}
+    for l in (2, 3, 4):
+        for kind in ("lateral", "output"):
+            n = "fpn_%s%d" % (kind, l)
+            report[n + "/kernel"] = _rel(st.grad(n + "/kernel").permute(1, 2, 3, 0), gpar[n + "/kernel"])      # (no L2 term in st.g: SGD adds it)
+            report[n + "/bias"] = _rel(st.grad(n + "/bias"), gpar[n + "/bias"])
+    report["rpn_intermediate_layer/kernel"] = _rel(st.grad("rpn_intermediate_layer/kernel").permute(1, 2, 3, 0), gpar["rpn_intermediate_layer/kernel"])
+    hd = st.grad("rpn_heads/kernel").cpu()
+    report["rpn_classification_head/kernel"] = _rel(hd[:2 * A].permute(1, 2, 3, 0), gpar["rpn_classification_head/kernel"])
+    report["rpn_regression_head/kernel"] = _rel(hd[2 * A:6 * A].permute(1, 2, 3, 0), gpar["rpn_regression_head/kernel"])
+    c1 = cfg["num_classes"] + 1
+    hk = st.grad("fast_rcnn_heads/kernel").cpu().view(64, -1)
+    report["fast_rcnn_classification_head/kernel"] = _rel(hk[:c1].t(), gpar["fast_rcnn_classification_head/kernel"])
+    report["fast_rcnn_regression_head/kernel"] = _rel(hk[c1:c1 + 4 * (c1 - 1)].t(), gpar["fast_rcnn_regression_head/kernel"])
+    print("fpn gradients, relative L2 vs autograd:", {k: round(v, 4) for k, v in report.items()})
+    bad = {k: v for k, v in report.items() if not v < 0.04}
+    assert not bad, bad
+    # the gradient w.r.t. C4 is what the neck wrote into g_feat
+    assert _rel(t["g_feat"].view(gstage[4].shape), gstage[4]) < 0.03
+    # C3 / C2: the neck's gradient is IN the block-input gradient of the next stage's first block, next to that block's own data
+    # gradients -- compared with the oracle's full backward pass (from the images) at the tap of the stage output
+    pf = {k: v.clone() for k, v in params.items()}
+    for n in pf:
+        if not (n.endswith("moving_mean") or n.endswith("moving_variance")):
+            pf[n].requires_grad_(True)
+    taps = {}
+    losses, _, _ = OF.compute_losses(pf, cfg, run["images"], gl, gb, True, step=0, seed=11, rpn_sample_indices=t["rpn_idx"].cpu(),
+                                     rcnn_sample_indices=t["rcnn_idx"].cpu(), quant=Q, taps=taps)
+    g3, g2 = torch.autograd.grad(sum(losses.values()), [taps["conv3_block4_out_nchw"], taps["conv2_block3_out_nchw"]])
+    g3, g2 = g3.permute(0, 2, 3, 1).contiguous(), g2.permute(0, 2, 3, 1).contiguous()
+    fe = model._train.fe
+    e3 = _rel(fe.acts["conv4_block1"]["gin"].view(g3.shape), g3)
+    e2 = _rel(fe.acts["conv3_block1"]["gin"].view(g2.shape), g2)
+    neck_share3 = float(gstage[3].norm() / g3.norm()), float(gstage[2].norm() / g2.norm())
+    print("stage-output gradients vs the oracle's full backward: C3 %.3f, C2 %.3f (the pyramid's share of their norm: %.2f, %.2f)" % (
+        e3, e2, neck_share3[0], neck_share3[1]))
+    assert e3 < 0.15 and e2 < 0.15, (e3, e2)
+    assert min(neck_share3) > 0.2, "the pyramid's gradient is too small a part of the total for this check to see its absence"
+
+
+def test_fpn_graph_replay_and_eval(run):
+    """hipGraph replay of the FPN train step equals the eager step; the eval step (all anchors, moving statistics) runs."""
+    cfg, params = run["cfg"], run["params"]
+    M, OPT = run["M"], run["OPT"]
+    images, gl, gb = run["images"].cuda(), run["gl"].cuda(), run["gb"].cuda()
+    outs = []
+    for graphs in (False, True):
+        m = M.FasterRCNN(cfg, sampling_seed=11, topology="fpn")
+        m.use_graphs = graphs
+        m.set_weights(params)
+        opt = OPT.SGD(learning_rate=1e-3, momentum=0.9)
+        for _ in range(2):
+            losses, preds = m.train_step(images, gl, gb, opt)
+        torch.cuda.synchronize()
+        outs.append(({k: float(v) for k, v in losses.items()}, preds["rcnn_boxes"].clone(), m.store.w.clone()))
+    for k in outs[0][0]:
+        assert abs(outs[0][0][k] - outs[1][0][k]) <= 2e-3 * abs(outs[0][0][k]) + 1e-5, (k, outs[0][0][k], outs[1][0][k])
+    assert _rel(outs[1][2], outs[0][2]) < 1e-5
+    m = M.FasterRCNN(cfg, sampling_seed=11, topology="fpn")
+    m.set_weights(params)
+    losses, preds = m.test_step(images, gl, gb)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v).all() for v in losses.values())
+    assert preds["rcnn_boxes"].shape == (2, 30, 4) and preds["rpn_boxes"].shape == (2, 48, 4)
+    n_eval = m._eval.rpn.n
+    assert n_eval == sum(m._eval.rpn.num_anchors.values())
