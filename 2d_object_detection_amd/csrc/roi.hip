@@ -364,9 +364,17 @@ static int roi_bwd_bf16_impl(const frcnn_bf16* gpooled, const uint8_t* argmax, c
     FRCNN_CHECK_ARG(gpooled && argmax && rois && rows && gfeat && nrows > 0 && b > 0, "roi_crop_pool_bwd_bf16: bad arguments");
     FRCNN_CHECK_ARG(c % 64 == 0 && ps >= 1 && ks >= 1 && ks * ks <= 255 && hf > 1 && wf > 1, "roi_crop_pool_bwd_bf16: bad sizes");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // 64-channel slabs: 8 RoI rows in flight per workgroup, 8 workgroups per CU (measured: 118 us; 128 channels 129, 32 channels 127)
+    // 64-channel slabs: 8 RoI rows in flight per workgroup, 8 workgroups per CU (measured: 118 us; 128 channels 129, 32 channels 127);
+    // 32-channel slabs where a row of 64 channels does not fit 64 KB of LDS (the stride-4 level of a feature pyramid: 311 pixels)
     const size_t smem = (size_t)wf * 64 * 4;
-    FRCNN_CHECK_ARG(smem <= 64 * 1024, "roi_crop_pool_bwd_bf16: feature map too wide (wf=%d)", wf);
+    if (smem > 64 * 1024) {
+        const size_t smem32 = (size_t)wf * 32 * 4;
+        FRCNN_CHECK_ARG(smem32 <= 64 * 1024 && c % 32 == 0, "roi_crop_pool_bwd_bf16: feature map too wide (wf=%d)", wf);
+        hipLaunchKernelGGL(roi_bwd_rows_kernel<32>, dim3(b * hf * (c / 32)), dim3(256), smem32, s, reinterpret_cast<const bf16_t*>(gpooled),
+                           argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat), levels, level);
+        FRCNN_CHECK_LAUNCH("roi_crop_pool_bwd_bf16");
+        return FRCNN_OK;
+    }
     hipLaunchKernelGGL(roi_bwd_rows_kernel<64>, dim3(b * hf * (c / 64)), dim3(256), smem, s, reinterpret_cast<const bf16_t*>(gpooled),
                        argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat), levels, level);
     FRCNN_CHECK_LAUNCH("roi_crop_pool_bwd_bf16");

@@ -598,11 +598,19 @@ class FeatureExtractor:
                     if s != 1:
                         plan.zero(a["gin"])         # (scatter target of the stride-2 data gradients)
                     u[1].backward_data(plan, a["gin"])
-                u[0].backward_data(plan, a["gin"], res=a["gin"], consumer=prev)   # gin is complete here (untouched pixels are zero)
+                if s != 1 and n in injected:
+                    # the pixels the stride-2 scatter does not touch hold the other consumer's gradient, not zeros: the fused
+                    # BatchNorm-backward reduce (which sums over the rows the kernel stores) would miss them -> stand-alone reduce
+                    u[0].backward_data(plan, a["gin"], res=a["gin"])
+                    fused = False
+                else:
+                    u[0].backward_data(plan, a["gin"], res=a["gin"], consumer=prev)   # gin is complete here (untouched pixels are zero)
+                    fused = prev is not None
             else:
                 u[1].backward_data(plan, a["gin"], res=gblock, consumer=prev, res_mask=mblock)
+                fused = prev is not None
             gout = a["gin"]
-            gout_reduced = prev is not None
+            gout_reduced = fused
             if len(deferred) >= 24:               # (the parameter table holds 32 layers per addressing mode)
                 flush_deferred()
         flush_deferred()

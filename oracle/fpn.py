@@ -182,7 +182,9 @@ def rcnn_forward(p, pyramid, rois, image_shape, config, quant=None):
 
 
 # --------------------------------------------------------------------------- model
-def forward(p, config, images, training, depth=50, quant=None, taps=None):
+def forward(p, config, images, training, depth=50, quant=None, taps=None, rois=None):
+    """rois (optional): proposals to feed the heads instead of this forward pass's own NMS output (teacher forcing: the proposal
+    list is a discrete function of near-tied scores at random init)."""
     image_shape = config["image_shape"]
     taps = {} if taps is None else taps
     _, new_stats = resnet.forward(p, images, training, depth, taps, quant)
@@ -190,16 +192,16 @@ def forward(p, config, images, training, depth=50, quant=None, taps=None):
     pyramid = neck(p, stage_maps, quant)
     rpn_out = rpn_forward(p, pyramid, config, image_shape, training, quant)
     nmsed_rpn = postprocess_output(image_shape, **rpn_out, **config["rpn"]["nms"])
-    rcnn_out = rcnn_forward(p, pyramid, nmsed_rpn["pred_boxes"], image_shape, config, quant)
+    rcnn_out = rcnn_forward(p, pyramid, nmsed_rpn["pred_boxes"] if rois is None else rois, image_shape, config, quant)
     taps["pyramid"] = pyramid
     return rpn_out, rcnn_out, nmsed_rpn, new_stats
 
 
 def compute_losses(p, config, images, gt_labels, gt_boxes, training, step=0, seed=0, depth=50, rpn_sample_indices=None,
-                   rcnn_sample_indices=None, quant=None, taps=None):
+                   rcnn_sample_indices=None, quant=None, taps=None, rois=None):
     """oracle.faster_rcnn.compute_losses on the pyramid (same targets, sampling, losses, post-processing)."""
     image_shape = config["image_shape"]
-    rpn_out, rcnn_out, nmsed_rpn, new_stats = forward(p, config, images, training, depth, quant, taps)
+    rpn_out, rcnn_out, nmsed_rpn, new_stats = forward(p, config, images, training, depth, quant, taps, rois)
     gt_obj = F.one_hot(gt_labels.sum(-1).to(torch.int64), 2).to(torch.float32)
     head = {k: rcnn_out[k] for k in ("regions", "pred_scores", "pred_boxes")}
     rs = _training_samples(gt_obj, gt_boxes, **rpn_out, image_shape=image_shape, sampling=config["rpn"]["sampling"], step=step, seed=seed,
