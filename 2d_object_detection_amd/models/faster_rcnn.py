@@ -343,6 +343,8 @@ class FasterRCNN:
             table, total = ops.make_transpose_flip_table(fe.flip_entries() + neck.flip_entries() + rpn.flip_entries() + rcnn.flip_entries(), dev)
             plan.hold(table)
             plan.add(ops.weights_transpose_flip_batched, table, total)
+            if fe.f8 is not None:                    # precision "fp8": the backbone's convolutions from conv3 on (the pyramid's own stay bf16)
+                fe.quantize_bwd_weights_plan(plan)
         fe.forward_plan(plan, training)
         stage_maps = {l: fe.acts[last[l]]["out"] for l in FPN_LEVELS}
         pyramid = neck.forward_plan(plan, stage_maps)
@@ -386,6 +388,9 @@ class FasterRCNN:
             fe.backward_plan(plan, g_feat, g_feat_reduced=True, injected=(first_of[4], first_of[3]))
             plan.cut("update")
             optimizer.apply_plan(plan)
+            if fe.f8 is not None:
+                fe.quantize_weights_plan(plan)
+                fe.f8.plan_update(plan)
             fe.stem.refresh_weights(plan)
             plan.add(ops.step_increment, optimizer.iterations)
         preds = {"rpn_boxes": nms_rpn["pred_boxes"], "rpn_scores": nms_rpn["pred_scores"], "rcnn_boxes": nms_rcnn["pred_boxes"],

@@ -56,15 +56,18 @@ def conv_flops(d, true_cin=None, true_cout=None):
     return 2.0 * m * k * (true_cout if true_cout is not None else d.cout)
 
 
+RPN_HEAD_ROWS = 72                 # real rows of the merged RPN head bank: 6 x 12 anchors per location (feature pyramid: 6 x 3 = 18)
+
+
 def _true_dims(d):
-    """un-padded channel counts: stem taps 7x(8x4) carry 7x7x3 real values; RPN heads 72 of 128; RCNN heads 36 of 64"""
+    """un-padded channel counts: stem taps 7x(8x4) carry 7x7x3 real values; RPN heads 72 (18) of 128; RCNN heads 36 of 64"""
     cin, cout = d.cin, d.cout
     if d.in_pix_stride == 4 and d.cin == 32:
         return 21.0, cout
     if d.kh == 1 and d.cin == 256 and d.cout == 128:
-        cout = 72
+        cout = RPN_HEAD_ROWS
     if d.kh == 1 and d.cin == 128 and d.cout == 256:
-        cin = 72
+        cin = RPN_HEAD_ROWS
     if d.cout == 64 and d.cin > 4096:
         cout = 36
     if d.cin == 64 and d.cout > 4096:
@@ -96,15 +99,16 @@ def classify(ops, fn, args, kwargs):
     name = getattr(fn, "__name__", str(fn))
     if name in ("bn_train_apply", "bn_apply", "bn_bwd_apply_fused", "bn_bwd_reduce", "bn_train_apply_maxpool", "bn_train_apply_dual"):
         return "batchnorm apply / reduce (bn_*_kernel)", 0.0, _tensor_bytes(args, kwargs)
-    if name == "roi_crop_pool_fwd":
+    if name in ("roi_crop_pool_fwd", "roi_crop_pool_fwd_level"):
         return "RoI crop+pool forward (roi_fwd_kernel)", 0.0, _tensor_bytes(args, kwargs)
-    if name == "roi_crop_pool_bwd_bf16":
+    if name in ("roi_crop_pool_bwd_bf16", "roi_crop_pool_bwd_bf16_level"):
         return "RoI crop+pool backward (roi_bwd_rows_kernel)", 0.0, _tensor_bytes(args, kwargs)
     if name == "nms_combined":
         # boxes [B,N,q,4] + scores [B,N,*] in, padded outputs out (the workspace is scratch)
         return "combined NMS (nms_class_kernel + nms_merge_kernel)", 0.0, float(sum(t.numel() * t.element_size() for t in (args[0], args[1], args[12], args[13], args[14])))
     if name in ("assign_targets", "sample_indices", "losses", "losses_head_grad", "losses_rpn_head_grad", "rpn_head_grad", "rcnn_head_grad",
-                "rpn_head_post", "rpn_head_post_decode", "rcnn_head_post", "decode_boxes", "boxes_scale"):
+                "rpn_head_post", "rpn_head_post_decode", "rcnn_head_post", "decode_boxes", "boxes_scale", "rpn_head_post_level", "rpn_head_grad_level",
+                "roi_assign_levels"):
         return "targets / sampling / losses / head post", 0.0, _tensor_bytes(args, kwargs)
     if name in ("sgd_momentum",):
         return "SGD-momentum update (sgd_kernel)", 0.0, float(args[4]) * (4 + 4 + 4 + 4 + 4 + 2)
@@ -282,10 +286,14 @@ def main():
     ap.add_argument("--no-segmented", action="store_true", help="skip the segmented-replay leg (config.segmented_ms_per_step)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--lr-scale", type=float, default=0.01)
+    ap.add_argument("--fpn", action="store_true", help="feature-pyramid topology (models/fpn.py): with --fp8 --batch-per-gpu 8 this is BASELINE.json configs[4]")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) MFMA conv path where a layer supports it (BASELINE.json configs[4]'s precision)")
     ap.add_argument("--depth", type=int, default=50, help="ResNet depth (101 with --proposals 1000 --batch-per-gpu 2 = BASELINE.json configs[3])")
     ap.add_argument("--proposals", type=int, default=0, help="RPN NMS max_total_size / max_output_size_per_class (0: config.json's 300)")
     args = ap.parse_args()
+    if args.fpn:
+        global RPN_HEAD_ROWS
+        RPN_HEAD_ROWS = 18
 
     D = importlib.import_module("2d_object_detection_amd.distributed")
     M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
@@ -303,7 +311,7 @@ def main():
         cfg["rpn"]["nms"]["max_total_size"] = cfg["rpn"]["nms"]["max_output_size_per_class"] = args.proposals
     B = args.batch_per_gpu
     model = M.FasterRCNN(cfg, depth=args.depth, device=dev, seed=0, sampling_seed=rank, world_size=world,     # (per-rank fg/bg sample positions)
-                         precision="fp8" if args.fp8 else "bf16")
+                         precision="fp8" if args.fp8 else "bf16", topology="fpn" if args.fpn else "c4")
     model.use_graphs = not args.no_graphs
     # Reference schedule shape (train_faster_rcnn.py:62-68: boundaries 40k/80k), scaled by --lr-scale: the reference's
     # 1e-3 presumes ImageNet-pretrained weights; with the seeded random init used here (no network) and the un-normalised
@@ -373,11 +381,16 @@ def main():
         "metric": METRIC, "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16",
         "data": "synthetic",
-        "config": {"workload": ("ResNet-%d(C4) Faster-RCNN full train step, fp8: e4m3 weights (per output channel) and activations (per tensor, "
-                                "delayed scaling) in every forward convolution with cin %% 128 == 0 (backbone from conv2_block2 on, RPN 3x3) on the "
-                                "f8f6f4 MFMA path, bf16 storage / backward / remaining layers, batch %d per GPU, 375x1242 synthetic KITTI, %d "
-                                "proposals, 7 classes (BASELINE.json configs[4]'s precision%s; its FPN topology is not built: C4 backbone)" % (
-                                    args.depth, B, args.proposals or 300, " and batch" if B == 8 else "")) if args.fp8 else
+        "config": {"workload": ("ResNet-%d%s Faster-RCNN full train step, fp8: e4m3 weights (per output channel) and activations (per tensor, delayed "
+                                "scaling), e5m2 gradients, in the forward convolutions and data gradients of the backbone from conv3 on (K >= 256)%s on "
+                                "the f8f6f4 MFMA path; bf16 storage, weight gradients and remaining layers; batch %d per GPU, 375x1242 synthetic KITTI, "
+                                "%d proposals, 7 classes (BASELINE.json configs[4]%s)" % (
+                                    args.depth, "-FPN (pyramid over C2..C4, RPN on P2..P5, per-level RoI heads)" if args.fpn else "(C4)",
+                                    "" if args.fpn else " and of the RPN's 3x3", B, args.proposals or 300,
+                                    ("" if B == 8 else ": its topology and precision at another batch") if args.fpn else
+                                    "'s precision%s; C4 backbone, no FPN" % (" and batch" if B == 8 else ""))) if args.fp8 else
+                               ("ResNet-%d-FPN Faster-RCNN full train step, bf16, batch %d per GPU, 375x1242 synthetic KITTI, %d proposals, 7 classes "
+                                "(BASELINE.json configs[4]'s topology in bf16)" % (args.depth, B, args.proposals or 300)) if args.fpn else
                                "ResNet-%d(C4) Faster-RCNN full train step, bf16, batch %d per GPU, 375x1242 synthetic KITTI, "
                                "%d proposals, 7 classes (BASELINE.json configs[%d])" % (
                                    args.depth, B, args.proposals or 300, 3 if args.depth == 101 else 1 if world == 1 else 2),

@@ -24,6 +24,9 @@ FPROP = [
     dict(id="c4_1x1_1024_256_stats", n=4, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
     dict(id="c4_3x3_256_256_stats", n=4, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     dict(id="rpn_3x3_1024_256_relu", n=1, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),
+    # feature-pyramid neck (BASELINE configs[4]): bias-only epilogues on shapes the C4 plans run with statistics
+    dict(id="fpn_lateral4_1x1_1024_256_bias", n=4, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=False),
+    dict(id="fpn_output4_3x3_256_256_bias_b8", n=8, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=False),
     # small shapes (tails, odd grids)
     dict(id="small_1x1_stats", n=2, h=13, w=17, cin=64, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
     dict(id="small_3x3_relu", n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1, bias=True, relu=True, stats=False),

@@ -16,7 +16,7 @@ import torch
 import conv_cases
 
 
-def _plan_instantiations(monkeypatch, depth, batch, proposals=None, precision="bf16"):
+def _plan_instantiations(monkeypatch, depth, batch, proposals=None, precision="bf16", topology="c4"):
     ops = importlib.import_module("2d_object_detection_amd.ops")
     # the two init-time kernels of the RPN detector (anchor table, clip) need a device; their values do not matter here
     monkeypatch.setattr(ops, "anchors_generate", lambda out, *a, **k: out.zero_())
@@ -27,7 +27,7 @@ def _plan_instantiations(monkeypatch, depth, batch, proposals=None, precision="b
     cfg = copy.deepcopy(C.default_config())
     if proposals:
         cfg["rpn"]["nms"]["max_total_size"] = cfg["rpn"]["nms"]["max_output_size_per_class"] = proposals
-    model = M.FasterRCNN(cfg, depth=depth, device="cpu", precision=precision)
+    model = M.FasterRCNN(cfg, depth=depth, device="cpu", precision=precision, topology=topology)
     opt = OPT.SGD(learning_rate=1e-3, momentum=0.9)
     opt.bind(model.store)
     plan = model._build(model._train, batch, True, opt)["plan"]
@@ -69,6 +69,17 @@ def test_every_fp8_plan_instantiation_has_a_parity_case(monkeypatch, ops):
         assert len(f8) >= 5, f8
         missing = sorted(k for k in used if k not in covered)
         assert not missing, "conv kernels of the fp8 R50 batch-%d train plan without an oracle-compared GPU case:\n  %s" % (batch, "\n  ".join(missing))
+
+
+def test_every_fpn_plan_instantiation_has_a_parity_case(monkeypatch, ops):
+    """The feature-pyramid topology (BASELINE.json configs[4]): batch 8 in fp8 (its own configuration), batch 4 and 2 in bf16."""
+    covered = conv_cases.covered_instantiations(ops)
+    for batch, precision in ((8, "fp8"), (4, "bf16"), (2, "bf16")):
+        used, launches = _plan_instantiations(monkeypatch, 50, batch, precision=precision, topology="fpn")
+        assert launches >= 280
+        missing = sorted(k for k in used if k not in covered)
+        assert not missing, "conv kernels of the FPN R50 batch-%d %s train plan without an oracle-compared GPU case:\n  %s" % (
+            batch, precision, "\n  ".join(missing))
 
 
 def test_describe_reports_errors(ops):

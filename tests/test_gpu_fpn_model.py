@@ -226,6 +226,15 @@ def test_fpn_graph_replay_and_eval(run):
         assert abs(outs[0][0][k] - outs[1][0][k]) <= 1e-5 * abs(outs[0][0][k]) + 1e-6, (k, outs[0][0][k], outs[1][0][k])
     assert _rel(outs[1][2], outs[0][2]) < 1e-5          # (the detections themselves are not bit-reproducible: the Dense-head GEMM sums
                                                         # its K splits with float atomics and the scores are nearly tied)
+    # the fp8 backbone under the pyramid (BASELINE.json configs[4]: FPN + fp8): runs, finite, its scales calibrate
+    m = M.FasterRCNN(cfg, sampling_seed=11, topology="fpn", precision="fp8")
+    m.set_weights(params)
+    opt = OPT.SGD(learning_rate=1e-3, momentum=0.9)
+    for _ in range(2):
+        losses, _ = m.train_step(images, gl, gb, opt)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(v).all()) for v in losses.values()) and m._train.fe.f8.n >= 20
+    assert abs(float(losses["rpn_cls"]) - outs[0][0]["rpn_cls"]) < 0.05
     m = M.FasterRCNN(cfg, sampling_seed=11, topology="fpn")
     m.set_weights(params)
     losses, preds = m.test_step(images, gl, gb)
