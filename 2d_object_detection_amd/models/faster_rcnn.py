@@ -319,8 +319,8 @@ class FasterRCNN:
         fe, neck, rpn, rcnn = mods.fe, mods.neck, mods.rpn, mods.rcnn
         last = {2: "conv2_block3", 3: "conv3_block4", 4: fe.specs[-1][0]}
         grids = {l: (fe.units[last[l]][1].ho, fe.units[last[l]][1].wo) for l in FPN_LEVELS}
-        neck.setup(batch, grids, training)
-        rpn.setup(batch, training)
+        neck.setup(batch, grids, training, f8_scales=fe.f8)
+        rpn.setup(batch, training, f8_scales=fe.f8)
         P = int(self._rpn_config["nms"]["max_total_size"])
         rs, cs = self._rpn_config["sampling"], self._rcnn_config["sampling"]
         S_rpn, S_rcnn = int(rs["num_samples"]), int(cs["num_samples"])
@@ -343,8 +343,8 @@ class FasterRCNN:
             table, total = ops.make_transpose_flip_table(fe.flip_entries() + neck.flip_entries() + rpn.flip_entries() + rcnn.flip_entries(), dev)
             plan.hold(table)
             plan.add(ops.weights_transpose_flip_batched, table, total)
-            if fe.f8 is not None:                    # precision "fp8": the backbone's convolutions from conv3 on (the pyramid's own stay bf16)
-                fe.quantize_bwd_weights_plan(plan)
+            if fe.f8 is not None:                    # precision "fp8": the backbone from conv3 on + the pyramid's 3x3 convolutions
+                fe.quantize_bwd_weights_plan(plan, extra=neck.quant_entries()[1] + rpn.quant_entries()[1])
         fe.forward_plan(plan, training)
         stage_maps = {l: fe.acts[last[l]]["out"] for l in FPN_LEVELS}
         pyramid = neck.forward_plan(plan, stage_maps)
@@ -389,7 +389,7 @@ class FasterRCNN:
             plan.cut("update")
             optimizer.apply_plan(plan)
             if fe.f8 is not None:
-                fe.quantize_weights_plan(plan)
+                fe.quantize_weights_plan(plan, extra=neck.quant_entries()[0] + rpn.quant_entries()[0])
                 fe.f8.plan_update(plan)
             fe.stem.refresh_weights(plan)
             plan.add(ops.step_increment, optimizer.iterations)

@@ -39,9 +39,17 @@ class _Conv:
         self.store, self.name, self.cin, self.cout, self.k = store, name, cin, cout, k
         store.register(name + "/kernel", (cout, k, k, cin), decay=decay)        # OHWI (Keras: HWIO)
 
-    def setup(self, n, h, w, device, relu=False):
+    def setup(self, n, h, w, device, relu=False, fp8=False):
+        """fp8: allocate e4m3 twins of the forward weights (per output channel) and of the tap-flipped transposes (per input
+        channel) for frcnn_conv2d_fprop_fp8 / frcnn_conv2d_dgrad_fp8 (precision "fp8": the 3x3 convolutions of the pyramid)."""
         k, p = self.k, self.k // 2
         self.n, self.h, self.w, self.m = n, h, w, n * h * w
+        self.w8 = None
+        if fp8 and self.cin % 128 == 0 and self.cout % 128 == 0:
+            self.w8 = torch.zeros(self.cout, k, k, self.cin, dtype=ops.FP8, device=device)
+            self.w8_scale = torch.ones(self.cout, dtype=torch.float32, device=device)
+            self.w_t8 = torch.zeros(self.cin, k, k, self.cout, dtype=ops.FP8, device=device)
+            self.w_t8_scale = torch.ones(self.cin, dtype=torch.float32, device=device)
         self.desc = ops.conv_desc(n, h, w, self.cin, k, k, 1, p, p, h, w, self.cout, flags=ops.CONV_BIAS | (ops.CONV_RELU if relu else 0))
         self.d_bwd = ops.conv_desc(n, h, w, self.cout, k, k, 1, p, p, h, w, self.cin)
         self.d_bwd_res = ops.conv_desc(n, h, w, self.cout, k, k, 1, p, p, h, w, self.cin, flags=ops.CONV_ADD_RES)
@@ -51,8 +59,17 @@ class _Conv:
     def flip_entry(self):
         return (self.store.weight(self.name + "/kernel"), self.w_t, self.cout, self.k, self.k, self.cin)
 
-    def forward(self, plan, x, y):
+    def quant_entries(self):
+        if self.w8 is None:
+            return [], []
+        return ([(self.store.weight(self.name + "/kernel").view(self.cout, -1), self.w8, self.w8_scale)],
+                [(self.w_t.view(self.cin, -1), self.w_t8, self.w_t8_scale)])
+
+    def forward(self, plan, x, y, x8=None):
         ops.conv_zero_counters(plan, self.desc)
+        if x8 is not None and self.w8 is not None:
+            plan.add(ops.conv2d_fprop_fp8, self.desc, x8.data, self.w8, x8.scale, self.w8_scale, y, bias=self.store.weight(self.name + "/bias"))
+            return
         plan.add(ops.conv2d_fprop, self.desc, x, self.store.weight_bf16(self.name + "/kernel"), y, bias=self.store.weight(self.name + "/bias"))
 
     def backward_params(self, plan, x, dz):
@@ -60,14 +77,37 @@ class _Conv:
         plan.add(ops.colsum_bf16, dz, self.m, self.cout, self.cout, st.grad(self.name + "/bias"))
         plan.add(ops.conv2d_wgrad, self.desc, x, dz, st.grad(self.name + "/kernel"))
 
-    def backward_data(self, plan, dz, gx, add_to_gx=False, red=None):
-        """gx = conv^T(dz) [+ gx]; red: fused BatchNorm-backward reduce of the layer that consumes gx."""
+    def backward_data(self, plan, dz, gx, add_to_gx=False, red=None, dz8=None):
+        """gx = conv^T(dz) [+ gx]; red: fused BatchNorm-backward reduce of the layer that consumes gx; dz8: e5m2 twin of dz."""
         d = self.d_bwd_res if add_to_gx else self.d_bwd
         ops.conv_zero_counters(plan, d)
-        if red is not None:
+        if dz8 is not None and self.w8 is not None:
+            plan.add(ops.conv2d_dgrad_fp8, d, dz8.data, self.w_t8, dz8.scale, self.w_t8_scale, gx, red=red, res=gx if add_to_gx else None)
+        elif red is not None:
             plan.add(ops.conv2d_dgrad_bnreduce, d, dz, self.w_t, gx, red, res=gx if add_to_gx else None)
         else:
             plan.add(ops.conv2d_fprop, d, dz, self.w_t, gx, res=gx if add_to_gx else None)
+
+
+def _twin(scales, like, device):
+    from .feature_extractor import Fp8Twin
+    return Fp8Twin(scales, tuple(like.shape), device)
+
+
+def _quantize(plan, twin, src, e5m2=False):
+    """one pass: src (bf16) -> twin bytes with this step's scale, amax for the next step's"""
+    sc = twin.scales
+    plan.add(ops.quantize_fp8, src, sc.qscale(twin.idx), twin.data, sc.amax(twin.idx), e5m2=e5m2)
+
+
+def _quantize_weights(mod, plan):
+    """(outside the train plan: initial / restored weights) e4m3 twins of a module's forward weights and of the transposes just rebuilt"""
+    fwd, bwd = mod.quant_entries()
+    if fwd or bwd:
+        key = tuple(e[1].data_ptr() for e in fwd + bwd)
+        if getattr(mod, "_qt_key", None) != key:
+            mod._qt, mod._qt_key = ops.make_weight_quant_table(fwd + bwd, mod.device), key
+        plan.add(ops.quantize_weights_fp8_batched, *mod._qt)
 
 
 class FPNNeck:
@@ -110,21 +150,29 @@ class FPNNeck:
     def refresh_weights(self, plan):
         for c in self.convs():
             plan.add(ops.weights_transpose_flip, *c.flip_entry())
+        _quantize_weights(self, plan)
 
-    def setup(self, batch, grids, training):
-        """grids: {level: (h, w)} of the backbone stage outputs."""
+    def setup(self, batch, grids, training, f8_scales=None):
+        """grids: {level: (h, w)} of the backbone stage outputs.  f8_scales (precision "fp8", training): the backbone's scale table;
+        the 3x3 output convolutions then run on e4m3 / e5m2 twins of the merged maps / of the pyramid gradients, written by one
+        quantise pass each (these tensors have no BatchNorm kernel that could write the twin on the way)."""
         dev = self.device
         self.batch, self.grids = batch, dict(grids)
         self.merged, self.p, self.gp, self.gm = {}, {}, {}, {}
+        self.f8 = f8_scales if training else None
+        self.merged8, self.gp8 = {}, {}
         for l in LEVELS:
             h, w = grids[l]
             self.lateral[l].setup(batch, h, w, dev)
-            self.output[l].setup(batch, h, w, dev)
+            self.output[l].setup(batch, h, w, dev, fp8=self.f8 is not None)
             self.merged[l] = torch.empty(batch * h * w, FPN_DIM, dtype=BF16, device=dev)     # lateral output, merged in place
             self.p[l] = torch.empty(batch, h, w, FPN_DIM, dtype=BF16, device=dev)
             if training:
                 self.gp[l] = torch.empty(batch * h * w, FPN_DIM, dtype=BF16, device=dev)       # gradient w.r.t. P_l (RoI + RPN branches)
                 self.gm[l] = torch.empty(batch * h * w, FPN_DIM, dtype=BF16, device=dev)       # gradient w.r.t. the merged map
+                if self.f8 is not None:
+                    self.merged8[l] = _twin(self.f8, self.merged[l], dev)
+                    self.gp8[l] = _twin(self.f8, self.gp[l], dev)
         h4, w4 = grids[4]
         self.grids[5] = ((h4 + 1) // 2, (w4 + 1) // 2)
         self.p[5] = torch.empty(batch, self.grids[5][0], self.grids[5][1], FPN_DIM, dtype=BF16, device=dev)
@@ -140,10 +188,20 @@ class FPNNeck:
             (ht, wt), (h, w) = self.grids[l + 1], self.grids[l]
             plan.add(ops.upsample_add, self.merged[l + 1], ht, wt, self.merged[l], self.merged[l], b, h, w, FPN_DIM)
         for l in LEVELS:
-            self.output[l].forward(plan, self.merged[l], self.p[l])
+            if self.merged8:
+                _quantize(plan, self.merged8[l], self.merged[l])
+            self.output[l].forward(plan, self.merged[l], self.p[l], self.merged8.get(l))
         h4, w4 = self.grids[4]
         plan.add(ops.subsample2, self.p[4], self.p[5], b, h4, w4, FPN_DIM)
         return self.p
+
+    def quant_entries(self):
+        fwd, bwd = [], []
+        for c in self.convs():
+            f, b_ = c.quant_entries()
+            fwd += f
+            bwd += b_
+        return fwd, bwd
 
     def backward_plan(self, plan, stage_maps, targets, red4=None):
         """self.gp[l] hold the gradients w.r.t. P2..P5 (complete).  targets {level: bf16 [B*h*w, C_level]}: receive the gradient
@@ -152,7 +210,9 @@ class FPNNeck:
         h4, w4 = self.grids[4]
         plan.add(ops.subsample2_bwd_add, self.gp[5], self.gp[4], b, h4, w4, FPN_DIM)
         for l in LEVELS:                                               # fine -> coarse: a merged map's gradient feeds the coarser one
-            self.output[l].backward_data(plan, self.gp[l], self.gm[l])
+            if self.gp8:
+                _quantize(plan, self.gp8[l], self.gp[l], e5m2=True)
+            self.output[l].backward_data(plan, self.gp[l], self.gm[l], dz8=self.gp8.get(l))
             if l > 2:
                 (h, w), (ht, wt) = self.grids[l - 1], self.grids[l]
                 plan.add(ops.upsample_add_bwd, self.gm[l - 1], h, w, self.gm[l], b, ht, wt, FPN_DIM, True)
@@ -233,9 +293,18 @@ class RPNDetectorFPN:
                 "rpn_classification_head/kernel": hd[:2 * A].permute(1, 2, 3, 0).contiguous(), "rpn_classification_head/bias": b[:2 * A].clone(),
                 "rpn_regression_head/kernel": hd[2 * A:6 * A].permute(1, 2, 3, 0).contiguous(), "rpn_regression_head/bias": b[2 * A:6 * A].clone()}
 
-    def setup(self, batch, training):
+    def setup(self, batch, training, f8_scales=None):
+        """f8_scales (precision "fp8", training): the shared 3x3 convolution runs on e4m3 twins of the pyramid levels and e5m2 twins of
+        its incoming gradients (one quantise pass each), with one e4m3 copy of its weights per direction."""
         dev = self.device
         self.batch = batch
+        self.f8 = f8_scales if training else None
+        self.w_inter8 = None
+        if self.f8 is not None:
+            self.w_inter8 = torch.zeros(256, self.ws, self.ws, FPN_DIM, dtype=ops.FP8, device=dev)
+            self.w_inter8_scale = torch.ones(256, dtype=torch.float32, device=dev)
+            self.w_inter_t8 = torch.zeros(FPN_DIM, self.ws, self.ws, 256, dtype=ops.FP8, device=dev)
+            self.w_inter_t8_scale = torch.ones(FPN_DIM, dtype=torch.float32, device=dev)
         self.n_level = {l: int(self.keep[l].numel()) if training else self.num_anchors[l] for l in RPN_LEVELS}
         self.offset, n = {}, 0
         for l in RPN_LEVELS:
@@ -257,6 +326,9 @@ class RPNDetectorFPN:
             e["d_heads"] = ops.conv_desc(batch, gh, gw, 256, 1, 1, 1, 0, 0, gh, gw, RPN_LD, flags=ops.CONV_BIAS | ops.CONV_OUT_F32)
             e["f"] = torch.empty(m, 256, dtype=BF16, device=dev)
             e["head"] = torch.empty(m, RPN_LD, device=dev)
+            if self.f8 is not None:
+                e["p8"] = _twin(self.f8, torch.empty(m, FPN_DIM, device="meta"), dev)
+                e["dz_f8"] = _twin(self.f8, torch.empty(m, 256, device="meta"), dev)
             e["ws"] = [ops.conv_attach_workspace(e["d_inter"], dev)]
             if training:
                 e["dhead32"] = torch.zeros(m, RPN_LD, device=dev)
@@ -274,9 +346,16 @@ class RPNDetectorFPN:
         return [(st.weight("rpn_intermediate_layer/kernel"), self.w_inter_t, 256, self.ws, self.ws, FPN_DIM),
                 (st.weight("rpn_heads/kernel"), self.w_heads_t, RPN_LD, 1, 1, 256)]
 
+    def quant_entries(self):
+        if self.w_inter8 is None:
+            return [], []
+        return ([(self.store.weight("rpn_intermediate_layer/kernel").view(256, -1), self.w_inter8, self.w_inter8_scale)],
+                [(self.w_inter_t.view(FPN_DIM, -1), self.w_inter_t8, self.w_inter_t8_scale)])
+
     def refresh_weights(self, plan):
         for e in self.flip_entries():
             plan.add(ops.weights_transpose_flip, *e)
+        _quantize_weights(self, plan)
 
     def forward_plan(self, plan, pyramid, training, decoded=None):
         st = self.store
@@ -284,8 +363,13 @@ class RPNDetectorFPN:
         for l in RPN_LEVELS:
             e = self.lv[l]
             ops.conv_zero_counters(plan, e["d_inter"])
-            plan.add(ops.conv2d_fprop, e["d_inter"], pyramid[l], st.weight_bf16("rpn_intermediate_layer/kernel"), e["f"],
-                     bias=st.weight("rpn_intermediate_layer/bias"))
+            if self.f8 is not None:
+                _quantize(plan, e["p8"], pyramid[l])
+                plan.add(ops.conv2d_fprop_fp8, e["d_inter"], e["p8"].data, self.w_inter8, e["p8"].scale, self.w_inter8_scale, e["f"],
+                         bias=st.weight("rpn_intermediate_layer/bias"))
+            else:
+                plan.add(ops.conv2d_fprop, e["d_inter"], pyramid[l], st.weight_bf16("rpn_intermediate_layer/kernel"), e["f"],
+                         bias=st.weight("rpn_intermediate_layer/bias"))
             plan.add(ops.conv2d_fprop, e["d_heads"], e["f"], st.weight_bf16("rpn_heads/kernel"), e["head"], bias=st.weight("rpn_heads/bias"))
             off, n = self.offset[l], self.n_level[l]
             plan.add(ops.rpn_head_post_level, e["head"], RPN_LD, self.batch, self.num_anchors[l], self.apl, self.keep[l] if training else None, n,
@@ -308,12 +392,14 @@ class RPNDetectorFPN:
             plan.add(ops.relu_bwd, e["g_f"], e["f"], e["dz_f"])
             plan.add(ops.colsum_bf16, e["dz_f"], e["m"], 256, 256, st.grad("rpn_intermediate_layer/bias"))
             plan.add(ops.conv2d_wgrad, e["d_inter"], pyramid[l], e["dz_f"], st.grad("rpn_intermediate_layer/kernel"))
-            if gp_written.get(l):
-                ops.conv_zero_counters(plan, e["d_inter_bwd_res"])
-                plan.add(ops.conv2d_fprop, e["d_inter_bwd_res"], e["dz_f"], self.w_inter_t, gp[l], res=gp[l])
+            d = e["d_inter_bwd_res"] if gp_written.get(l) else e["d_inter_bwd"]
+            res = gp[l] if gp_written.get(l) else None
+            ops.conv_zero_counters(plan, d)
+            if self.f8 is not None:
+                _quantize(plan, e["dz_f8"], e["dz_f"], e5m2=True)
+                plan.add(ops.conv2d_dgrad_fp8, d, e["dz_f8"].data, self.w_inter_t8, e["dz_f8"].scale, self.w_inter_t8_scale, gp[l], res=res)
             else:
-                ops.conv_zero_counters(plan, e["d_inter_bwd"])
-                plan.add(ops.conv2d_fprop, e["d_inter_bwd"], e["dz_f"], self.w_inter_t, gp[l])
+                plan.add(ops.conv2d_fprop, d, e["dz_f"], self.w_inter_t, gp[l], res=res)
 
 
 class FastRCNNDetectorFPN(FastRCNNDetector):
