@@ -306,8 +306,8 @@ class FasterRCNN:
 
     def _build_fpn(self, mods, batch, training, optimizer):
         """The step of _build on the feature pyramid (models/fpn.py): backbone -> neck -> RPN on P2..P5 -> ONE proposal NMS ->
-        per-level RoI pooling -> heads; backward through heads, RPN and neck into the backbone at C4, C3 and C2.  Everything on
-        the main stream (the side-stream branches of the C4 plan are a tuning step this topology has not had yet)."""
+        per-level RoI pooling -> heads; backward through heads, RPN and neck into the backbone at C4, C3 and C2; the same four
+        side-stream branches as the C4 plan (weight re-layouts, RPN targets -> loss, Fast-RCNN targets, detection NMS)."""
         cfg, dev = self.config, self.device
         H, W = self._image_shape[0], self._image_shape[1]
         nc1 = cfg["num_classes"] + 1
@@ -342,38 +342,47 @@ class FasterRCNN:
             plan.zero(self.store.g)
             table, total = ops.make_transpose_flip_table(fe.flip_entries() + neck.flip_entries() + rpn.flip_entries() + rcnn.flip_entries(), dev)
             plan.hold(table)
-            plan.add(ops.weights_transpose_flip_batched, table, total)
-            if fe.f8 is not None:                    # precision "fp8": the backbone from conv3 on + the pyramid's 3x3 convolutions
-                fe.quantize_bwd_weights_plan(plan, extra=neck.quant_entries()[1] + rpn.quant_entries()[1])
+            with plan.branch("weight_flips"):        # (first needed by the backward pass: a side stream under the forward pass)
+                plan.add(ops.weights_transpose_flip_batched, table, total)
+                if fe.f8 is not None:                # precision "fp8": the backbone from conv3 on + the pyramid's 3x3 convolutions
+                    fe.quantize_bwd_weights_plan(plan, extra=neck.quant_entries()[1] + rpn.quant_entries()[1])
         fe.forward_plan(plan, training)
         stage_maps = {l: fe.acts[last[l]]["out"] for l in FPN_LEVELS}
         pyramid = neck.forward_plan(plan, stage_maps)
         nms_cfg = self._rpn_config["nms"]
         rpn_nms = NmsBuffers(batch, n, 1, nms_cfg["max_output_size_per_class"], nms_cfg["max_total_size"], dev)
         rpn_out = rpn.forward_plan(plan, pyramid, training, decoded=rpn_nms.decoded)
-        plan.add(ops.assign_targets, rpn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
-                 rs["foreground_iou_interval"], rs["background_iou_interval"], t["rpn_tl"], t["rpn_tb"])
-        plan.add(ops.sample_indices, t["rpn_tl"], batch, n, 2, S_rpn, rs["foreground_proportion"], self.sampling_seed, step, 0,
-                 t["rpn_idx"], t["rpn_ws"], self.status, image_base=self.sampling_image_base)
-        plan.add(ops.losses, rpn_out["pred_scores"], rpn_out["pred_boxes"], t["rpn_tl"], t["rpn_tb"], t["rpn_idx"], batch, n, 2, S_rpn, cls_scale,
-                 1.0, losses[0:2], t.get("rpn_dl"), t.get("rpn_dd"))
+        # one-workgroup-per-image chains over ~82 k regions (targets -> sampling -> loss): side streams next to the proposal NMS, the
+        # RoI pooling and the head GEMM, as in the C4 plan
+        with plan.branch("rpn_side"):
+            plan.add(ops.assign_targets, rpn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
+                     rs["foreground_iou_interval"], rs["background_iou_interval"], t["rpn_tl"], t["rpn_tb"])
+            plan.add(ops.sample_indices, t["rpn_tl"], batch, n, 2, S_rpn, rs["foreground_proportion"], self.sampling_seed, step, 0,
+                     t["rpn_idx"], t["rpn_ws"], self.status, image_base=self.sampling_image_base)
+            plan.add(ops.losses, rpn_out["pred_scores"], rpn_out["pred_boxes"], t["rpn_tl"], t["rpn_tb"], t["rpn_idx"], batch, n, 2, S_rpn,
+                     cls_scale, 1.0, losses[0:2], t.get("rpn_dl"), t.get("rpn_dd"))
         nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"], buffers=rpn_nms, decoded_done=True)
         rois = nms_rpn["pred_boxes"]
-        regions_abs = rcnn.regions_plan(plan, rois)
-        plan.add(ops.assign_targets, regions_abs, io["gt_labels"], io["gt_boxes"], batch, P, G, nc1, False, W, H,
-                 cs["foreground_iou_interval"], cs["background_iou_interval"], t["rcnn_tl"], t["rcnn_tb"])
-        plan.add(ops.sample_indices, t["rcnn_tl"], batch, P, nc1, S_rcnn, cs["foreground_proportion"], self.sampling_seed, step, 2,
-                 t["rcnn_idx"], t["rcnn_ws"], self.status, image_base=self.sampling_image_base)
+        with plan.branch("rcnn_targets"):
+            regions_abs = rcnn.regions_plan(plan, rois)
+            plan.add(ops.assign_targets, regions_abs, io["gt_labels"], io["gt_boxes"], batch, P, G, nc1, False, W, H,
+                     cs["foreground_iou_interval"], cs["background_iou_interval"], t["rcnn_tl"], t["rcnn_tb"])
+            plan.add(ops.sample_indices, t["rcnn_tl"], batch, P, nc1, S_rcnn, cs["foreground_proportion"], self.sampling_seed, step, 2,
+                     t["rcnn_idx"], t["rcnn_ws"], self.status, image_base=self.sampling_image_base)
         rcnn_out = rcnn.forward_plan(plan, pyramid, rois, regions_done=True)
+        plan.join("rcnn_targets")
         if training:
             plan.add(ops.losses_head_grad, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"],
                      batch, P, nc1, S_rcnn, cls_scale, 1.0, losses[2:4], t["rcnn_dl"], t["rcnn_dd"], *rcnn.head_grad_rows())
         else:
             plan.add(ops.losses, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"], batch, P, nc1,
                      S_rcnn, cls_scale, 1.0, losses[2:4], None, None)
-        nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
+        with plan.branch("detections"):              # the step's predictions: nothing on the main chain needs them
+            nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
         if training:
+            plan.join("weight_flips")
             rcnn.backward_plan(plan, rois, neck.gp)                                  # gp[2..4]: complete RoI-branch gradients
+            plan.join("rpn_side")
             rpn.backward_plan(plan, t["rpn_dl"], t["rpn_dd"], t["rpn_idx"], S_rpn, pyramid, neck.gp, {2: True, 3: True, 4: True, 5: False})
             _, gh, gw, cf = fe.output_shape
             g_feat = torch.empty(batch * gh * gw, cf, dtype=BF16, device=dev)
@@ -384,6 +393,7 @@ class FasterRCNN:
             red4 = fe.last_unit().reduce_args(relu=True)
             plan.hold(red4)
             neck.backward_plan(plan, stage_maps, targets, red4=red4)
+            plan.join("detections")
             plan.cut("bwd_conv4")
             fe.backward_plan(plan, g_feat, g_feat_reduced=True, injected=(first_of[4], first_of[3]))
             plan.cut("update")

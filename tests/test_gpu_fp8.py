@@ -161,7 +161,8 @@ def test_conv_dgrad_fp8_vs_fp32_on_dequantised_operands(ops, case):
     assert got == ops.conv2d_describe_dgrad_fp8(d, case["red"]).split(" grid")[0] and "F8=2" in got, got
     torch.cuda.synchronize()
     oc, rc = out.float().cpu().reshape(mo, cout), ref.reshape(mo, cout)
-    _close(oc, rc, 2 ** -7, 2e-3 * amp, "fp8 data gradient")
+    # with a residual the kernel rounds the convolution term to bf16 before the add (as the bf16 kernel does): up to 2^-8 of |conv| more
+    _close(oc, rc, 2 ** -7, (6e-3 if case["res"] else 2e-3) * amp, "fp8 data gradient")
     assert float((oc - rc).norm() / rc.norm()) < 3e-3
     if case["red"]:
         gm = oc.double()[touched]
