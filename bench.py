@@ -416,7 +416,7 @@ def main():
             # while the kernel sources are the ones that trace was taken from.  The live HIP-event timing of the same launches is
             # reported beside it (`events`): raw pairs over-state a launch by the cost of the pair itself, pairs minus the calibrated
             # empty-pair cost under-state it; when the committed trace is stale the RAW (conservative) event figure is the headline.
-            off, source = offline_profile(dom, "_fp8" if args.fp8 else "")
+            off, source = offline_profile(dom, ("_fp8" if args.fp8 else "") + ("_fpn" if args.fpn else ""))
             ev_raw_us = (f["seconds"] + f["launches"] * f["event_pair_overhead_us"] * 1e-6) / f["launches"] * 1e6
             ev_net_us = f["seconds"] / f["launches"] * 1e6
             if off and off.get("avg_launch_us"):
@@ -426,7 +426,7 @@ def main():
             achieved = gflop_per_launch / head_us * 1e3       # GFLOP / us = PFLOP/s
             off_all = {}
             for k in fam:
-                off_all[k] = offline_profile(k, "_fp8" if args.fp8 else "")[0]
+                off_all[k] = offline_profile(k, ("_fp8" if args.fp8 else "") + ("_fpn" if args.fpn else ""))[0]
             families = {}
             for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["seconds"]):
                 o = off_all.get(k)
