@@ -442,9 +442,14 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
     // measured on the R50-C4 layer shapes (tools/wgrad_sweep.py): 64 x 64 tiles with a 3-slot ring (three workgroups per
     // CU) win nearly everywhere -- small tiles need few pixel splits to fill the chip, and every split costs one fp32 tile
     // of float atomics
-    int bm = 64;
-    int bn = d->cin >= 64 ? 64 : 32;
-    int stages = bn == 32 ? 2 : 3, want_split = 0;
+    // Long pixel streams under a multi-tap filter (the feature pyramid's 3x3 layers at stride 4 / 8: M = 58 k .. 234 k) are
+    // bound by what the workgroups pull through the CUs' load path -- every (cout tile, tap, cin tile) item streams its whole
+    // pixel range: 128 x 128 tiles halve that against 64 x 64 (tools/wgrad_sweep.py fpn: 305 vs 651 us at M = 233,872,
+    // 90 vs 156 us at M = 58,656; below M ~ 15 k the small tiles' better fill wins again)
+    const bool wide = d->kh * d->kw > 1 && d->cin % 128 == 0 && d->cout % 128 == 0 && M >= 24576;
+    int bm = wide ? 128 : 64;
+    int bn = wide ? 128 : d->cin >= 64 ? 64 : 32;
+    int stages = wide || bn == 32 ? 2 : 3, want_split = 0;
 #ifdef FRCNN_SWEEP
     if (const char* e = getenv("FRCNN_WGRAD")) {                // kernel development builds: "bm,bn,stages,split"
         int a = 0, b = 0, c = 0, sp = 0;
@@ -457,7 +462,7 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
     p.p_tiles = (int)((M + BKP - 1) / BKP);
     const int blocks_mn = p.tiles_co * p.taps * p.tiles_ci;
     // ~one workgroup per CU for 1x1 filters, two for multi-tap filters (their tile count is already large)
-    int split = want_split > 0 ? want_split : (num_cus() * (p.taps > 1 ? 2 : 1) + blocks_mn - 1) / blocks_mn;
+    int split = want_split > 0 ? want_split : wide ? 2 * num_cus() / blocks_mn : (num_cus() * (p.taps > 1 ? 2 : 1) + blocks_mn - 1) / blocks_mn;
     if (split > p.p_tiles) split = p.p_tiles;
     if (split < 1) split = 1;
     p.p_tiles_per_split = (p.p_tiles + split - 1) / split;
@@ -468,8 +473,8 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
     if (bm == BM_ && bn == BN_ && stages == S_) return launch<BM_, BN_, S_, OCC_>(p, split, s);
     FRCNN_DISPATCH(64, 64, 3, 3)           // the two shapes the rule above selects
     FRCNN_DISPATCH(64, 32, 2, 3)
-#ifdef FRCNN_SWEEP
     FRCNN_DISPATCH(128, 128, 2, 2)
+#ifdef FRCNN_SWEEP
     FRCNN_DISPATCH(128, 64, 2, 3)
     FRCNN_DISPATCH(128, 32, 2, 3)
     FRCNN_DISPATCH(64, 128, 2, 3)

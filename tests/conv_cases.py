@@ -138,6 +138,7 @@ WGRAD = [
     dict(id="small_1x1", n=2, h=9, w=13, cin=128, cout=256, k=1, s=1, p=0),
     dict(id="c4_3x3", n=3, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1),
     dict(id="c2_1x1", n=2, h=30, w=40, cin=64, cout=256, k=1, s=1, p=0),
+    dict(id="fpn_p2_3x3_wide", n=1, h=94, w=311, cin=256, cout=256, k=3, s=1, p=1),             # M >= 24576, multi-tap: 128 x 128 tiles
 ]
 
 # ---- grouped weight gradients: one launch per addressing mode; tile 128 x 64 when every layer of the mode has cout >= 128

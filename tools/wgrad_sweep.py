@@ -20,8 +20,17 @@ SHAPES = [  # n, h, w, cin, cout, k, stride, pad
 ]
 
 
+FPN_SHAPES = [  # the feature pyramid's layers at batch 8 (BASELINE.json configs[4]): laterals, output / RPN 3x3 convolutions per level
+    (8, 94, 311, 256, 256, 3, 1, 1), (8, 47, 156, 256, 256, 3, 1, 1), (8, 24, 78, 256, 256, 3, 1, 1), (8, 12, 39, 256, 256, 3, 1, 1),
+    (8, 94, 311, 256, 256, 1, 1, 0), (8, 47, 156, 512, 256, 1, 1, 0), (8, 24, 78, 1024, 256, 1, 1, 0),
+]
+
+
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    global SHAPES
+    if len(sys.argv) > 2 and sys.argv[2] == "fpn":
+        SHAPES = FPN_SHAPES
     g = torch.Generator(device="cuda").manual_seed(0)
     for (n, h, w, cin, cout, k, s, p) in SHAPES:
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
@@ -36,7 +45,7 @@ def main():
                 if (bm == 128 and cout < 128) or (bn == 128 and cin < 128):
                     continue
                 for st in (2, 3):
-                    for sp in (1, 2, 4, 8, 16, 32, 64):
+                    for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 64):
                         tiles = ((cout + bm - 1) // bm) * ((cin + bn - 1) // bn) * k * k
                         if tiles * sp < 128 or tiles * sp > 4096 or sp > (m + 63) // 64:
                             continue
