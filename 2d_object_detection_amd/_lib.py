@@ -22,7 +22,7 @@ class ConvDesc(Structure):
 class WgradItem(Structure):
     """struct frcnn_wgrad_item (include/frcnn_hip.h)."""
     _fields_ = [("desc", POINTER(ConvDesc)), ("x", c_void_p), ("dz", c_void_p), ("dw", c_void_p), ("dz_stride", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("reserved", ctypes.c_int32), ("x_scale", c_void_p), ("dz_scale", c_void_p)]
 
 
 class Fp8Out(Structure):
@@ -35,7 +35,7 @@ class BnReduce(Structure):
     _fields_ = [("z", c_void_p), ("relu_mask", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("partial", c_void_p)]
 
 
-ABI_VERSION = 3          # FRCNN_ABI_VERSION of include/frcnn_hip.h this table was written against (load() refuses any other library)
+ABI_VERSION = 4          # FRCNN_ABI_VERSION of include/frcnn_hip.h this table was written against (load() refuses any other library)
 
 CONV_BIAS, CONV_RELU, CONV_OUT_F32, CONV_ADD_RES, CONV_STATS, CONV_SPLITK_ATOMIC = 1, 2, 4, 8, 16, 32
 
@@ -60,6 +60,8 @@ _SIGNATURES = {
     "frcnn_fp8_update_scales": (c_int, [P, P, P, c_int, c_float, P]),
     "frcnn_conv2d_dgrad_bnreduce": (c_int, [POINTER(ConvDesc), P, P, P, P, P, POINTER(BnReduce), P]),
     "frcnn_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
+    "frcnn_conv2d_wgrad_fp8": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P, P]),
+    "frcnn_conv2d_wgrad_describe_fp8": (c_char_p, [POINTER(ConvDesc)]),
     "frcnn_wgrad_group_bytes": (c_size_t, []),
     "frcnn_conv2d_wgrad_group_plan": (c_int, [P, c_int, P, c_size_t]),
     "frcnn_conv2d_wgrad_grouped": (c_int, [P, P, P]),

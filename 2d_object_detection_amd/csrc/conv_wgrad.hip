@@ -29,6 +29,8 @@ struct WgradParams {
     int in_row_stride32;
     unsigned x_bytes, dz_bytes;
     int plain_store;                            // one pixel split: every dw element is written once -> plain stores, no float atomics
+    const float* f8_x_scale;                    // fp8 operands (x: e4m3, dz: e5m2, one byte per element): device scalars, the
+    const float* f8_z_scale;                    // dequantisation scales of the two tensors; NULL for bf16 operands
 };
 
 // 32-byte-chunk XOR swizzle of a pixel-major tile of W channels: the 4x16 blocks fetched by one
@@ -57,6 +59,19 @@ __device__ __forceinline__ bf16x8 load_frag_tr(const unsigned char* tile, int kp
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// fp8 operands (one byte per element, 128-pixel slices): ds_read_b64_tr_b8 hands lane i of a 16-lane block byte k = the byte
+// (i & 7) that source lane 2 k + (i >> 3) addressed -- source lane s points at row s >> 1, byte column 8 (s & 1) of an
+// 8-row x 16-byte block and gets back channel i of the block for its 8 rows (tools/probes/tr8_probe.hip).  One half-wave
+// fetches 16 rows x 16 bytes: the 16-byte-chunk XOR below puts them on 16 distinct bank groups.
+template <int W>
+__device__ __forceinline__ int fsw8(int r) {
+    return W == 128 ? (r >> 1) & 7 : (r >> 2) & 3;   // W == 64
+}
+template <int W>
+__device__ __forceinline__ int tile_off8(int r, int c) {   // byte offset of byte column c of pixel row r
+    return r * W + ((((c >> 4) ^ fsw8<W>(r)) << 4) | (c & 15));
+}
+
 enum { X_LINEAR = 0, X_ROWIDX = 1, X_GENERAL = 2 };   // how the x operand's pixel rows are addressed
 
 // Lanes whose channel chunk lies outside the tensor start here: the per-slice pixel advance keeps them inside
@@ -71,16 +86,17 @@ __device__ __forceinline__ int xcd_chunk(int bid, int total) {
 }
 
 // bid: logical workgroup index inside this layer's (pixel split, tile) list, tile fastest
-template <int BM /*co*/, int BN /*ci*/, int S, int MODE, int OCC>
+template <int BM /*co*/, int BN /*ci*/, int S, int MODE, int OCC, bool F8>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NW = 8, T = 512, BKP = 64, KK = BKP / 32;
+    constexpr int ES = F8 ? 1 : 2;                             // bytes per operand element
+    constexpr int NW = 8, T = 512, BKP = F8 ? 128 : 64, KK = 2;
     constexpr int WM = 2, WN = 4;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = (WTM + 15) / 16, NI = (WTN + 15) / 16;
     constexpr bool N_SPLIT = WTN >= 16;                       // BN = 32: only waves with wn < 2 own columns
-    constexpr int Z_BYTES = BKP * BM * 2, X_BYTES = BKP * BN * 2;
-    constexpr int Z_RPI = 1024 / (BM * 2), X_RPI = 1024 / (BN * 2);          // pixel rows per 1-KiB DMA instruction
+    constexpr int Z_BYTES = BKP * BM * ES, X_BYTES = BKP * BN * ES;
+    constexpr int Z_RPI = 1024 / (BM * ES), X_RPI = 1024 / (BN * ES);        // pixel rows per 1-KiB DMA instruction
     constexpr int Z_INSTR = BKP / Z_RPI, X_INSTR = BKP / X_RPI;
     constexpr int Z_IT = (Z_INSTR + NW - 1) / NW, X_IT = (X_INSTR + NW - 1) / NW;
     constexpr bool Z_UNI = Z_INSTR % NW == 0, X_UNI = X_INSTR % NW == 0;
@@ -114,35 +130,36 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
 
     // descriptors: x shifted back by the halo so that the per-lane pixel offset and the scalar tap offset are >= 0
     const long long halo = (long long)p.pad_h * p.in_row_stride32 + (long long)p.pad_w * p.in_pix_stride;
-    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - halo), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.x) - halo * ES), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.dz_bytes, 0x00020000);
-    const unsigned soff_x = (unsigned)((kh * p.in_row_stride32 + kw * p.in_pix_stride + ci0) * 2);
-    const unsigned soff_z = (unsigned)(co0 * 2);
+    const unsigned soff_x = (unsigned)((kh * p.in_row_stride32 + kw * p.in_pix_stride + ci0) * ES);
+    const unsigned soff_z = (unsigned)(co0 * ES);
 
     // per-lane DMA state.  dz (and x when its rows are linear in the pixel index): a byte offset that advances by a
     // constant per slice; pixel rows beyond M fall outside the descriptor and read zeros.
     unsigned z_vo[Z_IT], x_vo[X_IT], x_col[X_IT];
     int x_row[X_IT], x_n[X_IT], x_oy[X_IT], x_ox[X_IT];    // im2col walk of the lane's pixel (X_GENERAL)
-    const unsigned z_step = (unsigned)(BKP * p.dz_stride * 2), x_step = (unsigned)(BKP * p.in_pix_stride * 2);
+    const unsigned z_step = (unsigned)(BKP * p.dz_stride * ES), x_step = (unsigned)(BKP * p.in_pix_stride * ES);
 #pragma unroll
     for (int i = 0; i < Z_IT; ++i) {
         const int ins = wave + NW * i;
-        const int lanes_per_row = (BM * 2) / 16;
+        const int lanes_per_row = (BM * ES) / 16;
         const int r = ins * Z_RPI + lane / lanes_per_row, s16 = lane % lanes_per_row;
-        const int col = (((s16 >> 1) ^ fsw<BM>(r)) << 4) + (s16 & 1) * 8;          // element column that LDS slot s16 of row r must hold
-        z_vo[i] = (ins < Z_INSTR && co0 + col < p.Cout) ? (unsigned)(pix0 + r) * (unsigned)(p.dz_stride * 2) + (unsigned)(col * 2) : kColOob;
+        const int col = F8 ? (s16 ^ fsw8<BM>(r)) << 4                               // element column that LDS slot s16 of row r must hold
+                           : (((s16 >> 1) ^ fsw<BM>(r)) << 4) + (s16 & 1) * 8;
+        z_vo[i] = (ins < Z_INSTR && co0 + col < p.Cout) ? (unsigned)(pix0 + r) * (unsigned)(p.dz_stride * ES) + (unsigned)(col * ES) : kColOob;
     }
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
         const int ins = wave + NW * i;
-        const int lanes_per_row = (BN * 2) / 16;
+        const int lanes_per_row = (BN * ES) / 16;
         const int r = ins * X_RPI + lane / lanes_per_row, s16 = lane % lanes_per_row;
-        const int col = (((s16 >> 1) ^ fsw<BN>(r)) << 4) + (s16 & 1) * 8;
+        const int col = F8 ? (s16 ^ fsw8<BN>(r)) << 4 : (((s16 >> 1) ^ fsw<BN>(r)) << 4) + (s16 & 1) * 8;
         const bool col_ok = ins < X_INSTR && ci0 + col < p.Cin;
         x_row[i] = r;
-        x_col[i] = col_ok ? (unsigned)(col * 2) : kColOob;
-        x_vo[i] = col_ok ? (unsigned)(pix0 + r) * (unsigned)(p.in_pix_stride * 2) + (unsigned)(col * 2) : kColOob;
+        x_col[i] = col_ok ? (unsigned)(col * ES) : kColOob;
+        x_vo[i] = col_ok ? (unsigned)(pix0 + r) * (unsigned)(p.in_pix_stride * ES) + (unsigned)(col * ES) : kColOob;
         if (MODE == X_GENERAL) {
             const int m = pix0 + r;
             x_n[i] = m / hw;
@@ -173,11 +190,11 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
                     x_vo[i] += x_step;
                 } else if (MODE == X_ROWIDX) {
                     const int m = ld_pix0 + x_row[i];
-                    vo = (m < p.M && x_col[i] != kColOob) ? (unsigned)p.row_index[m] * (unsigned)(p.in_pix_stride * 2) + x_col[i] : kOob;
+                    vo = (m < p.M && x_col[i] != kColOob) ? (unsigned)p.row_index[m] * (unsigned)(p.in_pix_stride * ES) + x_col[i] : kOob;
                 } else {
                     const int iy = x_oy[i] * p.stride - p.pad_h + kh, ix = x_ox[i] * p.stride - p.pad_w + kw;
                     const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && x_n[i] * hw < p.M && x_col[i] != kColOob;
-                    vo = ok ? (unsigned)(((x_n[i] * p.Hi + x_oy[i] * p.stride) * p.Wi + x_ox[i] * p.stride) * p.in_pix_stride * 2) + x_col[i] : kOob;
+                    vo = ok ? (unsigned)(((x_n[i] * p.Hi + x_oy[i] * p.stride) * p.Wi + x_ox[i] * p.stride) * p.in_pix_stride * ES) + x_col[i] : kOob;
                     x_ox[i] += BKP;                          // advance this lane's pixel by BKP (division-free)
                     while (x_ox[i] >= p.Wo) { x_ox[i] -= p.Wo; ++x_oy[i]; }
                     while (x_oy[i] >= p.Ho) { x_oy[i] -= p.Ho; ++x_n[i]; }
@@ -201,10 +218,15 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
     {
         const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
         const int r1 = 8 * g + q;
+        const int r8 = 8 * g + (li >> 1), c8 = (li & 1) * 8;   // fp8: the lane's source row / byte column inside its block's 8 x 16 bytes
 #pragma unroll
-        for (int i = 0; i < MI; ++i) z_foff[i] = (unsigned)tile_off<BM>(r1, wm * WTM + i * 16 + 4 * pp);
+        for (int i = 0; i < MI; ++i)
+            z_foff[i] = F8 ? (unsigned)tile_off8<BM>(r8, wm * WTM + i * 16 + c8) : (unsigned)tile_off<BM>(r1, wm * WTM + i * 16 + 4 * pp);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) x_foff[j] = (unsigned)tile_off<BN>(r1, (N_SPLIT ? wn * WTN : wn * 16) + j * 16 + 4 * pp);
+        for (int j = 0; j < NI; ++j) {
+            const int cb = (N_SPLIT ? wn * WTN : wn * 16) + j * 16;
+            x_foff[j] = F8 ? (unsigned)tile_off8<BN>(r8, cb + c8) : (unsigned)tile_off<BN>(r1, cb + 4 * pp);
+        }
     }
     // The transposing reads go through inline asm: hipcc orders every ds_read_b64_tr_b16 it emits itself behind ALL pending
     // LDS-DMA (s_waitcnt vmcnt(0) right after the DMA issue -- no prefetch left).  The asm forms are invisible to that pass;
@@ -220,19 +242,38 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
     static_assert(NR <= 15, "lgkmcnt is a 4-bit counter");
     auto read_step = [&](auto slot_c, auto kk_c, u32x2 (&zl)[MI], u32x2 (&zh)[MI], u32x2 (&xl)[NI], u32x2 (&xh)[NI]) {
         constexpr int slot = decltype(slot_c)::value, kk = decltype(kk_c)::value;
-        constexpr int zo = slot * Z_BYTES + kk * 32 * (BM * 2), xo = slot * X_BYTES + kk * 32 * (BN * 2);
+        // bf16: step kk = pixel rows 32 kk .. 32 kk + 31, lo / hi = the lane's rows q and q + 4 of its block's 8.
+        // fp8: step kk = pixel rows 64 kk .. 64 kk + 63, lo / hi = rows 8 g + (0..7) and 32 + 8 g + (0..7) of them (the K order
+        // inside the 128-pixel MFMA is a permutation shared by both operands).
+        constexpr int zo = slot * Z_BYTES + kk * (F8 ? 64 : 32) * (BM * ES), xo = slot * X_BYTES + kk * (F8 ? 64 : 32) * (BN * ES);
+        constexpr int zh_o = zo + (F8 ? 32 : 4) * (BM * ES), xh_o = xo + (F8 ? 32 : 4) * (BN * ES);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const unsigned za = z_addr[i];       // (asm operands cannot name a captured variable of a generic lambda directly)
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(zl[i]) : "v"(za), "n"(zo) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(zh[i]) : "v"(za), "n"(zo + 4 * (BM * 2)) : "memory");
+            if (F8) {
+                asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(zl[i]) : "v"(za), "n"(zo) : "memory");
+                asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(zh[i]) : "v"(za), "n"(zh_o) : "memory");
+            } else {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(zl[i]) : "v"(za), "n"(zo) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(zh[i]) : "v"(za), "n"(zh_o) : "memory");
+            }
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const unsigned xa = x_addr[j];
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xl[j]) : "v"(xa), "n"(xo) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xh[j]) : "v"(xa), "n"(xo + 4 * (BN * 2)) : "memory");
+            if (F8) {
+                asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(xl[j]) : "v"(xa), "n"(xo) : "memory");
+                asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(xh[j]) : "v"(xa), "n"(xh_o) : "memory");
+            } else {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xl[j]) : "v"(xa), "n"(xo) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xh[j]) : "v"(xa), "n"(xh_o) : "memory");
+            }
         }
+    };
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    auto frag8 = [](const u32x2 a, const u32x2 b, const u32x2 c, const u32x2 d) -> i32x8 {
+        const i32x8 v = {(int)a[0], (int)a[1], (int)b[0], (int)b[1], (int)c[0], (int)c[1], (int)d[0], (int)d[1]};
+        return v;
     };
     auto frag = [](const u32x2 lo, const u32x2 hi) -> bf16x8 {
         const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
@@ -254,6 +295,18 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
         static_assert(KK == 2, "two 32-pixel steps per 64-pixel slice");
         read_step(slot_c, std::integral_constant<int, 1>{}, zl[1], zh[1], xl[1], xh[1]);
         wait_step(std::integral_constant<int, NR>{}, zl[0], zh[0], xl[0], xh[0]);
+        if (F8) {
+            // one 128-pixel MFMA per accumulator: x is e4m3 (A, cbsz 0), dz is e5m2 (B, blgp 1), unit block scales
+            wait_step(std::integral_constant<int, 0>{}, zl[1], zh[1], xl[1], xh[1]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(frag8(xl[0][j], xh[0][j], xl[1][j], xh[1][j]),
+                                                                                 frag8(zl[0][i], zh[0][i], zl[1][i], zh[1][i]), acc[i][j], 0, 1, 0,
+                                                                                 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -322,11 +375,13 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
         }
     }
     __syncthreads();
+    const float dq = F8 ? *p.f8_x_scale * *p.f8_z_scale : 1.f;       // per-tensor dequantisation of the fp8 product
     for (int idx = tid; idx < BM * BN; idx += T) {
         const int r = idx / BN, c = idx - r * BN;
         const int co = co0 + r, ci = ci0 + c;
         if (co < p.Cout && ci < p.Cin) {
-            const float v = *reinterpret_cast<const float*>(stage + r * SROW + c * 4);
+            float v = *reinterpret_cast<const float*>(stage + r * SROW + c * 4);
+            if (F8) v *= dq;
             float* dst = p.dw + ((long long)co * p.taps + tap) * p.Cin + ci;
             if (p.plain_store) *dst = v;
             else atomicAdd(dst, v);
@@ -335,9 +390,9 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
 #endif
 }
 
-template <int BM, int BN, int S, int MODE, int OCC>
+template <int BM, int BN, int S, int MODE, int OCC, bool F8 = false>
 __global__ __launch_bounds__(512, 2 * OCC) void wgrad_kernel(const WgradParams p) {
-    wgrad_body<BM, BN, S, MODE, OCC>(p, xcd_chunk(blockIdx.x, gridDim.x));
+    wgrad_body<BM, BN, S, MODE, OCC, F8>(p, xcd_chunk(blockIdx.x, gridDim.x));
 }
 
 // Grouped launch: the weight gradients of several layers (same tile shape and addressing mode) in ONE grid.  A stage of
@@ -351,41 +406,47 @@ struct WgradGroup {
     WgradParams p[kGroupMax];
 };
 
-template <int BM, int BN, int S, int MODE, int OCC>
+template <int BM, int BN, int S, int MODE, int OCC, bool F8 = false>
 __global__ __launch_bounds__(512, 2 * OCC) void wgrad_group_kernel(const WgradGroup* __restrict__ g) {
     const int id = xcd_chunk(blockIdx.x, gridDim.x);
     int layer = 0;
     while (layer + 1 < g->n && id >= g->first[layer + 1]) ++layer;             // (uniform: scalar loads)
     const WgradParams p = g->p[layer];
-    wgrad_body<BM, BN, S, MODE, OCC>(p, id - g->first[layer]);
+    wgrad_body<BM, BN, S, MODE, OCC, F8>(p, id - g->first[layer]);
 }
 
 thread_local bool t_dry_run = false;            // frcnn_conv2d_wgrad*_describe: stop before the launch
 
-template <int BM, int BN, int S, int MODE, int OCC>
+template <int BM, int BN, int S, int MODE, int OCC, bool F8 = false>
 int launch_mode(const WgradParams& p, int split, hipStream_t s) {
-    constexpr int ring_bytes = S * 64 * (BM + BN) * 2;
+    constexpr int ring_bytes = S * 64 * (BM + BN) * 2;        // (fp8: 128-pixel slices of one-byte elements, the same bytes)
     constexpr int stage_bytes = BM * (BN * 4 + 16);
     constexpr int smem = ring_bytes > stage_bytes ? ring_bytes : stage_bytes;
     static_assert(smem * OCC <= 163840, "LDS budget");
-    if (!t_dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_kernel<BM, BN, S, MODE, OCC>), smem) != 0) {
+    if (!t_dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_kernel<BM, BN, S, MODE, OCC, F8>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_wgrad: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
     dim3 grid(p.tiles_co * p.taps * p.tiles_ci * split, 1, 1);
     {
         char name[160];
-        snprintf(name, sizeof(name), "wgrad<BM=%d,BN=%d,S=%d,MODE=%d,OCC=%d> grid=%d split=%d", BM, BN, S, MODE, OCC, (int)grid.x, split);
+        snprintf(name, sizeof(name), "wgrad<BM=%d,BN=%d,S=%d,MODE=%d,OCC=%d%s> grid=%d split=%d", BM, BN, S, MODE, OCC, F8 ? ",F8" : "", (int)grid.x, split);
         frcnn_note_instantiation(name);
     }
     if (t_dry_run) return FRCNN_OK;
-    hipLaunchKernelGGL((wgrad_kernel<BM, BN, S, MODE, OCC>), grid, dim3(512), smem, s, p);
+    hipLaunchKernelGGL((wgrad_kernel<BM, BN, S, MODE, OCC, F8>), grid, dim3(512), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad");
     return FRCNN_OK;
 }
 
 template <int BM, int BN, int S, int OCC>
 int launch(const WgradParams& p, int split, hipStream_t s) {
+    if constexpr (BN >= 64) {
+        if (p.f8_x_scale) {
+            if (p.linear_x) return launch_mode<BM, BN, S, X_LINEAR, OCC, true>(p, split, s);
+            return launch_mode<BM, BN, S, X_GENERAL, OCC, true>(p, split, s);
+        }
+    }
     if (p.row_index) return launch_mode<BM, BN, S, X_ROWIDX, OCC>(p, split, s);
     if (p.linear_x) return launch_mode<BM, BN, S, X_LINEAR, OCC>(p, split, s);
     return launch_mode<BM, BN, S, X_GENERAL, OCC>(p, split, s);
@@ -394,15 +455,24 @@ int launch(const WgradParams& p, int split, hipStream_t s) {
 }  // namespace
 
 // validation + geometry of one weight gradient (tile counts and the pixel split are set by the callers)
-static int wgrad_fill(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* dz, int dz_stride, const int32_t* row_index,
-                      float* dw, WgradParams& p) {
+// es: bytes per operand element (2: bf16; 1: fp8 with the two dequantisation scales)
+static int wgrad_fill(const frcnn_conv_desc* d, const void* x, const void* dz, int dz_stride, const int32_t* row_index,
+                      float* dw, WgradParams& p, int es = 2, const float* x_scale = nullptr, const float* dz_scale = nullptr) {
     FRCNN_CHECK_ARG(d && x && dz && dw, "conv2d_wgrad: null pointer");
     FRCNN_CHECK_ARG(d->cin % 8 == 0 && d->cout % 8 == 0 && dz_stride % 8 == 0, "conv2d_wgrad: channels must be multiples of 8");
     FRCNN_CHECK_ARG(!row_index || (d->kh == 1 && d->kw == 1), "conv2d_wgrad: row_index only for 1x1");
-    FRCNN_CHECK_ARG(d->in_pix_stride % 4 == 0 && (d->kw == 1 || d->in_pix_stride % 8 == 0) &&
-                        (d->stride * d->in_pix_stride) % 8 == 0 && (d->pad_w * d->in_pix_stride) % 8 == 0 &&
-                        ((long long)d->wi * d->in_pix_stride) % 8 == 0,
+    const int a16 = 16 / es;                     // elements per 16 bytes
+    FRCNN_CHECK_ARG(d->in_pix_stride % (a16 / 2) == 0 && (d->kw == 1 || d->in_pix_stride % a16 == 0) &&
+                        (d->stride * d->in_pix_stride) % a16 == 0 && (d->pad_w * d->in_pix_stride) % a16 == 0 &&
+                        ((long long)d->wi * d->in_pix_stride) % a16 == 0,
                     "conv2d_wgrad: pixel addressing breaks 16-byte alignment");
+    if (es == 1) {
+        FRCNN_CHECK_ARG(x_scale && dz_scale && !row_index, "conv2d_wgrad fp8: needs both dequantisation scales, no row_index");
+        FRCNN_CHECK_ARG(d->cin % 64 == 0 && d->cout % 64 == 0 && dz_stride % 16 == 0 && d->in_pix_stride % 16 == 0,
+                        "conv2d_wgrad fp8: channels must be multiples of 64, row strides of 16");
+    }
+    p.f8_x_scale = es == 1 ? x_scale : nullptr;
+    p.f8_z_scale = es == 1 ? dz_scale : nullptr;
     p.x = reinterpret_cast<const bf16_t*>(x);
     p.dz = reinterpret_cast<const bf16_t*>(dz);
     p.row_index = row_index;
@@ -423,7 +493,7 @@ static int wgrad_fill(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
         // with row_index the x extent is unknown here: the caller's rows are trusted (checked upstream), use the 4 GiB cap
         const long long x_elems = row_index ? 0x7FFF0000ll : (long long)d->n * d->hi * in_row_stride + (long long)d->kw * d->in_pix_stride + 64;
         // linear rows: the descriptor ends exactly at pixel M, so the pixel tail of the last slice reads zeros
-        const long long xb = p.linear_x ? M * d->in_pix_stride * 2 : (x_elems + halo) * 2, zb = M * dz_stride * 2;
+        const long long xb = p.linear_x ? M * d->in_pix_stride * es : (x_elems + halo) * es, zb = M * dz_stride * es;
         FRCNN_CHECK_ARG(xb < 0xFFFF0000ll && zb < 0x7FFF0000ll && (!p.linear_x || xb < 0x7FFF0000ll),
                         "conv2d_wgrad: operand too large for 32-bit buffer offsets");
         p.x_bytes = (unsigned)xb;
@@ -433,11 +503,12 @@ static int wgrad_fill(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     return FRCNN_OK;
 }
 
-extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* dz, int dz_stride,
-                                  const int32_t* row_index, float* dw, frcnn_stream_t stream) {
+static int wgrad_one(const frcnn_conv_desc* d, const void* x, const void* dz, int dz_stride, const int32_t* row_index, float* dw,
+                     int es, const float* x_scale, const float* dz_scale, frcnn_stream_t stream) {
     WgradParams p;
-    if (const int rc = wgrad_fill(d, x, dz, dz_stride, row_index, dw, p)) return rc;
+    if (const int rc = wgrad_fill(d, x, dz, dz_stride, row_index, dw, p, es, x_scale, dz_scale)) return rc;
     const long long M = p.M;
+    const int BKP = es == 1 ? 128 : 64;          // pixels per slice
 
     // measured on the R50-C4 layer shapes (tools/wgrad_sweep.py): 64 x 64 tiles with a 3-slot ring (three workgroups per
     // CU) win nearly everywhere -- small tiles need few pixel splits to fill the chip, and every split costs one fp32 tile
@@ -456,7 +527,6 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
         if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &sp) == 4) { bm = a; bn = b; stages = c; want_split = sp; }
     }
 #endif
-    constexpr int BKP = 64;
     p.tiles_co = (d->cout + bm - 1) / bm;
     p.tiles_ci = (d->cin + bn - 1) / bn;
     p.p_tiles = (int)((M + BKP - 1) / BKP);
@@ -488,8 +558,19 @@ extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x,
     return FRCNN_EINVAL;
 }
 
+extern "C" int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* dz, int dz_stride,
+                                  const int32_t* row_index, float* dw, frcnn_stream_t stream) {
+    return wgrad_one(d, x, dz, dz_stride, row_index, dw, 2, nullptr, nullptr, stream);
+}
+
+extern "C" int frcnn_conv2d_wgrad_fp8(const frcnn_conv_desc* d, const frcnn_fp8* x8, const frcnn_fp8* dz8, int dz_stride,
+                                      const float* x_scale, const float* dz_scale, float* dw, frcnn_stream_t stream) {
+    return wgrad_one(d, x8, dz8, dz_stride, nullptr, dw, 1, x_scale, dz_scale, stream);
+}
+
 // ---------------------------------------------------------------------------------------------------- grouped launches
-extern "C" size_t frcnn_wgrad_group_bytes(void) { return 2 * sizeof(WgradGroup); }
+constexpr int kGroups = 4;                      // {bf16, fp8} x {x rows linear in the pixel index, general addressing}
+extern "C" size_t frcnn_wgrad_group_bytes(void) { return kGroups * sizeof(WgradGroup); }
 
 // Fill `table_host` (frcnn_wgrad_group_bytes() bytes: one group of 1x1 / stride-1 layers whose x rows are the GEMM rows, one
 // group of everything else) for n weight gradients that are launched together with ONE small pixel split for the whole group
@@ -497,7 +578,7 @@ extern "C" size_t frcnn_wgrad_group_bytes(void) { return 2 * sizeof(WgradGroup);
 // table to device memory once -- shapes and pointers of a training plan are static -- and passes both copies to
 // frcnn_conv2d_wgrad_grouped.  Layers must have cin, cout multiples of 64 (64 x 64 tiles).
 extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int n, void* table_host, size_t table_bytes) {
-    FRCNN_CHECK_ARG(items && table_host && n > 0 && table_bytes >= 2 * sizeof(WgradGroup), "conv2d_wgrad_group_plan: bad arguments");
+    FRCNN_CHECK_ARG(items && table_host && n > 0 && table_bytes >= kGroups * sizeof(WgradGroup), "conv2d_wgrad_group_plan: bad arguments");
     WgradGroup* g = reinterpret_cast<WgradGroup*>(table_host);
     // tile shape of the grouped launches.  Launched alone a layer wants small tiles (few pixel splits fill the chip); a group
     // has tiles to spare, so it can afford more MFMA work per barrier.  FRCNN_WGRAD_GROUP="bm,bn" overrides (development aid)
@@ -508,20 +589,24 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
         if (sscanf(e, "%d,%d,%d", &a, &b, &c) >= 2 && (a == 0 || a == 64 || a == 128) && (b == 64 || b == 128)) { gbm = a; gbn = b; gst = c; }
     }
 #endif
-    g[0].n = g[1].n = 0;
-    g[0].total = g[1].total = 0;
-    int tiles[2] = {0, 0}, min_p_tiles[2] = {1 << 30, 1 << 30};
+    int tiles[kGroups], min_p_tiles[kGroups];
+    for (int m = 0; m < kGroups; ++m) {
+        g[m].n = g[m].total = tiles[m] = 0;
+        min_p_tiles[m] = 1 << 30;
+    }
     for (int i = 0; i < n; ++i) {
         WgradParams p;
-        if (const int rc = wgrad_fill(items[i].desc, items[i].x, items[i].dz, items[i].dz_stride, nullptr, items[i].dw, p)) return rc;
+        const bool f8 = items[i].x_scale || items[i].dz_scale;
+        if (const int rc = wgrad_fill(items[i].desc, items[i].x, items[i].dz, items[i].dz_stride, nullptr, items[i].dw, p, f8 ? 1 : 2,
+                                      items[i].x_scale, items[i].dz_scale)) return rc;
         FRCNN_CHECK_ARG(p.Cin % 64 == 0 && p.Cout % 64 == 0, "conv2d_wgrad_group_plan: layer %d: channels must be multiples of 64", i);
-        p.p_tiles = (p.M + 63) / 64;
-        const int m = p.linear_x ? 0 : 1;
+        p.p_tiles = f8 ? (p.M + 127) / 128 : (p.M + 63) / 64;
+        const int m = (f8 ? 2 : 0) + (p.linear_x ? 0 : 1);
         FRCNN_CHECK_ARG(g[m].n < kGroupMax, "conv2d_wgrad_group_plan: more than %d layers in one group", kGroupMax);
         g[m].p[g[m].n++] = p;
         if (p.p_tiles < min_p_tiles[m]) min_p_tiles[m] = p.p_tiles;
     }
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < kGroups; ++m) {
         // measured (train step, batch 4): 128 x 64 tiles 0.73 ms of weight-gradient time per step, 64 x 64 0.82, 64 x 128 0.77,
         // 128 x 128 0.83 -- twice the MFMA work per barrier for 1.5x the staged bytes; not for 64-channel outputs (half a tile idle)
         int min_cout = 1 << 30;
@@ -539,7 +624,7 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
     // one pixel split for the whole group: just enough workgroups for ~2 per CU.  The float atomics of a split cost
     // split x |dw| bytes at the memory side's 1.3 TB/s; launched alone, a layer with few tiles needs a far larger split to fill
     // the chip (conv2: 64-128) than the group does (~10)
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < kGroups; ++m) {
         if (g[m].n == 0) continue;
         int split = (2 * num_cus() + tiles[m] - 1) / tiles[m];
         if (split > min_p_tiles[m]) split = min_p_tiles[m];
@@ -571,42 +656,54 @@ extern "C" const char* frcnn_conv2d_wgrad_describe(const frcnn_conv_desc* d, int
     return rc == FRCNN_OK ? frcnn_last_conv_instantiation() : nullptr;
 }
 
+extern "C" const char* frcnn_conv2d_wgrad_describe_fp8(const frcnn_conv_desc* d) {
+    static const int32_t dummy[4] = {0};
+    const frcnn_fp8* q = reinterpret_cast<const frcnn_fp8*>(dummy);
+    const float* f = reinterpret_cast<const float*>(dummy);
+    frcnn_note_instantiation("");
+    t_dry_run = true;
+    const int rc = frcnn_conv2d_wgrad_fp8(d, q, q, d ? d->cout : 0, f, f, const_cast<float*>(f), nullptr);
+    t_dry_run = false;
+    return rc == FRCNN_OK ? frcnn_last_conv_instantiation() : nullptr;
+}
+
 extern "C" int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* table_dev, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(table_host && table_dev, "conv2d_wgrad_grouped: null pointer");
     const WgradGroup* h = reinterpret_cast<const WgradGroup*>(table_host);
     const WgradGroup* dv = reinterpret_cast<const WgradGroup*>(table_dev);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int launched = 0;
-    char name[192] = "";
-#define FRCNN_GROUP_LAUNCH(BM_, BN_, S_, OCC_, MODE_, IDX_)                                                                       \
-    if (h[IDX_].n > 0 && h[IDX_].bm == BM_ && h[IDX_].bn == BN_ && h[IDX_].stages == S_) {                                                             \
+    char name[384] = "";
+#define FRCNN_GROUP_LAUNCH1(BM_, BN_, S_, OCC_, MODE_, IDX_, F8_)                                                                  \
+    if (h[IDX_].n > 0 && h[IDX_].bm == BM_ && h[IDX_].bn == BN_ && h[IDX_].stages == S_) {                                         \
         constexpr int ring_b = S_ * 64 * (BM_ + BN_) * 2, stage_b = BM_ * (BN_ * 4 + 16);                                          \
         constexpr int smem_b = ring_b > stage_b ? ring_b : stage_b;                                                                \
         static_assert(smem_b * OCC_ <= 163840, "LDS budget");                                                                      \
-        FRCNN_CHECK_ARG(t_dry_run || frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_group_kernel<BM_, BN_, S_, MODE_, OCC_>), smem_b) == 0, \
+        FRCNN_CHECK_ARG(t_dry_run || frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_group_kernel<BM_, BN_, S_, MODE_, OCC_, F8_>), smem_b) == 0, \
                         "conv2d_wgrad_grouped: cannot reserve %d B of LDS", smem_b);                                              \
-        if (!t_dry_run) hipLaunchKernelGGL((wgrad_group_kernel<BM_, BN_, S_, MODE_, OCC_>), dim3(h[IDX_].total), dim3(512), smem_b, s, dv + IDX_);   \
-        snprintf(name + strlen(name), sizeof(name) - strlen(name), "wgrad_group<BM=%d,BN=%d,S=%d,MODE=%d,OCC=%d> grid=%d; ", BM_, BN_, S_, MODE_, OCC_, h[IDX_].total); \
-            if (!t_dry_run) FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad_grouped");                                                          \
+        if (!t_dry_run) hipLaunchKernelGGL((wgrad_group_kernel<BM_, BN_, S_, MODE_, OCC_, F8_>), dim3(h[IDX_].total), dim3(512), smem_b, s, dv + IDX_);   \
+        snprintf(name + strlen(name), sizeof(name) - strlen(name), "wgrad_group<BM=%d,BN=%d,S=%d,MODE=%d,OCC=%d%s> grid=%d; ", BM_, BN_, S_, MODE_, OCC_, \
+                 F8_ ? ",F8" : "", h[IDX_].total);                                                                                 \
+        if (!t_dry_run) FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad_grouped");                                                          \
         launched |= 1 << IDX_;                                                                                                     \
     }
-    FRCNN_GROUP_LAUNCH(64, 64, 3, 3, X_LINEAR, 0)
-    FRCNN_GROUP_LAUNCH(64, 64, 3, 3, X_GENERAL, 1)
-    FRCNN_GROUP_LAUNCH(128, 64, 3, 2, X_LINEAR, 0)
-    FRCNN_GROUP_LAUNCH(128, 64, 3, 2, X_GENERAL, 1)
+#define FRCNN_GROUP_LAUNCH(BM_, BN_, S_, OCC_)                    \
+    FRCNN_GROUP_LAUNCH1(BM_, BN_, S_, OCC_, X_LINEAR, 0, false)   \
+    FRCNN_GROUP_LAUNCH1(BM_, BN_, S_, OCC_, X_GENERAL, 1, false)  \
+    FRCNN_GROUP_LAUNCH1(BM_, BN_, S_, OCC_, X_LINEAR, 2, true)    \
+    FRCNN_GROUP_LAUNCH1(BM_, BN_, S_, OCC_, X_GENERAL, 3, true)
+    FRCNN_GROUP_LAUNCH(64, 64, 3, 3)
+    FRCNN_GROUP_LAUNCH(128, 64, 3, 2)
 #ifdef FRCNN_SWEEP
-    FRCNN_GROUP_LAUNCH(64, 128, 3, 2, X_LINEAR, 0)
-    FRCNN_GROUP_LAUNCH(64, 128, 3, 2, X_GENERAL, 1)
-    FRCNN_GROUP_LAUNCH(128, 128, 2, 2, X_LINEAR, 0)
-    FRCNN_GROUP_LAUNCH(128, 128, 2, 2, X_GENERAL, 1)
-    FRCNN_GROUP_LAUNCH(128, 64, 2, 3, X_LINEAR, 0)
-    FRCNN_GROUP_LAUNCH(128, 64, 2, 3, X_GENERAL, 1)
-    FRCNN_GROUP_LAUNCH(64, 64, 2, 3, X_LINEAR, 0)
-    FRCNN_GROUP_LAUNCH(64, 64, 2, 3, X_GENERAL, 1)
+    FRCNN_GROUP_LAUNCH(64, 128, 3, 2)
+    FRCNN_GROUP_LAUNCH(128, 128, 2, 2)
+    FRCNN_GROUP_LAUNCH(128, 64, 2, 3)
+    FRCNN_GROUP_LAUNCH(64, 64, 2, 3)
 #endif
 #undef FRCNN_GROUP_LAUNCH
+#undef FRCNN_GROUP_LAUNCH1
     frcnn_note_instantiation(name);
-    FRCNN_CHECK_ARG((h[0].n == 0 || (launched & 1)) && (h[1].n == 0 || (launched & 2)), "conv2d_wgrad_grouped: no kernel for tile %dx%d, %d slots",
-                    h[0].n ? h[0].bm : h[1].bm, h[0].n ? h[0].bn : h[1].bn, h[0].n ? h[0].stages : h[1].stages);
+    for (int m = 0; m < kGroups; ++m)
+        FRCNN_CHECK_ARG(h[m].n == 0 || (launched & (1 << m)), "conv2d_wgrad_grouped: no kernel for tile %dx%d, %d slots", h[m].bm, h[m].bn, h[m].stages);
     return FRCNN_OK;
 }

@@ -184,6 +184,7 @@ class RPNDetector:
         feature_maps8: Fp8Twin of the feature maps (fp8 training): the 3x3 convolution reads e4m3 operands."""
         st = self.store
         ops.conv_zero_counters(plan, self.d_inter)
+        self._feature_maps8 = feature_maps8 if (feature_maps8 is not None and self.w_inter8 is not None) else None
         if feature_maps8 is not None and self.w_inter8 is not None:
             plan.add(ops.conv2d_fprop_fp8, self.d_inter, feature_maps8.data, self.w_inter8, feature_maps8.scale, self.w_inter8_scale, self.f,
                      bias=st.weight("rpn_intermediate_layer/bias"))
@@ -230,7 +231,13 @@ class RPNDetector:
             sc = self.dz_f8.scales
             plan.add(ops.quantize_fp8, self.dz_f, sc.qscale(self.dz_f8.idx), self.dz_f8.data, sc.amax(self.dz_f8.idx), e5m2=True)
         plan.add(ops.colsum_bf16, self.dz_f, self.m, 256, 256, st.grad("rpn_intermediate_layer/bias"))
-        plan.add(ops.conv2d_wgrad, self.d_inter, feature_maps, self.dz_f, st.grad("rpn_intermediate_layer/kernel"))
+        from ..feature_extractor import FP8_WGRAD
+        f8 = getattr(self, "_feature_maps8", None)
+        if FP8_WGRAD and f8 is not None and self.dz_f8 is not None:
+            # fp8 weight gradient of the 3x3 convolution: the feature maps' e4m3 twin x the e5m2 twin of dz_f quantised above
+            plan.add(ops.conv2d_wgrad_fp8, self.d_inter, f8.data, self.dz_f8.data, f8.scale, self.dz_f8.scale, st.grad("rpn_intermediate_layer/kernel"))
+        else:
+            plan.add(ops.conv2d_wgrad, self.d_inter, feature_maps, self.dz_f, st.grad("rpn_intermediate_layer/kernel"))
 
     def backward_data_plan(self, plan, g_feat, consumer=None):
         """consumer: the backbone's last conv unit -- g_feat is complete after this kernel, so it also runs that unit's

@@ -34,6 +34,7 @@ def _out_hw(h, w):
 
 FP8_MIN_STAGE = int(os.environ.get("FRCNN_FP8_MIN_STAGE", "3"))      # first ResNet stage whose tensors get fp8 twins (measuring aid: 2 = all)
 FP8_BWD = os.environ.get("FRCNN_FP8_BWD", "1") != "0"                # measuring aid: 0 keeps the data gradients in bf16 (fp8 forward only)
+FP8_WGRAD = os.environ.get("FRCNN_FP8_WGRAD", "1") != "0"            # measuring aid: 0 keeps the weight gradients in bf16
 FP8_MARGIN = 2.0           # delayed scaling: next step's scale = margin * this step's amax / 448 (e4m3 is a float format: head-room costs no precision)
 
 
@@ -87,7 +88,7 @@ class Fp8Twin:
 class _ConvBN:
     """One conv + BatchNorm unit (Keras names <name>_conv / <name>_bn)."""
 
-    def __init__(self, store, name, cin, cout, k, stride, pad, sync_world=1, fp8=False, fp8_bwd=None):
+    def __init__(self, store, name, cin, cout, k, stride, pad, sync_world=1, fp8=False, fp8_bwd=None, fp8_wgrad=None):
         self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
         # fp8 forward convolution (e4m3 operands, 128-deep MFMA steps): a layer whose cin is a multiple of 128
         # ... and whose contraction is at least two 128-deep steps long (a single step has no K loop to shorten: measured at
@@ -95,6 +96,9 @@ class _ConvBN:
         self.fp8 = bool(fp8) and k != 7 and cin % 128 == 0 and k * k * cin >= 256
         # fp8 data gradient (e5m2 gradient x e4m3 transposed weights): its contraction runs over this layer's OUTPUT channels
         self.fp8_bwd = FP8_BWD and bool(fp8 if fp8_bwd is None else fp8_bwd) and k != 7 and cout % 128 == 0 and k * k * cout >= 256
+        # fp8 weight gradient (e4m3 input twin x e5m2 gradient twin, contraction over the pixels): bound by the bytes its workgroups
+        # stream, so it pays whatever the channel counts (tools/wgrad_sweep.py fp8: 1.3-1.8x) -- wherever the input already has a twin
+        self.fp8_wgrad = FP8_WGRAD and bool(fp8 if fp8_wgrad is None else fp8_wgrad) and k != 7 and cin % 64 == 0 and cout % 64 == 0
         self.store = store
         self.sync_world = int(sync_world)            # > 1: BatchNorm statistics are summed over this many data-parallel ranks
         store.register(name + "_conv/kernel", (cout, k, k, cin))          # OHWI (Keras: HWIO)
@@ -237,12 +241,19 @@ class _ConvBN:
                  f8=self.dz8.out if self.dz8 is not None else None)
         # the conv bias feeds a training-mode BN: its gradient is identically zero (flat grad buffer is pre-zeroed)
 
-    def backward_weights(self, plan, x, defer=None):
+    def backward_weights(self, plan, x, defer=None, x8=None):
         """defer: list collecting (desc, x, dz, dw) of layers whose weight gradients are launched together at the end of their
-        stage (ops.WgradGroup) instead of one launch each."""
+        stage (ops.WgradGroup) instead of one launch each.  x8: Fp8Twin of x -- with the e5m2 twin of dz the fp8 form."""
         st = self.store
+        f8 = self.fp8_wgrad and x8 is not None and self.dz8 is not None
         if defer is not None and not self.is_stem and self.cin % 64 == 0 and self.cout % 64 == 0:
-            defer.append((self.desc, x, self.dz, st.grad(self.name + "_conv/kernel")))
+            if f8:
+                defer.append((self.desc, x8.data, self.dz8.data, st.grad(self.name + "_conv/kernel"), x8.scale, self.dz8.scale))
+            else:
+                defer.append((self.desc, x, self.dz, st.grad(self.name + "_conv/kernel")))
+            return
+        if f8:
+            plan.add(ops.conv2d_wgrad_fp8, self.desc, x8.data, self.dz8.data, x8.scale, self.dz8.scale, st.grad(self.name + "_conv/kernel"))
             return
         if self.is_stem:
             plan.zero(self.dw_packed)
@@ -271,7 +282,7 @@ class _ConvBN:
             plan.hold(red)
         else:
             assert res_mask is None
-        if self.dz8 is not None:
+        if self.fp8_bwd and self.dz8 is not None:
             plan.add(ops.conv2d_dgrad_fp8, d, self.dz8.data, self.w_t8, self.dz8.scale, self.w_t8_scale, gx, red=red, res=res, res_mask=res_mask)
         elif consumer is not None:
             plan.add(ops.conv2d_dgrad_bnreduce, d, self.dz, self.w_t, gx, red, res=res, res_mask=res_mask)
@@ -326,10 +337,10 @@ class FeatureExtractor:
             f_in = fp8 and (stage - (1 if first else 0)) >= FP8_MIN_STAGE          # units reading the block input
             f_blk = fp8 and stage >= FP8_MIN_STAGE                                 # units reading this block's own activations
             if first:
-                u[0] = _ConvBN(self.store, n + "_0", ci, 4 * f, 1, s, 0, self.sync_bn_world, f_in, f_blk)
-            u[1] = _ConvBN(self.store, n + "_1", ci, f, 1, s, 0, self.sync_bn_world, f_in, f_blk)
-            u[2] = _ConvBN(self.store, n + "_2", f, f, 3, 1, 1, self.sync_bn_world, f_blk)
-            u[3] = _ConvBN(self.store, n + "_3", f, 4 * f, 1, 1, 0, self.sync_bn_world, f_blk)
+                u[0] = _ConvBN(self.store, n + "_0", ci, 4 * f, 1, s, 0, self.sync_bn_world, f_in, f_blk, f_in)
+            u[1] = _ConvBN(self.store, n + "_1", ci, f, 1, s, 0, self.sync_bn_world, f_in, f_blk, f_in)
+            u[2] = _ConvBN(self.store, n + "_2", f, f, 3, 1, 1, self.sync_bn_world, f_blk, None, f_blk)
+            u[3] = _ConvBN(self.store, n + "_3", f, 4 * f, 1, 1, 0, self.sync_bn_world, f_blk, None, f_blk)
             units[n] = u
         self.stem = _ConvBN(self.store, "conv1", 3, 64, 7, 2, 3, self.sync_bn_world)
         self.store.end_bucket("conv2+stem")
@@ -472,12 +483,13 @@ class FeatureExtractor:
             elif first:
                 a["sc"] = None                    # (training: the shortcut BatchNorm is fused into the block-final one)
             if self.f8 is not None:
-                for k_ in sorted(u):                     # e5m2 twins of the BatchNorm-backward outputs that feed fp8 data gradients
-                    if u[k_].fp8_bwd:
+                for k_ in sorted(u):                     # e5m2 twins of the BatchNorm-backward outputs that feed fp8 data / weight gradients
+                    if u[k_].fp8_bwd or u[k_].fp8_wgrad:
                         u[k_].dz8 = Fp8Twin(self.f8, (u[k_].m, u[k_].cout), dev)
-                # fp8 twins of the activations that feed fp8 convolutions: a1 -> 3x3, a2 -> 1x1 expansion, out -> the next block / RPN
-                a["a1_8"] = Fp8Twin(self.f8, (m, f), dev) if u[2].fp8 else None
-                a["a2_8"] = Fp8Twin(self.f8, (m, f), dev) if u[3].fp8 else None
+                # fp8 twins of the activations that feed fp8 convolutions (forward and weight gradient): a1 -> 3x3, a2 -> 1x1
+                # expansion, out -> the next block / RPN
+                a["a1_8"] = Fp8Twin(self.f8, (m, f), dev) if u[2].fp8 or u[2].fp8_wgrad else None
+                a["a2_8"] = Fp8Twin(self.f8, (m, f), dev) if u[3].fp8 or u[3].fp8_wgrad else None
                 a["out_8"] = Fp8Twin(self.f8, (m, 4 * f), dev) if u[3].fp8 or u[2].fp8 else None      # (this stage runs fp8: so do the readers of its output)
             if training:
                 a["g1"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a1
@@ -550,11 +562,11 @@ class FeatureExtractor:
         for i, spec in enumerate(self.specs):
             prev_of[spec[0]] = self.units[self.specs[i - 1][0]][3] if i > 0 else None
         prev_stage = None
-        xs = {}
-        x = self.pool
+        xs, xs8 = {}, {}
+        x, x8 = self.pool, None
         for (n, ci, f, s, first) in self.specs:
-            xs[n] = x
-            x = self.acts[n]["out"]
+            xs[n], xs8[n] = x, x8
+            x, x8 = self.acts[n]["out"], self.acts[n].get("out_8")
         # the weight gradients of a stage are launched together (ops.WgradGroup): one pixel split sized for the whole group
         # instead of one per layer -- none for conv4 (19 layers, 1728 tiles), ~10 instead of 64-128 for conv2 -- i.e. a
         # fraction of the float atomics, and one ramp-up / tail per stage
@@ -581,17 +593,17 @@ class FeatureExtractor:
             # shortcut branch and the residual add of the block-input gradient -- read gout and the block's ReLU bit mask
             gblock, mblock = gout, u[3].relu_mask
             u[3].backward_bn(plan, gout, a["out"], reduced=gout_reduced)
-            u[3].backward_weights(plan, a["a2"], defer)
+            u[3].backward_weights(plan, a["a2"], defer, a.get("a2_8"))
             u[3].backward_data(plan, a["g2"], consumer=u[2])
             u[2].backward_bn(plan, a["g2"], a["a2"], reduced=True)
-            u[2].backward_weights(plan, a["a1"], defer)
+            u[2].backward_weights(plan, a["a1"], defer, a.get("a1_8"))
             u[2].backward_data(plan, a["g1"], consumer=u[1])
             u[1].backward_bn(plan, a["g1"], a["a1"], reduced=True)
-            u[1].backward_weights(plan, xin, defer)
+            u[1].backward_weights(plan, xin, defer, xs8[n])
             prev = prev_of[n]                     # block whose output this block's input gradient is (None: max-pool output)
             if first:
                 u[0].backward_bn(plan, gblock, None, mask=mblock)
-                u[0].backward_weights(plan, xin, defer)
+                u[0].backward_weights(plan, xin, defer, xs8[n])
                 if s != 1 and n in injected:
                     u[1].backward_data(plan, a["gin"], res=a["gin"])      # add to the gradient the other consumer left there
                 else:

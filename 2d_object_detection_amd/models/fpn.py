@@ -24,6 +24,7 @@ from .. import ops
 from .detectors.fast_rcnn_detector import HEAD_LD as RCNN_LD
 from .detectors.fast_rcnn_detector import FastRCNNDetector
 from .detectors.rpn_detector import HEAD_LD as RPN_LD
+from .feature_extractor import FP8_WGRAD
 
 BF16 = torch.bfloat16
 FPN_DIM = 256
@@ -72,10 +73,15 @@ class _Conv:
             return
         plan.add(ops.conv2d_fprop, self.desc, x, self.store.weight_bf16(self.name + "/kernel"), y, bias=self.store.weight(self.name + "/bias"))
 
-    def backward_params(self, plan, x, dz):
+    def backward_params(self, plan, x, dz, x8=None, dz8=None):
+        """x8 / dz8: Fp8Twin of x (e4m3) and of dz (e5m2, already quantised in this plan): the fp8 weight gradient."""
+        from .feature_extractor import FP8_WGRAD
         st = self.store
         plan.add(ops.colsum_bf16, dz, self.m, self.cout, self.cout, st.grad(self.name + "/bias"))
-        plan.add(ops.conv2d_wgrad, self.desc, x, dz, st.grad(self.name + "/kernel"))
+        if FP8_WGRAD and x8 is not None and dz8 is not None and self.cin % 64 == 0 and self.cout % 64 == 0:
+            plan.add(ops.conv2d_wgrad_fp8, self.desc, x8.data, dz8.data, x8.scale, dz8.scale, st.grad(self.name + "/kernel"))
+        else:
+            plan.add(ops.conv2d_wgrad, self.desc, x, dz, st.grad(self.name + "/kernel"))
 
     def backward_data(self, plan, dz, gx, add_to_gx=False, red=None, dz8=None):
         """gx = conv^T(dz) [+ gx]; red: fused BatchNorm-backward reduce of the layer that consumes gx; dz8: e5m2 twin of dz."""
@@ -216,7 +222,7 @@ class FPNNeck:
             if l > 2:
                 (h, w), (ht, wt) = self.grids[l - 1], self.grids[l]
                 plan.add(ops.upsample_add_bwd, self.gm[l - 1], h, w, self.gm[l], b, ht, wt, FPN_DIM, True)
-            self.output[l].backward_params(plan, self.merged[l], self.gp[l])
+            self.output[l].backward_params(plan, self.merged[l], self.gp[l], self.merged8.get(l), self.gp8.get(l))
             self.lateral[l].backward_params(plan, stage_maps[l], self.gm[l])
         for l in LEVELS:
             self.lateral[l].backward_data(plan, self.gm[l], targets[l], red=red4 if l == 4 else None)
@@ -391,12 +397,17 @@ class RPNDetectorFPN:
             plan.add(ops.conv2d_fprop, e["d_heads_bwd"], e["dhead"], self.w_heads_t, e["g_f"])
             plan.add(ops.relu_bwd, e["g_f"], e["f"], e["dz_f"])
             plan.add(ops.colsum_bf16, e["dz_f"], e["m"], 256, 256, st.grad("rpn_intermediate_layer/bias"))
-            plan.add(ops.conv2d_wgrad, e["d_inter"], pyramid[l], e["dz_f"], st.grad("rpn_intermediate_layer/kernel"))
+            if self.f8 is not None:
+                _quantize(plan, e["dz_f8"], e["dz_f"], e5m2=True)
+            if self.f8 is not None and FP8_WGRAD:
+                plan.add(ops.conv2d_wgrad_fp8, e["d_inter"], e["p8"].data, e["dz_f8"].data, e["p8"].scale, e["dz_f8"].scale,
+                         st.grad("rpn_intermediate_layer/kernel"))
+            else:
+                plan.add(ops.conv2d_wgrad, e["d_inter"], pyramid[l], e["dz_f"], st.grad("rpn_intermediate_layer/kernel"))
             d = e["d_inter_bwd_res"] if gp_written.get(l) else e["d_inter_bwd"]
             res = gp[l] if gp_written.get(l) else None
             ops.conv_zero_counters(plan, d)
             if self.f8 is not None:
-                _quantize(plan, e["dz_f8"], e["dz_f"], e5m2=True)
                 plan.add(ops.conv2d_dgrad_fp8, d, e["dz_f8"].data, self.w_inter_t8, e["dz_f8"].scale, self.w_inter_t8_scale, gp[l], res=res)
             else:
                 plan.add(ops.conv2d_fprop, d, e["dz_f"], self.w_inter_t, gp[l], res=res)

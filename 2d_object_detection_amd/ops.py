@@ -176,18 +176,35 @@ def conv2d_wgrad(d, x, dz, dw, dz_stride=None, row_index=None):
     call("frcnn_conv2d_wgrad", byref(d), _p(x), _p(dz), d.cout if dz_stride is None else dz_stride, _p(row_index), _p(dw), _stream())
 
 
+def conv2d_wgrad_fp8(d, x8, dz8, x_scale, dz_scale, dw, dz_stride=None):
+    """dw += x_scale * dz_scale * sum_p dz8[p] (x) x8[im2col(p)]: the weight gradient from the fp8 twins (x8: e4m3, dz8: e5m2)."""
+    call("frcnn_conv2d_wgrad_fp8", byref(d), _p(x8), _p(dz8), d.cout if dz_stride is None else dz_stride, _p(x_scale), _p(dz_scale), _p(dw),
+         _stream())
+
+
+def conv2d_wgrad_describe_fp8(d):
+    r = _lib.load().frcnn_conv2d_wgrad_describe_fp8(byref(d))
+    if r is None:
+        raise RuntimeError("frcnn_conv2d_wgrad_describe_fp8: " + _lib.load().frcnn_last_error().decode())
+    return r.decode()
+
+
 class WgradGroup:
     """Several weight gradients launched together without a pixel split (frcnn_conv2d_wgrad_grouped).  items: list of
-    (conv_desc, x, dz, dw) with static shapes and buffers; the parameter table is built once and kept on the device."""
+    (conv_desc, x, dz, dw) -- bf16 operands -- or (conv_desc, x8, dz8, dw, x_scale, dz_scale) -- fp8 twins and their
+    dequantisation scales -- with static shapes and buffers; the parameter table is built once and kept on the device."""
 
     def __init__(self, items, device):
         self.items = list(items)                 # keeps descriptors and tensors alive
         n = len(self.items)
         arr = (_lib.WgradItem * n)()
-        for i, (d, x, dz, dw) in enumerate(self.items):
+        for i, it in enumerate(self.items):
+            d, x, dz, dw = it[:4]
             arr[i].desc = ctypes.pointer(d)
             arr[i].x, arr[i].dz, arr[i].dw = _p(x), _p(dz), _p(dw)
             arr[i].dz_stride = d.cout
+            if len(it) > 4:
+                arr[i].x_scale, arr[i].dz_scale = _p(it[4]), _p(it[5])
         nbytes = int(_lib.load().frcnn_wgrad_group_bytes())
         self.host = torch.zeros(nbytes, dtype=torch.uint8)
         call("frcnn_conv2d_wgrad_group_plan", ctypes.cast(arr, c_void_p), n, self.host.data_ptr(), nbytes)

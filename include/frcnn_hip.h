@@ -36,7 +36,7 @@ typedef uint8_t frcnn_fp8;     /* OCP e4m3fn (gfx950's fp8: 4 exponent bits, bia
  * gained workspace / workspace_bytes, frcnn_bn_bwd_apply_fused gained count / param_grad_scale; 3: the fp8 entry points).  A
  * binding must compare frcnn_abi_version() with the FRCNN_ABI_VERSION it was written against and refuse any other library:
  * an older build would read the descriptor past the caller's struct. */
-#define FRCNN_ABI_VERSION 3
+#define FRCNN_ABI_VERSION 4
 int frcnn_abi_version(void);
 const char* frcnn_last_error(void);
 
@@ -174,6 +174,15 @@ typedef struct frcnn_fp8_out {
 int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* dz, int dz_stride,
                        const int32_t* row_index, float* dw, frcnn_stream_t stream);
 
+/* The same from fp8 operands (round 3: the third fp8 convolution of a training step, after fprop and dgrad): x8 is the e4m3
+ * twin of the layer's input, dz8 the e5m2 twin of the output gradient, one byte per element (dz_stride, in_pix_stride in
+ * elements = bytes; channels multiples of 64), x_scale / dz_scale the tensors' dequantisation scales (device scalars).  The
+ * pixel contraction runs through v_mfma_scale_f32_16x16x128_f8f6f4 on 128-pixel slices that ds_read_b64_tr_b8 transposes out
+ * of the pixel-major LDS image; dw += x_scale * dz_scale * sum_p dz8[p, co] * x8[im2col(p, tap), ci] in fp32. */
+int frcnn_conv2d_wgrad_fp8(const frcnn_conv_desc* d, const frcnn_fp8* x8, const frcnn_fp8* dz8, int dz_stride,
+                           const float* x_scale, const float* dz_scale, float* dw, frcnn_stream_t stream);
+const char* frcnn_conv2d_wgrad_describe_fp8(const frcnn_conv_desc* d);
+
 /* Grouped weight gradients: several layers of one backward stage in ONE launch per addressing mode, with one pixel split
  * chosen for the whole group (just enough workgroups for ~2 per CU; none -- no float atomics, every dw element stored
  * once -- when the group's 64x64 tiles fill the chip, e.g. conv4 at 375x1242: 19 layers, 1728 tiles).
@@ -182,11 +191,13 @@ int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcn
  * both copies. */
 typedef struct frcnn_wgrad_item {
     const frcnn_conv_desc* desc;
-    const frcnn_bf16* x;
-    const frcnn_bf16* dz;
+    const void* x;              /* bf16, or fp8 e4m3 when the scales below are set */
+    const void* dz;             /* bf16, or fp8 e5m2 */
     float* dw;
     int32_t dz_stride;
     int32_t reserved;
+    const float* x_scale;       /* device scalars: dequantisation scales of the fp8 operands (frcnn_conv2d_wgrad_fp8), */
+    const float* dz_scale;      /* or both NULL for bf16 operands */
 } frcnn_wgrad_item;
 size_t frcnn_wgrad_group_bytes(void);
 int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int n, void* table_host, size_t table_bytes);

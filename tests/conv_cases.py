@@ -141,6 +141,23 @@ WGRAD = [
     dict(id="fpn_p2_3x3_wide", n=1, h=94, w=311, cin=256, cout=256, k=3, s=1, p=1),             # M >= 24576, multi-tap: 128 x 128 tiles
 ]
 
+# ---- fp8 weight gradients (x8: e4m3, dz8: e5m2; 128-pixel slices through ds_read_b64_tr_b8): both addressing modes, the pixel
+# tail of a slice (M % 128 != 0, M < 128), the wide tile
+WGRAD_FP8 = [
+    dict(id="f8_c4_3x3", n=3, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1),
+    dict(id="f8_c4_1x1_1024_256", n=2, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0),
+    dict(id="f8_small_s2", n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0),
+    dict(id="f8_small_3x3", n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1),
+    dict(id="f8_fpn_p2_3x3_wide", n=1, h=94, w=311, cin=256, cout=256, k=3, s=1, p=1),
+]
+# grouped: bf16 and fp8 layers in one table (up to four launches: {bf16, fp8} x {linear, general})
+WGRAD_GROUPS_FP8 = [
+    dict(id="f8_mixed", layers=[dict(n=2, h=24, w=39, cin=256, cout=256, k=3, s=1, p=1, f8=True), dict(n=2, h=24, w=39, cin=256, cout=1024, k=1, s=1, p=0, f8=True),
+                                dict(n=2, h=24, w=39, cin=1024, cout=256, k=1, s=1, p=0, f8=False), dict(n=1, h=47, w=77, cin=512, cout=256, k=1, s=2, p=0, f8=True),
+                                dict(n=2, h=12, w=10, cin=128, cout=128, k=3, s=1, p=1, f8=False)]),
+    dict(id="f8_narrow", layers=[dict(n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1, f8=True), dict(n=2, h=9, w=13, cin=128, cout=256, k=1, s=1, p=0, f8=True)]),
+]
+
 # ---- grouped weight gradients: one launch per addressing mode; tile 128 x 64 when every layer of the mode has cout >= 128
 WGRAD_GROUPS = [
     dict(id="mixed_64x64", layers=[dict(n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1), dict(n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0),
@@ -210,13 +227,14 @@ def covered_instantiations(ops):
     note(ops.conv2d_wgrad_describe(ops.conv_desc(1, 1, 24, 1024, 1, 1, 1, 0, 0, 1, 24, 64), with_row_index=True), "head wgrad (row_index)")
     note(ops.conv2d_wgrad_describe(ops.conv_desc(2, 43, 52, 32, 7, 1, 2, 0, 0, 19, 23, 64, in_pix_stride=4)), "stem wgrad")
     note(ops.conv2d_describe(ops.conv_desc(2, 43, 52, 32, 7, 1, 2, 0, 0, 19, 23, 64, in_pix_stride=4, flags=ops.CONV_BIAS | ops.CONV_STATS)), "stem fprop")
-    for grp in WGRAD_GROUPS:
+    for c in WGRAD_FP8:
+        note(ops.conv2d_wgrad_describe_fp8(conv_desc(ops, c)), c["id"])
+    for grp in WGRAD_GROUPS + WGRAD_GROUPS_FP8:
         items = []
         for c in grp["layers"]:
             d = conv_desc(ops, c)
-            m = d.n * d.ho * d.wo
-            items.append((d, torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8)))
-            del m
+            it = (d, torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8))
+            items.append(it + (torch.zeros(1), torch.zeros(1)) if c.get("f8") else it)
         g = ops.WgradGroup(items, "cpu")
         for part in ops.conv2d_wgrad_describe(group=g).split("; "):
             if part.strip():

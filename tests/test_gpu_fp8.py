@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conv_cases import DGRAD_FP8, FPROP_FP8, dgrad_desc, fprop_desc
+from conv_cases import DGRAD_FP8, FPROP_FP8, WGRAD_FP8, WGRAD_GROUPS_FP8, conv_desc, dgrad_desc, fprop_desc
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -224,6 +224,89 @@ def test_weight_quantiser_bf16_source(ops):
     exp8 = (wc * (1.0 / exp_sc).view(-1, 1)).clamp(-448, 448).to(E4M3).view(torch.uint8)
     got = w8.cpu()
     assert bool(((got == exp8) | ((got & 0x7F) == 0) & ((exp8 & 0x7F) == 0)).all())
+
+
+def _ohwi(w):
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+def _wgrad_fp8_problem(case, g, integers=False):
+    """x8 (e4m3), dz8 (e5m2) bytes, their scales and the fp32 weight gradient of the dequantised operands"""
+    n, h, w, cin, cout, k, s, p = (case[x] for x in ("n", "h", "w", "cin", "cout", "k", "s", "p"))
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    if integers:                                           # small integers: exact in both formats, exact fp32 sums
+        xq = torch.randint(-3, 4, (n, cin, h, w), generator=g).float().to(E4M3)
+        zq = torch.randint(-2, 3, (n, cout, ho, wo), generator=g).float().to(E5M2)
+        xs, zs = torch.tensor([1.0]), torch.tensor([1.0])
+    else:
+        xq = (torch.randn(n, cin, h, w, generator=g) * torch.exp2(torch.randint(-5, 4, (n, cin, h, w), generator=g).float())).clamp(-448, 448).to(E4M3)
+        zq = (torch.randn(n, cout, ho, wo, generator=g) * torch.exp2(torch.randint(-8, 6, (n, cout, ho, wo), generator=g).float())).clamp(-57344, 57344).to(E5M2)
+        xs, zs = torch.tensor([3.1e-2]), torch.tensor([2.3e-3])
+    wt = torch.zeros(cout, cin, k, k, requires_grad=True)
+    y = F.conv2d(xq.float() * xs, wt, stride=s, padding=p)
+    y.backward(zq.float() * zs)
+    x8 = xq.view(torch.uint8).permute(0, 2, 3, 1).contiguous().cuda()
+    z8 = zq.view(torch.uint8).permute(0, 2, 3, 1).contiguous().cuda()
+    return x8, z8, xs.cuda(), zs.cuda(), _ohwi(wt.grad), n * ho * wo
+
+
+@pytest.mark.parametrize("case", WGRAD_FP8, ids=[c["id"] for c in WGRAD_FP8])
+def test_conv_wgrad_fp8_exact_on_integers(ops, case):
+    """Small-integer operands (exact in e4m3 / e5m2, sums exact in fp32): the weight gradient must equal the integer result bit for
+    bit -- this pins the ds_read_b64_tr_b8 transposition, the 16-byte-chunk swizzle, the shared K permutation of the two MFMA
+    operands, the im2col walk and the pixel tail of the 128-pixel slices all at once."""
+    g = torch.Generator().manual_seed(21)
+    x8, z8, xs, zs, ref, m = _wgrad_fp8_problem(case, g, integers=True)
+    d = conv_desc(ops, case)
+    dw = torch.zeros(case["cout"], case["k"], case["k"], case["cin"], device="cuda")
+    ops.conv2d_wgrad_fp8(d, x8, z8, xs, zs, dw)
+    assert ops.last_conv_instantiation().split(" grid")[0] == ops.conv2d_wgrad_describe_fp8(d).split(" grid")[0]
+    assert ",F8>" in ops.last_conv_instantiation()
+    torch.cuda.synchronize()
+    assert torch.equal(dw.cpu(), ref), "fp8 wgrad on integers: %d mismatches, max err %g" % (int((dw.cpu() != ref).sum()), float((dw.cpu() - ref).abs().max()))
+
+
+@pytest.mark.parametrize("case", WGRAD_FP8, ids=[c["id"] for c in WGRAD_FP8])
+def test_conv_wgrad_fp8_vs_fp32_on_dequantised_operands(ops, case):
+    """Random fp8 operands with a wide exponent spread: every e4m3 x e5m2 product is exact in fp32 and the MFMA accumulates in fp32,
+    so the tolerance is the bf16 weight-gradient test's accumulation-order term (scaled by the operands' magnitudes), not an fp8 one."""
+    g = torch.Generator().manual_seed(22)
+    x8, z8, xs, zs, ref, m = _wgrad_fp8_problem(case, g)
+    d = conv_desc(ops, case)
+    dw = torch.zeros(case["cout"], case["k"], case["k"], case["cin"], device="cuda")
+    ops.conv2d_wgrad_fp8(d, x8, z8, xs, zs, dw)
+    torch.cuda.synchronize()
+    _close(dw, ref, 2e-4, 2e-4 * float(ref.abs().max()) + 1e-12, "fp8 wgrad")
+
+
+@pytest.mark.parametrize("grp", WGRAD_GROUPS_FP8, ids=[c["id"] for c in WGRAD_GROUPS_FP8])
+def test_conv_wgrad_grouped_with_fp8_layers(ops, grp):
+    """bf16 and fp8 layers in one group table: one launch per (precision, addressing mode) that has layers."""
+    g = torch.Generator().manual_seed(23)
+    items, refs = [], []
+    for case in grp["layers"]:
+        dw = torch.zeros(case["cout"], case["k"], case["k"], case["cin"], device="cuda")
+        if case["f8"]:
+            x8, z8, xs, zs, ref, m = _wgrad_fp8_problem(case, g)
+            items.append((conv_desc(ops, case), x8, z8, dw, xs, zs))
+        else:
+            x = torch.randn(case["n"], case["cin"], case["h"], case["w"], generator=g).to(BF).float()
+            wt = torch.zeros(case["cout"], case["cin"], case["k"], case["k"], requires_grad=True)
+            y = F.conv2d(x, wt, stride=case["s"], padding=case["p"])
+            dz = torch.randn(y.shape, generator=g).to(BF).float()
+            y.backward(dz)
+            ref = _ohwi(wt.grad)
+            items.append((conv_desc(ops, case), x.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dz.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dw))
+        refs.append(ref)
+    group = ops.WgradGroup(items, "cuda")
+    ops.conv2d_wgrad_grouped(group)
+    got = ops.last_conv_instantiation()
+    want = ops.conv2d_wgrad_describe(group=group)
+    assert [p.split(" grid")[0] for p in got.split("; ")] == [p.split(" grid")[0] for p in want.split("; ")], (got, want)
+    assert ",F8>" in got
+    torch.cuda.synchronize()
+    for it, ref in zip(items, refs):
+        _close(it[3], ref, 2e-4, 2e-4 * float(ref.abs().max()) + 1e-12, "grouped wgrad (%s)" % ("fp8" if len(it) > 4 else "bf16"))
 
 
 def test_quantize_fp8_bit_exact_and_amax(ops):

@@ -26,6 +26,9 @@ FPN_SHAPES = [  # the feature pyramid's layers at batch 8 (BASELINE.json configs
 ]
 
 
+F8 = "fp8" in sys.argv
+
+
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     global SHAPES
@@ -37,12 +40,18 @@ def main():
         m = n * ho * wo
         x = torch.randn(n, h, w, cin, device="cuda", generator=g).to(BF)
         dz = torch.randn(m, cout, device="cuda", generator=g).to(BF)
+        if F8:                                      # fp8 twins (e4m3 / e5m2 bytes) and unit scales
+            x, dz = x.to(torch.float8_e4m3fn).view(torch.uint8), dz.to(torch.float8_e5m2).view(torch.uint8)
+            one = torch.ones(1, device="cuda")
         dw = torch.zeros(cout, k, k, cin, device="cuda")
         d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout)
+        run = (lambda d_, x_, z_, w_: ops.conv2d_wgrad_fp8(d_, x_, z_, one, one, w_)) if F8 else ops.conv2d_wgrad
         res = []
         for bm in (128, 64):
             for bn in (128, 64):
                 if (bm == 128 and cout < 128) or (bn == 128 and cin < 128):
+                    continue
+                if F8 and (cin % 64 or cout % 64):
                     continue
                 for st in (2, 3):
                     for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 64):
@@ -52,12 +61,12 @@ def main():
                         os.environ["FRCNN_WGRAD"] = "%d,%d,%d,%d" % (bm, bn, st, sp)
                         try:
                             for _ in range(2):
-                                ops.conv2d_wgrad(d, x, dz, dw)
+                                run(d, x, dz, dw)
                             torch.cuda.synchronize()
                             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             e0.record()
                             for _ in range(iters):
-                                ops.conv2d_wgrad(d, x, dz, dw)
+                                run(d, x, dz, dw)
                             e1.record()
                             torch.cuda.synchronize()
                             res.append((e0.elapsed_time(e1) * 1e3 / iters, (bm, bn, st, sp)))
