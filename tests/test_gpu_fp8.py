@@ -483,7 +483,7 @@ def test_fp8_backbone_deviation_from_bf16():
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-20))
     cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm() + 1e-20))
     fe = f8["fe"]
-    n_f8 = sum(1 for u in fe.conv_units() if u.fp8), sum(1 for u in fe.conv_units() if u.dz8 is not None)
+    n_f8 = sum(1 for u in fe.conv_units() if u.fp8), sum(1 for u in fe.conv_units() if u.fp8_bwd and u.dz8 is not None)
     cosines = {n: round(cos(f8["g"][b:e], ref["g"][b:e]), 4) for n, b, e in ref["buckets"]}
     print("fp8 vs bf16 backbone (R50, 192x256, batch 2; %d fp8 forward convs, %d fp8 data gradients): feature maps rel L2 %.4f, "
           "block-input gradient rel L2 %.4f, parameter-gradient cosine per bucket %s" % (n_f8[0], n_f8[1], rel(f8["feat"], ref["feat"]),
@@ -497,6 +497,21 @@ def test_fp8_backbone_deviation_from_bf16():
     # measured: feature maps 0.105; gradients with the forward pass alone in fp8 (FRCNN_FP8_BWD=0) vs forward + backward: see DESIGN.md 5
     assert rel(f8["gin"], ref["gin"]) < 0.9
     assert min(cosines.values()) > 0.7, cosines
+    # the fp8 weight gradients' own share: the same fp8 run with the weight gradients alone back in bf16 (same forward pass, same
+    # data gradients, same twins: the two runs differ only in the operands of the pixel contraction)
+    n_wg = sum(1 for u in fe.conv_units() if u.fp8_wgrad and u.dz8 is not None)
+    assert n_wg >= 25 or not FE.FP8_WGRAD
+    if FE.FP8_WGRAD:
+        FE.FP8_WGRAD = False
+        try:
+            f8_bw = _backbone_fwd_bwd("fp8")
+        finally:
+            FE.FP8_WGRAD = True
+        own = {n: (round(cos(f8["g"][b:e], f8_bw["g"][b:e]), 4), round(rel(f8["g"][b:e], f8_bw["g"][b:e]), 4)) for n, b, e in ref["buckets"]}
+        print("fp8 weight gradients (%d layers) vs bf16 weight gradients on the same fp8 forward / data-gradient pass: (cosine, rel L2) per bucket %s"
+              % (n_wg, own))
+        assert torch.equal(f8["feat"], f8_bw["feat"])
+        assert min(c for c, _ in own.values()) > 0.99, own
 
 
 def test_fp8_train_step_runs_and_stays_close():
