@@ -1004,7 +1004,10 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
         // measured (per-layer table of the train step): pays where two workgroups share a CU (conv2 / conv3: -8 % / -14 %);
         // with one 128 x 64 tile per CU (M = 7488) the slice time is a latency chain that the smaller fill does not shorten,
         // and the wide 128 x 128 tiles of the RPN data gradient are faster there
-        const bool kws_pays = tiles_m128 >= 160;
+        // ... and not where the layer has 256+ output channels: the filter slab, not the A image, is then most of what a 128 x 64
+        // tile takes in, and the plain 128 x 128 tile halves it (tools/tile_sweep.py --fpn, M = 233,872 / 58,656, 3x3 256 -> 256,
+        // us: bf16 kw-shared 393 / 98 against 322 / 79; fp8 220 / 52 against 165 / 42)
+        const bool kws_pays = tiles_m128 >= 160 && !(d->cout >= 256 && d->cout % 128 == 0);
         if (kws_ok && (force_kws >= 0 ? force_kws == 1 : kws_pays)) {
             p.k_tiles = p.Ktot / 64;
             p.k_tiles_per_split = p.k_tiles;

@@ -92,10 +92,10 @@ def classify(ops, fn, args, kwargs):
         return FAM_CONV, conv_flops(args[0], *_true_dims(args[0])), 0.0
     if fn is ops.conv2d_fprop_fp8 or fn is ops.conv2d_dgrad_fp8:
         return FAM_CONV_F8, conv_flops(args[0], *_true_dims(args[0])), 0.0
-    if fn is ops.conv2d_wgrad:
+    if fn is ops.conv2d_wgrad or fn is ops.conv2d_wgrad_fp8:
         return FAM_WGRAD, conv_flops(args[0], *_true_dims(args[0])), 0.0
     if fn is ops.conv2d_wgrad_grouped:
-        return FAM_WGRAD, sum(conv_flops(d, *_true_dims(d)) for (d, _x, _dz, _dw) in args[0].items), 0.0
+        return FAM_WGRAD, sum(conv_flops(it[0], *_true_dims(it[0])) for it in args[0].items), 0.0
     name = getattr(fn, "__name__", str(fn))
     if name in ("bn_train_apply", "bn_apply", "bn_bwd_apply_fused", "bn_bwd_reduce", "bn_train_apply_maxpool", "bn_train_apply_dual"):
         return "batchnorm apply / reduce (bn_*_kernel)", 0.0, _tensor_bytes(args, kwargs)

@@ -28,6 +28,9 @@ CONFIGS += [(bm, bn, 64, 2, t) for (bm, bn) in ((128, 64), (128, 128), (64, 64))
 
 
 COLD = "--cold" in sys.argv
+F8 = "--fp8" in sys.argv                     # e4m3 operands (frcnn_conv2d_fprop_fp8), no statistics
+FPN = "--fpn" in sys.argv                    # the feature pyramid's 3x3 layers at batch 8
+FPN_SHAPES = [None, (8, 94, 311, 256, 256, 3, 1, 1), (8, 47, 156, 256, 256, 3, 1, 1), (8, 24, 78, 256, 256, 3, 1, 1)]
 FLUSH = None
 
 
@@ -38,7 +41,7 @@ def main():
         FLUSH = torch.zeros(160 * 1024 * 1024, device="cuda")
     g = torch.Generator(device="cuda").manual_seed(0)
     only = [a for a in sys.argv[1:] if a.startswith("--m=")]
-    for (n, h, w, cin, cout, k, s, p) in SHAPES[1:]:
+    for (n, h, w, cin, cout, k, s, p) in (FPN_SHAPES if FPN else SHAPES)[1:]:
         if only and str(n * ((h + 2 * p - k) // s + 1) * ((w + 2 * p - k) // s + 1)) != only[0][4:]:
             continue
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
@@ -48,15 +51,43 @@ def main():
         bias = torch.zeros(cout, device="cuda")
         y = torch.empty(m, cout, dtype=BF, device="cuda")
         stats = torch.zeros(16, 2, cout, dtype=torch.float64, device="cuda")
-        d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout, flags=ops.CONV_BIAS | ops.CONV_STATS)
+        d = ops.conv_desc(n, h, w, cin, k, k, s, p, p, ho, wo, cout, flags=ops.CONV_BIAS | (0 if F8 else ops.CONV_STATS))
+        if F8:
+            if cin % 128:
+                continue
+            x8, w8 = x.to(torch.float8_e4m3fn).view(torch.uint8), wt.to(torch.float8_e4m3fn).view(torch.uint8)
+            one, ones = torch.ones(1, device="cuda"), torch.ones(cout, device="cuda")
+            run = lambda: ops.conv2d_fprop_fp8(d, x8, w8, one, ones, y, bias=bias)
+        else:
+            run = lambda: ops.conv2d_fprop(d, x, wt, y, bias=bias, stats=stats)
         res = []
-        for cfg in CONFIGS:
+        for cfg in [None, "kws"] + CONFIGS:
+            if cfg is None or cfg == "kws":                    # the dispatcher's own choice / kw sharing forced on
+                os.environ.pop("FRCNN_TILE", None)
+                os.environ.pop("FRCNN_KWS", None)
+                if cfg == "kws":
+                    os.environ["FRCNN_KWS"] = "1"
+                try:
+                    for _ in range(2):
+                        run()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(iters):
+                        run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    res.append((e0.elapsed_time(e1) * 1e3 / iters, ("default",) if cfg is None else ("kws",)))
+                except Exception:  # noqa: BLE001
+                    pass
+                os.environ.pop("FRCNN_KWS", None)
+                continue
             if cin % cfg[2] != 0 or (cfg[1] == 128 and cout < 128):
                 continue
             os.environ["FRCNN_TILE"] = ",".join(str(v) for v in cfg)
             try:
                 for _ in range(2):
-                    ops.conv2d_fprop(d, x, wt, y, bias=bias, stats=stats)
+                    run()
                 torch.cuda.synchronize()
                 if COLD:
                     # one call at a time behind a 640 MB write that evicts L2 and the Infinity Cache: in the training step
@@ -66,7 +97,7 @@ def main():
                         FLUSH.add_(1.0)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                        ops.conv2d_fprop(d, x, wt, y, bias=bias, stats=stats)
+                        run()
                         e1.record()
                         torch.cuda.synchronize()
                         tot += e0.elapsed_time(e1) * 1e3
@@ -75,7 +106,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(iters):
-                    ops.conv2d_fprop(d, x, wt, y, bias=bias, stats=stats)
+                    run()
                 e1.record()
                 torch.cuda.synchronize()
                 res.append((e0.elapsed_time(e1) * 1e3 / iters, cfg))
