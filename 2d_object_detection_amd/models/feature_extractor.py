@@ -44,14 +44,14 @@ class Fp8Scales:
     accumulation target of the step (atomic max, zeroed by the plan's fill); `update` -- once per step, after the last producer -- turns it into the NEXT
     step's scales (delayed scaling with one step of history; the first step runs on scale 1)."""
 
-    def __init__(self, device, capacity=128):
+    def __init__(self, device, capacity=384):      # (ResNet-101 under the pyramid takes ~250 columns)
         self.buf = torch.zeros(2, capacity, dtype=torch.float32, device=device)             # [scale | 1 / scale]
         self.buf.fill_(1.0)
         self.amax_buf = torch.zeros(capacity, ops.FP8_AMAX_SLOTS, dtype=torch.float32, device=device)   # slots per tensor (one word would serialise the atomics)
         self.n = 0
 
     def new(self):
-        assert self.n < self.buf.shape[1]
+        assert self.n < self.buf.shape[1], "Fp8Scales: more than %d fp8 tensors" % self.buf.shape[1]
         self.n += 1
         return self.n - 1
 

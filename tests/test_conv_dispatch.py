@@ -41,6 +41,8 @@ def _plan_instantiations(monkeypatch, depth, batch, proposals=None, precision="b
                 found = [ops.conv2d_describe_fp8(args[0])]
             elif fn is ops.conv2d_dgrad_fp8:
                 found = [ops.conv2d_describe_dgrad_fp8(args[0], kwargs.get("red") is not None)]
+            elif fn is ops.conv2d_wgrad_fp8:
+                found = [ops.conv2d_wgrad_describe_fp8(args[0])]
             elif fn is ops.conv2d_wgrad:
                 found = [ops.conv2d_wgrad_describe(args[0], with_row_index=kwargs.get("row_index") is not None)]
             elif fn is ops.conv2d_wgrad_grouped:
@@ -63,12 +65,13 @@ def test_every_plan_instantiation_has_a_parity_case(monkeypatch, ops, depth, bat
 def test_every_fp8_plan_instantiation_has_a_parity_case(monkeypatch, ops):
     """BASELINE.json configs[4]'s precision (fp8 forward convolutions) at its batch of 8, and at the bench's batch 4."""
     covered = conv_cases.covered_instantiations(ops)
-    for batch in (8, 4):
-        used, launches = _plan_instantiations(monkeypatch, 50, batch, precision="fp8")
+    for depth, batch, proposals in ((50, 8, None), (50, 4, None), (101, 2, 1000)):       # (ResNet-101: ~250 fp8 tensors in the scale table)
+        used, launches = _plan_instantiations(monkeypatch, depth, batch, proposals, precision="fp8")
         f8 = sorted(k for k in used if "F8=1" in k)
         assert len(f8) >= 5, f8
+        assert any(",F8>" in k for k in used), "no fp8 weight gradient in the fp8 plan"
         missing = sorted(k for k in used if k not in covered)
-        assert not missing, "conv kernels of the fp8 R50 batch-%d train plan without an oracle-compared GPU case:\n  %s" % (batch, "\n  ".join(missing))
+        assert not missing, "conv kernels of the fp8 R%d batch-%d train plan without an oracle-compared GPU case:\n  %s" % (depth, batch, "\n  ".join(missing))
 
 
 def test_every_fpn_plan_instantiation_has_a_parity_case(monkeypatch, ops):
