@@ -18,7 +18,8 @@ FPROP = [
     dict(id="c3_3x3_128_128_stats", n=3, h=47, w=156, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     # tile runs (short K)
     dict(id="c2_1x1_64_256_stats_run4", n=4, h=94, w=311, cin=64, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
-    dict(id="c3_s2_256_512_stats_run2", n=4, h=94, w=311, cin=256, cout=512, k=1, s=2, p=0, bias=True, relu=False, stats=True),
+    dict(id="c3_s2_256_128_stats_run2", n=6, h=94, w=311, cin=256, cout=128, k=1, s=2, p=0, bias=True, relu=False, stats=True),    # strided A rows in a run (344 m-tiles)
+    dict(id="c3_s2_256_512_stats", n=4, h=94, w=311, cin=256, cout=512, k=1, s=2, p=0, bias=True, relu=False, stats=True),         # 4 slices, 512 channels: one 128 x 128 tile
     # one 128 x 64 tile per workgroup at the benchmark's sizes
     dict(id="c2_1x1_256_64_stats", n=4, h=94, w=311, cin=256, cout=64, k=1, s=1, p=0, bias=True, relu=False, stats=True),
     dict(id="c4_1x1_1024_256_stats", n=4, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
@@ -48,8 +49,9 @@ FPROP_FP8 = [
     dict(id="f8_c4_s2_512_1024_stats", n=4, h=47, w=156, cin=512, cout=1024, k=1, s=2, p=0, bias=True, relu=False, stats=True),
     dict(id="f8_c3_3x3_128_128_stats", n=3, h=47, w=156, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),       # kw-sharing
     dict(id="f8_c3_1x1_128_512_stats_run", n=4, h=47, w=156, cin=128, cout=512, k=1, s=1, p=0, bias=True, relu=False, stats=True),   # ONE slice per tile
+    dict(id="f8_c3_1x1_512_128_stats_b2", n=2, h=47, w=156, cin=512, cout=128, k=1, s=1, p=0, bias=True, relu=False, stats=True),     # 115 m-tiles: 128 x 64, three workgroups per CU
     dict(id="f8_c3_1x1_512_128_stats", n=4, h=47, w=156, cin=512, cout=128, k=1, s=1, p=0, bias=True, relu=False, stats=True),
-    dict(id="f8_c3_s2_256_512_stats_run", n=4, h=94, w=311, cin=256, cout=512, k=1, s=2, p=0, bias=True, relu=False, stats=True),
+    dict(id="f8_c3_s2_256_512_stats", n=4, h=94, w=311, cin=256, cout=512, k=1, s=2, p=0, bias=True, relu=False, stats=True),
     dict(id="f8_c3_s2_256_128_stats", n=4, h=94, w=311, cin=256, cout=128, k=1, s=2, p=0, bias=True, relu=False, stats=True),
     dict(id="f8_c2_1x1_256_64_stats", n=4, h=94, w=311, cin=256, cout=64, k=1, s=1, p=0, bias=True, relu=False, stats=True),
     dict(id="f8_c4_1x1_1024_256_stats", n=4, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
@@ -70,6 +72,7 @@ DGRAD_FP8 = [
     dict(id="f8_c4_dg_1024_256_red", n=4, h=24, w=78, cin=1024, cout=256, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1),
     dict(id="f8_c4_dg_3x3_256_256_red", n=4, h=24, w=78, cin=256, cout=256, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
     dict(id="f8_c4_dg_256_1024_res_mask_red", n=4, h=24, w=78, cin=256, cout=1024, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
+    dict(id="f8_c4_dg_s2_256_512_scatter_plain_b2", n=2, h=24, w=78, cin=256, cout=512, k=1, res=False, res_mask=False, red=False, mask=False, scatter=2),
     dict(id="f8_c4_dg_s2_256_512_scatter_plain", n=4, h=24, w=78, cin=256, cout=512, k=1, res=False, res_mask=False, red=False, mask=False, scatter=2),
     dict(id="f8_c3_dg_3x3_128_128_red", n=3, h=47, w=156, cin=128, cout=128, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),      # kw-sharing
     dict(id="f8_c3_dg_128_512_res_mask_red_run", n=4, h=47, w=156, cin=128, cout=512, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
@@ -108,6 +111,8 @@ DGRAD = [
     dict(id="c4_dg_1024_256_red", n=4, h=24, w=78, cin=1024, cout=256, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1),
     dict(id="c4_dg_3x3_256_256_red", n=4, h=24, w=78, cin=256, cout=256, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
     dict(id="rpn_heads_dg_128_256", n=4, h=24, w=78, cin=128, cout=256, k=1, res=False, res_mask=False, red=False, mask=False, scatter=1),
+    dict(id="rpn_heads_dg_128_256_b8", n=8, h=24, w=78, cin=128, cout=256, k=1, res=False, res_mask=False, red=False, mask=False, scatter=1),   # 128 x 128 tiles
+    dict(id="c4_dg_s2_256_512_scatter_plain", n=4, h=24, w=78, cin=256, cout=512, k=1, res=False, res_mask=False, red=False, mask=False, scatter=2),
     # small shapes
     dict(id="small_dg_run", n=2, h=12, w=39, cin=256, cout=64, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
     dict(id="small_dg_3x3", n=2, h=13, w=17, cin=128, cout=128, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
