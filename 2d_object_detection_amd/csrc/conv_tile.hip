@@ -957,13 +957,19 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
     }
     FRCNN_CHECK_ARG(d->split_k <= 1, "conv2d_fprop: split_k needs SPLITK_ATOMIC");
     // measured on the R50-C4 layer shapes (tools/tile_sweep.py): 128-row tiles and BK = 64 win almost everywhere (two
-    // workgroups per CU); 128 output channels per tile once that still leaves >= ~200 tiles, else 64; a third ring slot
+    // workgroups per CU); 128 output channels per tile once that still leaves >= ~400 tiles, else 64; a third ring slot
     // only pays on very long K with the narrow tile
     int bk = d->cin % 64 == 0 ? 64 : 32;
     const long long M = p.M;
     int bm = 128;
     const long long tiles_m128 = (M + 127) / 128;
-    int bn = (bk == 64 && d->cout >= 128 && tiles_m128 * ((d->cout + 127) / 128) >= 200) ? 128 : 64;
+    // (same-box A/B of this threshold in the step, ms: batch 4: 200 4.29-4.31, 300 / 400 4.26-4.28, 500 4.29-4.31; R101 batch 2:
+    // 6.09 -> 6.03; fp8 batch 8: 6.86 -> 6.77: a wide tile wants ~1.5 workgroups per CU, else two narrow ones per CU fill better)
+    int wide_min = 400;
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_WIDE_MIN")) wide_min = atoi(e);
+#endif
+    int bn = (bk == 64 && d->cout >= 128 && tiles_m128 * ((d->cout + 127) / 128) >= wide_min) ? 128 : 64;
     int stages = (bn == 64 && bk == 64 && p.Ktot / bk >= 8) ? 3 : 2;     // (cold-cache sweep: the third slot pays from 8 slices on)
     // short K (<= 4 slices): runs of consecutive m-tiles per workgroup -- the ring prefetches the next tile under the
     // epilogue, bias / statistics / addressing are set up once per run; narrow tiles keep two workgroups per CU

@@ -27,6 +27,8 @@ FPROP = [
     dict(id="rpn_3x3_1024_256_relu", n=1, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),
     # feature-pyramid neck (BASELINE configs[4]): bias-only epilogues on shapes the C4 plans run with statistics
     dict(id="fpn_lateral4_1x1_1024_256_bias", n=4, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=False),
+    dict(id="fpn_lateral3_1x1_512_256_bias", n=4, h=47, w=156, cin=512, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=False),       # 460 tiles: 128 x 128
+    dict(id="fpn_p2_3x3_256_256_bias_relu", n=1, h=94, w=311, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),        # 256 output channels: plain 128 x 128 tiles, no kw sharing
     dict(id="fpn_output4_3x3_256_256_bias_b8", n=8, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=False),
     # small shapes (tails, odd grids)
     dict(id="small_1x1_stats", n=2, h=13, w=17, cin=64, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
@@ -60,7 +62,7 @@ FPROP_FP8 = [
     dict(id="f8_rpn_3x3_1024_256_relu", n=1, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),
     dict(id="f8_rpn_3x3_1024_256_relu_fix_b4", n=4, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),
     dict(id="f8_rpn_3x3_1024_256_relu_b8", n=8, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),    # configs[4]'s batch: 128 x 128 tiles
-    dict(id="f8_fpn_3x3_256_256_bias_kws", n=1, h=94, w=311, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=False),         # pyramid level 2: kw sharing, no statistics
+    dict(id="f8_fpn_p2_3x3_256_256_bias", n=1, h=94, w=311, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=False),         # pyramid level 2: 128 x 128 tiles, no statistics
     dict(id="f8_small_s2_stats", n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0, bias=False, relu=False, stats=True),
     dict(id="f8_small_3x3_128_stats", n=1, h=9, w=11, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     dict(id="f8_small_1x1_relu", n=2, h=13, w=17, cin=384, cout=72, k=1, s=1, p=0, bias=True, relu=True, stats=False),
@@ -84,7 +86,9 @@ DGRAD_FP8 = [
     # the pyramid's 3x3 convolutions (no BatchNorm behind them: plain data gradients, with or without the RoI branch's gradient as residual)
     dict(id="f8_fpn_dg_3x3_256_256_plain_b8", n=8, h=24, w=78, cin=256, cout=256, k=3, res=False, res_mask=False, red=False, mask=False, scatter=1),
     dict(id="f8_fpn_dg_3x3_256_256_plain_p5", n=8, h=12, w=39, cin=256, cout=256, k=3, res=False, res_mask=False, red=False, mask=False, scatter=1),
-    dict(id="f8_fpn_dg_3x3_256_256_res_kws", n=1, h=94, w=311, cin=256, cout=256, k=3, res=True, res_mask=False, red=False, mask=False, scatter=1),
+    dict(id="f8_fpn_dg_p2_3x3_256_256_res", n=1, h=94, w=311, cin=256, cout=256, k=3, res=True, res_mask=False, red=False, mask=False, scatter=1),
+    dict(id="f8_c4_dg_s2_1024_512_scatter_res_red_b8", n=8, h=24, w=78, cin=1024, cout=512, k=1, res=True, res_mask=False, red=True, mask=True, scatter=2),
+    dict(id="f8_c4_dg_s2_1024_512_scatter_res_plain_b8", n=8, h=24, w=78, cin=1024, cout=512, k=1, res=True, res_mask=False, red=False, mask=False, scatter=2),
     dict(id="f8_small_dg_scatter_res_red", n=2, h=12, w=39, cin=512, cout=256, k=1, res=True, res_mask=False, red=True, mask=True, scatter=2),
     dict(id="f8_small_dg_3x3_nomask", n=2, h=13, w=17, cin=128, cout=128, k=3, res=False, res_mask=False, red=True, mask=False, scatter=1),
 ]
@@ -113,6 +117,7 @@ DGRAD = [
     dict(id="rpn_heads_dg_128_256", n=4, h=24, w=78, cin=128, cout=256, k=1, res=False, res_mask=False, red=False, mask=False, scatter=1),
     dict(id="rpn_heads_dg_128_256_b8", n=8, h=24, w=78, cin=128, cout=256, k=1, res=False, res_mask=False, red=False, mask=False, scatter=1),   # 128 x 128 tiles
     dict(id="c4_dg_s2_256_512_scatter_plain", n=4, h=24, w=78, cin=256, cout=512, k=1, res=False, res_mask=False, red=False, mask=False, scatter=2),
+    dict(id="fpn_dg_p2_3x3_256_256_res", n=1, h=94, w=311, cin=256, cout=256, k=3, res=True, res_mask=False, red=False, mask=False, scatter=1),   # plain 128 x 128 tiles
     # small shapes
     dict(id="small_dg_run", n=2, h=12, w=39, cin=256, cout=64, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
     dict(id="small_dg_3x3", n=2, h=13, w=17, cin=128, cout=128, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
