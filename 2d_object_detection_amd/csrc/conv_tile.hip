@@ -970,7 +970,11 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
     if (const char* e = getenv("FRCNN_WIDE_MIN")) wide_min = atoi(e);
 #endif
     int bn = (bk == 64 && d->cout >= 128 && tiles_m128 * ((d->cout + 127) / 128) >= wide_min) ? 128 : 64;
-    int stages = (bn == 64 && bk == 64 && p.Ktot / bk >= 8) ? 3 : 2;     // (cold-cache sweep: the third slot pays from 8 slices on)
+    int s3_min = 8;
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_S3_MIN")) s3_min = atoi(e);
+#endif
+    int stages = (bn == 64 && bk == 64 && p.Ktot / bk >= s3_min) ? 3 : 2;     // (cold-cache sweep: the third slot pays from 8 slices on)
     // short K (<= 4 slices): runs of consecutive m-tiles per workgroup -- the ring prefetches the next tile under the
     // epilogue, bias / statistics / addressing are set up once per run; narrow tiles keep two workgroups per CU
     int tpb = 1;                                                // tiles per workgroup (1: one-tile kernel)
@@ -1022,7 +1026,11 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
         // ... and not where the layer has 256+ output channels: the filter slab, not the A image, is then most of what a 128 x 64
         // tile takes in, and the plain 128 x 128 tile halves it (tools/tile_sweep.py --fpn, M = 233,872 / 58,656, 3x3 256 -> 256,
         // us: bf16 kw-shared 393 / 98 against 322 / 79; fp8 220 / 52 against 165 / 42)
-        const bool kws_pays = tiles_m128 >= 160 && !(d->cout >= 256 && d->cout % 128 == 0);
+        int kws_min = 160;
+#ifdef FRCNN_SWEEP
+        if (const char* e = getenv("FRCNN_KWS_MIN")) kws_min = atoi(e);
+#endif
+        const bool kws_pays = tiles_m128 >= kws_min && !(d->cout >= 256 && d->cout % 128 == 0);
         if (kws_ok && (force_kws >= 0 ? force_kws == 1 : kws_pays)) {
             p.k_tiles = p.Ktot / 64;
             p.k_tiles_per_split = p.k_tiles;

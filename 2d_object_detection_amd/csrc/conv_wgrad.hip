@@ -531,8 +531,13 @@ static int wgrad_one(const frcnn_conv_desc* d, const void* x, const void* dz, in
     p.tiles_ci = (d->cin + bn - 1) / bn;
     p.p_tiles = (int)((M + BKP - 1) / BKP);
     const int blocks_mn = p.tiles_co * p.taps * p.tiles_ci;
-    // ~one workgroup per CU for 1x1 filters, two for multi-tap filters (their tile count is already large)
-    int split = want_split > 0 ? want_split : wide ? 2 * num_cus() / blocks_mn : (num_cus() * (p.taps > 1 ? 2 : 1) + blocks_mn - 1) / blocks_mn;
+    // ~two workgroups per CU for 1x1 filters, four for multi-tap ones (same-box A/B in the step, ms: one / two per CU: batch 4
+    // 4.19 -> 4.16, pyramid fp8 batch 8 9.53 -> 9.47; three: 4.165 / 9.50)
+    int one_f = 2;
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_WG1_FACTOR")) one_f = atoi(e);
+#endif
+    int split = want_split > 0 ? want_split : wide ? 2 * num_cus() / blocks_mn : (one_f * num_cus() * (p.taps > 1 ? 2 : 1) + blocks_mn - 1) / blocks_mn;
     if (split > p.p_tiles) split = p.p_tiles;
     if (split < 1) split = 1;
     p.p_tiles_per_split = (p.p_tiles + split - 1) / split;
@@ -621,12 +626,18 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
             tiles[m] += p.tiles_co * p.taps * p.tiles_ci;
         }
     }
-    // one pixel split for the whole group: just enough workgroups for ~2 per CU.  The float atomics of a split cost
+    // one pixel split for the whole group: just enough workgroups for ~4 per CU.  The float atomics of a split cost
     // split x |dw| bytes at the memory side's 1.3 TB/s; launched alone, a layer with few tiles needs a far larger split to fill
     // the chip (conv2: 64-128) than the group does (~10)
     for (int m = 0; m < kGroups; ++m) {
         if (g[m].n == 0) continue;
-        int split = (2 * num_cus() + tiles[m] - 1) / tiles[m];
+        // (same-box A/B of the workgroups-per-CU target in the step, ms: batch 4: 2 4.215, 4 4.19, 6 4.19, 8 4.215, 12 4.275; fp8 batch 8
+        // 6.79 -> 6.74; pyramid 9.64 -> 9.56: more, shorter pixel ranges even out the tail; the extra float atomics cost less)
+        int per_cu = 4;
+#ifdef FRCNN_SWEEP
+        if (const char* e = getenv("FRCNN_WG_PER_CU")) per_cu = atoi(e);
+#endif
+        int split = (per_cu * num_cus() + tiles[m] - 1) / tiles[m];
         if (split > min_p_tiles[m]) split = min_p_tiles[m];
         if (split < 1) split = 1;
         for (int i = 0; i < g[m].n; ++i) {

@@ -35,6 +35,7 @@ def _out_hw(h, w):
 FP8_MIN_STAGE = int(os.environ.get("FRCNN_FP8_MIN_STAGE", "3"))      # first ResNet stage whose tensors get fp8 twins (measuring aid: 2 = all)
 FP8_BWD = os.environ.get("FRCNN_FP8_BWD", "1") != "0"                # measuring aid: 0 keeps the data gradients in bf16 (fp8 forward only)
 FP8_WGRAD = os.environ.get("FRCNN_FP8_WGRAD", "1") != "0"            # measuring aid: 0 keeps the weight gradients in bf16
+FP8_MIN_K = int(os.environ.get("FRCNN_FP8_MIN_K", "256"))            # measuring aid: shortest contraction (k * k * channels) that runs in fp8
 FP8_MARGIN = 2.0           # delayed scaling: next step's scale = margin * this step's amax / 448 (e4m3 is a float format: head-room costs no precision)
 
 
@@ -93,9 +94,9 @@ class _ConvBN:
         # fp8 forward convolution (e4m3 operands, 128-deep MFMA steps): a layer whose cin is a multiple of 128
         # ... and whose contraction is at least two 128-deep steps long (a single step has no K loop to shorten: measured at
         # 375x1242, batch 4, the 1x1 128 -> 512 layers of conv3 run 16.4 -> 15.3 us forward and 30.9 -> 35.0 us backward in fp8)
-        self.fp8 = bool(fp8) and k != 7 and cin % 128 == 0 and k * k * cin >= 256
+        self.fp8 = bool(fp8) and k != 7 and cin % 128 == 0 and k * k * cin >= FP8_MIN_K
         # fp8 data gradient (e5m2 gradient x e4m3 transposed weights): its contraction runs over this layer's OUTPUT channels
-        self.fp8_bwd = FP8_BWD and bool(fp8 if fp8_bwd is None else fp8_bwd) and k != 7 and cout % 128 == 0 and k * k * cout >= 256
+        self.fp8_bwd = FP8_BWD and bool(fp8 if fp8_bwd is None else fp8_bwd) and k != 7 and cout % 128 == 0 and k * k * cout >= FP8_MIN_K
         # fp8 weight gradient (e4m3 input twin x e5m2 gradient twin, contraction over the pixels): bound by the bytes its workgroups
         # stream, so it pays whatever the channel counts (tools/wgrad_sweep.py fp8: 1.3-1.8x) -- wherever the input already has a twin
         self.fp8_wgrad = FP8_WGRAD and bool(fp8 if fp8_wgrad is None else fp8_wgrad) and k != 7 and cin % 64 == 0 and cout % 64 == 0
