@@ -983,6 +983,9 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
         // (four slices and 512+ output channels: the 128 x 128 one-tile kernel is as fast or faster -- tools/tile_sweep.py, us:
         // 256 -> 512 stride 2 at M = 29,328 24.2 against 30.4, 256 -> 1024 at M = 7,488 13.5 against 13.7)
         tpb = kt == 1 ? 8 : kt == 2 ? 4 : (kt <= 4 && d->cout < 512) ? 2 : 1;
+#ifdef FRCNN_SWEEP
+        if (const char* e = tpb > 1 ? getenv("FRCNN_TPB_SCALE") : nullptr) { const int sc = atoi(e); tpb = sc > 0 ? tpb * sc : tpb > 1 ? tpb / (-sc) : 1; if (tpb < 1) tpb = 1; if (tpb > 16) tpb = 16; }
+#endif
         const int tn64 = (d->cout + 63) / 64;
         // a run is shortened until the launch has at least ~300 workgroups: in the step (same-box A/B, batch 4, ms) 512: 4.280 / 4.287 /
         // 4.294, 400: 4.247 / 4.259, 300: 4.242 / 4.220 / 4.250, 256: 4.265 / 4.249, 200: 4.244 / 4.255, 128: 4.248 / 4.260 -- one

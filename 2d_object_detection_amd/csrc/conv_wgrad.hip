@@ -517,7 +517,11 @@ static int wgrad_one(const frcnn_conv_desc* d, const void* x, const void* dz, in
     // bound by what the workgroups pull through the CUs' load path -- every (cout tile, tap, cin tile) item streams its whole
     // pixel range: 128 x 128 tiles halve that against 64 x 64 (tools/wgrad_sweep.py fpn: 305 vs 651 us at M = 233,872,
     // 90 vs 156 us at M = 58,656; below M ~ 15 k the small tiles' better fill wins again)
-    const bool wide = d->kh * d->kw > 1 && d->cin % 128 == 0 && d->cout % 128 == 0 && M >= 24576;
+    long long wide_m = 24576;
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_WG_WIDE_M")) wide_m = atoll(e);
+#endif
+    const bool wide = d->kh * d->kw > 1 && d->cin % 128 == 0 && d->cout % 128 == 0 && M >= wide_m;
     int bm = wide ? 128 : 64;
     int bn = wide ? 128 : d->cin >= 64 ? 64 : 32;
     int stages = wide || bn == 32 ? 2 : 3, want_split = 0;
