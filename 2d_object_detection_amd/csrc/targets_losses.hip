@@ -30,6 +30,13 @@ struct AssignParams {
     float* tl; float* tb;
 };
 
+// MODE 0: the whole assignment of one image in one workgroup (pass 1, reduction, pass 2).
+// Long region lists (the feature pyramid's ~82 k anchors per image: 400 us in one workgroup) are cut into gridDim.y slices and three
+// launches: MODE 1 = pass 1 of a slice (max IoU / first arg-max of every region, stashed in the label rows); MODE 2 = one workgroup
+// per image finds the first region attaining the global maximum and marks it in its stash (bit 30 of the arg-max word: no scratch
+// memory, nothing a later pass overwrites is read by another workgroup); MODE 3 = pass 2 of a slice.  Same arithmetic, same results.
+constexpr int kForceBit = 0x40000000;
+template <int MODE>
 __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams p) {
     __shared__ f32x4 gbox[kMaxGt];
     __shared__ float garea[kMaxGt];
@@ -45,7 +52,13 @@ __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams
     float* tl = p.tl + (int64_t)b * p.R * p.C1;
     float* tb = p.tb + (int64_t)b * p.R * (p.C1 - 1) * 4;
     const int C = p.C1 - 1;
-
+    const int per_slice = (p.R + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int r_begin = MODE == 1 || MODE == 3 ? (int)blockIdx.y * per_slice : 0;
+    const int r_end = MODE == 1 || MODE == 3 ? min(p.R, r_begin + per_slice) : p.R;
+    int ng = 0, nlive = 0;
+    __shared__ int live_idx[kMaxGt];
+    __shared__ int live_cnt[3];
+    if (MODE != 2) {
     // ---- compact the non-padding ground truth in order (training.py:43-45), absolute coords (:48): one thread per gt row,
     // order-preserving slots from wave ballots (G <= 128: two waves)
     __shared__ int wave_cnt[2];
@@ -82,14 +95,12 @@ __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams
     }
     if (threadIdx.x == 0) nvalid = wave_cnt[0] + wave_cnt[1];
     __syncthreads();
-    const int ng = nvalid;
+    ng = nvalid;
     // The RPN path keeps all G = 100 rows (the objectness conversion turns zero padding into a "background" row,
     // rpn_detector.py:141 -- SURVEY A.6) although a handful are real boxes.  A row of zero or negative extent has IoU exactly 0
     // with every region (utils/metrics.py:150-208: its intersection width or height clamps to 0), so it can only decide the
     // arg-max when NO row has a positive IoU -- and then the first maximum is row 0 whatever the rows are.  The IoU loop
     // therefore runs over the live rows only (compacted, in order): max / first-arg-max are unchanged, the work drops ~10x.
-    __shared__ int live_idx[kMaxGt];
-    __shared__ int live_cnt[3];
     {
         const unsigned long long lm = threadIdx.x < kMaxGt ? __ballot(live) : 0ull;
         if (threadIdx.x < kMaxGt && (threadIdx.x & 63) == 0) live_cnt[threadIdx.x >> 6] = __popcll(lm);
@@ -101,12 +112,14 @@ __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams
         if (threadIdx.x == 0) live_cnt[2] = live_cnt[0] + live_cnt[1];
         __syncthreads();
     }
-    const int nlive = live_cnt[2];
+    nlive = live_cnt[2];
+    }   // MODE != 2
 
     // ---- pass 1: per-region max IoU / first argmax; stash them in the output buffers
     float best_v = -1.f;
     int best_i = 0x7FFFFFFF;
-    for (int r = threadIdx.x; r < p.R; r += blockDim.x) {
+    if (MODE == 0 || MODE == 1)
+    for (int r = r_begin + (int)threadIdx.x; r < r_end; r += blockDim.x) {
         const f32x4 rb = *reinterpret_cast<const f32x4*>(regions + (int64_t)r * 4);
         const float ra = (rb[2] - rb[0]) * (rb[3] - rb[1]);
         float mx = 0.f;                   // (every kept row contributes an IoU >= 0; rows of no extent exactly 0)
@@ -120,6 +133,14 @@ __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams
         tl[(int64_t)r * p.C1 + 1] = __int_as_float(am);
         if (mx > best_v || (mx == best_v && r < best_i)) { best_v = mx; best_i = r; }
     }
+    if (MODE == 1) return;
+    if (MODE == 2)                        // the stashed maxima of ALL regions of the image
+        for (int r = threadIdx.x; r < p.R; r += blockDim.x) {
+            const float mx = tl[(int64_t)r * p.C1];
+            if (mx > best_v || (mx == best_v && r < best_i)) { best_v = mx; best_i = r; }
+        }
+    int force_idx = -1;
+    if (MODE != 3) {
     red_v[threadIdx.x] = best_v;
     red_i[threadIdx.x] = best_i;
     __syncthreads();
@@ -134,14 +155,23 @@ __global__ __launch_bounds__(1024) void assign_targets_kernel(const AssignParams
         }
         __syncthreads();
     }
-    const int force_idx = red_i[0];       // first region attaining the global max (training.py:137-138)
+    force_idx = red_i[0];                 // first region attaining the global max (training.py:137-138)
+    }
+    if (MODE == 2) {
+        if (threadIdx.x == 0 && force_idx >= 0 && force_idx < p.R) {
+            float* w = tl + (int64_t)force_idx * p.C1 + 1;
+            *w = __int_as_float(__float_as_int(*w) | kForceBit);
+        }
+        return;
+    }
 
     // ---- pass 2: labels + encoded target boxes
-    for (int r = threadIdx.x; r < p.R; r += blockDim.x) {
+    for (int r = r_begin + (int)threadIdx.x; r < r_end; r += blockDim.x) {
         const float mx = tl[(int64_t)r * p.C1];
-        const int am = __float_as_int(tl[(int64_t)r * p.C1 + 1]);
+        const int am_raw = __float_as_int(tl[(int64_t)r * p.C1 + 1]);
+        const int am = am_raw & ~kForceBit;
         const bool bg = (mx >= p.bg_lo) && (mx < p.bg_hi);
-        const bool fg = ((mx >= p.fg_lo) && (mx < p.fg_hi)) || (r == force_idx);
+        const bool fg = ((mx >= p.fg_lo) && (mx < p.fg_hi)) || (MODE == 3 ? (am_raw & kForceBit) != 0 : r == force_idx);
         float lab[kMaxC1];
 #pragma unroll 1
         for (int c = 0; c < p.C1; ++c) lab[c] = 0.f;
@@ -184,8 +214,9 @@ struct SampleParams {
 };
 constexpr int kFgLds = 8192;
 
-__global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
-    __shared__ int wave_fg[4], wave_bg[4];
+// blockDim.x = 256 (short lists) or 1024 (the pyramid's ~82 k regions per image: the two ordered sweeps are split over 16 waves)
+__global__ __launch_bounds__(1024) void sample_kernel(const SampleParams p) {
+    __shared__ int wave_fg[16], wave_bg[16];
     __shared__ int fg_lds[kFgLds];
     __shared__ int swap_j[1024];          // partner position of step i of the partial Fisher-Yates (S <= 1024)
     const int b = blockIdx.x;
@@ -193,9 +224,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     int* fg_list = p.ws + (int64_t)b * 2 * p.R;
     int* bg_list = fg_list + p.R;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // candidate lists in ascending region order (training.py:99-104).  Every wave owns a contiguous quarter of the regions and
+    // candidate lists in ascending region order (training.py:99-104).  Every wave owns a contiguous share of the regions and
     // walks it 64 rows at a time (coalesced); ballots give the order-preserving slots.  Two sweeps: count, then write.
-    const int per_wave = ((p.R + 3) / 4 + 63) / 64 * 64;
+    const int nw = blockDim.x >> 6;
+    const int per_wave = ((p.R + nw - 1) / nw + 63) / 64 * 64;
     const int w0 = wave * per_wave, w1 = min(p.R, w0 + per_wave);
     auto classify = [&](const int r, bool& is_fg, bool& is_bg) {
         float s = 0.f, l0 = 0.f;
@@ -216,8 +248,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     if (lane == 0) { wave_fg[wave] = nf; wave_bg[wave] = nb; }
     __syncthreads();
     int of = 0, ob = 0, nfg = 0, nbg = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < nw; ++w) {
         if (w < wave) { of += wave_fg[w]; ob += wave_bg[w]; }
         nfg += wave_fg[w];
         nbg += wave_bg[w];
@@ -485,7 +516,16 @@ extern "C" int frcnn_assign_targets(const float* regions, int regions_per_image,
     p.R = r; p.G = g; p.C1g = c1g; p.C1 = c1; p.objectness = objectness;
     p.W = img_w; p.H = img_h; p.fg_lo = fg_lo; p.fg_hi = fg_hi; p.bg_lo = bg_lo; p.bg_hi = bg_hi;
     p.tl = target_labels; p.tb = target_boxes;
-    hipLaunchKernelGGL(assign_targets_kernel, dim3(b), dim3(1024), 0, S_(stream), p);
+    if (r >= 4096) {
+        // long lists: slices of ~2 k regions (two per thread), at most 64 per image
+        int ns = (r + 2047) / 2048;
+        if (ns > 64) ns = 64;
+        hipLaunchKernelGGL(assign_targets_kernel<1>, dim3(b, ns), dim3(1024), 0, S_(stream), p);
+        hipLaunchKernelGGL(assign_targets_kernel<2>, dim3(b, 1), dim3(1024), 0, S_(stream), p);
+        hipLaunchKernelGGL(assign_targets_kernel<3>, dim3(b, ns), dim3(1024), 0, S_(stream), p);
+    } else {
+        hipLaunchKernelGGL(assign_targets_kernel<0>, dim3(b, 1), dim3(1024), 0, S_(stream), p);
+    }
     FRCNN_CHECK_LAUNCH("assign_targets");
     return FRCNN_OK;
 }
@@ -500,7 +540,7 @@ extern "C" int frcnn_sample_indices(const float* target_labels, int b, int r, in
     p.max_fg = (int)nearbyint((double)num_samples * (double)fg_proportion);   // tf.math.round: half to even
     p.k0 = (unsigned int)(seed & 0xFFFFFFFFull); p.k1 = (unsigned int)(seed >> 32);
     p.step = step; p.stream_base = stream_base; p.image_base = image_base; p.out = indices; p.ws = workspace; p.status = status;
-    hipLaunchKernelGGL(sample_kernel, dim3(b), dim3(256), 0, S_(stream), p);
+    hipLaunchKernelGGL(sample_kernel, dim3(b), dim3(r >= 4096 ? 1024 : 256), 0, S_(stream), p);
     FRCNN_CHECK_LAUNCH("sample_indices");
     return FRCNN_OK;
 }

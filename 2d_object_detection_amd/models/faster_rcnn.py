@@ -354,6 +354,8 @@ class FasterRCNN:
         rpn_out = rpn.forward_plan(plan, pyramid, training, decoded=rpn_nms.decoded)
         # one-workgroup-per-image chains over ~82 k regions (targets -> sampling -> loss): side streams next to the proposal NMS, the
         # RoI pooling and the head GEMM, as in the C4 plan
+        if training:
+            plan.join("weight_flips")                # (the RPN's parameter gradients below read the transposed head weights)
         with plan.branch("rpn_side"):
             plan.add(ops.assign_targets, rpn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
                      rs["foreground_iou_interval"], rs["background_iou_interval"], t["rpn_tl"], t["rpn_tb"])
@@ -361,6 +363,10 @@ class FasterRCNN:
                      t["rpn_idx"], t["rpn_ws"], self.status, image_base=self.sampling_image_base)
             plan.add(ops.losses, rpn_out["pred_scores"], rpn_out["pred_boxes"], t["rpn_tl"], t["rpn_tb"], t["rpn_idx"], batch, n, 2, S_rpn,
                      cls_scale, 1.0, losses[0:2], t.get("rpn_dl"), t.get("rpn_dd"))
+            if training:
+                # the part of the RPN backward pass that does not need the RoI branch's gradient fills the chip while the proposal
+                # NMS (one workgroup per image over ~82 k candidates: ~0.2 ms) holds the main chain
+                rpn.backward_params_plan(plan, t["rpn_dl"], t["rpn_dd"], t["rpn_idx"], S_rpn, pyramid)
         nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"], buffers=rpn_nms, decoded_done=True)
         rois = nms_rpn["pred_boxes"]
         with plan.branch("rcnn_targets"):
@@ -380,10 +386,9 @@ class FasterRCNN:
         with plan.branch("detections"):              # the step's predictions: nothing on the main chain needs them
             nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
         if training:
-            plan.join("weight_flips")
             rcnn.backward_plan(plan, rois, neck.gp)                                  # gp[2..4]: complete RoI-branch gradients
             plan.join("rpn_side")
-            rpn.backward_plan(plan, t["rpn_dl"], t["rpn_dd"], t["rpn_idx"], S_rpn, pyramid, neck.gp, {2: True, 3: True, 4: True, 5: False})
+            rpn.backward_data_plan(plan, neck.gp, {2: True, 3: True, 4: True, 5: False})
             _, gh, gw, cf = fe.output_shape
             g_feat = torch.empty(batch * gh * gw, cf, dtype=BF16, device=dev)
             plan.hold(g_feat)

@@ -385,6 +385,12 @@ class RPNDetectorFPN:
     def backward_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, pyramid, gp, gp_written):
         """Per-sample loss gradients -> shared head parameter gradients (accumulated over the levels) and the gradient w.r.t. every
         level's map: ADDED into gp[l] where gp_written[l] (the RoI branch wrote it), plain otherwise."""
+        self.backward_params_plan(plan, dlogits_s, ddeltas_s, indices, num_samples, pyramid)
+        self.backward_data_plan(plan, gp, gp_written)
+
+    def backward_params_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, pyramid):
+        """Everything of the RPN backward pass that does not need the RoI branch's gradient: the training plan runs it on the RPN's
+        side stream, under proposal NMS / RoI pooling / the Fast-RCNN heads (as RPNDetector.backward_params_plan in the C4 plan)."""
         st = self.store
         for l in RPN_LEVELS:
             e = self.lv[l]
@@ -404,6 +410,11 @@ class RPNDetectorFPN:
                          st.grad("rpn_intermediate_layer/kernel"))
             else:
                 plan.add(ops.conv2d_wgrad, e["d_inter"], pyramid[l], e["dz_f"], st.grad("rpn_intermediate_layer/kernel"))
+
+    def backward_data_plan(self, plan, gp, gp_written):
+        """gp[l] (+)= the 3x3 convolution's data gradient of every level (after backward_params_plan)."""
+        for l in RPN_LEVELS:
+            e = self.lv[l]
             d = e["d_inter_bwd_res"] if gp_written.get(l) else e["d_inter_bwd"]
             res = gp[l] if gp_written.get(l) else None
             ops.conv_zero_counters(plan, d)

@@ -295,7 +295,8 @@ def test_backbone_gradient_injection_is_additive():
     ga = fa.store.grad("conv3_block4_3_bn/gamma").cpu()
     gb_ = fb.store.grad("conv3_block4_3_bn/gamma").cpu()
     assert _rel(gb_, ga) > 1e-2, "parameter gradients upstream of the injection point did not change"
-    assert torch.equal(fa.store.grad("conv4_block2_1_conv/kernel"), fb.store.grad("conv4_block2_1_conv/kernel")), "downstream gradients must not"
+    # (the grouped weight gradients split their pixel range at this small size: float atomics, equal up to the order of the sums)
+    assert _rel(fa.store.grad("conv4_block2_1_conv/kernel"), fb.store.grad("conv4_block2_1_conv/kernel")) < 1e-5, "downstream gradients must not"
 
 
 def test_fpn_full_size_step():
