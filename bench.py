@@ -255,10 +255,25 @@ def cpu_baseline(cfg, budget_s=150.0):
             "legs": legs}
 
 
-def offline_profile(family, variant=""):
+def workload_key(depth, batch, proposals, fp8, fpn):
+    """What a trace's per-launch figures belong to: the step's shapes (network, batch, proposals, precision, topology)."""
+    return "R%d,b%d,P%d,%s,%s" % (int(depth), int(batch), int(proposals) or 300, "fp8" if fp8 else "bf16", "fpn" if fpn else "c4")
+
+
+def workload_key_of_command(cmd):
+    """workload_key of a recorded `... bench.py <flags>` command line (profiles/hbm_traffic.py stores it with the trace)."""
+    tok = cmd.split()
+
+    def val(flag, default):
+        return int(tok[tok.index(flag) + 1]) if flag in tok else default
+    return workload_key(val("--depth", 50), val("--batch-per-gpu", 4), val("--proposals", 0), "--fp8" in tok, "--fpn" in tok)
+
+
+def offline_profile(family, variant="", workload=None):
     """rocprofv3 numbers for `family` committed under profiles/ (kernel-trace summary + PMC HBM traffic of this same command),
-    valid only for the kernel sources they were taken from: the newest profiles/r*_offline<variant>.json whose source hash is
-    this tree's.  Returns (family record or None, provenance / reason string)."""
+    valid only for the kernel sources AND the workload they were taken from: the newest profiles/r*_offline<variant>.json whose
+    source hash is this tree's and whose recorded command ran the same shapes (a batch-8 trace says nothing about a batch-4
+    launch).  Returns (family record or None, provenance / reason string)."""
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_offline%s.json" % variant)), reverse=True)
     if not cands:
@@ -267,11 +282,15 @@ def offline_profile(family, variant=""):
     stale = []
     for path in cands:
         off = json.load(open(path))
+        theirs = off.get("workload") or workload_key_of_command(off.get("from", ""))
+        if workload is not None and theirs != workload:
+            stale.append("%s is a trace of %s, not of %s" % (os.path.basename(path), theirs, workload))
+            continue
         if off.get("kernel_source_hash") == mine:
             return off.get("families", {}).get(family), "offline: profiles/%s (%s) @ kernel sources %s" % (
                 os.path.basename(path), off.get("from", "?"), mine)
         stale.append("%s@%s" % (os.path.basename(path), off.get("kernel_source_hash")))
-    return None, "stale: %s were taken from other kernel sources, this tree is %s" % (", ".join(stale), mine)
+    return None, "no committed trace for this run: %s (this tree's kernel sources: %s)" % ("; ".join(stale), mine)
 
 
 def main():
@@ -416,17 +435,19 @@ def main():
             # while the kernel sources are the ones that trace was taken from.  The live HIP-event timing of the same launches is
             # reported beside it (`events`): raw pairs over-state a launch by the cost of the pair itself, pairs minus the calibrated
             # empty-pair cost under-state it; when the committed trace is stale the RAW (conservative) event figure is the headline.
-            off, source = offline_profile(dom, ("_fp8" if args.fp8 else "") + ("_fpn" if args.fpn else ""))
+            variant = ("_fp8" if args.fp8 else "") + ("_fpn" if args.fpn else "")
+            wkey = workload_key(args.depth, B, args.proposals, args.fp8, args.fpn)
+            off, source = offline_profile(dom, variant, wkey)
             ev_raw_us = (f["seconds"] + f["launches"] * f["event_pair_overhead_us"] * 1e-6) / f["launches"] * 1e6
             ev_net_us = f["seconds"] / f["launches"] * 1e6
             if off and off.get("avg_launch_us"):
                 head_us, head_src = float(off["avg_launch_us"]), "rocprofv3 kernel trace, " + source
             else:
-                head_us, head_src = ev_raw_us, "live HIP events, raw pairs (no committed trace for these kernel sources: %s)" % source
+                head_us, head_src = ev_raw_us, "live HIP events, raw pairs (%s)" % source
             achieved = gflop_per_launch / head_us * 1e3       # GFLOP / us = PFLOP/s
             off_all = {}
             for k in fam:
-                off_all[k] = offline_profile(k, ("_fp8" if args.fp8 else "") + ("_fpn" if args.fpn else ""))[0]
+                off_all[k] = offline_profile(k, variant, wkey)[0]
             families = {}
             for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["seconds"]):
                 o = off_all.get(k)

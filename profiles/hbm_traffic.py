@@ -83,8 +83,8 @@ def main():
             f = fams[family(k)]
             f["ns"] += ns
             f["trace_launches"] += calls
-    from bench import kernel_source_hash
-    off = {"kernel_source_hash": kernel_source_hash(), "from": command, "steps": steps, "per_kernel_table": os.path.relpath(out_csv, ROOT), "families": {}}
+    from bench import kernel_source_hash, workload_key_of_command
+    off = {"kernel_source_hash": kernel_source_hash(), "workload": workload_key_of_command(command), "from": command, "steps": steps, "per_kernel_table": os.path.relpath(out_csv, ROOT), "families": {}}
     for name, f in fams.items():
         off["families"][name] = {
             "launches_per_step": round(f["launches"] / steps, 2) if f["launches"] else round(f["trace_launches"] / steps, 2),
