@@ -23,7 +23,9 @@ import torch
 from .. import ops
 from .detectors.fast_rcnn_detector import HEAD_LD as RCNN_LD
 from .detectors.fast_rcnn_detector import FastRCNNDetector
-from .detectors.rpn_detector import HEAD_LD as RPN_LD
+# padded row length of the RPN head's [cls | reg] output: 3 anchors per location x 6 = 18 real columns here (the single-map detector
+# has 12 anchors: 72 of 128) -- 64 keeps the head's fp32 output, its gradient and their casts / column sums at half the bytes of 128
+RPN_LD = 64
 from .feature_extractor import FP8_WGRAD
 
 BF16 = torch.bfloat16
