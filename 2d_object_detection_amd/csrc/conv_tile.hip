@@ -1113,6 +1113,8 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
     FRCNN_TILE(128, 64, 64, 6, 1)
     FRCNN_TILE(128, 128, 64, 4, 1)
     FRCNN_TILE(64, 64, 64, 6, 1)
+    FRCNN_TILE(256, 128, 64, 2, 1)
+    FRCNN_TILE(256, 64, 64, 2, 1)
 #endif
 #undef FRCNN_TILE
 #undef FRCNN_RUN

@@ -24,6 +24,7 @@ SHAPES = [  # n, h, w, cin, cout, k, stride, pad
 ]
 CONFIGS = [(bm, bn, bk, s, 1) for bk in (64, 128) for bm in (128, 64) for bn in (128, 64) for s in (2, 3) if not (bk == 128 and s == 3)]
 CONFIGS += [(128, 64, 64, 4, 1), (128, 64, 64, 6, 1), (128, 128, 64, 4, 1), (64, 64, 64, 6, 1)]               # deep rings
+CONFIGS += [(256, 128, 64, 2, 1), (256, 64, 64, 2, 1)]                                                         # 256-row tiles
 CONFIGS += [(bm, bn, 64, 2, t) for (bm, bn) in ((128, 64), (128, 128), (64, 64)) for t in (2, 4, 8, 16)]      # tile runs
 
 
@@ -112,7 +113,7 @@ def main():
                 res.append((e0.elapsed_time(e1) * 1e3 / iters, cfg))
             except Exception as ex:  # noqa: BLE001
                 res.append((1e9, cfg))
-        res.sort()
+        res.sort(key=lambda e: e[0])
         fl = 2.0 * m * cout * k * k * cin
         print("M=%6d cin=%5d cout=%5d k=%d s=%d : " % (m, cin, cout, k, s) + "  ".join("%s %.1fus(%.0fTF)" % (",".join(map(str, c)), t, fl / t / 1e6) for t, c in res[:int(os.environ.get("SWEEP_TOP", "5"))]), flush=True)
     os.environ.pop("FRCNN_TILE", None)
