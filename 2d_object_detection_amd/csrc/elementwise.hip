@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
             for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
         }
         const u32x4 pk = pack8(x);
-        *reinterpret_cast<u32x4*>(out + i * 8) = pk;
+        if (out) *reinterpret_cast<u32x4*>(out + i * 8) = pk;      // (NULL: every consumer of the activation reads the e4m3 twin below)
         if (b2.out8) {                           // fp8 twin of the STORED (bf16-rounded) activation
             float xr[8];
             unpack8(pk, xr);
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
             o[e] = bf16_round(v);
             carry[e] = v - o[e];
         }
-        *reinterpret_cast<u32x4*>(dz + i * 8) = pack8(o);
+        if (dz) *reinterpret_cast<u32x4*>(dz + i * 8) = pack8(o);      // (NULL: every consumer of dz reads the e5m2 twin below)
         if (gpre) *reinterpret_cast<u32x4*>(gpre + i * 8) = pack8(g);
         if (dz8) {
             store_fp8_pair(dz8 + i * 8, pack8_bf8(o, f8_qs), v, (C & 15) == 0);
@@ -949,9 +949,9 @@ extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_par
     FRCNN_CHECK_ARG(!f8 || (f8->out8 && f8->qscale), "bn_train_apply: fp8 output without buffer / scale");
     Bn2 extra{};
     if (f8) { extra.out8 = f8->out8; extra.qscale = f8->qscale; extra.amax = f8->amax; }
-    FRCNN_CHECK_ARG(z && stats_partial && gamma && beta && moving_mean && moving_var && out && mean && invstd && count > 0 &&
+    FRCNN_CHECK_ARG(z && stats_partial && gamma && beta && moving_mean && moving_var && (out || f8) && mean && invstd && count > 0 &&
                         slots > 0 && c % 8 == 0,
-                    "bn_train_apply: bad arguments");
+                    "bn_train_apply: bad arguments (out may be NULL only with an fp8 twin)");
     const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
     const int rows = strip_rows_per_block(m, c);
     const int strips = (c + 63) / 64, chunks = (int)((m + rows - 1) / rows);
@@ -976,9 +976,9 @@ extern "C" int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16
                                         const float* mean, const float* invstd, const float* gamma, const float* partial, int slots,
                                         float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, int64_t count,
                                         float param_grad_scale, const frcnn_fp8_out* f8, frcnn_stream_t stream) {
-    FRCNN_CHECK_ARG(gout && z && mean && invstd && gamma && partial && dgamma && dbeta && dz && m > 0 && slots > 0 && c % 8 == 0 &&
+    FRCNN_CHECK_ARG(gout && z && mean && invstd && gamma && partial && dgamma && dbeta && (dz || f8) && m > 0 && slots > 0 && c % 8 == 0 &&
                         !(act && relu_mask),
-                    "bn_bwd_apply_fused: bad arguments");
+                    "bn_bwd_apply_fused: bad arguments (dz may be NULL only with an fp8 twin)");
     FRCNN_CHECK_ARG(!f8 || (f8->out8 && f8->qscale), "bn_bwd_apply_fused: fp8 output without buffer / scale");
     const int rows = strip_rows_per_block(m, c);
     const int strips = (c + 63) / 64, chunks = (int)((m + rows - 1) / rows);

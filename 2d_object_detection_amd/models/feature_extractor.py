@@ -35,6 +35,7 @@ def _out_hw(h, w):
 FP8_MIN_STAGE = int(os.environ.get("FRCNN_FP8_MIN_STAGE", "3"))      # first ResNet stage whose tensors get fp8 twins (measuring aid: 2 = all)
 FP8_BWD = os.environ.get("FRCNN_FP8_BWD", "1") != "0"                # measuring aid: 0 keeps the data gradients in bf16 (fp8 forward only)
 FP8_WGRAD = os.environ.get("FRCNN_FP8_WGRAD", "1") != "0"            # measuring aid: 0 keeps the weight gradients in bf16
+FP8_DZ_TWIN_ONLY = os.environ.get("FRCNN_FP8_DZ_TWIN_ONLY", "1") != "0"   # measuring aid: 0 always stores the bf16 dz beside its twin
 FP8_MIN_K = int(os.environ.get("FRCNN_FP8_MIN_K", "256"))            # measuring aid: shortest contraction (k * k * channels) that runs in fp8
 FP8_MARGIN = 2.0           # delayed scaling: next step's scale = margin * this step's amax / 448 (e4m3 is a float format: head-room costs no precision)
 
@@ -197,7 +198,7 @@ class _ConvBN:
             g, b = st.weight(self.name + "_bn/gamma"), st.weight(self.name + "_bn/beta")
             plan.add(ops.bn_finalize_eval, self.cout, g, b, self.mm, self.mv, BN_EPS, self.scale, self.shift)
 
-    def apply(self, plan, out, res=None, relu=True, dual=None, out8=None):
+    def apply(self, plan, out, res=None, relu=True, dual=None, out8=None, twin_only=False):
         """dual: a second conv unit of the same output shape whose BatchNorm (no ReLU) is added before the ReLU -- the shortcut
         branch of a stage's first block: out = ReLU(BN(z) + BN_dual(z_dual)) in one kernel, the shortcut's output never stored."""
         if self._training and dual is not None:
@@ -212,6 +213,9 @@ class _ConvBN:
         if self._training:
             # batch statistics -> scale/shift inside the apply kernel (every workgroup reduces its own 64 channels)
             st = self.store
+            if twin_only:
+                assert out8 is not None and res is None
+                out = None                               # every consumer of this activation reads its e4m3 twin: no bf16 store
             plan.add(ops.bn_train_apply, self.z, self.stats, self.tiles, self.m * self.sync_world, st.weight(self.name + "_bn/gamma"),
                      st.weight(self.name + "_bn/beta"), self.mm, self.mv, BN_MOMENTUM, BN_EPS, out, self.mean, self.invstd, self.m,
                      self.cout, res=res, relu=relu, relu_mask=self.relu_mask if relu else None, f8=out8.out if out8 is not None else None)
@@ -236,8 +240,10 @@ class _ConvBN:
             plan.add(ops.bn_bwd_reduce, gout, None, self.z, self.mean, self.invstd, self.bwd_partial, self.m, self.cout, relu_mask=mask)
         if self.sync_world > 1:
             plan.sync_point(self.name + "_bn_bwd", [self.bwd_partial])
+        # fp8 mode: where both consumers of dz (data gradient, weight gradient) read its e5m2 twin, the bf16 tensor is not stored
+        dz = None if (getattr(self, "dz_twin_only", False) and self.dz8 is not None) else self.dz
         plan.add(ops.bn_bwd_apply_fused, gout, None, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"),
-                 self.bwd_partial, self.bwd_blocks, st.grad(self.name + "_bn/gamma"), st.grad(self.name + "_bn/beta"), self.dz, gpre,
+                 self.bwd_partial, self.bwd_blocks, st.grad(self.name + "_bn/gamma"), st.grad(self.name + "_bn/beta"), dz, gpre,
                  self.m, self.cout, relu_mask=mask, count=self.m * self.sync_world, param_grad_scale=1.0 / self.sync_world,
                  f8=self.dz8.out if self.dz8 is not None else None)
         # the conv bias feeds a training-mode BN: its gradient is identically zero (flat grad buffer is pre-zeroed)
@@ -247,6 +253,7 @@ class _ConvBN:
         stage (ops.WgradGroup) instead of one launch each.  x8: Fp8Twin of x -- with the e5m2 twin of dz the fp8 form."""
         st = self.store
         f8 = self.fp8_wgrad and x8 is not None and self.dz8 is not None
+        assert f8 or not getattr(self, "dz_twin_only", False), self.name + ": the bf16 dz is not stored, but its weight gradient would read it"
         if defer is not None and not self.is_stem and self.cin % 64 == 0 and self.cout % 64 == 0:
             if f8:
                 defer.append((self.desc, x8.data, self.dz8.data, st.grad(self.name + "_conv/kernel"), x8.scale, self.dz8.scale))
@@ -283,6 +290,7 @@ class _ConvBN:
             plan.hold(red)
         else:
             assert res_mask is None
+        assert (self.fp8_bwd and self.dz8 is not None) or not getattr(self, "dz_twin_only", False)
         if self.fp8_bwd and self.dz8 is not None:
             plan.add(ops.conv2d_dgrad_fp8, d, self.dz8.data, self.w_t8, self.dz8.scale, self.w_t8_scale, gx, red=red, res=res, res_mask=res_mask)
         elif consumer is not None:
@@ -468,6 +476,7 @@ class FeatureExtractor:
         hi, wi = self.hp1, self.wp1
         self.acts = {}
         self.f8 = Fp8Scales(dev) if (training and self.precision == "fp8") else None
+        prev_out8 = None
         for (n, ci, f, s, first) in self.specs:
             u = self.units[n]
             if first:
@@ -492,6 +501,16 @@ class FeatureExtractor:
                 a["a1_8"] = Fp8Twin(self.f8, (m, f), dev) if u[2].fp8 or u[2].fp8_wgrad else None
                 a["a2_8"] = Fp8Twin(self.f8, (m, f), dev) if u[3].fp8 or u[3].fp8_wgrad else None
                 a["out_8"] = Fp8Twin(self.f8, (m, 4 * f), dev) if u[3].fp8 or u[2].fp8 else None      # (this stage runs fp8: so do the readers of its output)
+                # a unit whose data gradient AND weight gradient both run on the e5m2 twin of dz never reads the bf16 tensor
+                x8_of = {0: prev_out8, 1: prev_out8, 2: a["a1_8"], 3: a["a2_8"]}
+                for k_ in sorted(u):
+                    u[k_].dz_twin_only = bool(FP8_DZ_TWIN_ONLY and u[k_].dz8 is not None and u[k_].fp8_bwd and u[k_].fp8_wgrad
+                                              and x8_of[k_] is not None)
+                # likewise the bf16 activations a1 / a2 when the convolution that reads them runs its forward pass AND its weight
+                # gradient on the e4m3 twin (the BatchNorm backward pass reads the ReLU bit mask, not the activation)
+                a["a1_twin_only"] = bool(FP8_DZ_TWIN_ONLY and a["a1_8"] is not None and u[2].fp8 and u[2].fp8_wgrad and u[2].dz8 is not None)
+                a["a2_twin_only"] = bool(FP8_DZ_TWIN_ONLY and a["a2_8"] is not None and u[3].fp8 and u[3].fp8_wgrad and u[3].dz8 is not None)
+            prev_out8 = a.get("out_8")
             if training:
                 a["g1"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a1
                 a["g2"] = torch.empty(m, f, dtype=BF16, device=dev)      # grad wrt a2
@@ -535,9 +554,9 @@ class FeatureExtractor:
             else:
                 res = x
             u[1].forward(plan, x, training, x8)
-            u[1].apply(plan, a["a1"], out8=a.get("a1_8") if f8 is not None else None)
+            u[1].apply(plan, a["a1"], out8=a.get("a1_8") if f8 is not None else None, twin_only=f8 is not None and a.get("a1_twin_only", False))
             u[2].forward(plan, a["a1"], training, a.get("a1_8") if f8 is not None else None)
-            u[2].apply(plan, a["a2"], out8=a.get("a2_8") if f8 is not None else None)
+            u[2].apply(plan, a["a2"], out8=a.get("a2_8") if f8 is not None else None, twin_only=f8 is not None and a.get("a2_twin_only", False))
             u[3].forward(plan, a["a2"], training, a.get("a2_8") if f8 is not None else None)
             o8 = a.get("out_8") if f8 is not None else None
             if fused_shortcut:

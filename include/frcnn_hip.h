@@ -272,11 +272,13 @@ int frcnn_bn_bwd_apply(const frcnn_bf16* gout, const frcnn_bf16* act, const frcn
 int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_partial, int slots, int64_t count, const float* gamma,
                          const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
                          const frcnn_bf16* res, int relu, frcnn_bf16* out, uint8_t* relu_mask, float* mean, float* invstd,
-                         int64_t m, int c, const struct frcnn_fp8_out* f8 /* NULL: no fp8 twin */, frcnn_stream_t stream);
+                         int64_t m, int c, const struct frcnn_fp8_out* f8 /* NULL: no fp8 twin; with a twin `out` may be NULL (the bf16
+                         activation is then not stored: ReLU bit mask and twin only) */, frcnn_stream_t stream);
 int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z,
                              const float* mean, const float* invstd, const float* gamma, const float* partial, int slots,
                              float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, int64_t count,
-                             float param_grad_scale, const struct frcnn_fp8_out* f8 /* NULL, or the e5m2 twin of dz */, frcnn_stream_t stream);
+                             float param_grad_scale, const struct frcnn_fp8_out* f8 /* NULL, or the e5m2 twin of dz; with a twin dz may be
+                             NULL: the bf16 tensor is then not stored (every consumer reads the twin) */, frcnn_stream_t stream);
 /* g_out = g * (act > 0): ReLU backward without BN (RPN intermediate layer) */
 int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, int64_t n, frcnn_stream_t stream);
 /* per-channel column sum of a bf16 [m,c] matrix ADDED (float atomics) to fp32 out[c] (bias gradients;
