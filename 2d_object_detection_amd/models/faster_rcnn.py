@@ -344,7 +344,7 @@ class FasterRCNN:
             plan.hold(table)
             with plan.branch("weight_flips"):        # (first needed by the backward pass: a side stream under the forward pass)
                 plan.add(ops.weights_transpose_flip_batched, table, total)
-                if fe.f8 is not None:                # precision "fp8": the backbone from conv3 on + the pyramid's 3x3 convolutions
+                if fe.f8 is not None:                # precision "fp8": the backbone + the pyramid's 3x3 convolutions
                     fe.quantize_bwd_weights_plan(plan, extra=neck.quant_entries()[1] + rpn.quant_entries()[1])
         fe.forward_plan(plan, training)
         stage_maps = {l: fe.acts[last[l]]["out"] for l in FPN_LEVELS}

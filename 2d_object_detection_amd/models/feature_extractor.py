@@ -32,7 +32,7 @@ def _out_hw(h, w):
     return f1(h), f1(w), f2(f1(h)), f2(f1(w))
 
 
-FP8_MIN_STAGE = int(os.environ.get("FRCNN_FP8_MIN_STAGE", "3"))      # first ResNet stage whose tensors get fp8 twins (measuring aid: 2 = all)
+FP8_MIN_STAGE = int(os.environ.get("FRCNN_FP8_MIN_STAGE", "2"))      # first ResNet stage whose tensors get fp8 twins (measuring aid: 3 = conv3 on)
 FP8_BWD = os.environ.get("FRCNN_FP8_BWD", "1") != "0"                # measuring aid: 0 keeps the data gradients in bf16 (fp8 forward only)
 FP8_WGRAD = os.environ.get("FRCNN_FP8_WGRAD", "1") != "0"            # measuring aid: 0 keeps the weight gradients in bf16
 FP8_DZ_TWIN_ONLY = os.environ.get("FRCNN_FP8_DZ_TWIN_ONLY", "1") != "0"   # measuring aid: 0 always stores the bf16 dz beside its twin
@@ -338,10 +338,11 @@ class FeatureExtractor:
                 self.store.end_bucket("conv%d" % last_stage)
             last_stage = stage_of(n)
             u = {}
-            # fp8 from conv3 on.  At conv2's resolution (94 x 311) the convolutions are bound by HBM and their epilogues, not by
-            # operand fill: measured per block (375x1242, batch 4), the e4m3 twin costs the BatchNorm kernel that writes it +9 us
-            # (40 -> 49) and saves the 1x1 256 -> 64 convolution that reads it 5 us -- so conv2 stays bf16, and so do the two
-            # stride-2 convolutions of conv3_block1 that read conv2's output (they touch a quarter of its pixels).
+            # fp8 from conv2 on (FP8_MIN_STAGE).  At conv2's resolution (94 x 311) the forward convolutions are bound by HBM and
+            # their epilogues, not by operand fill, and in the first half of round 3 a twin cost its BatchNorm kernel more than it
+            # saved the one convolution reading it -- conv2 stayed bf16.  With the weight gradients in fp8 as well (a twin has two or
+            # three readers) and the bf16 tensors that lose their last reader no longer stored (dz_twin_only), conv2's twins pay:
+            # same-box A/B of stage 3 -> 2: batch 8 6.41 -> 6.35 ms, pyramid 8.73 -> 8.67, batch 4 3.94 -> 3.92.
             stage = stage_of(n)
             f_in = fp8 and (stage - (1 if first else 0)) >= FP8_MIN_STAGE          # units reading the block input
             f_blk = fp8 and stage >= FP8_MIN_STAGE                                 # units reading this block's own activations

@@ -401,8 +401,8 @@ def main():
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16",
         "data": "synthetic",
         "config": {"workload": ("ResNet-%d%s Faster-RCNN full train step, fp8: e4m3 weights (per output channel) and activations (per tensor, delayed "
-                                "scaling), e5m2 gradients, in the forward convolutions and data gradients of the backbone from conv3 on (K >= 256)%s on "
-                                "the f8f6f4 MFMA path; bf16 storage, weight gradients and remaining layers; batch %d per GPU, 375x1242 synthetic KITTI, "
+                                "scaling), e5m2 gradients, in the forward convolutions, data gradients and weight gradients of the backbone wherever the channel counts allow (K >= 256 for forward / data gradients)%s on "
+                                "the f8f6f4 MFMA path; bf16 storage and remaining layers; batch %d per GPU, 375x1242 synthetic KITTI, "
                                 "%d proposals, 7 classes (BASELINE.json configs[4]%s)" % (
                                     args.depth, "-FPN (pyramid over C2..C4, RPN on P2..P5, per-level RoI heads)" if args.fpn else "(C4)",
                                     "" if args.fpn else " and of the RPN's 3x3", B, args.proposals or 300,
