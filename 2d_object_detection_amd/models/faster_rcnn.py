@@ -348,7 +348,7 @@ class FasterRCNN:
                     fe.quantize_bwd_weights_plan(plan, extra=neck.quant_entries()[1] + rpn.quant_entries()[1])
         fe.forward_plan(plan, training)
         stage_maps = {l: fe.acts[last[l]]["out"] for l in FPN_LEVELS}
-        pyramid = neck.forward_plan(plan, stage_maps)
+        pyramid = neck.forward_plan(plan, stage_maps, {l: fe.acts[last[l]].get("out_8") for l in FPN_LEVELS} if training else None)
         nms_cfg = self._rpn_config["nms"]
         rpn_nms = NmsBuffers(batch, n, 1, nms_cfg["max_output_size_per_class"], nms_cfg["max_total_size"], dev)
         rpn_out = rpn.forward_plan(plan, pyramid, training, decoded=rpn_nms.decoded)

@@ -171,7 +171,7 @@ class FPNNeck:
         self.merged8, self.gp8 = {}, {}
         for l in LEVELS:
             h, w = grids[l]
-            self.lateral[l].setup(batch, h, w, dev)
+            self.lateral[l].setup(batch, h, w, dev, fp8=self.f8 is not None)     # (forward on the backbone's twin of the stage output)
             self.output[l].setup(batch, h, w, dev, fp8=self.f8 is not None)
             self.merged[l] = torch.empty(batch * h * w, FPN_DIM, dtype=BF16, device=dev)     # lateral output, merged in place
             self.p[l] = torch.empty(batch, h, w, FPN_DIM, dtype=BF16, device=dev)
@@ -187,11 +187,11 @@ class FPNNeck:
         if training:
             self.gp[5] = torch.empty(batch * self.grids[5][0] * self.grids[5][1], FPN_DIM, dtype=BF16, device=dev)
 
-    def forward_plan(self, plan, stage_maps):
-        """stage_maps {level: bf16 [B*h*w, C_level]} -> pyramid {2..5: bf16 [B, h, w, 256]}"""
+    def forward_plan(self, plan, stage_maps, stage_maps8=None):
+        """stage_maps {level: bf16 [B*h*w, C_level]} -> pyramid {2..5: bf16 [B, h, w, 256]}; stage_maps8: their Fp8Twins (fp8 training)"""
         b = self.batch
         for l in LEVELS:
-            self.lateral[l].forward(plan, stage_maps[l], self.merged[l])
+            self.lateral[l].forward(plan, stage_maps[l], self.merged[l], (stage_maps8 or {}).get(l) if self.f8 is not None else None)
         for l in (3, 2):
             (ht, wt), (h, w) = self.grids[l + 1], self.grids[l]
             plan.add(ops.upsample_add, self.merged[l + 1], ht, wt, self.merged[l], self.merged[l], b, h, w, FPN_DIM)

@@ -63,6 +63,9 @@ FPROP_FP8 = [
     dict(id="f8_rpn_3x3_1024_256_relu_fix_b4", n=4, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),
     dict(id="f8_rpn_3x3_1024_256_relu_b8", n=8, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),    # configs[4]'s batch: 128 x 128 tiles
     dict(id="f8_fpn_p2_3x3_256_256_bias", n=1, h=94, w=311, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=False),         # pyramid level 2: 128 x 128 tiles, no statistics
+    # the pyramid's lateral 1x1 convolutions on the backbone's twins: bias only, no statistics
+    dict(id="f8_fpn_lateral4_1024_256_bias", n=8, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=False),
+    dict(id="f8_fpn_lateral3_512_256_bias_run", n=8, h=47, w=156, cin=512, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=False),
     dict(id="f8_small_s2_stats", n=1, h=15, w=21, cin=256, cout=128, k=1, s=2, p=0, bias=False, relu=False, stats=True),
     dict(id="f8_small_3x3_128_stats", n=1, h=9, w=11, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     dict(id="f8_small_1x1_relu", n=2, h=13, w=17, cin=384, cout=72, k=1, s=1, p=0, bias=True, relu=True, stats=False),
@@ -165,7 +168,8 @@ WGRAD_GROUPS_FP8 = [
     dict(id="f8_mixed", layers=[dict(n=2, h=24, w=39, cin=256, cout=256, k=3, s=1, p=1, f8=True), dict(n=2, h=24, w=39, cin=256, cout=1024, k=1, s=1, p=0, f8=True),
                                 dict(n=2, h=24, w=39, cin=1024, cout=256, k=1, s=1, p=0, f8=False), dict(n=1, h=47, w=77, cin=512, cout=256, k=1, s=2, p=0, f8=True),
                                 dict(n=2, h=12, w=10, cin=128, cout=128, k=3, s=1, p=1, f8=False)]),
-    dict(id="f8_narrow", layers=[dict(n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1, f8=True), dict(n=2, h=9, w=13, cin=128, cout=256, k=1, s=1, p=0, f8=True)]),
+    dict(id="f8_narrow", layers=[dict(n=2, h=12, w=10, cin=64, cout=64, k=3, s=1, p=1, f8=True), dict(n=2, h=9, w=13, cin=128, cout=256, k=1, s=1, p=0, f8=True),
+                                 dict(n=2, h=10, w=12, cin=256, cout=64, k=1, s=1, p=0, f8=True)]),                       # linear, 64 output channels: 64 x 64 tiles
 ]
 
 # ---- grouped weight gradients: one launch per addressing mode; tile 128 x 64 when every layer of the mode has cout >= 128
