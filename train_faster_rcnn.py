@@ -45,7 +45,10 @@ def parse_args(argv=None):
     parser.add_argument("--init-weights", default=None, type=str, help="weight file (FasterRCNN.save_weights format) to start from")
     parser.add_argument("--seed", default=0, type=int)
     parser.add_argument("--precision", default="bf16", choices=("bf16", "fp8"),
-                        help="fp8: e4m3 / e5m2 operands in the training step's convolutions from conv3 on (BASELINE.json configs[4]'s precision)")
+                        help="fp8: e4m3 / e5m2 operands in the training step's convolutions (BASELINE.json configs[4]'s precision)")
+    parser.add_argument("--topology", default="c4", choices=("c4", "fpn"),
+                        help="c4: the reference's single conv4 feature map; fpn: feature pyramid over C2..C4 (BASELINE.json configs[4]; "
+                             "config['anchors']['scales'] then holds one scale per level P2..P5)")
     parser.add_argument("--collective-timeout-minutes", default=120.0, type=float,
                         help="time-out of the process group's collectives (several ranks): must exceed the chief's validation pass, "
                              "during which the other ranks wait in a barrier")
@@ -182,7 +185,7 @@ def main(argv=None):
     optimizer = OPT.SGD(learning_rate=learning_rate, momentum=0.9)
     # every rank draws its own fg/bg sample positions (the Philox key differs per rank); the weights' seed is shared
     model = M.FasterRCNN(config, depth=args.depth, device=dev, seed=args.seed, sampling_seed=args.seed + rank, world_size=world,
-                         precision=args.precision)
+                         precision=args.precision, topology=args.topology)
     if args.init_weights:
         model.load_weights(args.init_weights)
     optimizer.bind(model.store)
