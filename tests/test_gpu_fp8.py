@@ -514,6 +514,34 @@ def test_fp8_backbone_deviation_from_bf16():
         assert min(c for c, _ in own.values()) > 0.99, own
 
 
+def test_fp8_twin_only_stores_change_nothing():
+    """fp8 mode skips the bf16 store of tensors whose every reader takes the fp8 twin (BatchNorm backward outputs, inner activations).
+    The twin is the image of the bf16-ROUNDED value either way, so forward pass, data gradients and parameter gradients must not move
+    (up to the order of float-atomic sums in the backward partial sums and split weight gradients)."""
+    import importlib
+    FE = importlib.import_module("2d_object_detection_amd.models.feature_extractor")
+    assert FE.FP8_DZ_TWIN_ONLY
+    a = _backbone_fwd_bwd("fp8")
+    n_skip_dz = sum(1 for u in a["fe"].conv_units() if getattr(u, "dz_twin_only", False))
+    n_skip_act = sum(1 for n in a["fe"].acts for k in ("a1_twin_only", "a2_twin_only") if a["fe"].acts[n].get(k))
+    assert n_skip_dz >= 20 and n_skip_act >= 10, (n_skip_dz, n_skip_act)
+    FE.FP8_DZ_TWIN_ONLY = False
+    try:
+        b = _backbone_fwd_bwd("fp8")
+    finally:
+        FE.FP8_DZ_TWIN_ONLY = True
+    assert not any(getattr(u, "dz_twin_only", False) for u in b["fe"].conv_units())
+    rel = lambda x, y: float((x - y).norm() / (y.norm() + 1e-20))
+    assert torch.equal(a["feat"], b["feat"]), "forward pass moved"
+    # Two runs of ONE configuration already differ by the order of their float-atomic sums, and the train-mode backward pass of a
+    # random-init ResNet amplifies that on its way down (measured, same configuration twice: conv4 2e-9, conv3 4e-7, conv2 + stem
+    # 4e-3, block-input gradient 3e-3 .. 1.3e-2 -- in bf16 as in fp8).  The two modes must agree to that noise: tight where it is small.
+    tol = {"conv4": 1e-6, "conv3": 1e-5}
+    for n, lo, hi in a["buckets"]:
+        assert rel(a["g"][lo:hi], b["g"][lo:hi]) < tol.get(n, 3e-2), (n, rel(a["g"][lo:hi], b["g"][lo:hi]))
+    assert rel(a["gin"], b["gin"]) < 3e-2, rel(a["gin"], b["gin"])
+
+
 def test_fp8_train_step_runs_and_stays_close():
     ref = _small_step("bf16")
     f8 = _small_step("fp8")
