@@ -279,6 +279,16 @@ __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(const bf16_t* __restr
                     g2v[u] = pw < ps ? *reinterpret_cast<const unsigned int*>(gpooled + (int64_t)r * items + it) : 0u;
                     a2v[u] = *reinterpret_cast<const unsigned short*>(amax + (int64_t)row * items + it);
                 }
+                // Consecutive bins of a bin row land on the same or the next column (a proposal is a few cells wide, its 14 sample
+                // columns lie ~0.4 cells apart): their contributions are run-length combined in registers -- pending sums for column
+                // px and px + 1 -- and leave as ONE LDS atomic per column instead of two per bin (which, back to back on one address,
+                // are what this kernel costs when the gradient is dense).
+                float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
+                int px[2] = {-4, -4};
+                auto flush = [&](const int e) {
+                    if (a0[e] != 0.f) atomicAdd(racc + px[e] * CS + cl + e, a0[e]);
+                    if (a1[e] != 0.f) atomicAdd(racc + (px[e] + 1) * CS + cl + e, a1[e]);      // (non-zero only where column px + 1 exists)
+                };
 #pragma unroll
                 for (int u = 0; u < PWMAX; ++u) {
                     const int pw = pw0 + u;
@@ -297,12 +307,28 @@ __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(const bf16_t* __restr
                         const float ty = floorf(in_y), by = ceilf(in_y), ly = in_y - ty;
                         const float wy = (ty == fy ? (1.f - ly) : 0.f) + (by == fy ? ly : 0.f);
                         if (wy == 0.f) continue;
-                        const float lxf = floorf(in_x), rxf = ceilf(in_x), lx = in_x - lxf;
+                        const float lxf = floorf(in_x), lx = in_x - lxf;
                         const float d = wy * gv;
-                        atomicAdd(racc + (int)lxf * CS + cl + e, (1.f - lx) * d);
-                        atomicAdd(racc + (int)rxf * CS + cl + e, lx * d);
+                        const int xi = (int)lxf;
+                        const float c_l = (1.f - lx) * d, c_r = lx * d;
+                        if (xi == px[e]) {
+                            a0[e] += c_l;
+                            a1[e] += c_r;
+                        } else if (xi == px[e] + 1) {
+                            if (a0[e] != 0.f) atomicAdd(racc + px[e] * CS + cl + e, a0[e]);
+                            a0[e] = a1[e] + c_l;
+                            a1[e] = c_r;
+                            px[e] = xi;
+                        } else {
+                            flush(e);
+                            a0[e] = c_l;
+                            a1[e] = c_r;
+                            px[e] = xi;
+                        }
                     }
                 }
+                flush(0);
+                flush(1);
             }
         }
     }
