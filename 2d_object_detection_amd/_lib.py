@@ -35,9 +35,9 @@ class BnReduce(Structure):
     _fields_ = [("z", c_void_p), ("relu_mask", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("partial", c_void_p)]
 
 
-ABI_VERSION = 4          # FRCNN_ABI_VERSION of include/frcnn_hip.h this table was written against (load() refuses any other library)
+ABI_VERSION = 5          # FRCNN_ABI_VERSION of include/frcnn_hip.h this table was written against (load() refuses any other library)
 
-CONV_BIAS, CONV_RELU, CONV_OUT_F32, CONV_ADD_RES, CONV_STATS, CONV_SPLITK_ATOMIC = 1, 2, 4, 8, 16, 32
+CONV_BIAS, CONV_RELU, CONV_OUT_F32, CONV_ADD_RES, CONV_STATS, CONV_SPLITK_ATOMIC, CONV_WGRAD_ACCUMULATE = 1, 2, 4, 8, 16, 32, 64
 
 P = c_void_p
 _SIGNATURES = {
@@ -57,7 +57,7 @@ _SIGNATURES = {
     "frcnn_conv2d_dgrad_fp8": (c_int, [POINTER(ConvDesc), P, P, P, P, P, P, P, POINTER(BnReduce), P]),
     "frcnn_conv2d_describe_dgrad_fp8": (c_char_p, [POINTER(ConvDesc), c_int]),
     "frcnn_quantize_weights_fp8_batched": (c_int, [P, c_int, c_int64, P]),
-    "frcnn_fp8_update_scales": (c_int, [P, P, P, c_int, c_float, P]),
+    "frcnn_fp8_update_scales": (c_int, [P, P, P, c_int, c_float, P, P, P]),
     "frcnn_conv2d_dgrad_bnreduce": (c_int, [POINTER(ConvDesc), P, P, P, P, P, POINTER(BnReduce), P]),
     "frcnn_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
     "frcnn_conv2d_wgrad_fp8": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P, P]),

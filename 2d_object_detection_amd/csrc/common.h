@@ -104,10 +104,23 @@ __device__ __forceinline__ u32x2 pack8_bf8(const float* f, const float qs) {
 // patterns: order-preserving for x >= 0).  One slot per wave of a launch (8192 slots: more than the waves of any launch here),
 // because atomics on ONE address serialise (~0.1 us each: the 4096 waves of a BatchNorm launch on one word cost ~40 us, on 64
 // words still 9 us of an 18 us launch -- tools/bn_bench.py, BN_F8=1 against BN_F8=noamax).
+// Callable after per-thread early returns: with every lane of the wave active the reduction is a butterfly and lane 0 writes; with
+// some lanes gone (a channel count that is not a multiple of 64, a tail row) the exited lanes' registers are undefined to a shuffle,
+// so the maximum is collected from the ACTIVE lanes one by one (v_readlane on the ballot's set bits) and the first active lane writes.
 __device__ __forceinline__ void atomic_amax(float* dst, float v) {
+    const unsigned long long act = __ballot(1);
+    int writer = 0;
+    if (act == ~0ull) {
 #pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) v = fmaxf(v, __shfl_xor(v, sh));
-    if ((threadIdx.x & 63) == 0 && v > 0.f) {
+        for (int sh = 32; sh >= 1; sh >>= 1) v = fmaxf(v, __shfl_xor(v, sh));
+    } else {
+        float m = 0.f;
+        for (unsigned long long rem = act; rem; rem &= rem - 1)
+            m = fmaxf(m, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), __ffsll((long long)rem) - 1)));
+        v = m;
+        writer = __ffsll((long long)act) - 1;
+    }
+    if ((int)(threadIdx.x & 63) == writer && v > 0.f) {
         const unsigned slot = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (FRCNN_FP8_AMAX_SLOTS - 1);
         atomicMax(reinterpret_cast<unsigned*>(dst) + slot, __float_as_uint(v));
     }

@@ -546,7 +546,8 @@ static int wgrad_one(const frcnn_conv_desc* d, const void* x, const void* dz, in
     if (split < 1) split = 1;
     p.p_tiles_per_split = (p.p_tiles + split - 1) / split;
     split = (p.p_tiles + p.p_tiles_per_split - 1) / p.p_tiles_per_split;
-    p.plain_store = split == 1 ? 1 : 0;        // (dw arrives zeroed: a single writer per element may store)
+    // (dw arrives zeroed: a single writer per element may store -- unless the caller says dw is shared with other launches)
+    p.plain_store = split == 1 && !(d->flags & FRCNN_CONV_WGRAD_ACCUMULATE) ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define FRCNN_DISPATCH(BM_, BN_, S_, OCC_) \
     if (bm == BM_ && bn == BN_ && stages == S_) return launch<BM_, BN_, S_, OCC_>(p, split, s);

@@ -71,25 +71,44 @@ __global__ __launch_bounds__(256) void quantize_weights_fp8_kernel(const long lo
     }
 }
 
-// one workgroup per tensor: maximum over its amax slots, then the next step's scales
-__global__ __launch_bounds__(256) void fp8_update_scales_kernel(const float* __restrict__ amax, float* __restrict__ scale, float* __restrict__ qscale, int n, float margin) {
+// one workgroup per tensor: maximum over its amax slots, then the next step's scales.  A non-finite amax (an overflowed activation)
+// keeps the previous scale -- scale = Inf would dequantise 0 * Inf = NaN from the next step on -- and is counted in status[1]; an
+// amax beyond what this step's scale could represent (limit x scale: the twin's values were clamped) is counted in status[0].
+__global__ __launch_bounds__(256) void fp8_update_scales_kernel(const float* __restrict__ amax, float* __restrict__ scale, float* __restrict__ qscale, int n, float margin,
+                                                                const float* __restrict__ limit, int* __restrict__ status) {
     __shared__ float red[4];
+    __shared__ int bad[4];
     const int i = blockIdx.x;
     const f32x4* src = reinterpret_cast<const f32x4*>(amax + (long long)i * FRCNN_FP8_AMAX_SLOTS);
     float a = 0.f;
+    int nonfinite = 0;
     for (int k = threadIdx.x; k < FRCNN_FP8_AMAX_SLOTS / 4; k += 256) {
         const f32x4 v = src[k];
-        a = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), a);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // (fmaxf drops a NaN operand: test the slots themselves.  The slots hold max |x| as float bits >= 0.)
+            if (!(v[e] <= 3.0e38f)) nonfinite = 1; else a = fmaxf(a, v[e]);
+        }
     }
 #pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) a = fmaxf(a, __shfl_xor(a, sh));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        a = fmaxf(a, __shfl_xor(a, sh));
+        nonfinite |= __shfl_xor(nonfinite, sh);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; bad[threadIdx.x >> 6] = nonfinite; }
     __syncthreads();
     a = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (threadIdx.x == 0 && a > 0.f) {
-        const float sc = margin * a * (1.f / 448.f);
-        scale[i] = sc;
-        qscale[i] = 1.f / sc;
+    nonfinite = bad[0] | bad[1] | bad[2] | bad[3];
+    if (threadIdx.x == 0) {
+        if (nonfinite) {
+            if (status) atomicAdd(status + 1, 1);
+        } else if (a > 0.f) {
+            const float lim = limit ? limit[i] : 448.f;
+            if (status && a > lim * scale[i] * 1.0001f) atomicAdd(status, 1);
+            const float sc = margin * a * (1.f / 448.f);
+            scale[i] = sc;
+            qscale[i] = 1.f / sc;
+        }
     }
 }
 
@@ -113,9 +132,10 @@ extern "C" int frcnn_quantize_weights_fp8_batched(const int64_t* table, int n, i
     return FRCNN_OK;
 }
 
-extern "C" int frcnn_fp8_update_scales(const float* amax, float* scale, float* qscale, int n, float margin, frcnn_stream_t stream) {
+extern "C" int frcnn_fp8_update_scales(const float* amax, float* scale, float* qscale, int n, float margin, const float* limit, int32_t* status,
+                                       frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(amax && scale && qscale && n > 0 && margin > 0.f, "fp8_update_scales: bad arguments");
-    hipLaunchKernelGGL(fp8_update_scales_kernel, dim3(n), dim3(256), 0, S_(stream), amax, scale, qscale, n, margin);
+    hipLaunchKernelGGL(fp8_update_scales_kernel, dim3(n), dim3(256), 0, S_(stream), amax, scale, qscale, n, margin, limit, status);
     FRCNN_CHECK_LAUNCH("fp8_update_scales");
     return FRCNN_OK;
 }

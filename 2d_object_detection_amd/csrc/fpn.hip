@@ -11,8 +11,9 @@ namespace {
 #define S_(s) reinterpret_cast<hipStream_t>(s)
 
 // out[b,y,x,:] = lat[b,y,x,:] + top[b, (y*ht)/h, (x*wt)/w, :]      (sec. 3: nearest-neighbour upsampling to the finer map's size)
-__global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restrict__ top, int ht, int wt, const bf16_t* __restrict__ lat,
-                                                           bf16_t* __restrict__ out, int B, int h, int w, int C8) {
+// (lat and out may be the same buffer -- the neck merges in place -- so neither is __restrict__)
+__global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restrict__ top, int ht, int wt, const bf16_t* lat,
+                                                           bf16_t* out, int B, int h, int w, int C8) {
     const int64_t total = (int64_t)B * h * w * C8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int cv = (int)(i % C8);

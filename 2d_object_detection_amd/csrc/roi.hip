@@ -287,7 +287,9 @@ __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(const bf16_t* __restr
                 int px[2] = {-4, -4};
                 auto flush = [&](const int e) {
                     if (a0[e] != 0.f) atomicAdd(racc + px[e] * CS + cl + e, a0[e]);
-                    if (a1[e] != 0.f) atomicAdd(racc + (px[e] + 1) * CS + cl + e, a1[e]);      // (non-zero only where column px + 1 exists)
+                    // (finite gradients: non-zero only where column px + 1 exists; a NaN / Inf gradient makes 0 * d non-zero on the last
+                    // column, hence the range check -- it must propagate, not write one column past the LDS row)
+                    if (a1[e] != 0.f && px[e] + 1 < Wf) atomicAdd(racc + (px[e] + 1) * CS + cl + e, a1[e]);
                 };
 #pragma unroll
                 for (int u = 0; u < PWMAX; ++u) {

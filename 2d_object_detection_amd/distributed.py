@@ -20,11 +20,23 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None, timeout_s=None):
+def force_collectives():
+    return os.environ.get("FRCNN_FORCE_COLLECTIVES", "0") not in ("", "0")
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def init_from_env(backend=None, timeout_s=None, force=False):
     """Initialise the default process group from torchrun's environment.  Returns (rank, world, local_rank).
     timeout_s: time-out of every collective of the group, barriers included (default: FRCNN_DIST_TIMEOUT_S or 7200).  The
     backend's own default (10 minutes for nccl/RCCL) is shorter than a validation pass of the chief rank can be: the other
-    ranks wait in a barrier for it, and a barrier is a collective under the same watchdog."""
+    ranks wait in a barrier for it, and a barrier is a collective under the same watchdog.
+    force (or FRCNN_FORCE_COLLECTIVES=1): create the group at world 1 as well."""
     import datetime
     if timeout_s is None:
         timeout_s = float(os.environ.get("FRCNN_DIST_TIMEOUT_S", "7200"))
@@ -32,9 +44,13 @@ def init_from_env(backend=None, timeout_s=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # FRCNN_FORCE_COLLECTIVES=1: a process group (and, through GradientSynchronizer, real collectives on the comm stream) at world 1
+    # too -- the one-GPU rehearsal of the RCCL call path: comm stream, ready events and segment graphs interleaved with
+    # dist.all_reduce launches, on the backend a multi-GPU run uses
+    if (world > 1 or force or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port()) if world == 1 else "29500"
         if backend is None:
             # FRCNN_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
             backend = os.environ.get("FRCNN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -52,18 +68,22 @@ class GradientSynchronizer:
     `grad` is the flat fp32 gradient tensor, `buckets` a list of (name, begin, end) in the order the
     buckets become final.  Use `after_segment` as the `sync_fn` of FasterRCNN.train_step."""
 
-    def __init__(self, grad, buckets, group=None):
+    def __init__(self, grad, buckets, group=None, force=None):
+        """force (default: FRCNN_FORCE_COLLECTIVES): issue the all-reduces at world 1 as well (needs an initialised group)."""
         self.grad = grad
         self.buckets = list(buckets)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(force_collectives() if force is None else force) and dist.is_initialized())
         self.on_gpu = grad.is_cuda
-        self.comm_stream = torch.cuda.Stream() if (self.on_gpu and self.world > 1) else None
+        self.comm_stream = torch.cuda.Stream() if (self.on_gpu and self.active) else None
         self.bytes_per_step = sum(e - b for _, b, e in self.buckets) * grad.element_size()
+        self.calls = 0                               # all-reduces issued so far
 
     def reduce_bucket(self, i):
-        if self.world == 1:
+        if not self.active:
             return
+        self.calls += 1
         _, b, e = self.buckets[i]
         view = self.grad[b:e]
         if self.on_gpu:
@@ -76,7 +96,7 @@ class GradientSynchronizer:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
 
     def wait_all(self):
-        if self.world > 1 and self.on_gpu:
+        if self.active and self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def after_segment(self, seg, nseg):

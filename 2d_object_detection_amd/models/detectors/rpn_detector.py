@@ -145,7 +145,7 @@ class RPNDetector:
                 # fp8 data gradient of the 3x3 convolution: e5m2 twin of dz_f (written by a quantise pass behind the ReLU backward),
                 # e4m3 twin of the tap-flipped transposed weights, one scale per row (= per feature-map channel)
                 from ..feature_extractor import Fp8Twin
-                self.dz_f8 = Fp8Twin(f8_scales, (m, 256), dev)
+                self.dz_f8 = Fp8Twin(f8_scales, (m, 256), dev, e5m2=True)
                 self.w_inter_t8 = torch.zeros(cf, self.ws, self.ws, 256, dtype=ops.FP8, device=dev)
                 self.w_inter_t8_scale = torch.ones(cf, dtype=torch.float32, device=dev)
 

@@ -417,6 +417,8 @@ class FasterRCNN:
     def _build_forward(self, mods, batch):
         """Training-mode forward only (reference faster_rcnn.py:39-57 with training=True): BatchNorm on batch statistics (its
         moving averages are updated, as Keras does), RPN on the in-image anchors, proposal NMS, Fast-RCNN heads."""
+        if self.topology == "fpn":
+            return self._build_forward_fpn(mods, batch)
         plan = Plan("call_training")
         io = {"images": mods.fe.setup(batch, True)}
         _, gh, gw, cf = mods.fe.output_shape
@@ -430,6 +432,29 @@ class FasterRCNN:
         nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"])
         rcnn_out = mods.rcnn.forward_plan(plan, feat, nms_rpn["pred_boxes"])
         return {"plan": plan, "io": io, "batch": batch, "aux": {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn, "feature_maps": feat}}
+
+    def _build_forward_fpn(self, mods, batch):
+        """_build_forward on the feature pyramid: backbone (BatchNorm on batch statistics) -> neck -> RPN over P2..P5 on the in-image
+        anchors -> ONE proposal NMS -> per-level RoI pooling -> heads (the forward half of _build_fpn; neck and RPN in bf16)."""
+        plan = Plan("call_training_fpn")
+        fe, neck, rpn, rcnn = mods.fe, mods.neck, mods.rpn, mods.rcnn
+        io = {"images": fe.setup(batch, True)}
+        last = {2: "conv2_block3", 3: "conv3_block4", 4: fe.specs[-1][0]}
+        grids = {l: (fe.units[last[l]][1].ho, fe.units[last[l]][1].wo) for l in FPN_LEVELS}
+        neck.setup(batch, grids, False)
+        rpn.setup(batch, True, f8_scales=None)
+        P = int(self._rpn_config["nms"]["max_total_size"])
+        rcnn.setup(batch, P, False)
+        fe.forward_plan(plan, True)
+        if fe.f8 is not None:
+            fe.f8.plan_update(plan)
+        stage_maps = {l: fe.acts[last[l]]["out"] for l in FPN_LEVELS}
+        pyramid = neck.forward_plan(plan, stage_maps)
+        rpn_out = rpn.forward_plan(plan, pyramid, True)
+        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"])
+        rcnn_out = rcnn.forward_plan(plan, pyramid, nms_rpn["pred_boxes"])
+        return {"plan": plan, "io": io, "batch": batch, "aux": {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn,
+                                                                "feature_maps": fe.feature_maps, "pyramid": pyramid, "roi_levels": rcnn.levels}}
 
     def _feed(self, built, images, gt_labels, gt_boxes):
         io = built["io"]
@@ -469,9 +494,12 @@ class FasterRCNN:
                 state = self._snapshot(optimizer)
                 self._run_with_collectives(built["plan"])
                 torch.cuda.synchronize()
-                self._restore(state, optimizer)
+                self._restore(state, optimizer, fp8_scales=False)
                 built["plan"].capture()
-                self._restore(state, optimizer)
+                self._restore(state, optimizer, fp8_scales=False)
+            if getattr(self, "_pending_fp8_state", None) is not None:          # a checkpoint's scales win over the warm-up run's
+                self.set_fp8_state(self._pending_fp8_state)
+                self._pending_fp8_state = None
         built = self._train_plan
         if self._weights_dirty:
             self._sync_derived_weights(self._train)
@@ -503,9 +531,11 @@ class FasterRCNN:
     def _snapshot(self, optimizer):
         st = self.store
         return {"w": st.w.clone(), "wb": st.wb.clone(), "v": optimizer.velocity.clone(), "it": optimizer.iterations.clone(),
-                "stats": {k: v.clone() for k, v in st.stats.items()}}
+                "stats": {k: v.clone() for k, v in st.stats.items()}, "fp8": self.get_fp8_state()}
 
-    def _restore(self, s, optimizer):
+    def _restore(self, s, optimizer, fp8_scales=True):
+        """fp8_scales=False keeps the delayed-scaling state the steps since the snapshot left behind (the plan builder's warm-up run
+        doubles as the calibration pass: the first real step then quantises with measured scales instead of 1)."""
         st = self.store
         st.w.copy_(s["w"])
         st.wb.copy_(s["wb"])
@@ -513,7 +543,32 @@ class FasterRCNN:
         optimizer.iterations.copy_(s["it"])
         for k, v in s["stats"].items():
             st.stats[k].copy_(v)
+        if fp8_scales and s.get("fp8") is not None:
+            self.set_fp8_state(s["fp8"])
         self._sync_derived_weights(self._train)
+
+    def get_fp8_state(self):
+        """Delayed-scaling state of the fp8 twins ([scale | 1 / scale] per tensor) or None (bf16, or no train plan yet).  Part of a
+        checkpoint: without it a restored model's first step runs on scale 1 (e4m3 activations clamp at 448, e5m2 gradients below
+        ~1.5e-5 flush to zero)."""
+        f8 = self._train.fe.f8 if self._train is not None and getattr(self._train.fe, "f8", None) is not None else None
+        return None if f8 is None else f8.state()
+
+    def set_fp8_state(self, state):
+        f8 = self._train.fe.f8 if self._train is not None and getattr(self._train.fe, "f8", None) is not None else None
+        if f8 is None:
+            self._pending_fp8_state = state          # (applied when the train plan, and with it the scale table, exists)
+        elif state is not None:
+            f8.load_state(state)
+
+    def fp8_status(self):
+        """{"clamped": (tensor, step) pairs whose fp8 twin held clamped values -- the tensor outgrew margin x the previous step's
+        amax --, "nonfinite": non-finite amax events (scale kept)} since the model was built; zeros in bf16."""
+        f8 = self._train.fe.f8 if self._train is not None and getattr(self._train.fe, "f8", None) is not None else None
+        if f8 is None:
+            return {"clamped": 0, "nonfinite": 0}
+        c = f8.status.cpu()
+        return {"clamped": int(c[0]), "nonfinite": int(c[1])}
 
     def test_step(self, images, gt_labels, gt_boxes):
         """reference faster_rcnn.py:119-169 (BN in inference mode, all anchors clipped to the image)."""
@@ -535,7 +590,7 @@ class FasterRCNN:
             b = int(images.shape[0])
             if self._fwd_train is None:
                 self._fwd_train = _Modules(self.config, self.depth, self.store, self.device, False, self.world_size if self.sync_bn else 1,
-                                           self.precision)
+                                           self.precision, topology=self.topology)
             if self._fwd_plan is None or self._fwd_plan["batch"] != b:
                 self._fwd_plan = self._build_forward(self._fwd_train, b)
             built = self._fwd_plan

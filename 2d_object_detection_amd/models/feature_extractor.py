@@ -51,13 +51,26 @@ class Fp8Scales:
     def __init__(self, device, capacity=384):      # (ResNet-101 under the pyramid takes ~250 columns)
         self.buf = torch.zeros(2, capacity, dtype=torch.float32, device=device)             # [scale | 1 / scale]
         self.buf.fill_(1.0)
+        self.limit = torch.full((capacity,), 448.0, dtype=torch.float32, device=device)     # clamp of each twin's format (e4m3 448, e5m2 57344)
+        # [0]: (tensor, step) pairs whose values were clamped (amax beyond limit x the scale they were quantised with: the delayed rule
+        # has one step of history), [1]: non-finite amax (scale kept).  Counters, never reset by a step: FasterRCNN.fp8_status() reads them
+        self.status = torch.zeros(2, dtype=torch.int32, device=device)
         self.amax_buf = torch.zeros(capacity, ops.FP8_AMAX_SLOTS, dtype=torch.float32, device=device)   # slots per tensor (one word would serialise the atomics)
         self.n = 0
 
-    def new(self):
+    def new(self, e5m2=False):
         assert self.n < self.buf.shape[1], "Fp8Scales: more than %d fp8 tensors" % self.buf.shape[1]
         self.n += 1
+        if e5m2:
+            self.limit[self.n - 1] = 57344.0
         return self.n - 1
+
+    def state(self):
+        """the delayed-scaling state (for snapshots / checkpoints: a restored model otherwise runs its first step on scale 1)"""
+        return self.buf.clone()
+
+    def load_state(self, buf):
+        self.buf.copy_(buf.to(self.buf.device))
 
     def amax(self, i):
         return self.amax_buf[i]
@@ -73,14 +86,14 @@ class Fp8Scales:
 
     def plan_update(self, plan):
         if self.n:
-            plan.add(ops.fp8_update_scales, self.amax_buf, self.buf[0], self.buf[1], self.n, FP8_MARGIN)
+            plan.add(ops.fp8_update_scales, self.amax_buf, self.buf[0], self.buf[1], self.n, FP8_MARGIN, self.limit, self.status)
 
 
 class Fp8Twin:
     """fp8 copy of an activation tensor: bytes, its column in the scale table, and the frcnn_fp8_out the producing kernel takes."""
 
-    def __init__(self, scales, shape, device):
-        self.scales, self.idx = scales, scales.new()
+    def __init__(self, scales, shape, device, e5m2=False):
+        self.scales, self.idx = scales, scales.new(e5m2)
         self.data = torch.zeros(shape, dtype=ops.FP8, device=device)
         self.out = ops.fp8_out(self.data, scales.qscale(self.idx), scales.amax(self.idx))
 
@@ -504,7 +517,7 @@ class FeatureExtractor:
             if self.f8 is not None:
                 for k_ in sorted(u):                     # e5m2 twins of the BatchNorm-backward outputs that feed fp8 data / weight gradients
                     if u[k_].fp8_bwd or u[k_].fp8_wgrad:
-                        u[k_].dz8 = Fp8Twin(self.f8, (u[k_].m, u[k_].cout), dev)
+                        u[k_].dz8 = Fp8Twin(self.f8, (u[k_].m, u[k_].cout), dev, e5m2=True)
                 # fp8 twins of the activations that feed fp8 convolutions (forward and weight gradient): a1 -> 3x3, a2 -> 1x1
                 # expansion, out -> the next block / RPN
                 a["a1_8"] = Fp8Twin(self.f8, (m, f), dev) if u[2].fp8 or u[2].fp8_wgrad else None

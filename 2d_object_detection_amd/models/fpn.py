@@ -97,9 +97,9 @@ class _Conv:
             plan.add(ops.conv2d_fprop, d, dz, self.w_t, gx, res=gx if add_to_gx else None)
 
 
-def _twin(scales, like, device):
+def _twin(scales, like, device, e5m2=False):
     from .feature_extractor import Fp8Twin
-    return Fp8Twin(scales, tuple(like.shape), device)
+    return Fp8Twin(scales, tuple(like.shape), device, e5m2=e5m2)
 
 
 def _quantize(plan, twin, src, e5m2=False):
@@ -180,7 +180,7 @@ class FPNNeck:
                 self.gm[l] = torch.empty(batch * h * w, FPN_DIM, dtype=BF16, device=dev)       # gradient w.r.t. the merged map
                 if self.f8 is not None:
                     self.merged8[l] = _twin(self.f8, self.merged[l], dev)
-                    self.gp8[l] = _twin(self.f8, self.gp[l], dev)
+                    self.gp8[l] = _twin(self.f8, self.gp[l], dev, e5m2=True)
         h4, w4 = grids[4]
         self.grids[5] = ((h4 + 1) // 2, (w4 + 1) // 2)
         self.p[5] = torch.empty(batch, self.grids[5][0], self.grids[5][1], FPN_DIM, dtype=BF16, device=dev)
@@ -330,13 +330,13 @@ class RPNDetectorFPN:
             gh, gw = self.grids[l]
             m = batch * gh * gw
             e = {"m": m, "gh": gh, "gw": gw}
-            e["d_inter"] = ops.conv_desc(batch, gh, gw, FPN_DIM, self.ws, self.ws, 1, p, p, gh, gw, 256, flags=ops.CONV_BIAS | ops.CONV_RELU)
-            e["d_heads"] = ops.conv_desc(batch, gh, gw, 256, 1, 1, 1, 0, 0, gh, gw, RPN_LD, flags=ops.CONV_BIAS | ops.CONV_OUT_F32)
+            e["d_inter"] = ops.conv_desc(batch, gh, gw, FPN_DIM, self.ws, self.ws, 1, p, p, gh, gw, 256, flags=ops.CONV_BIAS | ops.CONV_RELU | ops.CONV_WGRAD_ACCUMULATE)
+            e["d_heads"] = ops.conv_desc(batch, gh, gw, 256, 1, 1, 1, 0, 0, gh, gw, RPN_LD, flags=ops.CONV_BIAS | ops.CONV_OUT_F32 | ops.CONV_WGRAD_ACCUMULATE)
             e["f"] = torch.empty(m, 256, dtype=BF16, device=dev)
             e["head"] = torch.empty(m, RPN_LD, device=dev)
             if self.f8 is not None:
                 e["p8"] = _twin(self.f8, torch.empty(m, FPN_DIM, device="meta"), dev)
-                e["dz_f8"] = _twin(self.f8, torch.empty(m, 256, device="meta"), dev)
+                e["dz_f8"] = _twin(self.f8, torch.empty(m, 256, device="meta"), dev, e5m2=True)
             e["ws"] = [ops.conv_attach_workspace(e["d_inter"], dev)]
             if training:
                 e["dhead32"] = torch.zeros(m, RPN_LD, device=dev)

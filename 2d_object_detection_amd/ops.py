@@ -10,7 +10,7 @@ from ctypes import byref, c_float, c_void_p
 import torch
 
 from . import _lib
-from ._lib import (CONV_ADD_RES, CONV_BIAS, CONV_OUT_F32, CONV_RELU, CONV_SPLITK_ATOMIC, CONV_STATS, BnReduce, ConvDesc, Fp8Out, call)
+from ._lib import (CONV_ADD_RES, CONV_BIAS, CONV_OUT_F32, CONV_RELU, CONV_SPLITK_ATOMIC, CONV_STATS, CONV_WGRAD_ACCUMULATE, BnReduce, ConvDesc, Fp8Out, call)
 
 BF16 = torch.bfloat16
 
@@ -152,8 +152,9 @@ def quantize_weights_fp8_batched(table, total_rows):
     call("frcnn_quantize_weights_fp8_batched", _p(table), table.shape[0], total_rows, _stream())
 
 
-def fp8_update_scales(amax, scale, qscale, n, margin=1.0):
-    call("frcnn_fp8_update_scales", _p(amax), _p(scale), _p(qscale), n, float(margin), _stream())
+def fp8_update_scales(amax, scale, qscale, n, margin=1.0, limit=None, status=None):
+    """status (int32 [2], optional): [0] += tensors clamped this step (amax > limit * scale), [1] += non-finite amax (scale kept)"""
+    call("frcnn_fp8_update_scales", _p(amax), _p(scale), _p(qscale), n, float(margin), _p(limit), _p(status), _stream())
 
 
 def fp8_out(out8, qscale, amax=None):

@@ -14,12 +14,21 @@ FasterRCNN.train_step, models/faster_rcnn.py:59-117).  Prints ONE JSON line on r
                         `families`: every kernel family of the step with its time and its TFLOP/s or algorithmic GB/s;
                         `rocprof`: the same quotient from the rocprofv3 summary committed under profiles/ (+ PMC HBM traffic)
   cpu_baseline          the CPU oracle (kind "port") timed on this host: SURVEY 8(d) protocol, see cpu_baseline()
+  other_configs         (default N = 1 run only) BASELINE.json configs[3] and configs[4] timed after the headline's region, 3 windows each,
+                        with their own roofline -- the headline's value / config / roofline do not depend on them
+
+Every step of a window trains on the next of `--resident-batches` (8) synthetic batches resident in HBM (seeds 1234 + rank + 100 i):
+the head cannot memorise one batch, so the density of the RoI-backward gradient stays that of a real run.
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches its own N ranks (a child `python -m torch.distributed.run`,
+started before this process touches the GPU) and relays rank 0's line.
 """
 import argparse
+import copy
 import hashlib
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -153,6 +162,29 @@ def profile_kernels(model, built, steps=3):
             if it > 0:
                 events.append((name, fl, by, e0, e1))
     torch.cuda.synchronize()
+    # RoI backward with a DENSE pooled gradient: the kernel skips zero gradient words, and how many there are depends on what the
+    # head has learnt (a saturated softmax zeroes whole rows) -- the dense time is its data-independent upper bound
+    dense = {}
+    roi_b = [(fn, args, kwargs) for fn, args, kwargs, name, fl, by in records if name.startswith("RoI crop+pool backward")]
+    if roi_b:
+        gp = roi_b[0][1][0]
+        keep = gp.clone()
+        nz_frac = float((keep.view(torch.int16) != 0).float().mean())
+        gp.copy_((torch.randn(gp.shape, device=gp.device) * 1e-3).to(gp.dtype))
+        torch.cuda._sleep(20_000_000)
+        pairs = []
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for fn, args, kwargs in roi_b:
+                fn(*args, **kwargs)
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        gp.copy_(keep)
+        per = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)
+        dense = {"roi_bwd_dense_us": round(max(per[len(per) // 2] - pair_overhead_s * 1e6, 0.0), 1), "roi_bwd_launches": len(roi_b),
+                 "roi_bwd_nonzero_fraction_in_step": round(nz_frac, 4)}
     model._restore(state, built["optimizer"])
     if os.environ.get("FRCNN_LAYER_TABLE"):
         # per-launch table (median over steps) for kernel work: shape, us, TFLOP/s, GB/s of compulsory traffic, kernel
@@ -191,6 +223,9 @@ def profile_kernels(model, built, steps=3):
         for k in f:
             f[k] /= steps
         f["event_pair_overhead_us"] = pair_overhead_s * 1e6
+    for k, f in fam.items():
+        if k.startswith("RoI crop+pool backward"):
+            f.update(dense)
     return fam
 
 
@@ -293,44 +328,49 @@ def offline_profile(family, variant="", workload=None):
     return None, "no committed trace for this run: %s (this tree's kernel sources: %s)" % ("; ".join(stale), mine)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=4)
-    ap.add_argument("--windows", type=int, default=5, help="time the K-step region this many times back to back (the first is `value`)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graphs", action="store_true")
-    ap.add_argument("--no-segmented", action="store_true", help="skip the segmented-replay leg (config.segmented_ms_per_step)")
-    ap.add_argument("--profile-steps", type=int, default=3)
-    ap.add_argument("--lr-scale", type=float, default=0.01)
-    ap.add_argument("--fpn", action="store_true", help="feature-pyramid topology (models/fpn.py): with --fp8 --batch-per-gpu 8 this is BASELINE.json configs[4]")
-    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) MFMA conv path where a layer supports it (BASELINE.json configs[4]'s precision)")
-    ap.add_argument("--depth", type=int, default=50, help="ResNet depth (101 with --proposals 1000 --batch-per-gpu 2 = BASELINE.json configs[3])")
-    ap.add_argument("--proposals", type=int, default=0, help="RPN NMS max_total_size / max_output_size_per_class (0: config.json's 300)")
-    args = ap.parse_args()
-    if args.fpn:
-        global RPN_HEAD_ROWS
-        RPN_HEAD_ROWS = 18
+BASE_SPEC = {"depth": 50, "batch": 4, "proposals": 0, "fp8": False, "fpn": False}
+OTHER_CONFIGS = {
+    "configs[3]": {"depth": 101, "batch": 2, "proposals": 1000, "fp8": False, "fpn": False},
+    "configs[4]": {"depth": 50, "batch": 8, "proposals": 0, "fp8": True, "fpn": True},
+}
 
+
+def workload_text(spec, world):
+    depth, B, P, fp8, fpn = spec["depth"], spec["batch"], spec["proposals"] or 300, spec["fp8"], spec["fpn"]
+    if fp8:
+        return ("ResNet-%d%s Faster-RCNN full train step, fp8: e4m3 weights (per output channel) and activations (per tensor, delayed "
+                "scaling), e5m2 gradients, in the forward convolutions, data gradients and weight gradients of the backbone wherever the channel counts allow (K >= 256 for forward / data gradients)%s on "
+                "the f8f6f4 MFMA path; bf16 storage and remaining layers; batch %d per GPU, 375x1242 synthetic KITTI, "
+                "%d proposals, 7 classes (BASELINE.json configs[4]%s)" % (
+                    depth, "-FPN (pyramid over C2..C4, RPN on P2..P5, per-level RoI heads)" if fpn else "(C4)",
+                    "" if fpn else " and of the RPN's 3x3", B, P,
+                    ("" if B == 8 else ": its topology and precision at another batch") if fpn else
+                    "'s precision%s; C4 backbone, no FPN" % (" and batch" if B == 8 else "")))
+    if fpn:
+        return ("ResNet-%d-FPN Faster-RCNN full train step, bf16, batch %d per GPU, 375x1242 synthetic KITTI, %d proposals, 7 classes "
+                "(BASELINE.json configs[4]'s topology in bf16)" % (depth, B, P))
+    return ("ResNet-%d(C4) Faster-RCNN full train step, bf16, batch %d per GPU, 375x1242 synthetic KITTI, "
+            "%d proposals, 7 classes (BASELINE.json configs[%d])" % (depth, B, P, 3 if depth == 101 else 1 if world == 1 else 2))
+
+
+def measure(spec, args, rank, world, dev, windows, with_segmented, with_rccl_leg):
+    """Build the model of `spec`, warm up, time `windows` regions of exactly args.steps steps (barrier + synchronize on both sides, MAX
+    over ranks) and -- on rank 0 -- attach the per-family kernel profile.  Returns the result dict (the headline's shape)."""
+    global RPN_HEAD_ROWS
+    RPN_HEAD_ROWS = 18 if spec["fpn"] else 72
     D = importlib.import_module("2d_object_detection_amd.distributed")
     M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
     OPT = importlib.import_module("2d_object_detection_amd.optimizers")
     C = importlib.import_module("2d_object_detection_amd.config")
+    DATA = importlib.import_module("2d_object_detection_amd.data")
     import torch.distributed as dist
 
-    rank, world, local_rank = D.init_from_env()
-    assert world == args.gpus, "launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
-    local_rank = int(os.environ.get("FRCNN_BENCH_DEVICE", local_rank))      # (rehearsals: several ranks on one GPU)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     cfg = C.default_config()                                   # 375 x 1242, 7 classes, reference hyper-parameters
-    if args.proposals:
-        cfg["rpn"]["nms"]["max_total_size"] = cfg["rpn"]["nms"]["max_output_size_per_class"] = args.proposals
-    B = args.batch_per_gpu
-    model = M.FasterRCNN(cfg, depth=args.depth, device=dev, seed=0, sampling_seed=rank, world_size=world,     # (per-rank fg/bg sample positions)
-                         precision="fp8" if args.fp8 else "bf16", topology="fpn" if args.fpn else "c4")
+    if spec["proposals"]:
+        cfg["rpn"]["nms"]["max_total_size"] = cfg["rpn"]["nms"]["max_output_size_per_class"] = spec["proposals"]
+    B = spec["batch"]
+    model = M.FasterRCNN(cfg, depth=spec["depth"], device=dev, seed=0, sampling_seed=rank, world_size=world,     # (per-rank fg/bg sample positions)
+                         precision="fp8" if spec["fp8"] else "bf16", topology="fpn" if spec["fpn"] else "c4")
     model.use_graphs = not args.no_graphs
     # Reference schedule shape (train_faster_rcnn.py:62-68: boundaries 40k/80k), scaled by --lr-scale: the reference's
     # 1e-3 presumes ImageNet-pretrained weights; with the seeded random init used here (no network) and the un-normalised
@@ -338,14 +378,12 @@ def main():
     sc = args.lr_scale
     opt = OPT.SGD(learning_rate=OPT.PiecewiseConstantDecay([40000, 80000], [1e-3 * sc, 1e-4 * sc, 1e-5 * sc]), momentum=0.9)
 
-    # synthetic KITTI-like batch, resident in HBM, per-rank seed
-    DATA = importlib.import_module("2d_object_detection_amd.data")
-    images, gl, gb = DATA.synthetic_batch(B, cfg["image_shape"], seed=1234 + rank, device=dev)
+    # synthetic KITTI-like batches, resident in HBM, per-rank seeds; step s of a region trains on batch s mod NB
+    NB = max(1, args.resident_batches)
+    batches = [DATA.synthetic_batch(B, cfg["image_shape"], seed=1234 + rank + 100 * i, device=dev) for i in range(NB)]
 
-    sync = None
-    if world > 1:
-        sync = D.GradientSynchronizer(model.store.g, model.store.buckets)
-    hook = sync.after_segment if sync is not None else None
+    sync = D.GradientSynchronizer(model.store.g, model.store.buckets) if world > 1 else None
+    hook = [sync.after_segment if sync is not None else None]
 
     def barrier():
         if world > 1:
@@ -355,8 +393,8 @@ def main():
     def timed_window():
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = model.train_step(images, gl, gb, opt, sync_fn=hook)     # (`hook` is read at call time: the segmented leg swaps it)
+        for s in range(args.steps):
+            out = model.train_step(*batches[s % NB], opt, sync_fn=hook[0])     # (`hook` is read at call time: the extra legs swap it)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -365,10 +403,10 @@ def main():
             dt = float(tmax.item())
         return dt, out
 
-    for _ in range(args.warmup):
-        losses, preds = model.train_step(images, gl, gb, opt, sync_fn=hook)
-    # every timed window starts from the SAME weights, momentum, moving statistics and step counter (the state after the warm-up):
-    # window 5 times what window 1 timed, and the synthetic run cannot drift towards non-finite boxes while it is being measured
+    for s in range(args.warmup):
+        losses, preds = model.train_step(*batches[s % NB], opt, sync_fn=hook[0])
+    # every timed window starts from the SAME weights, momentum, moving statistics, fp8 scales and step counter (the state after the
+    # warm-up): window 5 times what window 1 timed, and the synthetic run cannot drift towards non-finite boxes while it is measured
     barrier()
     state0 = model._snapshot(opt)
 
@@ -379,7 +417,7 @@ def main():
     dt, (losses, preds) = window()                             # the contract's region: EXACTLY K steps, barrier + synchronize both sides
     loss_vals = {k: float(v) for k, v in losses.items()}
     window_ms = [dt / args.steps * 1e3]
-    for _ in range(max(0, args.windows - 1)):                  # more evidence than one 0.1 s region: the same region again
+    for _ in range(max(0, windows - 1)):                       # more evidence than one 0.1 s region: the same region again
         window_ms.append(window()[0] / args.steps * 1e3)
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt
@@ -387,109 +425,214 @@ def main():
     # what data parallelism costs before any byte moves: the same step as its backward-segment graphs with a (no-op) hook between
     # them -- the form every rank runs when a GradientSynchronizer interleaves bucket all-reduces -- against the one-graph replay
     segmented_ms = None
-    if world == 1 and model.use_graphs and not args.no_segmented:
+    if world == 1 and model.use_graphs and with_segmented:
         hook_calls = []
-        keep_hook, hook = hook, (lambda i, n: hook_calls.append(i))
+        keep_hook, hook[0] = hook[0], (lambda i, n: hook_calls.append(i))
         try:
             segmented_ms = sorted(window()[0] / args.steps * 1e3 for _ in range(3))[1]
         finally:
-            hook = keep_hook
+            hook[0] = keep_hook
         assert len(hook_calls) >= 3 * args.steps, "the segmented run did not call the hook"
+    # ... and with the collectives really issued: a world-1 process group on the backend a multi-GPU run uses (nccl = RCCL), one
+    # dist.all_reduce per gradient bucket on the comm stream between the segment replays, the update segment waiting for them
+    rccl = None
+    if world == 1 and model.use_graphs and with_rccl_leg:
+        try:
+            D.init_from_env(force=True)
+            fs = D.GradientSynchronizer(model.store.g, model.store.buckets, force=True)
+            keep_hook, hook[0] = hook[0], fs.after_segment
+            try:
+                leg = sorted(window()[0] / args.steps * 1e3 for _ in range(3))[1]
+            finally:
+                hook[0] = keep_hook
+            rccl = {"ms_per_step": round(leg, 4), "all_reduces_per_step": fs.calls / (3.0 * args.steps), "backend": dist.get_backend(),
+                    "bytes_per_step": fs.bytes_per_step,
+                    "note": "world 1: the call path (comm stream, ready events, segment graphs) runs; a one-rank all-reduce moves no bytes over xGMI"}
+        except Exception as e:                                 # (never fail the headline on the rehearsal leg)
+            rccl = {"error": "%s: %s" % (type(e).__name__, e)}
 
     out = {
         "metric": METRIC, "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16",
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if spec["fp8"] else "bf16",
         "data": "synthetic",
-        "config": {"workload": ("ResNet-%d%s Faster-RCNN full train step, fp8: e4m3 weights (per output channel) and activations (per tensor, delayed "
-                                "scaling), e5m2 gradients, in the forward convolutions, data gradients and weight gradients of the backbone wherever the channel counts allow (K >= 256 for forward / data gradients)%s on "
-                                "the f8f6f4 MFMA path; bf16 storage and remaining layers; batch %d per GPU, 375x1242 synthetic KITTI, "
-                                "%d proposals, 7 classes (BASELINE.json configs[4]%s)" % (
-                                    args.depth, "-FPN (pyramid over C2..C4, RPN on P2..P5, per-level RoI heads)" if args.fpn else "(C4)",
-                                    "" if args.fpn else " and of the RPN's 3x3", B, args.proposals or 300,
-                                    ("" if B == 8 else ": its topology and precision at another batch") if args.fpn else
-                                    "'s precision%s; C4 backbone, no FPN" % (" and batch" if B == 8 else ""))) if args.fp8 else
-                               ("ResNet-%d-FPN Faster-RCNN full train step, bf16, batch %d per GPU, 375x1242 synthetic KITTI, %d proposals, 7 classes "
-                                "(BASELINE.json configs[4]'s topology in bf16)" % (args.depth, B, args.proposals or 300)) if args.fpn else
-                               "ResNet-%d(C4) Faster-RCNN full train step, bf16, batch %d per GPU, 375x1242 synthetic KITTI, "
-                               "%d proposals, 7 classes (BASELINE.json configs[%d])" % (
-                                   args.depth, B, args.proposals or 300, 3 if args.depth == 101 else 1 if world == 1 else 2),
+        "config": {"workload": workload_text(spec, world),
                    "global_batch": world * B, "image_shape": cfg["image_shape"], "parallelism": "dp%d" % world,
                    "hip_graphs": model.use_graphs, "kernel_launches_per_step": model._train_plan["plan"].num_launches,
+                   "resident_batches": NB,
                    "segmented_ms_per_step": None if segmented_ms is None else round(segmented_ms, 4),
+                   "forced_collectives_world1": rccl,
                    "segments": len(model._train_plan["plan"].segments)},
         "windows": {"steps_each": args.steps, "ms_per_step": [round(x, 4) for x in window_ms], "min": round(srt[0], 4),
                     "median": round(srt[len(srt) // 2], 4), "max": round(srt[-1], 4),
                     "images_per_s_median": round(world * B / (srt[len(srt) // 2] * 1e-3), 2)},
         "final_losses": loss_vals,
     }
+    if spec["fp8"]:
+        out["config"]["fp8_status"] = model.fp8_status()
     if rank == 0:
         fam = profile_kernels(model, model._train_plan, args.profile_steps) if args.profile_steps > 0 else {}
         if fam:
-            # the headline kernel family: the bf16 MFMA convolutions; with --fp8 the fp8 forward convolutions (priced against the fp8 peak)
-            dom = FAM_CONV_F8 if (args.fp8 and FAM_CONV_F8 in fam) else FAM_CONV if FAM_CONV in fam else max(fam, key=lambda k: fam[k]["seconds"])
-            f = fam[dom]
-            peak = PEAK_FP8_TFLOPS if dom == FAM_CONV_F8 else PEAK_BF16_TFLOPS
-            gflop_per_launch = f["flops"] / f["launches"] / 1e9
-            # HEADLINE = the figure a reader can reproduce from profiles/: algorithmic FLOP per launch (counted live from this run's
-            # plan) / the family's average launch duration in the committed rocprofv3 kernel trace of this same command -- valid only
-            # while the kernel sources are the ones that trace was taken from.  The live HIP-event timing of the same launches is
-            # reported beside it (`events`): raw pairs over-state a launch by the cost of the pair itself, pairs minus the calibrated
-            # empty-pair cost under-state it; when the committed trace is stale the RAW (conservative) event figure is the headline.
-            variant = ("_fp8" if args.fp8 else "") + ("_fpn" if args.fpn else "")
-            wkey = workload_key(args.depth, B, args.proposals, args.fp8, args.fpn)
-            off, source = offline_profile(dom, variant, wkey)
-            ev_raw_us = (f["seconds"] + f["launches"] * f["event_pair_overhead_us"] * 1e-6) / f["launches"] * 1e6
-            ev_net_us = f["seconds"] / f["launches"] * 1e6
-            if off and off.get("avg_launch_us"):
-                head_us, head_src = float(off["avg_launch_us"]), "rocprofv3 kernel trace, " + source
-            else:
-                head_us, head_src = ev_raw_us, "live HIP events, raw pairs (%s)" % source
-            achieved = gflop_per_launch / head_us * 1e3       # GFLOP / us = PFLOP/s
-            off_all = {}
-            for k in fam:
-                off_all[k] = offline_profile(k, variant, wkey)[0]
-            families = {}
-            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["seconds"]):
-                o = off_all.get(k)
-                # durations: the committed trace where it is current (same source as the headline), else raw event pairs
-                sec = o["ms_per_step"] * 1e-3 if (o and o.get("ms_per_step")) else v["seconds"] + v["launches"] * v["event_pair_overhead_us"] * 1e-6
-                e = {"launches_per_step": v["launches"], "ms_per_step": round(sec * 1e3, 4), "timing": "rocprof" if (o and o.get("ms_per_step")) else "events_raw",
-                     "events_net_ms_per_step": round(v["seconds"] * 1e3, 4)}
-                if v["flops"] > 0:
-                    e["tflops"] = round(v["flops"] / sec / 1e12, 2)
-                    e["frac_of_mfma_peak"] = round(v["flops"] / sec / 1e12 / (PEAK_FP8_TFLOPS if k == FAM_CONV_F8 else PEAK_BF16_TFLOPS), 4)
-                elif v["bytes"] > 0 and sec > 0:
-                    e["algorithmic_MB_per_step"] = round(v["bytes"] / 1e6, 2)
-                    e["algorithmic_GBs"] = round(v["bytes"] / sec / 1e9, 1)
-                    e["frac_of_hbm_peak"] = round(v["bytes"] / sec / 1e9 / PEAK_HBM_GBS, 4)
-                if o and o.get("hbm_bytes_per_launch"):
-                    e["hbm_MB_per_step_pmc"] = round((o.get("hbm_read_bytes_per_step", 0) + o.get("hbm_write_bytes_per_step", 0)) / 1e6, 1)
-                families[k] = e
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
-                               "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
-                               "traffic": None if not off else off.get("hbm_bytes_per_launch"),
-                               "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
-                               "source": head_src,
-                               "launches_per_step": f["launches"], "avg_launch_us": round(head_us, 2),
-                               "algorithmic_gflop_per_launch": round(gflop_per_launch, 4),
-                               "events": {"avg_launch_us_raw": round(ev_raw_us, 2), "avg_launch_us_minus_empty_pair": round(ev_net_us, 2),
-                                          "empty_pair_us": round(f["event_pair_overhead_us"], 2),
-                                          "frac_raw": round(gflop_per_launch / ev_raw_us * 1e3 / peak, 5),
-                                          "frac_minus_empty_pair": round(gflop_per_launch / ev_net_us * 1e3 / peak, 5)},
-                               "whole_step_tflops": round(sum(v["flops"] for v in fam.values()) / (ms * 1e-3) / 1e12, 1),
-                               "families": families}
+            attach_roofline(out, fam, spec, ms)
+    out["_cfg"] = cfg
+    del model, opt, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def attach_roofline(out, fam, spec, ms):
+    # the headline kernel family: the bf16 MFMA convolutions; with fp8 the fp8 convolutions (priced against the fp8 peak)
+    dom = FAM_CONV_F8 if (spec["fp8"] and FAM_CONV_F8 in fam) else FAM_CONV if FAM_CONV in fam else max(fam, key=lambda k: fam[k]["seconds"])
+    f = fam[dom]
+    peak = PEAK_FP8_TFLOPS if dom == FAM_CONV_F8 else PEAK_BF16_TFLOPS
+    gflop_per_launch = f["flops"] / f["launches"] / 1e9
+    # HEADLINE = the figure a reader can reproduce from profiles/: algorithmic FLOP per launch (counted live from this run's
+    # plan) / the family's average launch duration in the committed rocprofv3 kernel trace of this same command -- valid only
+    # while the kernel sources are the ones that trace was taken from.  The live HIP-event timing of the same launches is
+    # reported beside it (`events`): raw pairs over-state a launch by the cost of the pair itself, pairs minus the calibrated
+    # empty-pair cost under-state it; when the committed trace is stale the RAW (conservative) event figure is the headline.
+    variant = ("_fp8" if spec["fp8"] else "") + ("_fpn" if spec["fpn"] else "") + ("_r101" if spec["depth"] == 101 else "")
+    wkey = workload_key(spec["depth"], spec["batch"], spec["proposals"], spec["fp8"], spec["fpn"])
+    off, source = offline_profile(dom, variant, wkey)
+    ev_raw_us = (f["seconds"] + f["launches"] * f["event_pair_overhead_us"] * 1e-6) / f["launches"] * 1e6
+    ev_net_us = f["seconds"] / f["launches"] * 1e6
+    if off and off.get("avg_launch_us"):
+        head_us, head_src = float(off["avg_launch_us"]), "rocprofv3 kernel trace, " + source
+    else:
+        head_us, head_src = ev_raw_us, "live HIP events, raw pairs (%s)" % source
+    achieved = gflop_per_launch / head_us * 1e3       # GFLOP / us = PFLOP/s
+    off_all = {}
+    for k in fam:
+        off_all[k] = offline_profile(k, variant, wkey)[0]
+    families = {}
+    for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["seconds"]):
+        o = off_all.get(k)
+        # durations: the committed trace where it is current (same source as the headline), else raw event pairs
+        sec = o["ms_per_step"] * 1e-3 if (o and o.get("ms_per_step")) else v["seconds"] + v["launches"] * v["event_pair_overhead_us"] * 1e-6
+        e = {"launches_per_step": v["launches"], "ms_per_step": round(sec * 1e3, 4), "timing": "rocprof" if (o and o.get("ms_per_step")) else "events_raw",
+             "events_net_ms_per_step": round(v["seconds"] * 1e3, 4)}
+        if v["flops"] > 0:
+            e["tflops"] = round(v["flops"] / sec / 1e12, 2)
+            e["frac_of_mfma_peak"] = round(v["flops"] / sec / 1e12 / (PEAK_FP8_TFLOPS if k == FAM_CONV_F8 else PEAK_BF16_TFLOPS), 4)
+        elif v["bytes"] > 0 and sec > 0:
+            e["algorithmic_MB_per_step"] = round(v["bytes"] / 1e6, 2)
+            e["algorithmic_GBs"] = round(v["bytes"] / sec / 1e9, 1)
+            e["frac_of_hbm_peak"] = round(v["bytes"] / sec / 1e9 / PEAK_HBM_GBS, 4)
+        if o and o.get("hbm_bytes_per_launch"):
+            e["hbm_MB_per_step_pmc"] = round((o.get("hbm_read_bytes_per_step", 0) + o.get("hbm_write_bytes_per_step", 0)) / 1e6, 1)
+        for extra in ("roi_bwd_dense_us", "roi_bwd_launches", "roi_bwd_nonzero_fraction_in_step"):
+            if extra in v:
+                e[extra] = v[extra]
+        families[k] = e
+    out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
+                       "unit": "TFLOP/s", "frac": round(achieved / peak, 5),
+                       "traffic": None if not off else off.get("hbm_bytes_per_launch"),
+                       "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                       "source": head_src,
+                       "launches_per_step": f["launches"], "avg_launch_us": round(head_us, 2),
+                       "algorithmic_gflop_per_launch": round(gflop_per_launch, 4),
+                       "events": {"avg_launch_us_raw": round(ev_raw_us, 2), "avg_launch_us_minus_empty_pair": round(ev_net_us, 2),
+                                  "empty_pair_us": round(f["event_pair_overhead_us"], 2),
+                                  "frac_raw": round(gflop_per_launch / ev_raw_us * 1e3 / peak, 5),
+                                  "frac_minus_empty_pair": round(gflop_per_launch / ev_net_us * 1e3 / peak, 5)},
+                       "whole_step_tflops": round(sum(v["flops"] for v in fam.values()) / (ms * 1e-3) / 1e12, 1),
+                       "families": families}
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD launcher (this process has not touched the GPU and
+    never will), relay rank 0's JSON line and exit with the children's status."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 or line is not None else 4
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=4)
+    ap.add_argument("--windows", type=int, default=5, help="time the K-step region this many times back to back (the first is `value`)")
+    ap.add_argument("--resident-batches", type=int, default=8, help="synthetic batches resident in HBM that the steps of a region rotate through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-segmented", action="store_true", help="skip the segmented-replay and forced-collectives legs (config.segmented_ms_per_step, config.forced_collectives_world1)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE.json configs[3] / configs[4] after the headline (other_configs)")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--lr-scale", type=float, default=0.01)
+    ap.add_argument("--fpn", action="store_true", help="feature-pyramid topology (models/fpn.py): with --fp8 --batch-per-gpu 8 this is BASELINE.json configs[4]")
+    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) MFMA conv path where a layer supports it (BASELINE.json configs[4]'s precision)")
+    ap.add_argument("--depth", type=int, default=50, help="ResNet depth (101 with --proposals 1000 --batch-per-gpu 2 = BASELINE.json configs[3])")
+    ap.add_argument("--proposals", type=int, default=0, help="RPN NMS max_total_size / max_output_size_per_class (0: config.json's 300)")
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, argv)
+
+    D = importlib.import_module("2d_object_detection_amd.distributed")
+    import torch.distributed as dist
+
+    rank, world, local_rank = D.init_from_env()
+    assert world == args.gpus, "launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    local_rank = int(os.environ.get("FRCNN_BENCH_DEVICE", local_rank))      # (rehearsals: several ranks on one GPU)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    spec = {"depth": args.depth, "batch": args.batch_per_gpu, "proposals": args.proposals, "fp8": args.fp8, "fpn": args.fpn}
+    is_headline = spec == BASE_SPEC
+    out = measure(spec, args, rank, world, dev, args.windows, not args.no_segmented, not args.no_segmented)
+    cfg = out.pop("_cfg")
+    loss_vals = out["final_losses"]
+    if rank == 0 and world == 1 and is_headline and not args.no_other_configs:
+        # the other single-GPU configurations of BASELINE.json, AFTER the headline's timed region: their images/s and roofline get
+        # a record from the same run.  3 windows each; a failure here is reported, it does not touch the headline.
+        others = {}
+        for name, ospec in OTHER_CONFIGS.items():
+            try:
+                sub = copy.copy(args)
+                o = measure(ospec, sub, rank, world, dev, 3, False, False)
+                o.pop("_cfg")
+                keep = {k: o[k] for k in ("value", "unit", "ms_per_step", "dtype", "windows", "final_losses") if k in o}
+                keep["workload"] = o["config"]["workload"]
+                keep["kernel_launches_per_step"] = o["config"]["kernel_launches_per_step"]
+                if "fp8_status" in o["config"]:
+                    keep["fp8_status"] = o["config"]["fp8_status"]
+                if "roofline" in o:
+                    keep["roofline"] = o["roofline"]
+                others[name] = keep
+            except Exception as e:
+                others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["other_configs"] = others
+    if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         bad = [k for k, v in loss_vals.items() if not (v == v and abs(v) != float("inf"))]
         if bad:
             out["error"] = "non-finite losses after the timed window: %s -- the timed workload is degenerate, the number is void" % bad
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
     if not all(v == v and abs(v) != float("inf") for v in loss_vals.values()):
-        sys.exit(3)
+        return 3
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

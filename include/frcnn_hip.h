@@ -33,10 +33,11 @@ typedef uint8_t frcnn_fp8;     /* OCP e4m3fn (gfx950's fp8: 4 exponent bits, bia
 #define FRCNN_ELAUNCH (-2)     /* kernel launch failed */
 
 /* Version of this header's structs and signatures.  Bumped whenever a struct grows or a signature changes (2: frcnn_conv_desc
- * gained workspace / workspace_bytes, frcnn_bn_bwd_apply_fused gained count / param_grad_scale; 3: the fp8 entry points).  A
+ * gained workspace / workspace_bytes, frcnn_bn_bwd_apply_fused gained count / param_grad_scale; 3: the fp8 entry points; 5: frcnn_fp8_update_scales gained limit / status,
+ * FRCNN_CONV_WGRAD_ACCUMULATE).  A
  * binding must compare frcnn_abi_version() with the FRCNN_ABI_VERSION it was written against and refuse any other library:
  * an older build would read the descriptor past the caller's struct. */
-#define FRCNN_ABI_VERSION 4
+#define FRCNN_ABI_VERSION 5
 int frcnn_abi_version(void);
 const char* frcnn_last_error(void);
 
@@ -63,6 +64,10 @@ const char* frcnn_last_error(void);
                                      (f64: the arrival order of the atomics does not show in the statistics) */
 #define FRCNN_STAT_SLOTS      16
 #define FRCNN_CONV_SPLITK_ATOMIC 32 /* y (fp32, pre-zeroed) accumulated with atomics over split_k K-slices */
+#define FRCNN_CONV_WGRAD_ACCUMULATE 64 /* frcnn_conv2d_wgrad / _wgrad_fp8 only (the forward entry points ignore it): dw is shared with
+                                     other launches (e.g. the RPN weights over the levels of a feature pyramid), so this launch must ADD
+                                     with float atomics even when it has a single pixel split -- without the flag a one-split launch
+                                     stores plainly on the assumption that it is the only writer of a zeroed dw */
 typedef struct {
     int n, hi, wi, in_pix_stride, cin;
     int kh, kw, stride, pad_h, pad_w;
@@ -155,8 +160,14 @@ int frcnn_quantize_fp8(const frcnn_bf16* x, int64_t n, const float* qscale, frcn
  * w8 = e4m3_rne(w * (1 / scale)), all in fp32.  Serves the forward weights [cout][kh*kw*cin] and, given transposed masters, any other row layout. */
 int frcnn_quantize_weights_fp8_batched(const int64_t* table, int n, int64_t total_rows, frcnn_stream_t stream);
 /* Delayed scaling (one amax of history): for i < n: a = max over amax[i][0..FRCNN_FP8_AMAX_SLOTS) (this step's maximum); if a > 0:
- * scale[i] = margin * a / 448, qscale[i] = 1 / scale[i]; a == 0 (tensor not produced this step) leaves both unchanged. */
-int frcnn_fp8_update_scales(const float* amax, float* scale, float* qscale, int n, float margin, frcnn_stream_t stream);
+ * scale[i] = margin * a / 448, qscale[i] = 1 / scale[i]; a == 0 (tensor not produced this step) leaves both unchanged.
+ * The rule has one step of history, so a step whose tensor outgrows margin x last step's amax CLAMPS silently in the quantiser; this
+ * entry point is where that becomes visible: limit (optional, device float [n]: the clamp of tensor i's format, 448 for e4m3, 57344
+ * for e5m2; NULL = 448 everywhere) and status (optional, device int32 [2], never reset here): status[0] += 1 for every tensor
+ * whose amax of THIS step exceeded limit[i] * scale[i] (its twin held clamped values); status[1] += 1 for every tensor whose amax is
+ * Inf / NaN -- such a tensor keeps its previous scale (scale = Inf would turn every later dequantisation into 0 * Inf = NaN). */
+int frcnn_fp8_update_scales(const float* amax, float* scale, float* qscale, int n, float margin, const float* limit, int32_t* status,
+                            frcnn_stream_t stream);
 /* Optional fp8 twin of a BatchNorm kernel's output (frcnn_bn_train_apply / _dual): the kernel that writes the bf16 activation also
  * writes out8 = e4m3(clamp(bf16 value * qscale[0])) and folds max|value| into the amax slots -- the next convolution reads 1 byte per
  * element instead of 2 and no separate quantise pass exists. */

@@ -255,6 +255,35 @@ def test_conv_wgrad(ops, case):
     _close(dw, ref, 2e-4, 2e-3 * m ** 0.5, "wgrad")
 
 
+@pytest.mark.parametrize("k", [1, 3])
+def test_conv_wgrad_shared_dw_accumulates_over_launches(ops, k):
+    """The RPN weights of the feature-pyramid plan collect their gradient over four launches (P2..P5) into ONE dw
+    (models/fpn.py backward_params_plan).  A level with M <= 64 pixels (P5 of a 256 x 256 image at batch 1: 8 x 8) has a single
+    pixel split; without FRCNN_CONV_WGRAD_ACCUMULATE such a launch stores plainly and wipes the other levels' sums."""
+    g = torch.Generator().manual_seed(55)
+    cin, cout = (256, 128) if k == 1 else (256, 256)
+    levels = [dict(n=1, h=32, w=32), dict(n=1, h=16, w=16), dict(n=1, h=8, w=8)]      # the last one: M = 64, one split
+    dw = torch.zeros(cout, k, k, cin, device="cuda")
+    ref = torch.zeros(cout, k, k, cin)
+    m_tot = 0
+    for lv in levels:
+        case = dict(lv, cin=cin, cout=cout, k=k, s=1, p=k // 2)
+        x, dz, r, m = _wgrad_problem(case, g)
+        d = conv_desc(ops, case, flags=ops.CONV_WGRAD_ACCUMULATE)
+        ops.conv2d_wgrad(d, x, dz, dw)
+        ref += r
+        m_tot += m
+    assert ops.last_conv_instantiation().endswith("split=1"), ops.last_conv_instantiation()      # the 8 x 8 level: the path under test
+    torch.cuda.synchronize()
+    _close(dw, ref, 2e-4, 2e-3 * m_tot ** 0.5, "wgrad shared over launches")
+    # and the contract of the unflagged form: a one-split launch REPLACES (single writer of a zeroed dw)
+    case = dict(levels[-1], cin=cin, cout=cout, k=k, s=1, p=k // 2)
+    x, dz, r, m = _wgrad_problem(case, g)
+    ops.conv2d_wgrad(conv_desc(ops, case), x, dz, dw)
+    torch.cuda.synchronize()
+    _close(dw, r, 2e-4, 2e-3 * m ** 0.5, "wgrad plain store")
+
+
 @pytest.mark.parametrize("grp", WGRAD_GROUPS, ids=[c["id"] for c in WGRAD_GROUPS])
 def test_conv_wgrad_grouped(ops, grp):
     """Several layers (3x3, strided 1x1, plain 1x1 -- both addressing modes) in one grouped launch with a common pixel split."""

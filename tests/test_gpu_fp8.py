@@ -279,6 +279,22 @@ def test_conv_wgrad_fp8_vs_fp32_on_dequantised_operands(ops, case):
     _close(dw, ref, 2e-4, 2e-4 * float(ref.abs().max()) + 1e-12, "fp8 wgrad")
 
 
+def test_conv_wgrad_fp8_shared_dw_accumulates_over_launches(ops):
+    """fp8 twin of test_conv_wgrad_shared_dw_accumulates_over_launches: a level of <= 128 pixels is one 128-pixel slice, hence one
+    split; with FRCNN_CONV_WGRAD_ACCUMULATE it must add to what the larger levels left in dw (integers: exact)."""
+    g = torch.Generator().manual_seed(56)
+    cin, cout, k = 256, 256, 3
+    dw = torch.zeros(cout, k, k, cin, device="cuda")
+    ref = torch.zeros(cout, k, k, cin)
+    for lv in (dict(n=1, h=32, w=32), dict(n=1, h=16, w=16), dict(n=1, h=8, w=8), dict(n=2, h=8, w=8)):
+        case = dict(lv, cin=cin, cout=cout, k=k, s=1, p=1)
+        x8, z8, xs, zs, r, m = _wgrad_fp8_problem(case, g, integers=True)
+        ops.conv2d_wgrad_fp8(conv_desc(ops, case, flags=ops.CONV_WGRAD_ACCUMULATE), x8, z8, xs, zs, dw)
+        ref += r
+    torch.cuda.synchronize()
+    assert torch.equal(dw.cpu(), ref), "fp8 wgrad shared over launches: max err %g" % float((dw.cpu() - ref).abs().max())
+
+
 @pytest.mark.parametrize("grp", WGRAD_GROUPS_FP8, ids=[c["id"] for c in WGRAD_GROUPS_FP8])
 def test_conv_wgrad_grouped_with_fp8_layers(ops, grp):
     """bf16 and fp8 layers in one group table: one launch per (precision, addressing mode) that has layers."""
@@ -493,10 +509,12 @@ def test_fp8_backbone_deviation_from_bf16():
     assert bool((sc != 1.0).all()) and bool(torch.isfinite(sc).all()) and bool((sc > 0).all()), "delayed scaling did not calibrate every tensor"
     # e4m3 / e5m2 operands: 2^-4 / 2^-3 relative per element, averaged down by the contractions; ReLU masks flip under the forward
     # difference, which is what the gradient deviation mostly is
-    assert rel(f8["feat"], ref["feat"]) < 0.12
-    # measured: feature maps 0.105; gradients with the forward pass alone in fp8 (FRCNN_FP8_BWD=0) vs forward + backward: see DESIGN.md 5
-    assert rel(f8["gin"], ref["gin"]) < 0.9
-    assert min(cosines.values()) > 0.7, cosines
+    # gates = 1.3x what MI355X measures (rounds 3 and 4: feature maps 0.105, block-input gradient rel L2 0.62, bucket cosines 0.80 .. 0.84;
+    # gradients with the forward pass alone in fp8 (FRCNN_FP8_BWD=0) vs forward + backward: DESIGN.md 5)
+    assert rel(f8["feat"], ref["feat"]) < 0.13
+    assert rel(f8["gin"], ref["gin"]) < 0.8 and cos(f8["gin"], ref["gin"]) > 0.75, (rel(f8["gin"], ref["gin"]), cos(f8["gin"], ref["gin"]))
+    assert min(cosines.values()) > 0.75, cosines
+    assert fe.f8.status.cpu().tolist() == [0, 0], "a steady two-step run must not clamp or overflow: %s" % fe.f8.status.cpu().tolist()
     # the fp8 weight gradients' own share: the same fp8 run with the weight gradients alone back in bf16 (same forward pass, same
     # data gradients, same twins: the two runs differ only in the operands of the pixel contraction)
     n_wg = sum(1 for u in fe.conv_units() if u.fp8_wgrad and u.dz8 is not None)
@@ -512,6 +530,118 @@ def test_fp8_backbone_deviation_from_bf16():
               % (n_wg, own))
         assert torch.equal(f8["feat"], f8_bw["feat"])
         assert min(c for c, _ in own.values()) > 0.99, own
+
+
+def test_fp8_delayed_scaling_amax_jump_is_visible_and_bounded(ops):
+    """Delayed scaling has ONE step of history: a tensor that outgrows margin x last step's amax is clamped by the quantiser.  That
+    must not be silent.  Kernel level: step t calibrates on x, step t+1 feeds 8 x -- the twin saturates at limit x scale (a BOUNDED
+    error: nothing wraps, nothing turns Inf / NaN), frcnn_fp8_update_scales counts the tensor in status[0], and step t+2 (same 8 x)
+    is clean again.  A non-finite amax keeps the previous scale and is counted in status[1]."""
+    g = torch.Generator().manual_seed(77)
+    n = 1 << 16
+    x = torch.randn(n, generator=g).to(BF).cuda()
+    amax = torch.zeros(2, ops.FP8_AMAX_SLOTS, device="cuda")
+    buf = torch.ones(2, 2, device="cuda")                        # [scale | 1 / scale] x 2 tensors (0: e4m3, 1: e5m2)
+    limit = torch.tensor([448.0, 57344.0], device="cuda")
+    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    out = torch.zeros(2, n, dtype=torch.uint8, device="cuda")
+    margin = 2.0
+
+    def step(src):
+        amax.zero_()
+        for i, e5 in ((0, False), (1, True)):
+            ops.quantize_fp8(src, buf[1, i:i + 1], out[i], amax[i], e5m2=e5)
+        deq = [out[0].view(E4M3).float() * buf[0, 0], out[1].view(E5M2).float() * buf[0, 1]]
+        ops.fp8_update_scales(amax, buf[0], buf[1], 2, margin, limit, status)
+        torch.cuda.synchronize()
+        return deq
+
+    step(x)                                                      # t - 1: scale 1 -> calibrated
+    a0 = float(x.float().abs().max())
+    assert status.tolist() == [0, 0] and abs(float(buf[0, 0]) - margin * a0 / 448) < 1e-6
+    deq = step(x)                                                # t: calibrated, nothing clamps
+    assert status.tolist() == [0, 0]
+    assert float((deq[0] - x.float()).abs().max()) <= a0 * 2 ** -3            # e4m3: 3 mantissa bits at the top binade
+    x8 = (x.float() * 8).to(BF)
+    sc_t = [float(buf[0, 0]), float(buf[0, 1])]
+    deq = step(x8)                                               # t + 1: amax jumps 8 x > margin
+    # e4m3 clamps at 448 x scale = margin x a0; e5m2 has 57344 / 448 = 128 x head-room: it does not
+    assert status.tolist() == [1, 0], status.tolist()
+    assert bool(torch.isfinite(deq[0]).all()) and abs(float(deq[0].abs().max()) - 448 * sc_t[0]) < 1e-3 * 448 * sc_t[0]
+    inside = x8.float().abs() <= 448 * sc_t[0]
+    assert float((deq[0] - x8.float())[inside].abs().max()) <= 448 * sc_t[0] * 2 ** -3       # unclamped values keep their precision
+    assert float((deq[1] - x8.float()).abs().max()) <= 8 * a0 * 2 ** -2                        # e5m2 (2 mantissa bits): not clamped
+    deq = step(x8)                                               # t + 2: the scale has followed
+    assert status.tolist() == [1, 0]
+    assert float((deq[0] - x8.float()).abs().max()) <= 8 * a0 * 2 ** -3
+    # a tensor that overflowed to Inf: scale kept, event counted, later steps still finite
+    keep = buf.clone()
+    xi = x8.clone()
+    xi[5] = float("inf")
+    step(xi)
+    assert status.tolist()[1] == 2 and torch.equal(buf, keep), (status.tolist(), buf, keep)
+    deq = step(x8)
+    assert bool(torch.isfinite(deq[0]).all()) and bool(torch.isfinite(buf).all())
+
+
+def test_fp8_backbone_amax_jump_sets_the_status_word():
+    """The same event in the model: every BatchNorm gamma x 8 between two steps makes the activations of step t+1 eight times what
+    the delayed scales were measured on -- FasterRCNN.fp8_status()'s source (Fp8Scales.status[0]) must count the clamped twins, the
+    outputs must stay finite, and one step later the run must be back at the steady-state deviation from bf16."""
+    import importlib
+    FE = importlib.import_module("2d_object_detection_amd.models.feature_extractor")
+    RT = importlib.import_module("2d_object_detection_amd.runtime")
+    shape, batch = (192, 256, 3), 2
+
+    def build(precision):
+        fe = FE.FeatureExtractor(shape, depth=50, device="cuda", precision=precision)
+        g = torch.Generator().manual_seed(5)
+        for u in fe.conv_units():
+            fe.store.weight(u.name + "_bn/gamma").copy_((torch.rand(u.cout, generator=g) + 0.5) * (0.25 if u.name.endswith("_3") else 1.0))
+            fe.store.weight(u.name + "_bn/beta").copy_(torch.randn(u.cout, generator=g) * 0.1)
+        fe.setup(batch, True)
+        fe.images.copy_(torch.randint(0, 256, (batch,) + shape, generator=g, dtype=torch.uint8))
+        _, gh, gw, cf = fe.output_shape
+        g_feat = (torch.randn(batch * gh * gw, cf, generator=g) * 1e-2).to(BF).cuda()
+        plan = RT.Plan("backbone")
+        plan.zero(fe.store.g)
+        plan.add(fe.store.refresh_bf16)
+        fe.refresh_weights(plan)
+        fe.forward_plan(plan, True)
+        fe.backward_plan(plan, g_feat, g_feat_reduced=False)
+        if fe.f8 is not None:
+            fe.f8.plan_update(plan)
+        return fe, plan
+
+    def scale_gammas(fe, k):
+        for u in fe.conv_units():
+            if not u.name.endswith("_3"):                     # (the inner activations a1 / a2 of every block: twins written by BatchNorm kernels)
+                fe.store.weight(u.name + "_bn/gamma").mul_(k)
+
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-20))
+    fe, plan = build("fp8")
+    for _ in range(2):
+        plan.run()
+    torch.cuda.synchronize()
+    assert fe.f8.status.cpu().tolist() == [0, 0]
+    scale_gammas(fe, 8.0)
+    plan.run()                                                   # step t + 1 on step t's scales
+    torch.cuda.synchronize()
+    clamped = int(fe.f8.status[0])
+    assert clamped >= 10, "an 8x activation jump under margin 2 must clamp the inner-activation twins (status[0] = %d)" % clamped
+    assert int(fe.f8.status[1]) == 0 and bool(torch.isfinite(fe.feature_maps.float()).all())
+    plan.run()                                                   # step t + 2: the scales have followed
+    plan.run()
+    torch.cuda.synchronize()
+    after = int(fe.f8.status[0])
+    fe_ref, plan_ref = build("bf16")
+    scale_gammas(fe_ref, 8.0)
+    plan_ref.run()
+    torch.cuda.synchronize()
+    e = rel(fe.feature_maps.float().cpu(), fe_ref.feature_maps.float().cpu())
+    print("fp8 amax jump (gamma x 8): %d twins clamped in the jump step, %d more in the two steps after; feature maps vs bf16 afterwards: rel L2 %.4f" % (
+        clamped, after - clamped, e))
+    assert e < 0.13, e
 
 
 def test_fp8_twin_only_stores_change_nothing():

@@ -299,10 +299,46 @@ def test_backbone_gradient_injection_is_additive():
     assert _rel(fa.store.grad("conv4_block2_1_conv/kernel"), fb.store.grad("conv4_block2_1_conv/kernel")) < 1e-5, "downstream gradients must not"
 
 
+def _full_size_discrete_checks(model, cfg, gl, gb, losses, step, seed):
+    """Every DISCRETE stage of a full-size pyramid step against oracle/fpn.py on the HIP path's own upstream tensors -- anchors of all
+    levels, proposal-NMS survivors, RoI levels, RPN / Fast-RCNN target labels, sample indices: exact -- and the four losses from
+    the HIP path's own predictions to 1e-4."""
+    aux = model._train_plan["aux"]
+    ishape = cfg["image_shape"]
+    b = gl.shape[0]
+    hip_rpn = {k: v.cpu() for k, v in aux["rpn_out"].items()}
+    assert hip_rpn["pred_scores"].shape[1] == model._train.rpn.n > 50000
+    grids = {l: tuple(aux["pyramid"][l].shape[1:3]) for l in (2, 3, 4, 5)}
+    assert grids == {2: (94, 311), 3: (47, 156), 4: (24, 78), 5: (12, 39)}
+    anchors = OF.level_anchors(cfg, grids)
+    assert sum(a.shape[0] for a in anchors.values()) == 116718                    # all anchors of the four levels ...
+    regions = torch.cat([anchors[l][O.inside_indices(anchors[l], ishape)] for l in (2, 3, 4, 5)])
+    assert regions.shape[0] == 81929                                               # ... of which these lie inside the image
+    assert torch.equal(hip_rpn["regions"], regions)
+    nms_ref = O.postprocess_output(ishape, **hip_rpn, **cfg["rpn"]["nms"])
+    assert torch.equal(aux["nms_rpn"]["num_valid_detections"].cpu(), nms_ref["num_valid_detections"])
+    assert torch.equal(aux["nms_rpn"]["pred_scores"].cpu(), nms_ref["pred_scores"])
+    rois = aux["nms_rpn"]["pred_boxes"].cpu()
+    lv = OF.roi_levels(rois, ishape)
+    assert torch.equal(aux["roi_levels"].cpu().view(b, -1), lv)
+    hip_rcnn = {k: v.cpu() for k, v in aux["rcnn_out"].items()}
+    gt_obj = F.one_hot(gl.sum(-1).long(), 2).float()
+    rs = O._training_samples(gt_obj, gb, **hip_rpn, image_shape=ishape, sampling=cfg["rpn"]["sampling"], step=step, seed=seed, stream_base=0)
+    cs = O._training_samples(gl, gb, **hip_rcnn, image_shape=ishape, sampling=cfg["rcnn"]["sampling"], step=step, seed=seed, stream_base=2)
+    t = aux["targets"]
+    assert torch.equal(t["rpn_tl"].cpu(), rs["all_target_labels"]) and torch.equal(t["rcnn_tl"].cpu(), cs["all_target_labels"])
+    assert torch.equal(t["rpn_idx"].cpu().long(), rs["sample_indices"]) and torch.equal(t["rcnn_idx"].cpu().long(), cs["sample_indices"])
+    exp = {"rpn_cls": classification_loss(rs["target_labels"], rs["pred_scores"]), "rpn_reg": regression_loss(rs["target_boxes"], rs["pred_boxes"]),
+           "rcnn_cls": classification_loss(cs["target_labels"], cs["pred_scores"]), "rcnn_reg": regression_loss(cs["target_boxes"], cs["pred_boxes"])}
+    for k, v in exp.items():
+        assert abs(float(losses[k]) - float(v)) <= 1e-4 * abs(float(v)) + 1e-5, (k, float(losses[k]), float(v))
+    return lv
+
+
 def test_fpn_full_size_step():
-    """BASELINE.json configs[4]'s geometry: ResNet-50 FPN at 375x1242, batch 2 (116,718 in-image anchors per image through one NMS):
-    the step runs, its losses are finite, proposals reach more than one pyramid level, and the discrete stages agree with the oracle
-    on the HIP path's own tensors."""
+    """BASELINE.json configs[4]'s geometry: ResNet-50 FPN at 375x1242, batch 2 (116,718 anchors per image over the four levels, the
+    81,929 inside the image through one NMS): the step runs, its losses are finite, and the discrete stages agree with the oracle on
+    the HIP path's own tensors."""
     M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
     OPT = importlib.import_module("2d_object_detection_amd.optimizers")
     C = importlib.import_module("2d_object_detection_amd.config")
@@ -314,24 +350,89 @@ def test_fpn_full_size_step():
     losses, preds = model.train_step(images.cuda(), gl.cuda(), gb.cuda(), opt)
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(v).all()) for v in losses.values()), losses
-    aux = model._train_plan["aux"]
-    ishape = cfg["image_shape"]
-    hip_rpn = {k: v.cpu() for k, v in aux["rpn_out"].items()}
-    assert hip_rpn["pred_scores"].shape[1] == model._train.rpn.n > 50000
-    grids = {l: tuple(aux["pyramid"][l].shape[1:3]) for l in (2, 3, 4, 5)}
-    assert grids == {2: (94, 311), 3: (47, 156), 4: (24, 78), 5: (12, 39)}
-    anchors = OF.level_anchors(cfg, grids)
-    regions = torch.cat([anchors[l][O.inside_indices(anchors[l], ishape)] for l in (2, 3, 4, 5)])
-    assert torch.equal(hip_rpn["regions"], regions)
-    nms_ref = O.postprocess_output(ishape, **hip_rpn, **cfg["rpn"]["nms"])
-    assert torch.equal(aux["nms_rpn"]["pred_scores"].cpu(), nms_ref["pred_scores"])
-    rois = aux["nms_rpn"]["pred_boxes"].cpu()
-    lv = OF.roi_levels(rois, ishape)
-    assert torch.equal(aux["roi_levels"].cpu().view(2, -1), lv)
+    lv = _full_size_discrete_checks(model, cfg, gl, gb, losses, step=0, seed=3)
     print("full-size FPN step: losses %s; RoI levels %s; launches %d" % ({k: round(float(v), 4) for k, v in losses.items()},
           dict(zip(*[x.tolist() for x in lv.unique(return_counts=True)])), model._train_plan["plan"].num_launches))
-    gt_obj = F.one_hot(gl.sum(-1).long(), 2).float()
-    rs = O._training_samples(gt_obj, gb, **hip_rpn, image_shape=ishape, sampling=cfg["rpn"]["sampling"], step=0, seed=3, stream_base=0)
-    t = aux["targets"]
-    assert torch.equal(t["rpn_tl"].cpu(), rs["all_target_labels"])
-    assert torch.equal(t["rpn_idx"].cpu().long(), rs["sample_indices"])
+
+
+def test_configs4_workload_fpn_fp8_batch8_full_size():
+    """BASELINE.json configs[4] ITSELF: ResNet-50-FPN, fp8 (e4m3 / e5m2 operands, delayed scaling), batch 8, 375x1242.  The reference has
+    neither a pyramid nor fp8 (models/faster_rcnn.py:25-34, models/feature_extractor.py:5-9): everything beyond it is this build's,
+    hence its own full-size gate.
+    (a) second eager step (the first calibrates the delayed scales): every discrete stage exact against oracle/fpn.py on the HIP
+        path's own tensors, the four losses to 1e-4 (_full_size_discrete_checks); no fp8 tensor clamped or non-finite;
+    (b) hipGraph replay of the same two steps == the eager run: losses 1e-5 relative (the forward pass is reproducible), weights 1e-5;
+    (c) the same two steps in bf16: a stated bound on the fp8-vs-bf16 loss difference (measured values in the assertion comments)."""
+    M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
+    OPT = importlib.import_module("2d_object_detection_amd.optimizers")
+    C = importlib.import_module("2d_object_detection_amd.config")
+    cfg = C.default_config()
+    B = 8
+    images, gl, gb = O.synthetic_batch(B, cfg["image_shape"], seed=7)
+    dimg, dgl, dgb = images.cuda(), gl.cuda(), gb.cuda()
+
+    def two_steps(precision, graphs):
+        m = M.FasterRCNN(cfg, seed=0, sampling_seed=3, topology="fpn", precision=precision)
+        m.use_graphs = graphs
+        opt = OPT.SGD(learning_rate=1e-5, momentum=0.9)
+        hist = []
+        for _ in range(2):
+            losses, _ = m.train_step(dimg, dgl, dgb, opt)
+            torch.cuda.synchronize()
+            hist.append({k: float(v) for k, v in losses.items()})
+        return m, hist
+
+    eager, h_eager = two_steps("fp8", False)
+    assert all(v == v and abs(v) != float("inf") for h in h_eager for v in h.values()), h_eager
+    fe = eager._train.fe
+    n_f8 = sum(1 for u in fe.conv_units() if u.fp8), sum(1 for u in fe.conv_units() if u.fp8_bwd and u.dz8 is not None)
+    assert n_f8[0] >= 25 and fe.f8.n >= 60, (n_f8, fe.f8.n)                 # the fp8 kernels carried the step: backbone + neck + RPN twins
+    sc = fe.f8.buf[0, :fe.f8.n].cpu()
+    assert bool((sc != 1.0).all()) and bool(torch.isfinite(sc).all()) and bool((sc > 0).all()), "delayed scaling did not calibrate every tensor"
+    assert eager.fp8_status() == {"clamped": 0, "nonfinite": 0}, eager.fp8_status()
+    lv = _full_size_discrete_checks(eager, cfg, gl, gb, h_eager[1], step=1, seed=3)
+    assert eager._train_plan["batch"] == B
+    # (b) graph replay
+    graph, h_graph = two_steps("fp8", True)
+    for k in h_eager[1]:
+        for s in (0, 1):
+            assert abs(h_graph[s][k] - h_eager[s][k]) <= 1e-5 * abs(h_eager[s][k]) + 1e-6, (k, s, h_graph[s][k], h_eager[s][k])
+    e_w = _rel(graph.store.w, eager.store.w.cpu())
+    assert e_w < 1e-5, e_w
+    launches = graph._train_plan["plan"].num_launches
+    del graph
+    # (c) bf16 twin of the same two steps
+    ref, h_ref = two_steps("bf16", False)
+    diff = {k: abs(h_eager[1][k] - h_ref[1][k]) for k in h_ref[1]}
+    print("configs[4] full size (R50-FPN fp8 batch 8, 375x1242): losses %s; bf16 twin %s; |fp8 - bf16| %s; RoI levels %s; %d fp8 forward convs, "
+          "%d fp8 data gradients, %d fp8 tensors; %d launches" % (
+              {k: round(v, 5) for k, v in h_eager[1].items()}, {k: round(v, 5) for k, v in h_ref[1].items()}, {k: round(v, 5) for k, v in diff.items()},
+              dict(zip(*[x.tolist() for x in lv.unique(return_counts=True)])), n_f8[0], n_f8[1], fe.f8.n, launches))
+    # classification losses are means over 8 x 256 / 8 x 64 samples of softmax outputs near the uniform prior at initialisation; the
+    # regression losses are SUMS (utils/losses.py:40) over rows whose samples differ as soon as one proposal score moves: relative
+    assert diff["rpn_cls"] < FP8_LOSS_BOUND["rpn_cls"] and diff["rcnn_cls"] < FP8_LOSS_BOUND["rcnn_cls"], diff
+    for k in ("rpn_reg", "rcnn_reg"):
+        assert diff[k] < FP8_LOSS_BOUND[k] * max(abs(h_ref[1][k]), 1e-3), (k, diff[k], h_ref[1][k])
+
+
+# bounds of the fp8-vs-bf16 loss difference at configs[4]'s full size after two steps: 1.3x .. 2x what was measured on MI355X
+# (round 4; values in DESIGN.md 5): absolute for the mean classification losses, relative for the summed regression losses
+FP8_LOSS_BOUND = {"rpn_cls": 0.02, "rcnn_cls": 0.05, "rpn_reg": 0.25, "rcnn_reg": 0.25}
+
+
+def test_call_training_mode_on_the_pyramid(run):
+    """FasterRCNN.__call__(images, training=True) with topology="fpn" (reference faster_rcnn.py:39-57 on the pyramid): returns what
+    the train step's own forward pass computes from the same weights (round 3: a bare AssertionError in ParamStore.register)."""
+    cfg, params, M = run["cfg"], run["params"], run["M"]
+    a = M.FasterRCNN(cfg, sampling_seed=11, topology="fpn")
+    a.set_weights(params)
+    rpn_o, rcnn_o = a(run["images"].cuda(), training=True)
+    torch.cuda.synchronize()
+    aux = run["model"]._train_plan["aux"]                       # (the fixture's eager train step on the same weights and images)
+    assert set(rpn_o) == {"regions", "pred_scores", "pred_boxes"} and set(rcnn_o) == {"regions", "pred_scores", "pred_boxes"}
+    for k in ("regions", "pred_scores", "pred_boxes"):
+        assert torch.equal(rpn_o[k], aux["rpn_out"][k]), "rpn " + k        # same kernels, f64 BN statistics: reproducible
+    assert torch.equal(rcnn_o["regions"], aux["rcnn_out"]["regions"])
+    for k in ("pred_scores", "pred_boxes"):                                 # (Dense heads: split-K float atomics)
+        assert float((rcnn_o[k] - aux["rcnn_out"][k]).abs().max()) < 1e-4, "rcnn " + k
+    assert rcnn_o["pred_scores"].shape == (2, 48, 8)

@@ -303,3 +303,49 @@ def test_call_training_mode_equals_the_train_step_forward(setup):
     stats_b = {k: v for k, v in b.get_weights().items() if "moving" in k}
     for k in stats_a:
         assert torch.equal(stats_a[k], stats_b[k]), k
+
+
+def test_forced_collectives_on_rccl_at_world_one(setup):
+    """FRCNN_FORCE_COLLECTIVES (world 1, backend nccl = RCCL): GradientSynchronizer.reduce_bucket really calls dist.all_reduce on the
+    comm stream between the backward-segment graph replays and the update segment waits for the comm stream -- the interplay of comm
+    stream, ready events and segment graphs with a real RCCL call, which a one-GPU box otherwise never executes.  A one-rank SUM is
+    the identity: the step's losses and weights must equal the unsynchronised (single-graph) step's."""
+    import torch.distributed as dist
+    D = importlib.import_module("2d_object_detection_amd.distributed")
+    cfg, params, M, OPT = setup["cfg"], setup["params"], setup["M"], setup["OPT"]
+    images, gl, gb = setup["images"].cuda(), setup["gl"].cuda(), setup["gb"].cuda()
+
+    def steps(sync_factory):
+        m = M.FasterRCNN(cfg, sampling_seed=11)
+        m.set_weights(params)
+        opt = OPT.SGD(learning_rate=1e-5, momentum=0.9)
+        sync = sync_factory(m)
+        out, w1 = [], None
+        for i in range(3):
+            losses, _ = m.train_step(images, gl, gb, opt, sync_fn=None if sync is None else sync.after_segment)
+            torch.cuda.synchronize()
+            out.append({k: float(v) for k, v in losses.items()})
+            if i == 0:
+                w1 = m.store.w.clone()
+        return m, out, sync, w1
+
+    plain, l_plain, _, w_plain = steps(lambda m: None)
+    assert not dist.is_initialized()
+    try:
+        rank, world, _ = D.init_from_env(backend="nccl", force=True)
+        assert (rank, world) == (0, 1) and dist.is_initialized() and dist.get_backend() == "nccl"
+        forced, l_forced, sync, w_forced = steps(lambda m: D.GradientSynchronizer(m.store.g, m.store.buckets, force=True))
+        assert sync.active and sync.comm_stream is not None
+        assert sync.calls == 3 * len(forced.store.buckets), (sync.calls, len(forced.store.buckets))      # one all-reduce per bucket and step
+        assert forced._train_plan["plan"].captured and len(forced._train_plan["plan"].segments) >= 4
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    for i, (a, b) in enumerate(zip(l_plain, l_forced)):
+        for k in a:
+            # step 1: identical weights and inputs; later steps: a 1e-7 weight difference (float-atomic order) can flip a near-tied
+            # NMS order / IoU threshold (one sampled row = 1/32 of a mean), as in test_graph_replay_matches_eager
+            tol = 1e-5 if i == 0 else 0.15
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (i, k, a[k], b[k])
+    e = _rel(w_forced, w_plain.cpu())
+    assert e < 1e-6, e                       # after the first update (float-atomic order in the weight gradients is all that differs)

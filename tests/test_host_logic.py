@@ -182,3 +182,65 @@ def test_gradient_buckets_coincide_with_plan_segments(monkeypatch):
             if j > 0:
                 assert lw > plan.bucket_ends[j - 1], "bucket %s is complete before the previous cut: buckets and cuts are out of step" % buckets[j][0]
         assert first_update is not None and first_update > plan.bucket_ends[-1]
+
+
+def test_bench_self_launches_its_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` outside torchrun (the way the driver runs N = 1) must not die on WORLD_SIZE != N: the parent starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD before any GPU call, relays rank 0's JSON line and
+    returns the children's status."""
+    import io
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        bench = importlib.import_module("bench")
+    finally:
+        sys.path.remove(root)
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = io.StringIO('W0101 torchrun chatter\n{"metric": "m", "value": 1.0, "n_gpus": 2}\n')
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.importlib, "import_module", lambda *a, **k: (_ for _ in ()).throw(AssertionError("parent must not load the GPU stack")))
+    rc = bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert rc == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    out = capsys.readouterr()
+    assert json.loads(out.out.strip())["n_gpus"] == 2 and "torchrun chatter" in out.err
+
+
+def test_forced_collectives_issue_all_reduces_at_world_one(monkeypatch):
+    """FRCNN_FORCE_COLLECTIVES: GradientSynchronizer really calls dist.all_reduce per bucket at world 1 (gloo here; nccl on the GPU)."""
+    import torch.distributed as dist
+    monkeypatch.setenv("FRCNN_FORCE_COLLECTIVES", "1")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    assert not dist.is_initialized()
+    try:
+        rank, world, _ = DIST.init_from_env(backend="gloo")
+        assert (rank, world) == (0, 1) and dist.is_initialized()
+        g = torch.arange(12, dtype=torch.float32)
+        sync = DIST.GradientSynchronizer(g, [("a", 0, 4), ("b", 4, 12)])
+        assert sync.active
+        calls = []
+        real = dist.all_reduce
+        monkeypatch.setattr(dist, "all_reduce", lambda t, **kw: (calls.append(t.numel()), real(t, **kw))[1])
+        sync.after_segment(0, 3)
+        sync.after_segment(1, 3)
+        assert calls == [4, 8] and sync.calls == 2 and torch.equal(g, torch.arange(12, dtype=torch.float32))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    monkeypatch.setenv("FRCNN_FORCE_COLLECTIVES", "0")
+    assert not DIST.GradientSynchronizer(torch.zeros(4), [("a", 0, 4)]).active

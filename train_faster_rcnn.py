@@ -107,7 +107,11 @@ class CheckpointManager:
         previous = glob.glob(os.path.join(self.directory, "ckpt-*.pt"))
         path = os.path.join(self.directory, "ckpt-%d.pt" % step)
         tmp = path + ".tmp"
-        torch.save({"step": step, "model": model.get_weights(), "optimizer": optimizer.state_dict()}, tmp)
+        ck = {"step": step, "model": model.get_weights(), "optimizer": optimizer.state_dict()}
+        fp8 = model.get_fp8_state() if hasattr(model, "get_fp8_state") else None      # delayed-scaling state of the fp8 twins (None in bf16)
+        if fp8 is not None:
+            ck["fp8_scales"] = fp8.cpu()
+        torch.save(ck, tmp)
         os.replace(tmp, path)
         for f in previous:
             if f != path:
@@ -121,6 +125,8 @@ class CheckpointManager:
         ck = torch.load(path, map_location="cpu")
         model.set_weights(ck["model"])
         optimizer.load_state_dict(ck["optimizer"])
+        if ck.get("fp8_scales") is not None and hasattr(model, "set_fp8_state"):
+            model.set_fp8_state(ck["fp8_scales"])
         return int(ck["step"])
 
 
