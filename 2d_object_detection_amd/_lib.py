@@ -35,9 +35,16 @@ class BnReduce(Structure):
     _fields_ = [("z", c_void_p), ("relu_mask", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("partial", c_void_p)]
 
 
+class SgdFused(Structure):
+    """frcnn_sgd_fused"""
+    _fields_ = [("decay_end", c_int64), ("l2", c_float), ("stem_begin", c_int64), ("stem_cout", c_int), ("stem_packed", c_void_p),
+                ("arrive", c_void_p)]
+
+
 ABI_VERSION = 5          # FRCNN_ABI_VERSION of include/frcnn_hip.h this table was written against (load() refuses any other library)
 
 CONV_BIAS, CONV_RELU, CONV_OUT_F32, CONV_ADD_RES, CONV_STATS, CONV_SPLITK_ATOMIC, CONV_WGRAD_ACCUMULATE = 1, 2, 4, 8, 16, 32, 64
+CONV_WGRAD_STEM_UNPACK = 128
 
 P = c_void_p
 _SIGNATURES = {
@@ -92,6 +99,9 @@ _SIGNATURES = {
     "frcnn_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "frcnn_sgd_momentum": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, P, P, P, c_int, P]),
     "frcnn_step_increment": (c_int, [P, P]),
+    "frcnn_cast_colsum": (c_int, [P, P, c_int64, c_int, P, P]),
+    "frcnn_relu_bwd_colsum": (c_int, [P, P, P, c_int64, c_int, P, P]),
+    "frcnn_sgd_momentum_fused": (c_int, [P, P, P, P, c_int64, c_float, c_float, P, P, P, c_int, POINTER(SgdFused), P]),
     "frcnn_anchors_generate": (c_int, [P, c_int, c_int, POINTER(c_float), c_int, POINTER(c_float), c_int,
                                        c_float, c_float, c_float, c_float, P]),
     "frcnn_rpn_head_post": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P]),
@@ -103,6 +113,8 @@ _SIGNATURES = {
     "frcnn_nms_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "frcnn_nms_combined": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                    P, P, P, P, P, c_size_t, P]),
+    "frcnn_nms_combined_abs": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                   P, P, P, P, P, c_size_t, P, c_float, c_float, P]),
     "frcnn_roi_crop_pool_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "frcnn_roi_crop_pool_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "frcnn_roi_crop_pool_bwd_bf16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
@@ -113,7 +125,8 @@ _SIGNATURES = {
     "frcnn_sample_indices": (c_int, [P, c_int, c_int, c_int, c_int, c_float, c_uint64, P, c_int, P, P, P, c_int, P]),
     "frcnn_losses": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P]),
     "frcnn_losses_rpn_head_grad": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_int, c_int, P, c_int, P]),
-    "frcnn_losses_head_grad": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_int, P, P]),
+    "frcnn_losses_head_grad": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_int, P, P, P]),
+    "frcnn_rcnn_head_post_decode": (c_int, [P, c_int, P, c_int, c_int, P, P, P, P, c_float, c_float, P]),
     "frcnn_rpn_head_grad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
     "frcnn_rcnn_head_grad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P]),
     "frcnn_upsample_add": (c_int, [P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, P]),

@@ -136,6 +136,35 @@ __global__ void decode_kernel(const float* __restrict__ regions, int rpi, const 
     }
 }
 
+// RCNN head post (bias + softmax / split: the arithmetic of rcnn_head_post_kernel, targets_losses.hip -- one wave per row, lane =
+// column, the exponentials summed in ascending class order) and, in the same launch, the decode step of detection NMS
+// (decode_kernel on this row's freshly computed deltas and its absolute region): frcnn_rcnn_head_post + frcnn_decode_boxes.
+__global__ __launch_bounds__(256) void rcnn_head_post_decode_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ bias, int R,
+                                                                    int C1, float* __restrict__ scores, float* __restrict__ deltas,
+                                                                    const float* __restrict__ regions, float* __restrict__ decoded, float W, float H) {
+    const int nreg = 4 * (C1 - 1);
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* row = logits + (int64_t)r * ld;
+    const float l = lane < C1 ? row[lane] + bias[lane] : -INFINITY;
+    float mx = l;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
+    const float e = lane < C1 ? expf(l - mx) : 0.f;
+    float s = 0.f;
+    for (int c = 0; c < C1; ++c) s += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), c));
+    const float inv = 1.f / s;
+    if (lane < C1) scores[(int64_t)r * C1 + lane] = e * inv;
+    for (int c = lane; c < nreg; c += 64) deltas[(int64_t)r * nreg + c] = row[C1 + c] + bias[C1 + c];
+    const f32x4 ref = *reinterpret_cast<const f32x4*>(regions + (int64_t)r * 4);
+    for (int c = lane; c < C1 - 1; c += 64) {
+        const f32x4 d = {row[C1 + 4 * c] + bias[C1 + 4 * c], row[C1 + 4 * c + 1] + bias[C1 + 4 * c + 1], row[C1 + 4 * c + 2] + bias[C1 + 4 * c + 2],
+                         row[C1 + 4 * c + 3] + bias[C1 + 4 * c + 3]};
+        *reinterpret_cast<f32x4*>(decoded + ((int64_t)r * (C1 - 1) + c) * 4) = decode_one(ref, d, W, H);
+    }
+}
+
 // ---------------------------------------------------------------- NMS
 __device__ __forceinline__ float nms_iou(const f32x4 a, const f32x4 b) {
     const float y0i = fminf(a[0], a[2]), x0i = fminf(a[1], a[3]);
@@ -216,6 +245,7 @@ struct NmsParams {
     // C == 1 only (proposal NMS): the class list IS the image's merged list, so this kernel also writes the final outputs
     // (no nms_merge_kernel launch); null otherwise
     float* out_boxes; float* out_scores; int* out_classes; int* out_valid; int max_total;
+    float* out_abs; float sx, sy;    // optional: the final boxes once more, scaled by [sx, sy, sx, sy] (frcnn_nms_combined_abs)
 };
 
 // LDS of nms_class_kernel; *lds_keys: the 32-bit score keys of the N candidates are staged in LDS (else re-read from global)
@@ -548,6 +578,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                 s = key_float((unsigned int)(p.kept_keys[o] >> 32));
             }
             *reinterpret_cast<f32x4*>(p.out_boxes + ((int64_t)b * p.max_total + t) * 4) = bx;
+            if (p.out_abs) *reinterpret_cast<f32x4*>(p.out_abs + ((int64_t)b * p.max_total + t) * 4) = f32x4{bx[0] * p.sx, bx[1] * p.sy, bx[2] * p.sx, bx[3] * p.sy};
             p.out_scores[(int64_t)b * p.max_total + t] = s;
             p.out_classes[(int64_t)b * p.max_total + t] = 0;
         }
@@ -559,6 +590,7 @@ struct MergeParams {
     const float* boxes; const unsigned long long* kept_keys; const int* kept_idx;
     int N, q, C, max_per_class, max_total, m_pad;
     float* out_boxes; float* out_scores; int* out_classes; int* out_valid;
+    float* out_abs; float sx, sy;
 };
 
 __global__ __launch_bounds__(NMS_T) void nms_merge_kernel(const MergeParams p) {
@@ -589,6 +621,7 @@ __global__ __launch_bounds__(NMS_T) void nms_merge_kernel(const MergeParams p) {
             ++cnt;
         }
         *reinterpret_cast<f32x4*>(p.out_boxes + ((int64_t)b * p.max_total + t) * 4) = bx;
+        if (p.out_abs) *reinterpret_cast<f32x4*>(p.out_abs + ((int64_t)b * p.max_total + t) * 4) = f32x4{bx[0] * p.sx, bx[1] * p.sy, bx[2] * p.sx, bx[3] * p.sy};
         p.out_scores[(int64_t)b * p.max_total + t] = s;
         p.out_classes[(int64_t)b * p.max_total + t] = cls;
     }
@@ -651,6 +684,16 @@ extern "C" int frcnn_rpn_head_post(const float* head, int ld, int b, int num_anc
     return frcnn_rpn_head_post_decode(head, ld, b, num_anchors_total, a_per_loc, keep, n, scores, deltas, nullptr, nullptr, 1.f, 1.f, stream);
 }
 
+extern "C" int frcnn_rcnn_head_post_decode(const float* logits, int ld, const float* bias, int r, int nc1, float* scores, float* deltas,
+                                           const float* regions, float* decoded, float img_w, float img_h, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(logits && bias && scores && deltas && regions && decoded && nc1 >= 2 && nc1 <= 64 && ld >= nc1 + 4 * (nc1 - 1) && r > 0,
+                    "rcnn_head_post_decode: bad arguments");
+    hipLaunchKernelGGL(rcnn_head_post_decode_kernel, dim3(cdiv(r, 4)), dim3(256), 0, S_(stream), logits, ld, bias, r, nc1, scores, deltas, regions,
+                       decoded, img_w, img_h);
+    FRCNN_CHECK_LAUNCH("rcnn_head_post_decode");
+    return FRCNN_OK;
+}
+
 extern "C" int frcnn_clip_to_window(const float* boxes, float* out, int64_t n, float x0, float y0, float x1, float y1, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(boxes && out, "clip_to_window: null pointer");
     hipLaunchKernelGGL(clip_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), boxes, out, n, x0, y0, x1, y1);
@@ -697,10 +740,10 @@ extern "C" size_t frcnn_nms_workspace_bytes(int b, int n, int c, int max_per_cla
     return (bytes + 255) & ~(size_t)255;
 }
 
-extern "C" int frcnn_nms_combined(const float* boxes, const float* scores, int b, int n, int q, int c, int score_stride, int score_offset,
-                                  int max_per_class, int max_total, float iou_thr, float score_thr, float* out_boxes, float* out_scores,
-                                  int32_t* out_classes, int32_t* out_valid, void* workspace, size_t workspace_bytes,
-                                  frcnn_stream_t stream) {
+static int nms_combined_impl(const float* boxes, const float* scores, int b, int n, int q, int c, int score_stride, int score_offset,
+                             int max_per_class, int max_total, float iou_thr, float score_thr, float* out_boxes, float* out_scores,
+                             int32_t* out_classes, int32_t* out_valid, void* workspace, size_t workspace_bytes, float* out_abs, float sx, float sy,
+                             frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(boxes && scores && out_boxes && out_scores && out_classes && out_valid && workspace, "nms_combined: null pointer");
     FRCNN_CHECK_ARG(b > 0 && n > 0 && c > 0 && (q == 1 || q == c) && max_per_class > 0 && max_total > 0, "nms_combined: bad sizes");
     FRCNN_CHECK_ARG(workspace_bytes >= frcnn_nms_workspace_bytes(b, n, c, max_per_class, max_total), "nms_combined: workspace too small");
@@ -719,6 +762,7 @@ extern "C" int frcnn_nms_combined(const float* boxes, const float* scores, int b
     const bool fused_merge = c == 1;
     p.out_boxes = fused_merge ? out_boxes : nullptr; p.out_scores = out_scores; p.out_classes = out_classes; p.out_valid = out_valid;
     p.max_total = max_total;
+    p.out_abs = out_abs; p.sx = sx; p.sy = sy;
     bool lds_keys;
     const size_t smem = nms_class_lds(n, max_per_class, &lds_keys);
     p.lds_keys = lds_keys ? 1 : 0;
@@ -736,7 +780,25 @@ extern "C" int frcnn_nms_combined(const float* boxes, const float* scores, int b
     m.boxes = boxes; m.kept_keys = p.kept_keys; m.kept_idx = p.kept_idx; m.N = n; m.q = q; m.C = c; m.max_per_class = max_per_class;
     m.max_total = max_total; m.m_pad = m_pad; m.out_boxes = out_boxes; m.out_scores = out_scores; m.out_classes = out_classes;
     m.out_valid = out_valid;
+    m.out_abs = out_abs; m.sx = sx; m.sy = sy;
     hipLaunchKernelGGL(nms_merge_kernel, dim3(b), dim3(NMS_T), (size_t)m_pad * 8 + 16, S_(stream), m);
     FRCNN_CHECK_LAUNCH("nms_combined(merge)");
     return FRCNN_OK;
+}
+
+extern "C" int frcnn_nms_combined(const float* boxes, const float* scores, int b, int n, int q, int c, int score_stride, int score_offset,
+                                  int max_per_class, int max_total, float iou_thr, float score_thr, float* out_boxes, float* out_scores,
+                                  int32_t* out_classes, int32_t* out_valid, void* workspace, size_t workspace_bytes,
+                                  frcnn_stream_t stream) {
+    return nms_combined_impl(boxes, scores, b, n, q, c, score_stride, score_offset, max_per_class, max_total, iou_thr, score_thr, out_boxes,
+                             out_scores, out_classes, out_valid, workspace, workspace_bytes, nullptr, 1.f, 1.f, stream);
+}
+
+extern "C" int frcnn_nms_combined_abs(const float* boxes, const float* scores, int b, int n, int q, int c, int score_stride, int score_offset,
+                                      int max_per_class, int max_total, float iou_thr, float score_thr, float* out_boxes, float* out_scores,
+                                      int32_t* out_classes, int32_t* out_valid, void* workspace, size_t workspace_bytes, float* out_boxes_abs,
+                                      float scale_x, float scale_y, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(out_boxes_abs, "nms_combined_abs: null pointer");
+    return nms_combined_impl(boxes, scores, b, n, q, c, score_stride, score_offset, max_per_class, max_total, iou_thr, score_thr, out_boxes,
+                             out_scores, out_classes, out_valid, workspace, workspace_bytes, out_boxes_abs, scale_x, scale_y, stream);
 }

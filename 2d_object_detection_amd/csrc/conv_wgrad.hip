@@ -29,6 +29,7 @@ struct WgradParams {
     int in_row_stride32;
     unsigned x_bytes, dz_bytes;
     int plain_store;                            // one pixel split: every dw element is written once -> plain stores, no float atomics
+    int stem_unpack;                            // FRCNN_CONV_WGRAD_STEM_UNPACK: dw is the un-padded [cout][7][7][3] stem kernel gradient
     const float* f8_x_scale;                    // fp8 operands (x: e4m3, dz: e5m2, one byte per element): device scalars, the
     const float* f8_z_scale;                    // dequantisation scales of the two tensors; NULL for bf16 operands
 };
@@ -382,7 +383,13 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
         if (co < p.Cout && ci < p.Cin) {
             float v = *reinterpret_cast<const float*>(stage + r * SROW + c * 4);
             if (F8) v *= dq;
-            float* dst = p.dw + ((long long)co * p.taps + tap) * p.Cin + ci;
+            long long off = ((long long)co * p.taps + tap) * p.Cin + ci;
+            if (p.stem_unpack) {                 // ci = kw * 4 + c of the padded 8-pixel x 4-channel tap row: 7 x 3 of them are real
+                const int kw = ci >> 2, c4 = ci & 3;
+                if (kw >= 7 || c4 == 3) continue;
+                off = ((long long)co * p.taps + tap) * 21 + kw * 3 + c4;
+            }
+            float* dst = p.dw + off;
             if (p.plain_store) *dst = v;
             else atomicAdd(dst, v);
         }
@@ -500,6 +507,9 @@ static int wgrad_fill(const frcnn_conv_desc* d, const void* x, const void* dz, i
         p.dz_bytes = (unsigned)zb;
     }
     p.plain_store = 0;
+    p.stem_unpack = (d->flags & FRCNN_CONV_WGRAD_STEM_UNPACK) ? 1 : 0;
+    FRCNN_CHECK_ARG(!p.stem_unpack || (d->cin == 32 && d->in_pix_stride == 4 && d->kw == 1 && d->kh == 7 && es == 2),
+                    "conv2d_wgrad: STEM_UNPACK is for the packed 7 x (8 px x 4 ch) stem descriptor");
     return FRCNN_OK;
 }
 

@@ -237,16 +237,20 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int block
 // control flow) pool their halves and the even lane stores both -- as many store instructions per wave, but full 16-byte lanes
 // (the strip kernels are bound by memory instructions in flight, not bytes: 8-byte stores of the twin cost as much as the
 // 16-byte stores of the bf16 tensor)
-__device__ __forceinline__ void store_fp8_pair(uint8_t* dst, const u32x2 q, const int v, const bool pair_ok) {
+__device__ __forceinline__ void store_fp8_pair(uint8_t* dst, const u32x2 q, const int v, const bool pair_ok, const bool ok = true) {
 #ifndef FRCNN_FP8_STORE8
-    if (pair_ok) {
+    if (pair_ok) {                               // (uniform; the shuffle runs on every lane, ok only gates the store)
         const unsigned p0 = __shfl_xor(q[0], 1), p1 = __shfl_xor(q[1], 1);
-        if (!(v & 1)) *reinterpret_cast<u32x4*>(dst) = u32x4{q[0], q[1], p0, p1};
+        if (!(v & 1) && ok) *reinterpret_cast<u32x4*>(dst) = u32x4{q[0], q[1], p0, p1};
         return;
     }
 #endif
-    *reinterpret_cast<u32x2*>(dst) = q;
+    if (ok) *reinterpret_cast<u32x2*>(dst) = q;
 }
+
+#ifndef FRCNN_BN_U
+#define FRCNN_BN_U 4                 // rows per thread and round of the strip kernels' streaming loops (A/B builds: FRCNN_DEFINES=FRCNN_BN_U=1)
+#endif
 
 struct Bn2 {
     const bf16_t* z; const double* part; const float* gamma; const float* beta;
@@ -356,7 +360,9 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
     const bf16_t* second = DUAL ? b2.z : res;
     const float f8_qs = b2.out8 ? *b2.qscale : 0.f;
     float f8_max = 0.f;
-    auto finish = [&](const int64_t i, const u32x4 zraw, const u32x4 qraw) {
+    // ok: this thread's row exists.  The cross-lane pooling below runs on every lane (its partners are the 8 channel-vector lanes of
+    // the SAME row: ok is uniform over them); only the stores are predicated.
+    auto finish = [&](const int64_t i, const u32x4 zraw, const u32x4 qraw, const bool ok) {
         float x[8];
         unpack8(zraw, x);
 #pragma unroll
@@ -377,13 +383,15 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
             for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
         }
         const u32x4 pk = pack8(x);
-        if (out) *reinterpret_cast<u32x4*>(out + i * 8) = pk;      // (NULL: every consumer of the activation reads the e4m3 twin below)
+        if (out && ok) *reinterpret_cast<u32x4*>(out + i * 8) = pk;      // (NULL: every consumer of the activation reads the e4m3 twin below)
         if (b2.out8) {                           // fp8 twin of the STORED (bf16-rounded) activation
             float xr[8];
             unpack8(pk, xr);
-            store_fp8_pair(b2.out8 + i * 8, pack8_fp8(xr, f8_qs), v, (C & 15) == 0);
+            store_fp8_pair(b2.out8 + i * 8, pack8_fp8(xr, f8_qs), v, (C & 15) == 0, ok);
+            if (ok) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f8_max = fmaxf(f8_max, fabsf(xr[e]));
+                for (int e = 0; e < 8; ++e) f8_max = fmaxf(f8_max, fabsf(xr[e]));
+            }
         }
         if (relu_mask) {
             // one bit per element: (stored bf16 activation > 0), i.e. exactly what the backward pass would derive from the
@@ -400,19 +408,33 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
             lo |= __shfl_xor(lo, 2);
             const unsigned hi = __shfl_xor(lo, 4);
             if (C8 % 8 == 0) {
-                if (v == 0) *reinterpret_cast<u32x2*>(relu_mask + i) = u32x2{lo, hi};      // i = r*C8 + cv, cv % 8 == 0 here
-            } else {
+                if (v == 0 && ok) *reinterpret_cast<u32x2*>(relu_mask + i) = u32x2{lo, hi};      // i = r*C8 + cv, cv % 8 == 0 here
+            } else if (ok) {
                 relu_mask[i] = (uint8_t)m;
             }
         }
     };
-#pragma unroll 4
-    for (int64_t r = row_begin + rl; r < row_end; r += 32) {
-        const int64_t i = r * C8 + cv;
-        const u32x4 zraw = NT ? load_stream(z + i * 8) : *reinterpret_cast<const u32x4*>(z + i * 8);
-        u32x4 qraw = {0u, 0u, 0u, 0u};
-        if (second) qraw = NT ? load_stream(second + i * 8) : *reinterpret_cast<const u32x4*>(second + i * 8);
-        finish(i, zraw, qraw);
+    // U rows per thread and round, ALL their loads issued before the first is consumed: the kernel is bound by bytes in flight
+    // (~16 waves per CU x 16-32 B per lane with one row at a time: a quarter of what HBM latency x bandwidth asks for).  The loop
+    // bound is uniform on purpose: `#pragma unroll` on the per-thread form (r = row_begin + rl; r < row_end) is REFUSED by the
+    // compiler -- a divergent trip count around the cross-lane pooling of finish() -- and left one row in flight (rounds 1-3).
+    constexpr int U = VAR == 4 ? 1 : FRCNN_BN_U;
+    for (int64_t rb = row_begin; rb < row_end; rb += 32 * U) {
+        u32x4 zraw[U], qraw[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = rb + u * 32 + rl;
+            ok[u] = r < row_end;
+            const int64_t i = r * C8 + cv;
+            zraw[u] = qraw[u] = u32x4{0u, 0u, 0u, 0u};
+            if (ok[u]) {
+                zraw[u] = NT ? load_stream(z + i * 8) : *reinterpret_cast<const u32x4*>(z + i * 8);
+                if (second) qraw[u] = NT ? load_stream(second + i * 8) : *reinterpret_cast<const u32x4*>(second + i * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) finish((rb + u * 32 + rl) * C8 + cv, zraw[u], qraw[u], ok[u]);
     }
     if (b2.out8 && b2.amax) atomic_amax(b2.amax, f8_max);
 }
@@ -600,35 +622,62 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
     // optional fp8 twin of dz for the fp8 data-gradient convolution: e5m2 bytes of the STORED bf16 value times *dz8_qscale
     const float f8_qs = dz8 ? *dz8_qscale : 0.f;
     float f8_max = 0.f;
-#pragma unroll 2
-    for (int64_t r = row_begin + rl; r < row_end; r += 32) {
-        const int64_t i = r * C8 + cv;
-        float g[8], zz[8], o[8];
-        unpack8(LEGACY ? *reinterpret_cast<const u32x4*>(gout + i * 8) : load_stream(gout + i * 8), g);   // (last use of the incoming
-        unpack8(LEGACY == 1 ? *reinterpret_cast<const u32x4*>(z + i * 8) : load_stream(z + i * 8), zz);    //  gradient and of z: streamed)
-        if (MASK == 1) {
-            float a[8];
-            unpack8(*reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(act) + i * 8), a);
+    // U rows per thread and round with all their loads issued first (see bn_train_apply_kernel: the per-thread loop could not be
+    // unrolled by the compiler); the rows of a thread are still consumed in order, so the error-feedback chain is unchanged.
+    constexpr int U = LEGACY == 1 ? 1 : FRCNN_BN_U;
+    for (int64_t rb = row_begin; rb < row_end; rb += 32 * U) {
+        u32x4 graw[U], zraw[U], araw[U];
+        unsigned mraw[U];
+        bool ok[U];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
-        } else if (MASK == 2) {
-            const unsigned m = reinterpret_cast<const uint8_t*>(act)[i];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = rb + u * 32 + rl;
+            ok[u] = r < row_end;
+            const int64_t i = r * C8 + cv;
+            graw[u] = zraw[u] = araw[u] = u32x4{0u, 0u, 0u, 0u};
+            mraw[u] = 0u;
+            if (ok[u]) {
+                graw[u] = LEGACY ? *reinterpret_cast<const u32x4*>(gout + i * 8) : load_stream(gout + i * 8);   // (last use of the incoming
+                zraw[u] = LEGACY == 1 ? *reinterpret_cast<const u32x4*>(z + i * 8) : load_stream(z + i * 8);    //  gradient and of z: streamed)
+                if (MASK == 1) araw[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(act) + i * 8);
+                if (MASK == 2) mraw[u] = reinterpret_cast<const uint8_t*>(act)[i];
+            }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float xh = (zz[e] - mu[e]) * is[e];
-            const float v = ga[e] * (g[e] - k1[e] - xh * k2[e]) + carry[e];
-            o[e] = bf16_round(v);
-            carry[e] = v - o[e];
-        }
-        if (dz) *reinterpret_cast<u32x4*>(dz + i * 8) = pack8(o);      // (NULL: every consumer of dz reads the e5m2 twin below)
-        if (gpre) *reinterpret_cast<u32x4*>(gpre + i * 8) = pack8(g);
-        if (dz8) {
-            store_fp8_pair(dz8 + i * 8, pack8_bf8(o, f8_qs), v, (C & 15) == 0);
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = (rb + u * 32 + rl) * C8 + cv;
+            float g[8], zz[8], o[8];
+            unpack8(graw[u], g);
+            unpack8(zraw[u], zz);
+            if (MASK == 1) {
+                float a[8];
+                unpack8(araw[u], a);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f8_max = fmaxf(f8_max, fabsf(o[e]));
+                for (int e = 0; e < 8; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+            } else if (MASK == 2) {
+                const unsigned m = mraw[u];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+            }
+            if (ok[u]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (zz[e] - mu[e]) * is[e];
+                    const float v = ga[e] * (g[e] - k1[e] - xh * k2[e]) + carry[e];
+                    o[e] = bf16_round(v);
+                    carry[e] = v - o[e];
+                }
+                if (dz) *reinterpret_cast<u32x4*>(dz + i * 8) = pack8(o);      // (NULL: every consumer of dz reads the e5m2 twin below)
+                if (gpre) *reinterpret_cast<u32x4*>(gpre + i * 8) = pack8(g);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = 0.f;
+            }
+            if (dz8) {
+                store_fp8_pair(dz8 + i * 8, pack8_bf8(o, f8_qs), v, (C & 15) == 0, ok[u]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f8_max = fmaxf(f8_max, fabsf(o[e]));
+            }
         }
     }
     if (dz8 && dz8_amax) atomic_amax(dz8_amax, f8_max);
@@ -704,6 +753,56 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
             for (int64_t r = r0 + rl; r < r1; r += 4) s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(x + r * ld + col));
         for (int k = rl; k < 32; k += 4) red[k][cl] = k == rl ? s : 0.f;
     }
+    __syncthreads();
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && col < c) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
+        atomicAdd(out + col, s);
+    }
+}
+
+// The column sums fused with the pass that PRODUCES the bf16 matrix (same grid, same per-thread row order and LDS tree as colsum_kernel's
+// vector path: the sums are the ones colsum_kernel would compute from the stored values):
+//   SRC 1: dst = bf16(src32), out[col] += sum_rows dst        (frcnn_cast_f32_bf16 + frcnn_colsum_bf16: the RPN head gradient and its bias gradient)
+//   SRC 2: dst = act > 0 ? g : 0, out[col] += sum_rows dst     (frcnn_relu_bwd + frcnn_colsum_bf16: the RPN 3x3 layer's dz and bias gradient)
+// [m][c] row-major, c % 8 == 0, 16-byte aligned.
+template <int SRC>
+__global__ __launch_bounds__(256) void colsum_produce_kernel(const float* __restrict__ src32, const bf16_t* __restrict__ g, const bf16_t* __restrict__ act,
+                                                             bf16_t* __restrict__ dst, int64_t m, int c, float* __restrict__ out) {
+    __shared__ float red[32][65];
+    const int64_t r0 = (int64_t)blockIdx.y * 256, r1 = min(m, r0 + 256);
+    const int v = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int col0 = blockIdx.x * 64 + v * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (col0 < c) {
+#pragma unroll 8
+        for (int64_t r = r0 + rl; r < r1; r += 32) {
+            float q[8];
+            u32x4 pk;
+            if (SRC == 1) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src32 + r * c + col0), b = *reinterpret_cast<const f32x4*>(src32 + r * c + col0 + 4);
+                const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                pk = pack8(f);
+            } else {
+                float gg[8], aa[8];
+                unpack8(*reinterpret_cast<const u32x4*>(g + r * c + col0), gg);
+                unpack8(*reinterpret_cast<const u32x4*>(act + r * c + col0), aa);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gg[e] = aa[e] > 0.f ? gg[e] : 0.f;
+                pk = pack8(gg);
+            }
+            *reinterpret_cast<u32x4*>(dst + r * c + col0) = pk;
+            unpack8(pk, q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += q[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][v * 8 + e] = acc[e];
     __syncthreads();
     const int col = blockIdx.x * 64 + threadIdx.x;
     if (threadIdx.x < 64 && col < c) {
@@ -809,6 +908,42 @@ __global__ void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, f
     }
 }
 __global__ void step_inc_kernel(int64_t* step) { *step += 1; }
+
+// the optimizer step of a training plan in one launch: both decay ranges, the stem's packed bf16 taps, the step counter
+__global__ void sgd_fused_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, bf16_t* __restrict__ wb,
+                                 int64_t n, float momentum, float gscale, int64_t* __restrict__ step, const int64_t* __restrict__ bounds,
+                                 const float* __restrict__ values, int nb, const frcnn_sgd_fused f) {
+    const int64_t st = *step;
+    int k = 0;
+    while (k < nb && st > bounds[k]) ++k;            // Keras: values[k] while step <= boundaries[k]
+    const float lr = values[k];
+    const float l2x2 = 2.f * f.l2;
+    const int64_t stem_end = f.stem_begin >= 0 ? f.stem_begin + (int64_t)f.stem_cout * 147 : -1;
+    bf16_t* wp = reinterpret_cast<bf16_t*>(f.stem_packed);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float wi = w[i];
+        const float gi = g[i] * gscale + (i < f.decay_end ? l2x2 : 0.f) * wi;
+        const float vi = momentum * v[i] - lr * gi;
+        const float wn = wi + vi;
+        v[i] = vi;
+        w[i] = wn;
+        if (wb) wb[i] = (bf16_t)wn;
+        if (i >= f.stem_begin && i < stem_end) {     // [co][kh][kw][c] of the 7x7x3 kernel -> [co][kh][8][4]
+            const int j = (int)(i - f.stem_begin);
+            const int c = j % 3, kw = (j / 3) % 7, kh = (j / 21) % 7, co = j / 147;
+            wp[((co * 7 + kh) * 8 + kw) * 4 + c] = (bf16_t)wn;
+        }
+    }
+    // every workgroup has read *step before it arrives here: the last arriver may move it
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(f.arrive, 1u) == gridDim.x - 1) {
+            *f.arrive = 0u;
+            *step = st + 1;
+        }
+    }
+}
 
 __global__ void cast_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (bf16_t)s[i];
@@ -935,7 +1070,11 @@ extern "C" int frcnn_bn_apply(const frcnn_bf16* z, const float* scale, const flo
 // must stay small next to the streamed rows)
 static int strip_rows_per_block(int64_t m, int c) {
     const int strips = (c + 63) / 64;
-    int64_t chunks = 1024 / strips;
+    int64_t wgs = 1024;
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_BN_WGS")) wgs = atoll(e);
+#endif
+    int64_t chunks = wgs / strips;
     if (chunks < 1) chunks = 1;
     int64_t rows = (m + chunks - 1) / chunks;
     if (rows < 64) rows = 64;
@@ -1106,6 +1245,26 @@ extern "C" int frcnn_colsum_bf16(const frcnn_bf16* x, int64_t m, int c, int ld, 
     return FRCNN_OK;
 }
 
+extern "C" int frcnn_cast_colsum(const float* src, frcnn_bf16* dst, int64_t m, int c, float* colsum, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(src && dst && colsum && m > 0 && c > 0 && c % 8 == 0 && ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) & 15) == 0,
+                    "cast_colsum: bad arguments (c %% 8, 16-byte aligned)");
+    hipLaunchKernelGGL(colsum_produce_kernel<1>, dim3(cdiv(c, 64), cdiv(m, 256)), dim3(256), 0, S_(stream), src, (const bf16_t*)nullptr,
+                       (const bf16_t*)nullptr, BF(dst), m, c, colsum);
+    FRCNN_CHECK_LAUNCH("cast_colsum");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_relu_bwd_colsum(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, int64_t m, int c, float* colsum,
+                                     frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(g && act && out && colsum && m > 0 && c > 0 && c % 8 == 0 &&
+                        ((reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(act) | reinterpret_cast<size_t>(out)) & 15) == 0,
+                    "relu_bwd_colsum: bad arguments (c %% 8, 16-byte aligned)");
+    hipLaunchKernelGGL(colsum_produce_kernel<2>, dim3(cdiv(c, 64), cdiv(m, 256)), dim3(256), 0, S_(stream), (const float*)nullptr, CBF(g), CBF(act),
+                       BF(out), m, c, colsum);
+    FRCNN_CHECK_LAUNCH("relu_bwd_colsum");
+    return FRCNN_OK;
+}
+
 extern "C" int frcnn_maxpool3x3s2_fwd(const frcnn_bf16* x, frcnn_bf16* y, uint8_t* argmax, int n, int h, int w, int c, int ho,
                                       int wo, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(x && y && argmax && c % 8 == 0 && ho == (h + 2 - 3) / 2 + 1 && wo == (w + 2 - 3) / 2 + 1, "maxpool_fwd: bad arguments");
@@ -1133,6 +1292,19 @@ extern "C" int frcnn_sgd_momentum(float* w, const float* g, float* v, frcnn_bf16
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, S_(stream), w, g, v, BF(w_bf16), n, momentum, 2.f * l2,
                        grad_scale, step, boundaries, values, nb);
     FRCNN_CHECK_LAUNCH("sgd_momentum");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_sgd_momentum_fused(float* w, const float* g, float* v, frcnn_bf16* w_bf16, int64_t n, float momentum, float grad_scale,
+                                        int64_t* step, const int64_t* boundaries, const float* values, int nb, const frcnn_sgd_fused* f,
+                                        frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(w && g && v && step && values && (nb == 0 || boundaries) && f && f->arrive, "sgd_momentum_fused: null pointer");
+    FRCNN_CHECK_ARG(f->decay_end >= 0 && f->decay_end <= n, "sgd_momentum_fused: decay_end outside [0, n]");
+    FRCNN_CHECK_ARG(f->stem_begin < 0 || (f->stem_packed && f->stem_cout > 0 && f->stem_begin + (int64_t)f->stem_cout * 147 <= n),
+                    "sgd_momentum_fused: stem range outside the buffer or no packed destination");
+    hipLaunchKernelGGL(sgd_fused_kernel, dim3(grid_for(n, 256)), dim3(256), 0, S_(stream), w, g, v, BF(w_bf16), n, momentum, grad_scale, step,
+                       boundaries, values, nb, *f);
+    FRCNN_CHECK_LAUNCH("sgd_momentum_fused");
     return FRCNN_OK;
 }
 

@@ -306,6 +306,7 @@ struct LossParams {
     float* losses; float* dlog; float* ddel;
     bf16_t* dhead; int ld; int* rows_out;          // optional fused Fast-RCNN head-gradient rows (what rcnn_head_grad_kernel writes)
     float* rpn_dhead; const int* keep; int locs, apl, rpn_ld;   // optional fused RPN scatter-add (what rpn_head_grad_kernel does; C1 == 2)
+    float* bias_grad;                              // optional (with dhead, ld <= 64): += column sums of the dhead rows (colsum_kernel's sums)
 };
 
 // One workgroup, one thread per sampled row (rows beyond 1024: strided).  MAXC bounds C1 at compile time (2 / 8 / 32): the row's
@@ -314,6 +315,7 @@ struct LossParams {
 template <int MAXC>
 __global__ __launch_bounds__(1024) void losses_kernel(const LossParams p) {
     __shared__ float red[2][16];
+    __shared__ float cs[32][65];
     const int C = p.C1 - 1;
     const int rows = p.B * p.S;
     const float inv_rows = 1.0f / (float)rows;
@@ -434,6 +436,32 @@ __global__ __launch_bounds__(1024) void losses_kernel(const LossParams p) {
         p.losses[0] = a * inv_rows;
         p.losses[1] = c2;
     }
+    if (p.bias_grad) {
+        // The head's bias gradient = column sums of the bf16 gradient rows written above, in colsum_kernel's order (row chunks of 256;
+        // per column 32 partial sums over rows rl, rl + 32, ..., added in ascending rl; one atomic per column and chunk): the bits
+        // frcnn_colsum_bf16(dhead_s, B*S, ld, ld, bias_grad) produces, without its launch.
+        __threadfence_block();
+        __syncthreads();
+        const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+        for (int r0 = 0; r0 < rows; r0 += 256) {
+            const int r1 = min(rows, r0 + 256);
+            for (int rl = part; rl < 32; rl += (int)(blockDim.x >> 6)) {
+                float s = 0.f;
+                if (col < p.ld)
+                    for (int r = r0 + rl; r < r1; r += 32)
+                        s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(p.dhead + (int64_t)r * p.ld + col));
+                cs[rl][col] = s;
+            }
+            __syncthreads();
+            if (threadIdx.x < 64 && threadIdx.x < p.ld) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) s += cs[k][threadIdx.x];
+                atomicAdd(p.bias_grad + threadIdx.x, s);
+            }
+            __syncthreads();
+        }
+    }
 }
 
 static void launch_losses(const LossParams& p, hipStream_t stream) {
@@ -548,16 +576,18 @@ extern "C" int frcnn_sample_indices(const float* target_labels, int b, int r, in
 extern "C" int frcnn_losses_head_grad(const float* scores, const float* deltas, const float* target_labels, const float* target_boxes,
                                       const int32_t* indices, int b, int r, int c1, int s, float cls_scale, float reg_scale,
                                       float* losses, float* dlogits_s, float* ddeltas_s, frcnn_bf16* dhead_s, int ld, int32_t* rows_out,
-                                      frcnn_stream_t stream) {
+                                      float* bias_grad, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(scores && deltas && target_labels && target_boxes && indices && losses, "losses: null pointer");
     FRCNN_CHECK_ARG(c1 >= 2 && c1 <= kMaxC1 && b > 0 && s > 0, "losses: bad sizes");
     FRCNN_CHECK_ARG(!dhead_s || (rows_out && ld >= c1 + 4 * (c1 - 1)), "losses: fused head gradient needs rows_out and ld >= 5*(C+1)-4");
+    FRCNN_CHECK_ARG(!bias_grad || (dhead_s && ld <= 64), "losses: the fused bias gradient needs dhead_s with ld <= 64");
     LossParams p;
     p.scores = scores; p.deltas = deltas; p.tl = target_labels; p.tb = target_boxes; p.idx = indices;
     p.B = b; p.R = r; p.C1 = c1; p.S = s; p.cls_scale = cls_scale; p.reg_scale = reg_scale;
     p.losses = losses; p.dlog = dlogits_s; p.ddel = ddeltas_s;
     p.dhead = reinterpret_cast<bf16_t*>(dhead_s); p.ld = ld; p.rows_out = rows_out;
     p.rpn_dhead = nullptr; p.keep = nullptr; p.locs = 0; p.apl = 1; p.rpn_ld = 0;
+    p.bias_grad = bias_grad;
     launch_losses(p, S_(stream));
     FRCNN_CHECK_LAUNCH("losses");
     return FRCNN_OK;
@@ -573,7 +603,7 @@ extern "C" int frcnn_losses_rpn_head_grad(const float* scores, const float* delt
     p.scores = scores; p.deltas = deltas; p.tl = target_labels; p.tb = target_boxes; p.idx = indices;
     p.B = b; p.R = r; p.C1 = 2; p.S = s; p.cls_scale = cls_scale; p.reg_scale = reg_scale;
     p.losses = losses; p.dlog = dlogits_s; p.ddel = ddeltas_s;
-    p.dhead = nullptr; p.ld = 0; p.rows_out = nullptr;
+    p.dhead = nullptr; p.ld = 0; p.rows_out = nullptr; p.bias_grad = nullptr;
     p.rpn_dhead = dhead; p.keep = keep; p.locs = num_anchors_total / a_per_loc; p.apl = a_per_loc; p.rpn_ld = ld;
     launch_losses(p, S_(stream));
     FRCNN_CHECK_LAUNCH("losses");
@@ -584,7 +614,7 @@ extern "C" int frcnn_losses(const float* scores, const float* deltas, const floa
                             const int32_t* indices, int b, int r, int c1, int s, float cls_scale, float reg_scale, float* losses,
                             float* dlogits_s, float* ddeltas_s, frcnn_stream_t stream) {
     return frcnn_losses_head_grad(scores, deltas, target_labels, target_boxes, indices, b, r, c1, s, cls_scale, reg_scale, losses, dlogits_s,
-                                  ddeltas_s, nullptr, 0, nullptr, stream);
+                                  ddeltas_s, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int frcnn_rpn_head_grad(const float* dlogits_s, const float* ddeltas_s, const int32_t* indices, const int32_t* keep, int b, int s,

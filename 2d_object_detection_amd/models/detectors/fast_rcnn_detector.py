@@ -134,18 +134,30 @@ class FastRCNNDetector:
         """(dhead_s, ld, rows): destination of the fused loss + head-gradient launch (ops.losses_head_grad)."""
         return self.dhead_s, HEAD_LD, self.rows
 
-    def forward_plan(self, plan, feature_maps, rois, regions_done=False):
+    def head_post_plan(self, plan, regions_done, decoded):
+        """bias + softmax / split of the head GEMM's logits; decoded [B,P,C,4] (with regions_done): also the decode step of detection
+        NMS in the same launch (self.regions_abs must be complete: the proposal NMS writes it, ops.nms_combined_abs)."""
+        st = self.store
+        if decoded is not None and regions_done:
+            plan.add(ops.rcnn_head_post_decode, self.logits, HEAD_LD, st.weight("fast_rcnn_heads/bias"), self.r, self.c1, self.scores, self.deltas,
+                     self.regions_abs, decoded, float(self._image_shape[1]), float(self._image_shape[0]))
+            return True
+        plan.add(ops.rcnn_head_post, self.logits, HEAD_LD, st.weight("fast_rcnn_heads/bias"), self.r, self.c1, self.scores, self.deltas)
+        return False
+
+    def forward_plan(self, plan, feature_maps, rois, regions_done=False, decoded=None):
+        """Returns the output dict; self.decoded_done tells whether `decoded` was filled (head_post_plan)."""
         st = self.store
         plan.add(ops.roi_crop_pool_fwd, feature_maps, rois, self.batch, self.p, self.hf, self.wf, self.cf, self.ps, self.ks, self.pooled,
                  self.argmax)
         plan.zero(self.logits)                      # (split-K float atomics)
         plan.add(ops.conv2d_fprop, self.d_fwd, self.pooled, st.weight_bf16("fast_rcnn_heads/kernel"), self.logits)
-        plan.add(ops.rcnn_head_post, self.logits, HEAD_LD, st.weight("fast_rcnn_heads/bias"), self.r, self.c1, self.scores, self.deltas)
+        self.decoded_done = self.head_post_plan(plan, regions_done, decoded)
         if not regions_done:
             self.regions_plan(plan, rois)
         return {"regions": self.regions_abs, "pred_scores": self.scores, "pred_boxes": self.deltas}
 
-    def backward_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, rois, g_feat_bf16, head_grad_done=False):
+    def backward_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, rois, g_feat_bf16, head_grad_done=False, bias_grad_done=False):
         """Per-sample loss gradients -> head parameter gradients and the RoI-branch feature-map
         gradient, written (bf16) to g_feat_bf16 [B*hf*wf, C].  head_grad_done: self.dhead_s / self.rows were already written
         by the loss launch (ops.losses_head_grad)."""
@@ -159,7 +171,8 @@ class FastRCNNDetector:
         # gather form: every element of g_feat is written once, in bf16, without global atomics (no memset / cast passes)
         plan.add(ops.roi_crop_pool_bwd_bf16, self.dpooled_s, self.argmax, rois, self.rows, self.rs, self.batch, self.p, self.hf, self.wf,
                  self.cf, self.ps, self.ks, g_feat_bf16)
-        plan.add(ops.colsum_bf16, self.dhead_s, self.rs, HEAD_LD, HEAD_LD, st.grad("fast_rcnn_heads/bias"))
+        if not bias_grad_done:                      # (the fused loss launch adds the bias gradient itself: ops.losses_head_grad(bias_grad=...))
+            plan.add(ops.colsum_bf16, self.dhead_s, self.rs, HEAD_LD, HEAD_LD, st.grad("fast_rcnn_heads/bias"))
         plan.add(ops.conv2d_wgrad, self.d_wgrad, self.pooled, self.dhead_s, st.grad("fast_rcnn_heads/kernel"), HEAD_LD, self.rows)
 
     # ------------------------------------------------------------------ reference call surface

@@ -222,15 +222,14 @@ class RPNDetector:
             plan.zero(self.dhead32)
             plan.add(ops.rpn_head_grad, dlogits_s, ddeltas_s, indices, self._keep, self.batch, num_samples, self.num_anchors, self.apl,
                      self.dhead32, HEAD_LD)
-        plan.add(ops.cast_f32_bf16, self.dhead32, self.dhead)
-        plan.add(ops.colsum_bf16, self.dhead, self.m, HEAD_LD, HEAD_LD, st.grad("rpn_heads/bias"))
+        # (each bias gradient comes out of the pass that produces its matrix: cast + column sums, ReLU backward + column sums)
+        plan.add(ops.cast_colsum, self.dhead32, self.dhead, self.m, HEAD_LD, st.grad("rpn_heads/bias"))
         plan.add(ops.conv2d_wgrad, self.d_heads, self.f, self.dhead, st.grad("rpn_heads/kernel"))
         plan.add(ops.conv2d_fprop, self.d_heads_bwd, self.dhead, self.w_heads_t, self.g_f)
-        plan.add(ops.relu_bwd, self.g_f, self.f, self.dz_f)
+        plan.add(ops.relu_bwd_colsum, self.g_f, self.f, self.dz_f, self.m, 256, st.grad("rpn_intermediate_layer/bias"))
         if self.dz_f8 is not None:
             sc = self.dz_f8.scales
             plan.add(ops.quantize_fp8, self.dz_f, sc.qscale(self.dz_f8.idx), self.dz_f8.data, sc.amax(self.dz_f8.idx), e5m2=True)
-        plan.add(ops.colsum_bf16, self.dz_f, self.m, 256, 256, st.grad("rpn_intermediate_layer/bias"))
         from ..feature_extractor import FP8_WGRAD
         f8 = getattr(self, "_feature_maps8", None)
         if FP8_WGRAD and f8 is not None and self.dz_f8 is not None:

@@ -241,7 +241,8 @@ class FasterRCNN:
             if training:
                 # loss, per-sample gradients and the head's bf16 gradient rows in one launch (frcnn_losses_head_grad)
                 plan.add(ops.losses_head_grad, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"],
-                         batch, P, nc1, S_rcnn, cls_scale, 1.0, losses[2:4], t["rcnn_dl"], t["rcnn_dd"], *mods.rcnn.head_grad_rows())
+                         batch, P, nc1, S_rcnn, cls_scale, 1.0, losses[2:4], t["rcnn_dl"], t["rcnn_dd"], *mods.rcnn.head_grad_rows(),
+                         bias_grad=self.store.grad("fast_rcnn_heads/bias"))
             else:
                 plan.add(ops.losses, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"], batch, P,
                          nc1, S_rcnn, cls_scale, 1.0, losses[2:4], None, None)
@@ -264,8 +265,12 @@ class FasterRCNN:
         else:
             rpn_targets(rpn_out["regions"])
             rpn_losses()
-        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"], buffers=rpn_nms, decoded_done=True)
+        # (the proposal NMS also writes the proposals in absolute coordinates: the Fast-RCNN stage's `regions`, fast_rcnn_detector.py:67)
+        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"], buffers=rpn_nms, decoded_done=True,
+                                   abs_boxes=mods.rcnn.regions_abs)
         rois = nms_rpn["pred_boxes"]
+        det_cfg = self._rcnn_config["nms"]
+        det_nms = NmsBuffers(batch, P, nc1 - 1, det_cfg["max_output_size_per_class"], det_cfg["max_total_size"], dev)
         # Target assignment and sampling of the Fast-RCNN stage need the proposals and the ground truth, not the head's
         # predictions: a side stream under RoI pooling and the head GEMM (the chain from the proposals to the head's loss
         # gradient is a string of one-workgroup kernels with the chip idle).  Branches are not free -- a forked hipGraph is
@@ -273,32 +278,31 @@ class FasterRCNN:
         # (tools/ab_plan.sh, one box) this one, the RPN side chain and the detection NMS pay; targets of the RPN at the head
         # of the step (+0.25 ms), a late zero fill (+0.12 ms), the step counter and the head's parameter gradients do not.
         with plan.branch("rcnn_targets"):
-            rcnn_targets(mods.rcnn.regions_plan(plan, rois))
-        rcnn_out = mods.rcnn.forward_plan(plan, feat, rois, regions_done=True)
+            rcnn_targets(mods.rcnn.regions_abs)
+        # (the head-post launch also decodes the detections' boxes: the first step of their NMS)
+        rcnn_out = mods.rcnn.forward_plan(plan, feat, rois, regions_done=True, decoded=det_nms.decoded)
         plan.join("rcnn_targets")
         if training:
             with plan.branch("detections"):
-                nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
+                nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **det_cfg, buffers=det_nms, decoded_done=mods.rcnn.decoded_done)
         rcnn_losses()
 
         if training:
-            mods.rcnn.backward_plan(plan, None, None, t["rcnn_idx"], S_rcnn, rois, g_feat, head_grad_done=True)
+            mods.rcnn.backward_plan(plan, None, None, t["rcnn_idx"], S_rcnn, rois, g_feat, head_grad_done=True, bias_grad_done=True)
             plan.join("rpn_side")
             mods.rpn.backward_data_plan(plan, g_feat, consumer=mods.fe.last_unit())
             plan.join("detections")
             plan.cut("bwd_conv4")
             mods.fe.backward_plan(plan, g_feat, g_feat_reduced=True)
             plan.cut("update")
-            optimizer.apply_plan(plan)
+            optimizer.apply_plan(plan, stem=mods.fe.stem)     # SGD + the stem's packed taps + the step counter: one launch
             if mods.fe.f8 is not None:
                 # fp8 mode: next step's e4m3 weights from the updated masters (one launch), next step's activation scales from this
                 # step's amax row
                 mods.fe.quantize_weights_plan(plan, extra=mods.rpn.quant_entries())
                 mods.fe.f8.plan_update(plan)
-            mods.fe.stem.refresh_weights(plan)
-            plan.add(ops.step_increment, optimizer.iterations)
         else:
-            nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
+            nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **det_cfg, buffers=det_nms, decoded_done=mods.rcnn.decoded_done)
         preds = {"rpn_boxes": nms_rpn["pred_boxes"], "rpn_scores": nms_rpn["pred_scores"], "rcnn_boxes": nms_rcnn["pred_boxes"],
                  "rcnn_scores": nms_rcnn["pred_scores"], "rcnn_classes": nms_rcnn["pred_classes"]}
         aux = {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn, "nms_rcnn": nms_rcnn, "targets": t, "feature_maps": feat}
@@ -367,26 +371,30 @@ class FasterRCNN:
                 # the part of the RPN backward pass that does not need the RoI branch's gradient fills the chip while the proposal
                 # NMS (one workgroup per image over ~82 k candidates: ~0.2 ms) holds the main chain
                 rpn.backward_params_plan(plan, t["rpn_dl"], t["rpn_dd"], t["rpn_idx"], S_rpn, pyramid)
-        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"], buffers=rpn_nms, decoded_done=True)
+        nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"], buffers=rpn_nms, decoded_done=True,
+                                   abs_boxes=rcnn.regions_abs)
         rois = nms_rpn["pred_boxes"]
+        det_cfg = self._rcnn_config["nms"]
+        det_nms = NmsBuffers(batch, P, nc1 - 1, det_cfg["max_output_size_per_class"], det_cfg["max_total_size"], dev)
         with plan.branch("rcnn_targets"):
-            regions_abs = rcnn.regions_plan(plan, rois)
+            regions_abs = rcnn.regions_abs
             plan.add(ops.assign_targets, regions_abs, io["gt_labels"], io["gt_boxes"], batch, P, G, nc1, False, W, H,
                      cs["foreground_iou_interval"], cs["background_iou_interval"], t["rcnn_tl"], t["rcnn_tb"])
             plan.add(ops.sample_indices, t["rcnn_tl"], batch, P, nc1, S_rcnn, cs["foreground_proportion"], self.sampling_seed, step, 2,
                      t["rcnn_idx"], t["rcnn_ws"], self.status, image_base=self.sampling_image_base)
-        rcnn_out = rcnn.forward_plan(plan, pyramid, rois, regions_done=True)
+        rcnn_out = rcnn.forward_plan(plan, pyramid, rois, regions_done=True, decoded=det_nms.decoded)
         plan.join("rcnn_targets")
         if training:
             plan.add(ops.losses_head_grad, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"],
-                     batch, P, nc1, S_rcnn, cls_scale, 1.0, losses[2:4], t["rcnn_dl"], t["rcnn_dd"], *rcnn.head_grad_rows())
+                     batch, P, nc1, S_rcnn, cls_scale, 1.0, losses[2:4], t["rcnn_dl"], t["rcnn_dd"], *rcnn.head_grad_rows(),
+                     bias_grad=self.store.grad("fast_rcnn_heads/bias"))
         else:
             plan.add(ops.losses, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"], batch, P, nc1,
                      S_rcnn, cls_scale, 1.0, losses[2:4], None, None)
         with plan.branch("detections"):              # the step's predictions: nothing on the main chain needs them
-            nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **self._rcnn_config["nms"])
+            nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **det_cfg, buffers=det_nms, decoded_done=rcnn.decoded_done)
         if training:
-            rcnn.backward_plan(plan, rois, neck.gp)                                  # gp[2..4]: complete RoI-branch gradients
+            rcnn.backward_plan(plan, rois, neck.gp, bias_grad_done=True)                                  # gp[2..4]: complete RoI-branch gradients
             plan.join("rpn_side")
             rpn.backward_data_plan(plan, neck.gp, {2: True, 3: True, 4: True, 5: False})
             _, gh, gw, cf = fe.output_shape
@@ -402,12 +410,10 @@ class FasterRCNN:
             plan.cut("bwd_conv4")
             fe.backward_plan(plan, g_feat, g_feat_reduced=True, injected=(first_of[4], first_of[3]))
             plan.cut("update")
-            optimizer.apply_plan(plan)
+            optimizer.apply_plan(plan, stem=fe.stem)          # SGD + the stem's packed taps + the step counter: one launch
             if fe.f8 is not None:
                 fe.quantize_weights_plan(plan, extra=neck.quant_entries()[0] + rpn.quant_entries()[0])
                 fe.f8.plan_update(plan)
-            fe.stem.refresh_weights(plan)
-            plan.add(ops.step_increment, optimizer.iterations)
         preds = {"rpn_boxes": nms_rpn["pred_boxes"], "rpn_scores": nms_rpn["pred_scores"], "rcnn_boxes": nms_rcnn["pred_boxes"],
                  "rcnn_scores": nms_rcnn["pred_scores"], "rcnn_classes": nms_rcnn["pred_classes"]}
         aux = {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn, "nms_rcnn": nms_rcnn, "targets": t, "feature_maps": fe.feature_maps,

@@ -135,8 +135,9 @@ class _ConvBN:
             self.hp, self.wp = hi + 6, max(wi + 6, 2 * (self.wo - 1) + 8)
             self.desc = ops.conv_desc(n, self.hp, self.wp, 32, 7, 1, 2, 0, 0, self.ho, self.wo, self.cout, in_pix_stride=4,
                                       flags=ops.CONV_BIAS | (ops.CONV_STATS if training else 0))
+            self.desc_wgrad = ops.conv_desc(n, self.hp, self.wp, 32, 7, 1, 2, 0, 0, self.ho, self.wo, self.cout, in_pix_stride=4,
+                                            flags=ops.CONV_WGRAD_STEM_UNPACK)
             self.w_packed = torch.zeros(self.cout, 7, 8, 4, dtype=BF16, device=device)
-            self.dw_packed = torch.zeros(self.cout, 7, 8, 4, dtype=torch.float32, device=device)
         else:
             self.ho, self.wo = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
             self.desc = ops.conv_desc(n, hi, wi, self.cin, k, k, s, p, p, self.ho, self.wo, self.cout,
@@ -279,9 +280,8 @@ class _ConvBN:
             plan.add(ops.conv2d_wgrad_fp8, self.desc, x8.data, self.dz8.data, x8.scale, self.dz8.scale, st.grad(self.name + "_conv/kernel"))
             return
         if self.is_stem:
-            plan.zero(self.dw_packed)
-            plan.add(ops.conv2d_wgrad, self.desc, x, self.dz, self.dw_packed)
-            plan.add(ops.stem_unpack_grad, self.dw_packed, st.grad(self.name + "_conv/kernel"), self.cout)
+            # the 7 x 3 real values of every packed tap row go straight into the (zeroed) Keras-layout gradient
+            plan.add(ops.conv2d_wgrad, self.desc_wgrad, x, self.dz, st.grad(self.name + "_conv/kernel"))
         else:
             plan.add(ops.conv2d_wgrad, self.desc, x, self.dz, st.grad(self.name + "_conv/kernel"))
 

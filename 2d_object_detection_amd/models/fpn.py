@@ -399,12 +399,10 @@ class RPNDetectorFPN:
             plan.zero(e["dhead32"])
             plan.add(ops.rpn_head_grad_level, dlogits_s, ddeltas_s, indices, self.keep[l], self.batch, num_samples, self.num_anchors[l], self.apl,
                      e["dhead32"], RPN_LD, self.offset[l], self.n_level[l])
-            plan.add(ops.cast_f32_bf16, e["dhead32"], e["dhead"])
-            plan.add(ops.colsum_bf16, e["dhead"], e["m"], RPN_LD, RPN_LD, st.grad("rpn_heads/bias"))
+            plan.add(ops.cast_colsum, e["dhead32"], e["dhead"], e["m"], RPN_LD, st.grad("rpn_heads/bias"))
             plan.add(ops.conv2d_wgrad, e["d_heads"], e["f"], e["dhead"], st.grad("rpn_heads/kernel"))
             plan.add(ops.conv2d_fprop, e["d_heads_bwd"], e["dhead"], self.w_heads_t, e["g_f"])
-            plan.add(ops.relu_bwd, e["g_f"], e["f"], e["dz_f"])
-            plan.add(ops.colsum_bf16, e["dz_f"], e["m"], 256, 256, st.grad("rpn_intermediate_layer/bias"))
+            plan.add(ops.relu_bwd_colsum, e["g_f"], e["f"], e["dz_f"], e["m"], 256, st.grad("rpn_intermediate_layer/bias"))
             if self.f8 is not None:
                 _quantize(plan, e["dz_f8"], e["dz_f"], e5m2=True)
             if self.f8 is not None and FP8_WGRAD:
@@ -437,7 +435,7 @@ class FastRCNNDetectorFPN(FastRCNNDetector):
         super().setup(batch, num_rois, self.grids[4][0], self.grids[4][1], training, num_samples)
         self.levels = torch.zeros(batch * num_rois, dtype=torch.int32, device=self.device)
 
-    def forward_plan(self, plan, pyramid, rois, regions_done=False):
+    def forward_plan(self, plan, pyramid, rois, regions_done=False, decoded=None):
         st = self.store
         plan.add(ops.roi_assign_levels, rois, float(self._image_shape[1]), float(self._image_shape[0]), self.levels)
         for l in LEVELS:
@@ -446,12 +444,12 @@ class FastRCNNDetectorFPN(FastRCNNDetector):
                      self.levels, l)
         plan.zero(self.logits)
         plan.add(ops.conv2d_fprop, self.d_fwd, self.pooled, st.weight_bf16("fast_rcnn_heads/kernel"), self.logits)
-        plan.add(ops.rcnn_head_post, self.logits, RCNN_LD, st.weight("fast_rcnn_heads/bias"), self.r, self.c1, self.scores, self.deltas)
+        self.decoded_done = self.head_post_plan(plan, regions_done, decoded)
         if not regions_done:
             self.regions_plan(plan, rois)
         return {"regions": self.regions_abs, "pred_scores": self.scores, "pred_boxes": self.deltas}
 
-    def backward_plan(self, plan, rois, gp):
+    def backward_plan(self, plan, rois, gp, bias_grad_done=False):
         """(the loss launch has written self.dhead_s / self.rows) -> head parameter gradients; gp[l] (l = 2..4) receive the
         COMPLETE RoI-branch gradient of their level's map."""
         st = self.store
@@ -460,5 +458,6 @@ class FastRCNNDetectorFPN(FastRCNNDetector):
             gh, gw = self.grids[l]
             plan.add(ops.roi_crop_pool_bwd_bf16_level, self.dpooled_s, self.argmax, rois, self.rows, self.rs, self.batch, self.p, gh, gw, self.cf,
                      self.ps, self.ks, gp[l], self.levels, l)
-        plan.add(ops.colsum_bf16, self.dhead_s, self.rs, RCNN_LD, RCNN_LD, st.grad("fast_rcnn_heads/bias"))
+        if not bias_grad_done:
+            plan.add(ops.colsum_bf16, self.dhead_s, self.rs, RCNN_LD, RCNN_LD, st.grad("fast_rcnn_heads/bias"))
         plan.add(ops.conv2d_wgrad, self.d_wgrad, self.pooled, self.dhead_s, st.grad("fast_rcnn_heads/kernel"), RCNN_LD, self.rows)

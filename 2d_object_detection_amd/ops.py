@@ -10,7 +10,7 @@ from ctypes import byref, c_float, c_void_p
 import torch
 
 from . import _lib
-from ._lib import (CONV_ADD_RES, CONV_BIAS, CONV_OUT_F32, CONV_RELU, CONV_SPLITK_ATOMIC, CONV_STATS, CONV_WGRAD_ACCUMULATE, BnReduce, ConvDesc, Fp8Out, call)
+from ._lib import (CONV_ADD_RES, CONV_BIAS, CONV_OUT_F32, CONV_RELU, CONV_SPLITK_ATOMIC, CONV_STATS, CONV_WGRAD_ACCUMULATE, CONV_WGRAD_STEM_UNPACK, BnReduce, ConvDesc, Fp8Out, call)
 
 BF16 = torch.bfloat16
 
@@ -369,6 +369,28 @@ def sgd_momentum(w, g, v, w_bf16, n, momentum, l2, grad_scale, step, boundaries,
          _stream())
 
 
+def sgd_momentum_fused(w, g, v, w_bf16, n, momentum, grad_scale, step, boundaries, values, nb, fused):
+    """the whole optimizer step in one launch (both decay ranges, the stem's packed taps, the step counter): fused = sgd_fused_args(...)"""
+    call("frcnn_sgd_momentum_fused", _p(w), _p(g), _p(v), _p(w_bf16), n, momentum, grad_scale, _p(step), _p(boundaries), _p(values), nb,
+         byref(fused), _stream())
+
+
+def sgd_fused_args(decay_end, l2, arrive, stem_begin=-1, stem_cout=0, stem_packed=None):
+    f = _lib.SgdFused(int(decay_end), float(l2), int(stem_begin), int(stem_cout), _p(stem_packed), _p(arrive))
+    f._keep = (arrive, stem_packed)              # the struct is passed by value at launch; the tensors must outlive the plan
+    return f
+
+
+def cast_colsum(src, dst, m, c, colsum):
+    """dst = bf16(src) and colsum[col] += column sums of dst, one launch (cast_f32_bf16 + colsum_bf16)"""
+    call("frcnn_cast_colsum", _p(src), _p(dst), m, c, _p(colsum), _stream())
+
+
+def relu_bwd_colsum(g, act, out, m, c, colsum):
+    """out = act > 0 ? g : 0 and colsum[col] += column sums of out, one launch (relu_bwd + colsum_bf16)"""
+    call("frcnn_relu_bwd_colsum", _p(g), _p(act), _p(out), m, c, _p(colsum), _stream())
+
+
 def step_increment(step):
     call("frcnn_step_increment", _p(step), _stream())
 
@@ -420,6 +442,14 @@ def nms_combined(boxes, scores, b, n, q, c, score_stride, score_offset, max_per_
     call("frcnn_nms_combined", _p(boxes), _p(scores), b, n, q, c, score_stride, score_offset, max_per_class, max_total, iou_thr,
          score_thr, _p(out_boxes), _p(out_scores), _p(out_classes), _p(out_valid), _p(workspace), workspace.numel() * workspace.element_size(),
          _stream())
+
+
+def nms_combined_abs(boxes, scores, b, n, q, c, score_stride, score_offset, max_per_class, max_total, iou_thr, score_thr, out_boxes,
+                     out_scores, out_classes, out_valid, workspace, out_boxes_abs, scale_x, scale_y):
+    """nms_combined + out_boxes_abs = out_boxes * [scale_x, scale_y, scale_x, scale_y] in the same launch"""
+    call("frcnn_nms_combined_abs", _p(boxes), _p(scores), b, n, q, c, score_stride, score_offset, max_per_class, max_total, iou_thr,
+         score_thr, _p(out_boxes), _p(out_scores), _p(out_classes), _p(out_valid), _p(workspace), workspace.numel() * workspace.element_size(),
+         _p(out_boxes_abs), float(scale_x), float(scale_y), _stream())
 
 
 def roi_crop_pool_fwd(feat, rois, b, p, hf, wf, c, ps, ks, pooled, argmax):
@@ -478,6 +508,12 @@ def rcnn_head_post(logits, ld, bias, r, nc1, scores, deltas):
     call("frcnn_rcnn_head_post", _p(logits), ld, _p(bias), r, nc1, _p(scores), _p(deltas), _stream())
 
 
+def rcnn_head_post_decode(logits, ld, bias, r, nc1, scores, deltas, regions, decoded, img_w, img_h):
+    """rcnn_head_post + the decode step of detection NMS (decode_boxes on the fresh deltas) in one launch"""
+    call("frcnn_rcnn_head_post_decode", _p(logits), ld, _p(bias), r, nc1, _p(scores), _p(deltas), _p(regions), _p(decoded), float(img_w),
+         float(img_h), _stream())
+
+
 def assign_targets(regions, gt_labels, gt_boxes, b, r, g, c1g, objectness, img_w, img_h, fg_interval, bg_interval, target_labels,
                    target_boxes):
     call("frcnn_assign_targets", _p(regions), 1 if regions.dim() == 3 else 0, _p(gt_labels), _p(gt_boxes), b, r, g, c1g,
@@ -497,10 +533,11 @@ def losses(scores, deltas, target_labels, target_boxes, indices, b, r, c1, s, cl
 
 
 def losses_head_grad(scores, deltas, target_labels, target_boxes, indices, b, r, c1, s, cls_scale, reg_scale, out_losses, dlogits_s,
-                     ddeltas_s, dhead_s, ld, rows_out):
-    """losses() + rcnn_head_grad() in one launch."""
+                     ddeltas_s, dhead_s, ld, rows_out, bias_grad=None):
+    """losses() + rcnn_head_grad() (+ the column sums of the gradient rows into bias_grad: colsum_bf16) in one launch."""
     call("frcnn_losses_head_grad", _p(scores), _p(deltas), _p(target_labels), _p(target_boxes), _p(indices), b, r, c1, s,
-         float(cls_scale), float(reg_scale), _p(out_losses), _p(dlogits_s), _p(ddeltas_s), _p(dhead_s), ld, _p(rows_out), _stream())
+         float(cls_scale), float(reg_scale), _p(out_losses), _p(dlogits_s), _p(ddeltas_s), _p(dhead_s), ld, _p(rows_out), _p(bias_grad),
+         _stream())
 
 
 def losses_rpn_head_grad(scores, deltas, target_labels, target_boxes, indices, b, r, s, cls_scale, reg_scale, out_losses, dlogits_s,

@@ -44,11 +44,29 @@ class SGD:
         self.values = torch.tensor(self.schedule.values, dtype=torch.float32, device=dev)
         self.nb = nb
 
-    def apply_plan(self, plan, grad_scale=1.0):
+    def apply_plan(self, plan, grad_scale=1.0, stem=None):
+        """The update of a training plan: SGD over the flat buffers, the stem's packed bf16 taps (stem: the backbone's stem unit, or
+        None), the step counter + 1 -- ONE launch when the store's decay ranges are [regularised | rest] (they are: the regularised
+        kernels are registered first), else one launch per range and the two small ones."""
         st = self.store
-        for (b, e, l2) in st.decay_ranges():
+        ranges = st.decay_ranges()
+        if len(ranges) == 2 and ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][2] == 0.0:
+            n = ranges[1][1]
+            self._arrive = torch.zeros(4, dtype=torch.int32, device=st.device)      # [0]: arrival counter of the fused launch
+            plan.zero(self._arrive)                  # (joins the plan's one zero fill: an aborted replay cannot leave it non-zero)
+            if stem is not None:
+                fused = ops.sgd_fused_args(ranges[0][1], ranges[0][2], self._arrive, st.offset(stem.name + "_conv/kernel"), stem.cout, stem.w_packed)
+            else:
+                fused = ops.sgd_fused_args(ranges[0][1], ranges[0][2], self._arrive)
+            plan.add(ops.sgd_momentum_fused, st.w[:n], st.g[:n], self.velocity[:n], st.wb[:n], n, self.momentum, grad_scale, self.iterations,
+                     self.boundaries, self.values, self.nb, fused)
+            return
+        for (b, e, l2) in ranges:
             plan.add(ops.sgd_momentum, st.w[b:e], st.g[b:e], self.velocity[b:e], st.wb[b:e], e - b, self.momentum, l2, grad_scale,
                      self.iterations, self.boundaries, self.values, self.nb)
+        if stem is not None:
+            stem.refresh_weights(plan)
+        plan.add(ops.step_increment, self.iterations)
 
     def state_dict(self):
         return {"velocity": self.velocity.cpu(), "iterations": int(self.iterations.item())}

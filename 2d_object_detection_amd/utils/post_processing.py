@@ -23,9 +23,11 @@ class NmsBuffers:
 
 
 def postprocess_plan(plan, image_shape, regions, pred_scores, pred_boxes, score_threshold, iou_threshold,
-                     max_output_size_per_class, max_total_size, buffers=None, decoded_done=False):
+                     max_output_size_per_class, max_total_size, buffers=None, decoded_done=False, abs_boxes=None):
     """Append the launches to `plan`; returns the output dict (static buffers).  decoded_done: `buffers.decoded` already holds
-    the decoded boxes (the RPN writes them from its head kernel: ops.rpn_head_post_decode)."""
+    the decoded boxes (the head-post kernels write them: ops.rpn_head_post_decode, ops.rcnn_head_post_decode).
+    abs_boxes [B,T,4]: also receives the kept boxes in absolute image coordinates (to_absolute, reference
+    fast_rcnn_detector.py:67) from the NMS launch itself."""
     b, n, c, _ = pred_boxes.shape
     c1 = pred_scores.shape[-1]
     buf = buffers or NmsBuffers(b, n, c, max_output_size_per_class, max_total_size, pred_boxes.device)
@@ -33,8 +35,13 @@ def postprocess_plan(plan, image_shape, regions, pred_scores, pred_boxes, score_
     if not decoded_done:
         plan.add(ops.decode_boxes, regions, pred_boxes, buf.decoded, b, n, c, image_shape[1], image_shape[0])
     # pred_scores[..., 1:] is expressed as (row stride C+1, column offset 1): no slice copy
-    plan.add(ops.nms_combined, buf.decoded, pred_scores, b, n, c, c1 - 1, c1, 1, int(max_output_size_per_class), int(max_total_size),
-             float(iou_threshold), float(score_threshold), buf.boxes, buf.scores, buf.classes, buf.valid, buf.workspace)
+    if abs_boxes is not None:
+        plan.add(ops.nms_combined_abs, buf.decoded, pred_scores, b, n, c, c1 - 1, c1, 1, int(max_output_size_per_class), int(max_total_size),
+                 float(iou_threshold), float(score_threshold), buf.boxes, buf.scores, buf.classes, buf.valid, buf.workspace, abs_boxes,
+                 float(image_shape[1]), float(image_shape[0]))
+    else:
+        plan.add(ops.nms_combined, buf.decoded, pred_scores, b, n, c, c1 - 1, c1, 1, int(max_output_size_per_class), int(max_total_size),
+                 float(iou_threshold), float(score_threshold), buf.boxes, buf.scores, buf.classes, buf.valid, buf.workspace)
     return {"pred_boxes": buf.boxes, "pred_scores": buf.scores, "pred_classes": buf.classes, "num_valid_detections": buf.valid}
 
 

@@ -119,8 +119,8 @@ def classify(ops, fn, args, kwargs):
                 "rpn_head_post", "rpn_head_post_decode", "rcnn_head_post", "decode_boxes", "boxes_scale", "rpn_head_post_level", "rpn_head_grad_level",
                 "roi_assign_levels"):
         return "targets / sampling / losses / head post", 0.0, _tensor_bytes(args, kwargs)
-    if name in ("sgd_momentum",):
-        return "SGD-momentum update (sgd_kernel)", 0.0, float(args[4]) * (4 + 4 + 4 + 4 + 4 + 2)
+    if name in ("sgd_momentum", "sgd_momentum_fused"):
+        return "SGD-momentum update (sgd_fused_kernel)", 0.0, float(args[4]) * (4 + 4 + 4 + 4 + 4 + 2)
     return "other (pool, preprocess, re-layouts, fills, column sums)", 0.0, _tensor_bytes(args, kwargs)
 
 

@@ -34,7 +34,7 @@ typedef uint8_t frcnn_fp8;     /* OCP e4m3fn (gfx950's fp8: 4 exponent bits, bia
 
 /* Version of this header's structs and signatures.  Bumped whenever a struct grows or a signature changes (2: frcnn_conv_desc
  * gained workspace / workspace_bytes, frcnn_bn_bwd_apply_fused gained count / param_grad_scale; 3: the fp8 entry points; 5: frcnn_fp8_update_scales gained limit / status,
- * FRCNN_CONV_WGRAD_ACCUMULATE).  A
+ * frcnn_losses_head_grad gained bias_grad, FRCNN_CONV_WGRAD_ACCUMULATE / _STEM_UNPACK, the fused launches of round 4).  A
  * binding must compare frcnn_abi_version() with the FRCNN_ABI_VERSION it was written against and refuse any other library:
  * an older build would read the descriptor past the caller's struct. */
 #define FRCNN_ABI_VERSION 5
@@ -68,6 +68,10 @@ const char* frcnn_last_error(void);
                                      other launches (e.g. the RPN weights over the levels of a feature pyramid), so this launch must ADD
                                      with float atomics even when it has a single pixel split -- without the flag a one-split launch
                                      stores plainly on the assumption that it is the only writer of a zeroed dw */
+#define FRCNN_CONV_WGRAD_STEM_UNPACK 128 /* frcnn_conv2d_wgrad only, on the stem's packed descriptor (kh 7, kw 1, cin 32 = 8 pixels x 4 channels,
+                                     in_pix_stride 4): dw is the UN-padded Keras kernel gradient [cout][7][7][3] (models/feature_extractor.py:8,
+                                     conv1_conv) -- the 7 x 3 real values of every tap row are stored there directly, the padding taps dropped
+                                     (replaces a packed scratch gradient + frcnn_stem_unpack_grad) */
 typedef struct {
     int n, hi, wi, in_pix_stride, cin;
     int kh, kw, stride, pad_h, pad_w;
@@ -295,6 +299,13 @@ int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, 
 /* per-channel column sum of a bf16 [m,c] matrix ADDED (float atomics) to fp32 out[c] (bias gradients;
  * the flat gradient buffer is zeroed at the start of a step) */
 int frcnn_colsum_bf16(const frcnn_bf16* x, int64_t m, int c, int ld, float* out, frcnn_stream_t stream);
+/* The same column sums fused with the pass that produces the matrix (one launch and one read of it less; [m][c] row-major, c % 8 == 0,
+ * 16-byte aligned; colsum accumulates, as frcnn_colsum_bf16):
+ *   frcnn_cast_colsum:      dst = bf16(src);  colsum[col] += sum_rows dst   -- the RPN head gradient scattered in fp32 and its bias gradient
+ *   frcnn_relu_bwd_colsum:  out = act > 0 ? g : 0;  colsum[col] += sum_rows out   -- the ReLU backward of the RPN's 3x3 layer
+ *                           (models/detectors/rpn_detector.py:26-34) and that layer's bias gradient */
+int frcnn_cast_colsum(const float* src, frcnn_bf16* dst, int64_t m, int c, float* colsum, frcnn_stream_t stream);
+int frcnn_relu_bwd_colsum(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, int64_t m, int c, float* colsum, frcnn_stream_t stream);
 
 /* out = [ReLU](BN(z) + BN2(z2)) with batch statistics for both BatchNorm layers in one pass (the block-final BatchNorm of a
  * stage's first bottleneck block and the BatchNorm of its shortcut convolution, reference Keras ResNet50 conv*_block1_0_bn /
@@ -332,6 +343,26 @@ int frcnn_sgd_momentum(float* w, const float* g, float* v, frcnn_bf16* w_bf16, i
                        float grad_scale, const int64_t* step, const int64_t* boundaries, const float* values, int nb,
                        frcnn_stream_t stream);
 int frcnn_step_increment(int64_t* step, frcnn_stream_t stream);
+/* The whole optimizer step of a training plan in ONE launch (was: one frcnn_sgd_momentum per decay range + frcnn_stem_pack_weights
+ * + frcnn_step_increment): frcnn_sgd_momentum over the n elements of the flat buffers, where
+ *   - elements [0, decay_end) take the regulariser l2, the rest none (the L2-regularised kernels are registered first);
+ *   - stem (optional): the 7x7x3 stem kernel occupies [stem_begin, stem_begin + stem_cout * 147) of w; every updated value of it
+ *     is also written, as bf16, to its place in the packed [stem_cout][7][8][4] tap layout the stem convolution reads
+ *     (padding taps stay as they are: zero);
+ *   - *step is incremented by 1 AFTER every workgroup has read it: each workgroup bumps *arrive (device uint32, zero before the
+ *     launch) when it is done and the last one resets it to zero and increments the step -- same arithmetic as the separate launches,
+ *     element for element. */
+typedef struct frcnn_sgd_fused {
+    int64_t decay_end;
+    float l2;
+    int64_t stem_begin;           /* -1: no stem re-pack */
+    int stem_cout;
+    frcnn_bf16* stem_packed;
+    uint32_t* arrive;
+} frcnn_sgd_fused;
+int frcnn_sgd_momentum_fused(float* w, const float* g, float* v, frcnn_bf16* w_bf16, int64_t n, float momentum, float grad_scale,
+                             int64_t* step, const int64_t* boundaries, const float* values, int nb, const frcnn_sgd_fused* f,
+                             frcnn_stream_t stream);
 
 /* ------------------------------------------------------------------ boxes / RPN / NMS */
 
@@ -370,6 +401,14 @@ int frcnn_nms_combined(const float* boxes, const float* scores, int b, int n, in
                        int score_offset, int max_per_class, int max_total, float iou_thr, float score_thr,
                        float* out_boxes, float* out_scores, int32_t* out_classes, int32_t* out_valid,
                        void* workspace, size_t workspace_bytes, frcnn_stream_t stream);
+/* The same, and in the same launch the kept boxes once more in absolute image coordinates: out_boxes_abs [B,T,4] =
+ * out_boxes * [scale_x, scale_y, scale_x, scale_y] -- to_absolute of the proposals (utils/boxes.py:76-83 as called at
+ * fast_rcnn_detector.py:67), which the Fast-RCNN stage needs as its `regions` (replaces a frcnn_boxes_scale launch). */
+int frcnn_nms_combined_abs(const float* boxes, const float* scores, int b, int n, int q, int c, int score_stride,
+                           int score_offset, int max_per_class, int max_total, float iou_thr, float score_thr,
+                           float* out_boxes, float* out_scores, int32_t* out_classes, int32_t* out_valid,
+                           void* workspace, size_t workspace_bytes, float* out_boxes_abs, float scale_x, float scale_y,
+                           frcnn_stream_t stream);
 
 /* ------------------------------------------------------------------ RoI pooling + heads */
 
@@ -394,6 +433,10 @@ int frcnn_roi_crop_pool_bwd_bf16(const frcnn_bf16* gpooled, const uint8_t* argma
  * nc1 columns -> scores [R,nc1]; columns [nc1, nc1+4*(nc1-1)) -> deltas. */
 int frcnn_rcnn_head_post(const float* logits, int ld, const float* bias, int r, int nc1, float* scores, float* deltas,
                          frcnn_stream_t stream);
+/* The same, and in the same launch the decode step of detection NMS (frcnn_decode_boxes with regions_per_image = 1 on the deltas
+ * just computed): decoded [R, nc1-1, 4] = decode(deltas, regions [R,4] absolute) / [W,H,W,H] (utils/post_processing.py:39-49). */
+int frcnn_rcnn_head_post_decode(const float* logits, int ld, const float* bias, int r, int nc1, float* scores, float* deltas,
+                                const float* regions, float* decoded, float img_w, float img_h, frcnn_stream_t stream);
 /* rois_abs = rois_rel * [W,H,W,H]  (utils/boxes.py:76-83, fast_rcnn_detector.py:67) */
 int frcnn_boxes_scale(const float* in, float* out, int64_t n, float sx, float sy, frcnn_stream_t stream);
 
@@ -460,6 +503,8 @@ int frcnn_losses(const float* scores, const float* deltas, const float* target_l
 int frcnn_losses_head_grad(const float* scores, const float* deltas, const float* target_labels, const float* target_boxes,
                            const int32_t* indices, int b, int r, int c1, int s, float cls_scale, float reg_scale,
                            float* losses, float* dlogits_s, float* ddeltas_s, frcnn_bf16* dhead_s, int ld, int32_t* rows_out,
+                           float* bias_grad /* optional, ld <= 64: += the column sums of dhead_s, exactly what
+                           frcnn_colsum_bf16(dhead_s, B*S, ld, ld, bias_grad) adds (the Dense heads' bias gradient) */,
                            frcnn_stream_t stream);
 /* frcnn_losses (C1 = 2) followed by frcnn_rpn_head_grad in ONE launch: the per-sample gradients are scatter-ADDED into dhead
  * [B*gh*gw, ld] (pre-zeroed) as frcnn_rpn_head_grad would; dlogits_s / ddeltas_s may be NULL. */

@@ -79,7 +79,7 @@ def test_every_fpn_plan_instantiation_has_a_parity_case(monkeypatch, ops):
     covered = conv_cases.covered_instantiations(ops)
     for batch, precision in ((8, "fp8"), (4, "bf16"), (2, "bf16")):
         used, launches = _plan_instantiations(monkeypatch, 50, batch, precision=precision, topology="fpn")
-        assert launches >= 280
+        assert launches >= 260           # (round 4: 12 + 4 x 2 launches folded into their neighbours)
         missing = sorted(k for k in used if k not in covered)
         assert not missing, "conv kernels of the FPN R50 batch-%d %s train plan without an oracle-compared GPU case:\n  %s" % (
             batch, precision, "\n  ".join(missing))

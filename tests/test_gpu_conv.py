@@ -332,8 +332,14 @@ def test_conv_wgrad_stem_and_rowindex(ops):
     ops.conv2d_wgrad(d, xflat, dz.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dwp)
     dw = torch.empty(64, 7, 7, 3, device="cuda")
     ops.stem_unpack_grad(dwp, dw)
+    # ... and the form the train plan uses: the 7 x 3 real values of every tap row stored straight into the Keras-layout gradient
+    du = ops.conv_desc(n, hp, wp, 32, 7, 1, 2, 0, 0, ho, wo, 64, in_pix_stride=4, flags=ops.CONV_WGRAD_STEM_UNPACK)
+    dw_direct = torch.zeros(64, 7, 7, 3, device="cuda")
+    ops.conv2d_wgrad(du, xflat, dz.permute(0, 2, 3, 1).contiguous().to(BF).cuda(), dw_direct)
     torch.cuda.synchronize()
     _close(dw, ref, 2e-4, 2e-3 * (n * ho * wo) ** 0.5, "stem wgrad")
+    _close(dw_direct, ref, 2e-4, 2e-3 * (n * ho * wo) ** 0.5, "stem wgrad, unpacked in the store")
+    _close(dw_direct, dw.cpu(), 1e-5, 1e-4, "stem wgrad: direct store against packed + unpack")      # (float-atomic order)
     # Dense-head form: rows gathered through row_index, dz padded to 64 columns
     R, K, S = 40, 1024, 24
     pooled = _rt(torch.randn(R, K, generator=g))

@@ -797,3 +797,141 @@ def test_metrics_on_device_match_loop_oracle():
     b1 = torch.rand(5, 4)
     b1[:, 2:] += b1[:, :2]
     assert torch.equal(MET.iou(b1.cuda(), b1.cuda(), pairwise=True).cpu(), om.iou(b1, b1, pairwise=True))
+
+
+# ------------------------------------------------------------------ round 4: launches folded into their neighbours (each fused form == its parts)
+def test_sgd_fused_equals_separate_launches(ops):
+    """frcnn_sgd_momentum_fused == frcnn_sgd_momentum per decay range + frcnn_stem_pack_weights + frcnn_step_increment, bit for bit; the
+    step counter moves exactly once however many workgroups the launch has, and the arrival counter is left at zero."""
+    g = torch.Generator().manual_seed(31)
+    dev = "cuda"
+    n, decay_end, stem_begin, cout = 300_000, 70_016, 120_000, 64
+    w, gr, v = torch.randn(n, generator=g), torch.randn(n, generator=g), torch.randn(n, generator=g)
+    bounds = torch.tensor([40000, 80000, 0], dtype=torch.int64, device=dev)
+    values = torch.tensor([1e-3, 1e-4, 1e-5], device=dev)
+    for step_val in (0, 40001):
+        wa, va, wb_a = w.to(dev), v.to(dev), torch.zeros(n, dtype=BF, device=dev)
+        wbb, vb, wb_b = w.to(dev), v.to(dev), torch.zeros(n, dtype=BF, device=dev)
+        gd = gr.to(dev)
+        step_a = torch.tensor([step_val], dtype=torch.int64, device=dev)
+        step_b = step_a.clone()
+        pk_a = torch.full((cout, 7, 8, 4), 9.0, dtype=BF, device=dev)
+        pk_b = torch.zeros(cout, 7, 8, 4, dtype=BF, device=dev)        # (the fused form only writes the 7 x 7 x 3 real taps: padding stays as allocated, zero)
+        ops.sgd_momentum(wa[:decay_end], gd[:decay_end], va[:decay_end], wb_a[:decay_end], decay_end, 0.9, 0.0005, 1.0, step_a, bounds, values, 2)
+        ops.sgd_momentum(wa[decay_end:], gd[decay_end:], va[decay_end:], wb_a[decay_end:], n - decay_end, 0.9, 0.0, 1.0, step_a, bounds, values, 2)
+        ops.stem_pack_weights(wa[stem_begin:stem_begin + cout * 147], pk_a, cout)
+        ops.step_increment(step_a)
+        arrive = torch.zeros(4, dtype=torch.int32, device=dev)
+        fused = ops.sgd_fused_args(decay_end, 0.0005, arrive, stem_begin, cout, pk_b)
+        ops.sgd_momentum_fused(wbb, gd, vb, wb_b, n, 0.9, 1.0, step_b, bounds, values, 2, fused)
+        torch.cuda.synchronize()
+        assert torch.equal(wa, wbb) and torch.equal(va, vb) and torch.equal(wb_a.view(torch.int16), wb_b.view(torch.int16))
+        assert torch.equal(pk_a.view(torch.int16), pk_b.view(torch.int16)), "packed stem taps"
+        assert int(step_a) == int(step_b) == step_val + 1 and int(arrive[0]) == 0
+        ops.sgd_momentum_fused(wbb, gd, vb, wb_b, n, 0.9, 1.0, step_b, bounds, values, 2, fused)       # a second launch on the reset counter
+        torch.cuda.synchronize()
+        assert int(step_b) == step_val + 2 and int(arrive[0]) == 0
+
+
+@pytest.mark.parametrize("m,c", [(7488, 128), (200, 64), (29952, 256)])
+def test_cast_and_relu_colsum_fused_equal_two_launches(ops, m, c):
+    """frcnn_cast_colsum == frcnn_cast_f32_bf16 + frcnn_colsum_bf16 and frcnn_relu_bwd_colsum == frcnn_relu_bwd + frcnn_colsum_bf16: the
+    stored matrices bit for bit; the sums equal up to the arrival order of one float atomic per (column, 256-row chunk) -- exactly when
+    there is a single chunk."""
+    g = torch.Generator().manual_seed(m + c)
+    dev = "cuda"
+    src = (torch.randn(m, c, generator=g) * 0.1).to(dev)
+    src[::3] = 0.0
+    d_a, d_b = torch.empty(m, c, dtype=BF, device=dev), torch.empty(m, c, dtype=BF, device=dev)
+    s_a, s_b = torch.full((c,), 0.5, device=dev), torch.full((c,), 0.5, device=dev)
+    ops.cast_f32_bf16(src, d_a)
+    ops.colsum_bf16(d_a, m, c, c, s_a)
+    ops.cast_colsum(src, d_b, m, c, s_b)
+    gg = torch.randn(m, c, generator=g).to(BF).to(dev)
+    act = torch.randn(m, c, generator=g).clamp(min=0).to(BF).to(dev)
+    r_a, r_b = torch.empty_like(gg), torch.empty_like(gg)
+    t_a, t_b = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    ops.relu_bwd(gg, act, r_a)
+    ops.colsum_bf16(r_a, m, c, c, t_a)
+    ops.relu_bwd_colsum(gg, act, r_b, m, c, t_b)
+    torch.cuda.synchronize()
+    assert torch.equal(d_a.view(torch.int16), d_b.view(torch.int16)) and torch.equal(r_a.view(torch.int16), r_b.view(torch.int16))
+    if m <= 256:
+        assert torch.equal(s_a, s_b) and torch.equal(t_a, t_b)
+    _close(s_b, s_a.cpu(), 1e-6, 1e-6, "cast + column sums")
+    _close(t_b, t_a.cpu(), 1e-6, 1e-5, "ReLU backward + column sums")
+    _close(t_b, r_a.double().sum(0).float().cpu(), 1e-5, 1e-3, "column sums against torch")
+
+
+@pytest.mark.parametrize("B,N,q,C,mpc,mt", [(2, 8768, 1, 1, 300, 300), (2, 300, 7, 7, 100, 300)])
+def test_nms_combined_abs_equals_nms_then_scale(ops, B, N, q, C, mpc, mt):
+    """frcnn_nms_combined_abs == frcnn_nms_combined + frcnn_boxes_scale on its boxes (single-class and merged forms), bit for bit."""
+    g = torch.Generator().manual_seed(N)
+    dev = "cuda"
+    boxes = _random_boxes(g, B, N, q).to(dev)
+    scores = torch.stack([torch.randperm(N * C, generator=g) for _ in range(B)]).reshape(B, N, C).float().add(1).div(N * C + 1).to(dev)
+    outs = []
+    for fused in (False, True):
+        ob, os_ = torch.full((B, mt, 4), -1.0, device=dev), torch.full((B, mt), -1.0, device=dev)
+        oc, ov = torch.full((B, mt), -1, dtype=torch.int32, device=dev), torch.full((B,), -1, dtype=torch.int32, device=dev)
+        oa = torch.full((B, mt, 4), -1.0, device=dev)
+        ws = torch.empty(ops.nms_workspace_bytes(B, N, C, mpc, mt), dtype=torch.uint8, device=dev)
+        if fused:
+            ops.nms_combined_abs(boxes, scores, B, N, q, C, C, 0, mpc, mt, 0.7, 0.0, ob, os_, oc, ov, ws, oa, 1242.0, 375.0)
+        else:
+            ops.nms_combined(boxes, scores, B, N, q, C, C, 0, mpc, mt, 0.7, 0.0, ob, os_, oc, ov, ws)
+            ops.boxes_scale(ob, oa, 1242.0, 375.0)
+        torch.cuda.synchronize()
+        outs.append((ob, os_, oc, ov, oa))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float(outs[1][4].max()) > 300.0
+
+
+def test_rcnn_head_post_decode_equals_two_launches(ops):
+    """frcnn_rcnn_head_post_decode == frcnn_rcnn_head_post + frcnn_decode_boxes (per-image regions), bit for bit."""
+    g = torch.Generator().manual_seed(16)
+    dev = "cuda"
+    B, P, c1, ld = 2, 300, 8, 64
+    R = B * P
+    logits = torch.randn(R, ld, generator=g).to(dev)
+    bias = torch.randn(ld, generator=g).to(dev)
+    ctr = torch.rand(B, P, 2, generator=g) * torch.tensor([1242.0, 375.0])
+    sz = torch.rand(B, P, 2, generator=g) * 200 + 8
+    regions = torch.cat([ctr - sz / 2, ctr + sz / 2], -1).to(dev)
+    s_a, d_a = torch.empty(B, P, c1, device=dev), torch.empty(B, P, c1 - 1, 4, device=dev)
+    s_b, d_b = torch.empty_like(s_a), torch.empty_like(d_a)
+    dec_a, dec_b = torch.empty(B, P, c1 - 1, 4, device=dev), torch.empty(B, P, c1 - 1, 4, device=dev)
+    ops.rcnn_head_post(logits, ld, bias, R, c1, s_a, d_a)
+    ops.decode_boxes(regions, d_a, dec_a, B, P, c1 - 1, 1242, 375)
+    ops.rcnn_head_post_decode(logits, ld, bias, R, c1, s_b, d_b, regions, dec_b, 1242, 375)
+    torch.cuda.synchronize()
+    assert torch.equal(s_a, s_b) and torch.equal(d_a, d_b)
+    assert torch.equal(dec_a, dec_b) and bool(torch.isfinite(dec_b).all())
+
+
+@pytest.mark.parametrize("B,S", [(4, 64), (8, 64), (2, 16)])
+def test_losses_head_grad_bias_gradient_equals_colsum(ops, B, S):
+    """frcnn_losses_head_grad(bias_grad=...) adds exactly what frcnn_colsum_bf16 adds from the head-gradient rows it writes (same
+    chunking, same order of additions: bit for bit, also over two 256-row chunks at batch 8)."""
+    g = torch.Generator().manual_seed(23 + B)
+    dev = "cuda"
+    R, c1, C, ld = 300, 8, 7, 64
+    scores = torch.softmax(torch.randn(B, R, c1, generator=g), -1).to(dev)
+    deltas = (torch.randn(B, R, C, 4, generator=g) * 1.5).to(dev)
+    tl = F.one_hot(torch.randint(0, c1, (B, R), generator=g), c1).float()
+    tb = torch.zeros(B, R, C, 4)
+    fg = tl[..., 0] == 0
+    tb[fg, tl[..., 1:].argmax(-1)[fg]] = torch.randn(int(fg.sum()), 4, generator=g)
+    idx = torch.randint(0, R, (B, S), generator=g, dtype=torch.int32).to(dev)
+    tl, tb = tl.to(dev), tb.to(dev)
+    out = torch.empty(2, device=dev)
+    rows = torch.empty(B * S, dtype=torch.int32, device=dev)
+    h_a, h_b = torch.empty(B * S, ld, dtype=BF, device=dev), torch.empty(B * S, ld, dtype=BF, device=dev)
+    bg_a, bg_b = torch.zeros(ld, device=dev), torch.zeros(ld, device=dev)
+    ops.losses_head_grad(scores, deltas, tl, tb, idx, B, R, c1, S, 0.25, 1.0, out, None, None, h_a, ld, rows)
+    ops.colsum_bf16(h_a, B * S, ld, ld, bg_a)
+    ops.losses_head_grad(scores, deltas, tl, tb, idx, B, R, c1, S, 0.25, 1.0, out, None, None, h_b, ld, rows, bias_grad=bg_b)
+    torch.cuda.synchronize()
+    assert torch.equal(h_a.view(torch.int16), h_b.view(torch.int16))
+    assert float(bg_a.abs().sum()) > 0 and torch.equal(bg_a, bg_b), (bg_a - bg_b).abs().max()

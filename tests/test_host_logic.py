@@ -168,9 +168,9 @@ def test_gradient_buckets_coincide_with_plan_segments(monkeypatch):
             for fn, args, kwargs, _br in seg:
                 if fn is None:
                     continue
-                if fn is ops.sgd_momentum and first_update is None:
+                if fn in (ops.sgd_momentum, ops.sgd_momentum_fused) and first_update is None:
                     first_update = si
-                if fn is ops.sgd_momentum:
+                if fn in (ops.sgd_momentum, ops.sgd_momentum_fused):
                     continue
                 for off in _grad_writes(ops, model.store, fn, args, kwargs):
                     j = next(i for i, (_n, b, e) in enumerate(buckets) if b <= off < e)

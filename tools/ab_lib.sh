@@ -6,7 +6,7 @@
 i=0
 for v in ${AB_LIST}; do
   i=$((i+1))
-  env FRCNN_LIB=lib2dod_hip_sweep.so ${v//+/ } timeout -k 10 200 python bench.py --no-cpu-baseline --profile-steps 0 --windows 3 $BENCH_ARGS > gpurun_out/abl_$i.json 2>/dev/null
+  env FRCNN_LIB=lib2dod_hip_sweep.so ${v//+/ } timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-configs --no-segmented --profile-steps 0 --windows 3 $BENCH_ARGS > gpurun_out/abl_$i.json 2>/dev/null
   python - <<PY
 import json
 d=json.load(open("gpurun_out/abl_$i.json"))
