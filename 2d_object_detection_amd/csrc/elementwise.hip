@@ -249,7 +249,10 @@ __device__ __forceinline__ void store_fp8_pair(uint8_t* dst, const u32x2 q, cons
 }
 
 #ifndef FRCNN_BN_U
-#define FRCNN_BN_U 4                 // rows per thread and round of the strip kernels' streaming loops (A/B builds: FRCNN_DEFINES=FRCNN_BN_U=1)
+// rows per thread and round of the strip kernels' streaming loops, all their loads issued before the first is consumed.  Measured in
+// the step on one box (round 4, tools/ab_lib.sh, FRCNN_DEFINES=FRCNN_BN_U=n): 1: 4.215 ms, 4: 4.315 ms -- more bytes in flight per
+// wave cost more (118 / 157 VGPRs, fewer resident waves) than they bring: these kernels are not bound by the latency of one row
+#define FRCNN_BN_U 1
 #endif
 
 struct Bn2 {
@@ -414,10 +417,10 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
             }
         }
     };
-    // U rows per thread and round, ALL their loads issued before the first is consumed: the kernel is bound by bytes in flight
-    // (~16 waves per CU x 16-32 B per lane with one row at a time: a quarter of what HBM latency x bandwidth asks for).  The loop
-    // bound is uniform on purpose: `#pragma unroll` on the per-thread form (r = row_begin + rl; r < row_end) is REFUSED by the
-    // compiler -- a divergent trip count around the cross-lane pooling of finish() -- and left one row in flight (rounds 1-3).
+    // U rows per thread and round, all their loads issued before the first is consumed (FRCNN_BN_U; uniform loop bound: `#pragma
+    // unroll` on the per-thread form r = row_begin + rl; r < row_end is refused by the compiler -- a divergent trip count around the
+    // cross-lane pooling of finish() -- so rounds 1-3 ran one row at a time without saying so).  Measured: U = 4 is SLOWER than U = 1
+    // in the step (4.315 vs 4.215 ms on one box): the kernel is not bound by the latency of a single row per wave.
     constexpr int U = VAR == 4 ? 1 : FRCNN_BN_U;
     for (int64_t rb = row_begin; rb < row_end; rb += 32 * U) {
         u32x4 zraw[U], qraw[U];
@@ -622,8 +625,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
     // optional fp8 twin of dz for the fp8 data-gradient convolution: e5m2 bytes of the STORED bf16 value times *dz8_qscale
     const float f8_qs = dz8 ? *dz8_qscale : 0.f;
     float f8_max = 0.f;
-    // U rows per thread and round with all their loads issued first (see bn_train_apply_kernel: the per-thread loop could not be
-    // unrolled by the compiler); the rows of a thread are still consumed in order, so the error-feedback chain is unchanged.
+    // U rows per thread and round (FRCNN_BN_U, see bn_train_apply_kernel); the rows of a thread are consumed in order, so the
+    // error-feedback chain does not depend on U.
     constexpr int U = LEGACY == 1 ? 1 : FRCNN_BN_U;
     for (int64_t rb = row_begin; rb < row_end; rb += 32 * U) {
         u32x4 graw[U], zraw[U], araw[U];

@@ -9,6 +9,7 @@
 // channels so that every float-atomic wave instruction adds 256 contiguous bytes of one
 // feature-map pixel.
 #include "common.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -166,6 +167,176 @@ __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__
         a[0] = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
         a[1] = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
         *reinterpret_cast<u32x2*>(amax + o * 8) = a;
+    }
+}
+
+// ---- 2 x 2 pooling window, round 4 form.  The round-3 kernel above spends 527 VALU instructions per (bin, 8-channel vector) item and is
+// VALU-bound (rocprofv3 --pmc, profiles/r03_c_pmc_counters.txt).  Three changes, same arithmetic per element (bit-identical output):
+//   1. A wave owns whole bins (lanes = channel vectors), so everything that depends on the bin alone -- tap offsets, interpolation
+//      weights, validity -- is WAVE-UNIFORM: read once per wave from the LDS tables into scalar registers instead of per lane (with
+//      32-channel-vector slices a wave carries two bins, one per half: two scalar sets and one select per value).
+//   2. The 2 x 2 samples of a bin lie a fraction of a cell apart whenever the proposal is small: when both sample rows fall between the
+//      same two feature rows (and / or both columns between the same two feature columns) the taps are the same cells -- loaded and
+//      unpacked once (4 or 8 taps instead of 16), and the horizontal interpolations of a shared row pair are computed once per sample
+//      column instead of once per sample.  The case is a wave-uniform branch.
+//   3. The interpolations run on channel PAIRS (v_pk_add_f32 / v_pk_fma_f32).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool RS, bool CS, int HALVES>
+__device__ __forceinline__ void roi_bin_ks2(const __amdgpu_buffer_rsrc_t rs, const unsigned c16, const unsigned (&rowoff)[4], const unsigned (&coloff)[4],
+                                            const float (&ly)[2], const float (&lx)[2], bf16_t* __restrict__ pooled_o, uint8_t* __restrict__ amax_o,
+                                            const bool store) {
+    constexpr int NR = RS ? 2 : 4, NC = CS ? 2 : 4;
+    f32x2 f[NR][NC][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, rowoff[r] + coloff[c] + c16, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[r][c][q] = f32x2{__uint_as_float(raw[q] << 16), __uint_as_float(raw[q] & 0xFFFF0000u)};
+        }
+    }
+    // horizontal interpolation of every (feature row, sample column) pair in use
+    f32x2 hz[NR][2][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int clo = CS ? 0 : 2 * j, chi = CS ? 1 : 2 * j + 1;
+            const f32x2 w = {lx[j], lx[j]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hz[r][j][q] = __builtin_elementwise_fma(f[r][chi][q] - f[r][clo][q], w, f[r][clo][q]);
+        }
+    }
+    float v[4][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rlo = RS ? 0 : 2 * i, rhi = RS ? 1 : 2 * i + 1;
+        const f32x2 w = {ly[i], ly[i]};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 t = __builtin_elementwise_fma(hz[rhi][j][q] - hz[rlo][j][q], w, hz[rlo][j][q]);
+                v[i * 2 + j][2 * q] = t[0];
+                v[i * 2 + j][2 * q + 1] = t[1];
+            }
+        }
+    }
+    float best[8];
+    unsigned arg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        best[e] = fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0][e], v[1][e]), v[2][e]), v[3][e]);
+        arg[e] = v[0][e] == best[e] ? 0u : v[1][e] == best[e] ? 1u : v[2][e] == best[e] ? 2u : 3u;
+    }
+    if (store) {
+        *reinterpret_cast<u32x4*>(pooled_o) = pack8(best);
+        u32x2 a;
+        a[0] = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+        a[1] = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+        *reinterpret_cast<u32x2*>(amax_o) = a;
+    }
+}
+
+template <int HALVES>     // bins per wave: 1 (channel-vector slices in multiples of 64) or 2 (slices of 32)
+__global__ __launch_bounds__(256) void roi_fwd_ks2_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ rois, int P, int Hf, int Wf, int C8,
+                                                          int ps, bf16_t* __restrict__ pooled, uint8_t* __restrict__ amax, int nsplit, int npairs,
+                                                          const int* __restrict__ levels, int level) {
+    int row, cv_begin, cv_count;
+    {   // workgroup -> (RoI, channel slice): as roi_fwd_kernel (one (image, slice) pair per XCD lane)
+        const int lanes_x = npairs < 8 ? npairs : 8;
+        const int xcd = blockIdx.x % lanes_x, q = blockIdx.x / lanes_x;
+        const int pair = xcd + lanes_x * (q / P);
+        const int p_ = q % P;
+        if (pair >= npairs) return;
+        const int b_ = pair / nsplit, slice = pair - b_ * nsplit;
+        row = b_ * P + p_;
+        cv_count = C8 / nsplit;
+        cv_begin = slice * cv_count;
+    }
+    const int b = row / P;
+    const int crop = ps * 2;
+    if (levels && levels[row] != level) return;
+    // {first tap byte offset, second tap byte offset, weight bits} per crop row / column; a sample outside the map points both taps
+    // 1 GiB beyond the descriptor: the range check returns zeros for all four taps and the interpolation of zeros is exactly 0
+    __shared__ int4 ys[kMaxCrop], xs[kMaxCrop];
+    if ((int)threadIdx.x < 2 * crop) {
+        const RoiGeom g = roi_geom(rois + (int64_t)row * 4, Hf, Wf, crop);
+        const bool is_x = (int)threadIdx.x >= crop;
+        const int k = is_x ? threadIdx.x - crop : threadIdx.x;
+        const float in = is_x ? g.x1s + (float)k * g.ws : g.y1s + (float)k * g.hs;
+        const float lim = is_x ? (float)(Wf - 1) : (float)(Hf - 1);
+        const bool ok = in >= 0.f && in <= lim;                // NaN-safe
+        const float lo = floorf(in), hi = ceilf(in), w = in - lo;
+        const int pitch = (is_x ? 1 : Wf) * C8 * 16;
+        int4 e;
+        e.x = ok ? (int)lo * pitch : 0x40000000;
+        e.y = ok ? (int)hi * pitch : 0x40000000;
+        e.z = __float_as_int(ok ? w : 0.f);
+        e.w = 0;
+        if (is_x) xs[k] = e;
+        else ys[k] = e;
+    }
+    __syncthreads();
+    const unsigned char* fb = reinterpret_cast<const unsigned char*>(feat + (int64_t)b * Hf * Wf * C8 * 8);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fb, 0, Hf * Wf * C8 * 16, 0x00020000);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    const int nbins = ps * ps;
+    const int blocks = HALVES == 2 ? 1 : cv_count / 64;
+    const int units = HALVES == 2 ? (nbins + 1) / 2 : nbins * blocks;
+    const bool upper = HALVES == 2 && lane >= 32;
+    for (int u = wave; u < units; u += nwaves) {
+        // scalar set per bin of this wave: 4 row offsets, 4 column offsets (lo / hi of the two samples), 2 + 2 weights
+        int ro[HALVES][4], co[HALVES][4];
+        float wy[HALVES][2], wx[HALVES][2];
+        int bins[HALVES];
+        bool rsame = true, csame = true;
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) {
+            int bin = HALVES == 2 ? 2 * u + h : u / blocks;
+            bins[h] = bin;
+            if (bin >= nbins) bin = nbins - 1;                   // (odd bin count: the last wave's upper half computes a duplicate, stores nothing)
+            const int ph = bin / ps, pw = bin - ph * ps;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int4 yy = ys[ph * 2 + i], xx = xs[pw * 2 + i];
+                ro[h][2 * i] = __builtin_amdgcn_readfirstlane(yy.x);
+                ro[h][2 * i + 1] = __builtin_amdgcn_readfirstlane(yy.y);
+                wy[h][i] = __int_as_float(__builtin_amdgcn_readfirstlane(yy.z));
+                co[h][2 * i] = __builtin_amdgcn_readfirstlane(xx.x);
+                co[h][2 * i + 1] = __builtin_amdgcn_readfirstlane(xx.y);
+                wx[h][i] = __int_as_float(__builtin_amdgcn_readfirstlane(xx.z));
+            }
+            rsame = rsame && ro[h][0] == ro[h][2] && ro[h][1] == ro[h][3];
+            csame = csame && co[h][0] == co[h][2] && co[h][1] == co[h][3];
+        }
+        unsigned rowoff[4], coloff[4];
+        float ly[2], lx[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rowoff[k] = (unsigned)(HALVES == 2 && upper ? ro[HALVES - 1][k] : ro[0][k]);
+            coloff[k] = (unsigned)(HALVES == 2 && upper ? co[HALVES - 1][k] : co[0][k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            ly[k] = HALVES == 2 && upper ? wy[HALVES - 1][k] : wy[0][k];
+            lx[k] = HALVES == 2 && upper ? wx[HALVES - 1][k] : wx[0][k];
+        }
+        const int bin = HALVES == 2 ? (upper ? bins[HALVES - 1] : bins[0]) : bins[0];
+        const int cv = cv_begin + (HALVES == 2 ? (lane & 31) : (u % blocks) * 64 + lane);
+        const bool store = bin < nbins;
+        const int64_t o = ((int64_t)row * nbins + (store ? bin : 0)) * C8 + cv;
+        const unsigned c16 = (unsigned)cv * 16u;
+        if (rsame) {                                             // (shared rows: slots 0 / 1 serve both samples)
+            if (csame) roi_bin_ks2<true, true, HALVES>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8, store);
+            else roi_bin_ks2<true, false, HALVES>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8, store);
+        } else {
+            if (csame) roi_bin_ks2<false, true, HALVES>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8, store);
+            else roi_bin_ks2<false, false, HALVES>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8, store);
+        }
     }
 }
 
@@ -356,7 +527,19 @@ static int roi_fwd_impl(const frcnn_bf16* feat, const float* rois, int b, int p,
     while (b * nsplit < 8 && (c / 8) % (2 * nsplit) == 0 && (c / 8) / (2 * nsplit) >= 8) nsplit *= 2;
     const int pairs = b * nsplit, lanes_x = pairs < 8 ? pairs : 8, per_lane = (pairs + lanes_x - 1) / lanes_x;
     const dim3 grid((unsigned)(lanes_x * per_lane * p));
-    if (ks == 2)
+    // the round-4 form of the 2 x 2 window wants whole bins per wave (or per half wave): channel-vector slices of 32 or of multiples of 64
+    const int cv_count = (c / 8) / nsplit;
+    int form = ks == 2 ? (cv_count % 64 == 0 ? 1 : cv_count == 32 ? 2 : 0) : 0;
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_ROI_FWD_OLD")) { if (atoi(e)) form = 0; }
+#endif
+    if (form == 1)
+        hipLaunchKernelGGL(roi_fwd_ks2_kernel<1>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(feat), rois,
+                           p, hf, wf, c / 8, ps, reinterpret_cast<bf16_t*>(pooled), argmax, nsplit, pairs, levels, level);
+    else if (form == 2)
+        hipLaunchKernelGGL(roi_fwd_ks2_kernel<2>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(feat), rois,
+                           p, hf, wf, c / 8, ps, reinterpret_cast<bf16_t*>(pooled), argmax, nsplit, pairs, levels, level);
+    else if (ks == 2)
         hipLaunchKernelGGL(roi_fwd_kernel<2>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                            reinterpret_cast<const bf16_t*>(feat), rois, p, hf, wf, c / 8, ps, ks, reinterpret_cast<bf16_t*>(pooled), argmax, nsplit, pairs, levels, level);
     else

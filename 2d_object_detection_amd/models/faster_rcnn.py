@@ -495,14 +495,17 @@ class FasterRCNN:
             self._sync_derived_weights(self._train)
             self._weights_dirty = False
             self._feed(built, images, gt_labels, gt_boxes)
-            if self.use_graphs:
-                # warm-up eagerly on a scratch copy of the mutable state, then capture
+            if self.use_graphs or self.get_fp8_state() is not None:
+                # warm-up eagerly on a scratch copy of the mutable state, then capture.  In fp8 mode the same run is the calibration
+                # pass of the delayed scales (kept: the first real step quantises with measured scales, not with 1) -- also without
+                # graphs, so that eager and replayed runs are the same computation
                 state = self._snapshot(optimizer)
                 self._run_with_collectives(built["plan"])
                 torch.cuda.synchronize()
                 self._restore(state, optimizer, fp8_scales=False)
-                built["plan"].capture()
-                self._restore(state, optimizer, fp8_scales=False)
+                if self.use_graphs:
+                    built["plan"].capture()
+                    self._restore(state, optimizer, fp8_scales=False)
             if getattr(self, "_pending_fp8_state", None) is not None:          # a checkpoint's scales win over the warm-up run's
                 self.set_fp8_state(self._pending_fp8_state)
                 self._pending_fp8_state = None

@@ -462,6 +462,44 @@ def test_roi_crop_pool_fwd_bwd(ops):
     _close(gbf, fr.grad, 2 ** -6, 5e-2, "roi grad (gather) vs oracle")
 
 
+@pytest.mark.parametrize("B,C", [(8, 512), (2, 1024), (4, 1024), (8, 256)])
+def test_roi_fwd_wave_uniform_form_equals_generic_kernel(ops, B, C):
+    """The round-4 form of the fused crop + pool forward (a wave owns whole bins: scalar tap offsets / weights, taps shared between the
+    samples of a bin that fall into the same cells, packed-pair interpolation) against (a) the oracle and (b) the per-item kernel it
+    replaces, which still serves channel slices that are not 32 or a multiple of 64 vectors wide: 64-channel slices of the same map go
+    through that kernel and must give the same bits.  (8, 512) / (4, 1024): one bin per wave; (2, 1024) / (8, 256): two bins per
+    wave -- 49 bins, so the last wave's upper half is the stores-nothing duplicate.  Boxes: padding rows, the whole image, partly and
+    wholly outside, a few cells wide (shared taps in both axes), one cell wide and many cells wide (no shared taps)."""
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    P, Hf, Wf = 24, 24, 78
+    feat = _rt(torch.randn(B, Hf, Wf, C, generator=g))
+    x0, y0 = torch.rand(B, P, generator=g) * 0.8, torch.rand(B, P, generator=g) * 0.8
+    wh = torch.rand(B, P, 2, generator=g) * torch.tensor([0.02, 0.05, 0.1, 0.2, 0.5, 0.9]).repeat(4)[None, :, None]
+    rois = torch.stack([x0, y0, x0 + wh[..., 0] + 0.004, y0 + wh[..., 1] + 0.01], -1)
+    rois[0, 0] = 0.0
+    rois[0, 1] = torch.tensor([0.0, 0.0, 1.0, 1.0])
+    rois[1, 0] = torch.tensor([0.9, 0.9, 1.3, 1.2])
+    rois[1, 1] = torch.tensor([1.1, 0.2, 1.4, 0.6])
+    rois[1, 2] = torch.tensor([-0.2, -0.1, 0.3, 0.4])
+    rois[0, 2] = torch.tensor([0.25, 0.5, 0.25 + 1.0 / 77, 0.5 + 1.0 / 23])           # exactly one cell: integer sample coordinates at the corners
+    exp = oroi.roi_pooling(feat.clone(), rois, 7, 2)
+    dev = "cuda"
+    fd, rd = feat.to(BF).to(dev), rois.to(dev)
+    pooled = torch.empty(B * P, 49 * C, dtype=BF, device=dev)
+    am = torch.empty(B * P, 49 * C, dtype=torch.uint8, device=dev)
+    ops.roi_crop_pool_fwd(fd, rd, B, P, Hf, Wf, C, 7, 2, pooled, am)
+    torch.cuda.synchronize()
+    _close(pooled.view(B, P, -1), exp, 2 ** -7, 2e-2, "roi pooled (round-4 form)")
+    for c0 in (0, C - 64):
+        sl = fd[..., c0:c0 + 64].contiguous()
+        p64 = torch.empty(B * P, 49 * 64, dtype=BF, device=dev)
+        a64 = torch.empty(B * P, 49 * 64, dtype=torch.uint8, device=dev)
+        ops.roi_crop_pool_fwd(sl, rd, B, P, Hf, Wf, 64, 7, 2, p64, a64)
+        torch.cuda.synchronize()
+        assert torch.equal(pooled.view(B * P, 49, C)[:, :, c0:c0 + 64].contiguous().view(torch.int16), p64.view(B * P, 49, 64).view(torch.int16)), "pooled values"
+        assert torch.equal(am.view(B * P, 49, C)[:, :, c0:c0 + 64].contiguous(), a64.view(B * P, 49, 64)), "arg-max bytes"
+
+
 def test_roi_bwd_with_mostly_padding_rois(ops):
     """Regression case of the gather-form backward: more than half of the sampled RoI rows are boxes of zero extent -- the zero
     padding of an NMS output (all at pixel (0,0)) and degenerate boxes at fractional positions.  All ps*ps bins of such a box

@@ -6,8 +6,8 @@ pass + epoch summary (:145-225), `{step, optimizer, model}` checkpoint every 5 e
 :236-239) with restore at start, and the final weight file (:242-244).  Differences, all additive: the data paths may be the
 reference's TFRecord files, files written by `python -m 2d_object_detection_amd.data.build_records`, or a raw KITTI
 directory; `--synthetic N` trains on N generated records instead (no data set in the container); scalars go to
-`<logs-dir>/<time>/faster-rcnn/{train,valid}/scalars.jsonl` with the reference's tag names (TensorBoard's event format
-needs TensorFlow); launched under `python -m torch.distributed.run` every rank reads its own shard of the records and
+`<logs-dir>/<time>/faster-rcnn/{train,valid}/` as a TensorBoard event file (events.out.tfevents.*, data/tfevents.py) and as
+scalars.jsonl, both with the reference's tag names; launched under `python -m torch.distributed.run` every rank reads its own shard of the records and
 gradients are all-reduced over RCCL (one process per GPU).  Image summaries (utils/images.py) are not produced."""
 import argparse
 import datetime
@@ -79,16 +79,22 @@ class Mean:
 
 
 class ScalarWriter:
+    """tf.summary.create_file_writer(directory) + tf.summary.scalar(tag, value, step) (reference train_faster_rcnn.py:102-106,
+    146-154): a TensorBoard event file (events.out.tfevents.*: data/tfevents.py writes the TFRecord-framed Event protos itself)
+    and, beside it, the same scalars as scalars.jsonl for tools without TensorBoard."""
+
     def __init__(self, directory, enabled=True):
-        self.fh = None
+        self.fh = self.events = None
         if enabled:
             os.makedirs(directory, exist_ok=True)
             self.fh = open(os.path.join(directory, "scalars.jsonl"), "a")
+            self.events = importlib.import_module(PKG + ".data.tfevents").EventFileWriter(directory)
 
     def scalar(self, tag, value, step):
         if self.fh:
             self.fh.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
             self.fh.flush()
+            self.events.scalar(tag, value, step)
 
 
 class CheckpointManager:
