@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b, int iters
                 acc[i] = __builtin_elementwise_fma(acc[i], f32x2{a, a}, f32x2{b, b});
             } else {
                 float x = acc[i][0], y = acc[i][1];
-                asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3" : "+v"(x), "+v"(y) : "s"(a), "s"(b));
+                asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3" : "+v"(x), "+v"(y) : "v"(a), "v"(b));
                 acc[i] = f32x2{x, y};
             }
         }
