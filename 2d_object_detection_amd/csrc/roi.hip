@@ -173,8 +173,9 @@ __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__
 // ---- 2 x 2 pooling window, round 4 form.  The round-3 kernel above spends 527 VALU instructions per (bin, 8-channel vector) item and is
 // VALU-bound (rocprofv3 --pmc, profiles/r03_c_pmc_counters.txt).  Three changes, same arithmetic per element (bit-identical output):
 //   1. A wave owns whole bins (lanes = channel vectors), so everything that depends on the bin alone -- tap offsets, interpolation
-//      weights, validity -- is WAVE-UNIFORM: read once per wave from the LDS tables into scalar registers instead of per lane (with
-//      32-channel-vector slices a wave carries two bins, one per half: two scalar sets and one select per value).
+//      weights, validity -- is WAVE-UNIFORM: read once per wave from the LDS tables into scalar registers instead of per lane.  (A two-bins-per-wave form for
+//      32-vector slices was built and measured SLOWER than the per-item kernel -- 122 vs 85 us on the pyramid's 256-channel maps, 220
+//      vs 182 us at 1000 proposals: per-lane selects between two scalar sets and half the tap sharing; such slices stay on roi_fwd_kernel.)
 //   2. The 2 x 2 samples of a bin lie a fraction of a cell apart whenever the proposal is small: when both sample rows fall between the
 //      same two feature rows (and / or both columns between the same two feature columns) the taps are the same cells -- loaded and
 //      unpacked once (4 or 8 taps instead of 16), and the horizontal interpolations of a shared row pair are computed once per sample
@@ -182,16 +183,17 @@ __global__ __launch_bounds__(256) void roi_fwd_kernel(const bf16_t* __restrict__
 //   3. The interpolations run on channel PAIRS (v_pk_add_f32 / v_pk_fma_f32).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool RS, bool CS, int HALVES>
+template <bool RS, bool CS>
 __device__ __forceinline__ void roi_bin_ks2(const __amdgpu_buffer_rsrc_t rs, const unsigned c16, const unsigned (&rowoff)[4], const unsigned (&coloff)[4],
-                                            const float (&ly)[2], const float (&lx)[2], bf16_t* __restrict__ pooled_o, uint8_t* __restrict__ amax_o,
-                                            const bool store) {
+                                            const float (&ly)[2], const float (&lx)[2], bf16_t* __restrict__ pooled_o, uint8_t* __restrict__ amax_o) {
     constexpr int NR = RS ? 2 : 4, NC = CS ? 2 : 4;
     f32x2 f[NR][NC][4];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            // (the whole offset in the VECTOR operand: the descriptor's range check -- which turns an outside sample into zeros -- is
+            // specified on the vector offset; a scalar offset would be subtracted from the record count instead)
             const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, rowoff[r] + coloff[c] + c16, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) f[r][c][q] = f32x2{__uint_as_float(raw[q] << 16), __uint_as_float(raw[q] & 0xFFFF0000u)};
@@ -231,21 +233,19 @@ __device__ __forceinline__ void roi_bin_ks2(const __amdgpu_buffer_rsrc_t rs, con
         best[e] = fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0][e], v[1][e]), v[2][e]), v[3][e]);
         arg[e] = v[0][e] == best[e] ? 0u : v[1][e] == best[e] ? 1u : v[2][e] == best[e] ? 2u : 3u;
     }
-    if (store) {
-        *reinterpret_cast<u32x4*>(pooled_o) = pack8(best);
-        u32x2 a;
-        a[0] = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
-        a[1] = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
-        *reinterpret_cast<u32x2*>(amax_o) = a;
-    }
+    *reinterpret_cast<u32x4*>(pooled_o) = pack8(best);
+    u32x2 a;
+    a[0] = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+    a[1] = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+    *reinterpret_cast<u32x2*>(amax_o) = a;
 }
 
-template <int HALVES>     // bins per wave: 1 (channel-vector slices in multiples of 64) or 2 (slices of 32)
+// channel-vector slices in multiples of 64: a wave = one bin x 64 channel vectors
 __global__ __launch_bounds__(256) void roi_fwd_ks2_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ rois, int P, int Hf, int Wf, int C8,
                                                           int ps, bf16_t* __restrict__ pooled, uint8_t* __restrict__ amax, int nsplit, int npairs,
                                                           const int* __restrict__ levels, int level) {
     int row, cv_begin, cv_count;
-    {   // workgroup -> (RoI, channel slice): as roi_fwd_kernel (one (image, slice) pair per XCD lane)
+    {   // workgroup -> (RoI, channel slice): as roi_fwd_kernel (the (image, slice) pairs dealt over the XCD lanes)
         const int lanes_x = npairs < 8 ? npairs : 8;
         const int xcd = blockIdx.x % lanes_x, q = blockIdx.x / lanes_x;
         const int pair = xcd + lanes_x * (q / P);
@@ -284,58 +284,34 @@ __global__ __launch_bounds__(256) void roi_fwd_ks2_kernel(const bf16_t* __restri
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fb, 0, Hf * Wf * C8 * 16, 0x00020000);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
-    const int nbins = ps * ps;
-    const int blocks = HALVES == 2 ? 1 : cv_count / 64;
-    const int units = HALVES == 2 ? (nbins + 1) / 2 : nbins * blocks;
-    const bool upper = HALVES == 2 && lane >= 32;
-    for (int u = wave; u < units; u += nwaves) {
-        // scalar set per bin of this wave: 4 row offsets, 4 column offsets (lo / hi of the two samples), 2 + 2 weights
-        int ro[HALVES][4], co[HALVES][4];
-        float wy[HALVES][2], wx[HALVES][2];
-        int bins[HALVES];
-        bool rsame = true, csame = true;
-#pragma unroll
-        for (int h = 0; h < HALVES; ++h) {
-            int bin = HALVES == 2 ? 2 * u + h : u / blocks;
-            bins[h] = bin;
-            if (bin >= nbins) bin = nbins - 1;                   // (odd bin count: the last wave's upper half computes a duplicate, stores nothing)
-            const int ph = bin / ps, pw = bin - ph * ps;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int4 yy = ys[ph * 2 + i], xx = xs[pw * 2 + i];
-                ro[h][2 * i] = __builtin_amdgcn_readfirstlane(yy.x);
-                ro[h][2 * i + 1] = __builtin_amdgcn_readfirstlane(yy.y);
-                wy[h][i] = __int_as_float(__builtin_amdgcn_readfirstlane(yy.z));
-                co[h][2 * i] = __builtin_amdgcn_readfirstlane(xx.x);
-                co[h][2 * i + 1] = __builtin_amdgcn_readfirstlane(xx.y);
-                wx[h][i] = __int_as_float(__builtin_amdgcn_readfirstlane(xx.z));
-            }
-            rsame = rsame && ro[h][0] == ro[h][2] && ro[h][1] == ro[h][3];
-            csame = csame && co[h][0] == co[h][2] && co[h][1] == co[h][3];
-        }
+    const int nbins = ps * ps, blocks = cv_count / 64;
+    for (int u = wave; u < nbins * blocks; u += nwaves) {
+        const int bin = u / blocks;
+        const int ph = bin / ps, pw = bin - ph * ps;
+        // the bin's scalar set: 4 row offsets, 4 column offsets (lo / hi of its two sample rows / columns), 2 + 2 weights
         unsigned rowoff[4], coloff[4];
         float ly[2], lx[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            rowoff[k] = (unsigned)(HALVES == 2 && upper ? ro[HALVES - 1][k] : ro[0][k]);
-            coloff[k] = (unsigned)(HALVES == 2 && upper ? co[HALVES - 1][k] : co[0][k]);
+        for (int i = 0; i < 2; ++i) {
+            const int4 yy = ys[ph * 2 + i], xx = xs[pw * 2 + i];
+            rowoff[2 * i] = (unsigned)__builtin_amdgcn_readfirstlane(yy.x);
+            rowoff[2 * i + 1] = (unsigned)__builtin_amdgcn_readfirstlane(yy.y);
+            ly[i] = __int_as_float(__builtin_amdgcn_readfirstlane(yy.z));
+            coloff[2 * i] = (unsigned)__builtin_amdgcn_readfirstlane(xx.x);
+            coloff[2 * i + 1] = (unsigned)__builtin_amdgcn_readfirstlane(xx.y);
+            lx[i] = __int_as_float(__builtin_amdgcn_readfirstlane(xx.z));
         }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            ly[k] = HALVES == 2 && upper ? wy[HALVES - 1][k] : wy[0][k];
-            lx[k] = HALVES == 2 && upper ? wx[HALVES - 1][k] : wx[0][k];
-        }
-        const int bin = HALVES == 2 ? (upper ? bins[HALVES - 1] : bins[0]) : bins[0];
-        const int cv = cv_begin + (HALVES == 2 ? (lane & 31) : (u % blocks) * 64 + lane);
-        const bool store = bin < nbins;
-        const int64_t o = ((int64_t)row * nbins + (store ? bin : 0)) * C8 + cv;
+        const bool rsame = rowoff[0] == rowoff[2] && rowoff[1] == rowoff[3];
+        const bool csame = coloff[0] == coloff[2] && coloff[1] == coloff[3];
+        const int cv = cv_begin + (u - bin * blocks) * 64 + lane;
+        const int64_t o = ((int64_t)row * nbins + bin) * C8 + cv;
         const unsigned c16 = (unsigned)cv * 16u;
         if (rsame) {                                             // (shared rows: slots 0 / 1 serve both samples)
-            if (csame) roi_bin_ks2<true, true, HALVES>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8, store);
-            else roi_bin_ks2<true, false, HALVES>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8, store);
+            if (csame) roi_bin_ks2<true, true>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8);
+            else roi_bin_ks2<true, false>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8);
         } else {
-            if (csame) roi_bin_ks2<false, true, HALVES>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8, store);
-            else roi_bin_ks2<false, false, HALVES>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8, store);
+            if (csame) roi_bin_ks2<false, true>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8);
+            else roi_bin_ks2<false, false>(rs, c16, rowoff, coloff, ly, lx, pooled + o * 8, amax + o * 8);
         }
     }
 }
@@ -522,22 +498,25 @@ static int roi_fwd_impl(const frcnn_bf16* feat, const float* rois, int b, int p,
     FRCNN_CHECK_ARG(b > 0 && p > 0 && c % 8 == 0 && ps >= 1 && ks >= 1 && ps * ks >= 2 && ks * ks <= 255 && hf > 1 && wf > 1,
                     "roi_crop_pool_fwd: bad sizes");
     FRCNN_CHECK_ARG(ps * ks <= kMaxCrop && 2 * ps * ks <= 256 && (long long)hf * wf * c * 2 < (1ll << 31), "roi_crop_pool_fwd: crop or feature map too large");
-    // channel slices per RoI: enough (image, slice) pairs for the 8 XCDs, slices of at least 8 channel vectors (see the kernel)
+    // channel slices per RoI: enough (image, slice) pairs for the 8 XCDs, slices of at least 8 channel vectors (see the kernel) -- and,
+    // for the 2 x 2 window on maps of >= 64 channel vectors, slices in whole multiples of 64 vectors (the wave-uniform form: a wave owns
+    // whole bins); with fewer than 8 pairs two XCDs share a pair's slice of the map
+    const int c8 = c / 8;
+    const bool uniform_ok = ks == 2 && c8 % 64 == 0;
     int nsplit = 1;
-    while (b * nsplit < 8 && (c / 8) % (2 * nsplit) == 0 && (c / 8) / (2 * nsplit) >= 8) nsplit *= 2;
+    if (uniform_ok) {
+        while (b * nsplit < 8 && c8 % (2 * nsplit) == 0 && (c8 / (2 * nsplit)) % 64 == 0) nsplit *= 2;
+    } else {
+        while (b * nsplit < 8 && c8 % (2 * nsplit) == 0 && c8 / (2 * nsplit) >= 8) nsplit *= 2;
+    }
     const int pairs = b * nsplit, lanes_x = pairs < 8 ? pairs : 8, per_lane = (pairs + lanes_x - 1) / lanes_x;
     const dim3 grid((unsigned)(lanes_x * per_lane * p));
-    // the round-4 form of the 2 x 2 window wants whole bins per wave (or per half wave): channel-vector slices of 32 or of multiples of 64
-    const int cv_count = (c / 8) / nsplit;
-    int form = ks == 2 ? (cv_count % 64 == 0 ? 1 : cv_count == 32 ? 2 : 0) : 0;
+    int form = uniform_ok ? 1 : 0;
 #ifdef FRCNN_SWEEP
     if (const char* e = getenv("FRCNN_ROI_FWD_OLD")) { if (atoi(e)) form = 0; }
 #endif
     if (form == 1)
-        hipLaunchKernelGGL(roi_fwd_ks2_kernel<1>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(feat), rois,
-                           p, hf, wf, c / 8, ps, reinterpret_cast<bf16_t*>(pooled), argmax, nsplit, pairs, levels, level);
-    else if (form == 2)
-        hipLaunchKernelGGL(roi_fwd_ks2_kernel<2>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(feat), rois,
+        hipLaunchKernelGGL(roi_fwd_ks2_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(feat), rois,
                            p, hf, wf, c / 8, ps, reinterpret_cast<bf16_t*>(pooled), argmax, nsplit, pairs, levels, level);
     else if (ks == 2)
         hipLaunchKernelGGL(roi_fwd_kernel<2>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
