@@ -99,6 +99,7 @@ _SIGNATURES = {
     "frcnn_maxpool3x3s2_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "frcnn_sgd_momentum": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, P, P, P, c_int, P]),
     "frcnn_step_increment": (c_int, [P, P]),
+    "frcnn_maxpool3x3s2_bwd_bnreduce": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(BnReduce), P]),
     "frcnn_cast_colsum": (c_int, [P, P, c_int64, c_int, P, P]),
     "frcnn_relu_bwd_colsum": (c_int, [P, P, P, c_int64, c_int, P, P]),
     "frcnn_sgd_momentum_fused": (c_int, [P, P, P, P, c_int64, c_float, c_float, P, P, P, c_int, POINTER(SgdFused), P]),

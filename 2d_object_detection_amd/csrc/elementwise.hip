@@ -248,6 +248,31 @@ __device__ __forceinline__ void store_fp8_pair(uint8_t* dst, const u32x2 q, cons
     if (ok) *reinterpret_cast<u32x2*>(dst) = q;
 }
 
+// Sum of the slot partials of one channel handled by slot lane `sl` (slots sl, sl + 4, ...), both statistics.  With the usual
+// FRCNN_STAT_SLOTS slots the 2 x 4 loads are issued TOGETHER: as a runtime loop they were four dependent L2 round trips -- most of the
+// ~2 us during which a strip workgroup streams nothing (the additions keep the loop's order: same bits).
+template <typename T>
+__device__ __forceinline__ void slot_sums(const T* __restrict__ part, const int slots, const int sl, const int C, const int c, double& s0, double& s1) {
+    s0 = s1 = 0.0;
+#ifndef FRCNN_BN_SLOT_LOOP                       // (A/B builds: FRCNN_DEFINES=FRCNN_BN_SLOT_LOOP keeps the runtime loop)
+    if (slots == FRCNN_STAT_SLOTS) {
+        T a[FRCNN_STAT_SLOTS / 4], b[FRCNN_STAT_SLOTS / 4];
+#pragma unroll
+        for (int k = 0; k < FRCNN_STAT_SLOTS / 4; ++k) {
+            a[k] = part[((int64_t)(sl + 4 * k) * 2) * C + c];
+            b[k] = part[((int64_t)(sl + 4 * k) * 2 + 1) * C + c];
+        }
+#pragma unroll
+        for (int k = 0; k < FRCNN_STAT_SLOTS / 4; ++k) { s0 += (double)a[k]; s1 += (double)b[k]; }
+        return;
+    }
+#endif
+    for (int t = sl; t < slots; t += 4) {
+        s0 += (double)part[((int64_t)t * 2) * C + c];
+        s1 += (double)part[((int64_t)t * 2 + 1) * C + c];
+    }
+}
+
 #ifndef FRCNN_BN_U
 // rows per thread and round of the strip kernels' streaming loops, all their loads issued before the first is consumed.  Measured in
 // the step on one box (round 4, tools/ab_lib.sh, FRCNN_DEFINES=FRCNN_BN_U=n): 1: 4.215 ms, 4: 4.315 ms -- more bytes in flight per
@@ -294,11 +319,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
         float ga = 0.f, be = 0.f;
         if (sl == 0 && c < C) { ga = gamma[c]; be = beta[c]; }   // (requested with the partial sums, not after the barrier)
         double s = 0.0, ss = 0.0;
-        if (c < C)
-            for (int t = sl; t < slots; t += 4) {
-                s += (double)part[((int64_t)t * 2) * C + c];
-                ss += (double)part[((int64_t)t * 2 + 1) * C + c];
-            }
+        if (c < C) slot_sums(part, slots, sl, C, c, s, ss);
         red[0][sl][cl] = s;
         red[1][sl][cl] = ss;
         __syncthreads();
@@ -324,11 +345,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
             float ga2 = 0.f, be2 = 0.f;
             if (sl == 0 && c < C) { ga2 = b2.gamma[c]; be2 = b2.beta[c]; }
             s = ss = 0.0;
-            if (c < C)
-                for (int t = sl; t < slots; t += 4) {
-                    s += (double)b2.part[((int64_t)t * 2) * C + c];
-                    ss += (double)b2.part[((int64_t)t * 2 + 1) * C + c];
-                }
+            if (c < C) slot_sums(b2.part, slots, sl, C, c, s, ss);
             red[0][sl][cl] = s;
             red[1][sl][cl] = ss;
             __syncthreads();
@@ -470,11 +487,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_pool_kernel(const bf16_t* 
         float ga = 0.f, be = 0.f;
         if (sl == 0 && c < C) { ga = gamma[c]; be = beta[c]; }
         double s = 0.0, ss = 0.0;
-        if (c < C)
-            for (int t = sl; t < slots; t += 4) {
-                s += (double)part[((int64_t)t * 2) * C + c];
-                ss += (double)part[((int64_t)t * 2 + 1) * C + c];
-            }
+        if (c < C) slot_sums(part, slots, sl, C, c, s, ss);
         red[0][sl][cl] = s;
         red[1][sl][cl] = ss;
         __syncthreads();
@@ -577,11 +590,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
         float is = 0.f, ga_c = 0.f, mu_c = 0.f;                 // (requested with the partial sums, not after the barrier)
         if (sl == 0 && c < C) { is = invstd[c]; ga_c = gamma[c]; mu_c = mean[c]; }
         double s = 0.0, sx = 0.0;
-        if (c < C)
-            for (int t = sl; t < slots; t += 4) {
-                s += (double)part[((int64_t)t * 2) * C + c];
-                sx += (double)part[((int64_t)t * 2 + 1) * C + c];
-            }
+        if (c < C) slot_sums(part, slots, sl, C, c, s, sx);
         red[0][sl][cl] = s;
         red[1][sl][cl] = sx;
         __syncthreads();
@@ -889,6 +898,84 @@ __global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ gy, const uint8_t*
             }
         }
         *reinterpret_cast<u32x4*>(gx + i * 8) = pack8(acc);
+    }
+}
+
+// maxpool_bwd_kernel fused with the BatchNorm-backward REDUCE of the layer whose activation the pool read (the ResNet stem: conv1_bn ->
+// conv1_relu -> pool1): while the gradient of the activation is being written, its masked sums  sum g*m  and  sum g*m*xhat  (m: the
+// layer's ReLU bit mask, xhat = (z - mean) * invstd; g as STORED, i.e. rounded to bf16) go to the backward partial slots -- what
+// bn_bwd_reduce_kernel<2> would add after re-reading g, z and the mask (130 MB at 375x1242, batch 4, and a launch).  64 channels:
+// 8 channel vectors x 32 pixel lanes per workgroup, a run of pixels per workgroup.
+__global__ __launch_bounds__(256) void maxpool_bwd_bnreduce_kernel(const bf16_t* __restrict__ gy, const uint8_t* __restrict__ amax, bf16_t* __restrict__ gx,
+                                                                   int N, int H, int W, int Ho, int Wo, const bf16_t* __restrict__ z,
+                                                                   const uint8_t* __restrict__ relu_mask, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, float* __restrict__ part, int pix_per_block) {
+    __shared__ float red[32][8][17];
+    constexpr int C8 = 8, C = 64;
+    const int v = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    float mu[8], is[8], sg[8], sgx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mu[e] = mean[v * 8 + e]; is[e] = invstd[v * 8 + e]; sg[e] = sgx[e] = 0.f; }
+    const int64_t total = (int64_t)N * H * W;
+    const int64_t p_begin = (int64_t)blockIdx.x * pix_per_block, p_end = min(total, p_begin + (int64_t)pix_per_block);
+    for (int64_t px = p_begin + rl; px < p_end; px += 32) {
+        const int64_t i = px * C8 + v;
+        const unsigned m = relu_mask[i];
+        u32x4 zraw = *reinterpret_cast<const u32x4*>(z + i * 8);
+        int64_t t = px;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H);
+        const int n = (int)(t / H);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        const int oy_lo = (iy) / 2, oy_hi = (iy + 1) / 2;
+        const int ox_lo = (ix) / 2, ox_hi = (ix + 1) / 2;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (oy >= Ho) continue;
+            const int ky = iy - (oy * 2 - 1);
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ox >= Wo) continue;
+                const int kx = ix - (ox * 2 - 1);
+                const unsigned k = (unsigned)(ky * 3 + kx);
+                const int64_t o = (((int64_t)n * Ho + oy) * Wo + ox) * C8 + v;
+                const u32x2 a = *reinterpret_cast<const u32x2*>(amax + o * 8);
+                float g[8];
+                unpack8(*reinterpret_cast<const u32x4*>(gy + o * 8), g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned ak = (a[e >> 2] >> ((e & 3) * 8)) & 0xFFu;
+                    if (ak == k) acc[e] += g[e];
+                }
+            }
+        }
+        const u32x4 pk = pack8(acc);
+        *reinterpret_cast<u32x4*>(gx + i * 8) = pk;
+        float g[8], zz[8];
+        unpack8(pk, g);
+        unpack8(zraw, zz);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gm = ((m >> e) & 1u) ? g[e] : 0.f;
+            sg[e] += gm;
+            sgx[e] += gm * ((zz[e] - mu[e]) * is[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[rl][v][e] = sg[e]; red[rl][v][8 + e] = sgx[e]; }
+    __syncthreads();
+    for (int s_ = 16; s_ > 0; s_ >>= 1) {
+        if (rl < s_) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[rl][v][e] += red[rl + s_][v][e];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 128) {
+        const int stat = threadIdx.x >> 6, cl = threadIdx.x & 63;
+        const int slot = blockIdx.x & (FRCNN_STAT_SLOTS - 1);
+        atomicAdd(part + ((int64_t)slot * 2 + stat) * C + cl, red[0][cl >> 3][stat * 8 + (cl & 7)]);
     }
 }
 
@@ -1285,6 +1372,21 @@ extern "C" int frcnn_maxpool3x3s2_bwd(const frcnn_bf16* gy, const uint8_t* argma
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, S_(stream), CBF(gy), argmax, BF(gx), n, h, w, c / 8,
                        ho, wo);
     FRCNN_CHECK_LAUNCH("maxpool_bwd");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_maxpool3x3s2_bwd_bnreduce(const frcnn_bf16* gy, const uint8_t* argmax, frcnn_bf16* gx, int n, int h, int w, int c, int ho,
+                                               int wo, const struct frcnn_bn_reduce* red, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(gy && argmax && gx && red && red->z && red->relu_mask && red->mean && red->invstd && red->partial,
+                    "maxpool_bwd_bnreduce: null pointer (the reduce needs z, the ReLU bit mask, mean, invstd and the partial slots)");
+    FRCNN_CHECK_ARG(c == 64 && ho == (h + 2 - 3) / 2 + 1 && wo == (w + 2 - 3) / 2 + 1, "maxpool_bwd_bnreduce: 64 channels (the ResNet stem), 3x3 / 2 / pad 1 geometry");
+    const int64_t total = (int64_t)n * h * w;
+    int64_t per = (total + 1023) / 1024;         // ~1024 workgroups, whole 32-pixel rounds
+    per = (per + 31) / 32 * 32;
+    if (per < 32) per = 32;
+    hipLaunchKernelGGL(maxpool_bwd_bnreduce_kernel, dim3((unsigned)((total + per - 1) / per)), dim3(256), 0, S_(stream), CBF(gy), argmax, BF(gx), n, h, w,
+                       ho, wo, CBF(red->z), red->relu_mask, red->mean, red->invstd, red->partial, (int)per);
+    FRCNN_CHECK_LAUNCH("maxpool_bwd_bnreduce");
     return FRCNN_OK;
 }
 

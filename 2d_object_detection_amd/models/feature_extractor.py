@@ -672,8 +672,11 @@ class FeatureExtractor:
                 flush_deferred()
         flush_deferred()
         st = self.stem
-        plan.add(ops.maxpool_bwd, gout, self.pool_arg, self.g_stem, self.batch, st.ho, st.wo, 64, self.hp1, self.wp1)
-        st.backward_bn(plan, self.g_stem, st.z)            # (second argument: only "this layer ends in a ReLU")
+        # the pool's backward pass also accumulates the stem BatchNorm's backward sums (g_stem, z and the mask are not re-read)
+        red = st.reduce_args(relu=True)
+        plan.hold(red)
+        plan.add(ops.maxpool_bwd_bnreduce, gout, self.pool_arg, self.g_stem, self.batch, st.ho, st.wo, 64, self.hp1, self.wp1, red)
+        st.backward_bn(plan, self.g_stem, st.z, reduced=True)            # (second argument: only "this layer ends in a ReLU")
         st.backward_weights(plan, self.xpad_flat)
 
     # ------------------------------------------------------------------ Keras-model-like call

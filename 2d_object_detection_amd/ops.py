@@ -364,6 +364,11 @@ def maxpool_bwd(gy, argmax, gx, n, h, w, c, ho, wo):
     call("frcnn_maxpool3x3s2_bwd", _p(gy), _p(argmax), _p(gx), n, h, w, c, ho, wo, _stream())
 
 
+def maxpool_bwd_bnreduce(gy, argmax, gx, n, h, w, c, ho, wo, red):
+    """maxpool_bwd + the BatchNorm-backward reduce of the layer that produced the pooled activation (red: bn_reduce_args), one launch"""
+    call("frcnn_maxpool3x3s2_bwd_bnreduce", _p(gy), _p(argmax), _p(gx), n, h, w, c, ho, wo, byref(red), _stream())
+
+
 def sgd_momentum(w, g, v, w_bf16, n, momentum, l2, grad_scale, step, boundaries, values, nb):
     call("frcnn_sgd_momentum", _p(w), _p(g), _p(v), _p(w_bf16), n, momentum, l2, grad_scale, _p(step), _p(boundaries), _p(values), nb,
          _stream())

@@ -584,6 +584,11 @@ def main(argv=None):
     args = ap.parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus, argv)
+    # stdout carries ONE JSON line and nothing else: everything any library prints there while the benchmark runs (RCCL greets with a
+    # version banner on stdout when a communicator is created) is sent to stderr; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     D = importlib.import_module("2d_object_detection_amd.distributed")
     import torch.distributed as dist
@@ -624,7 +629,7 @@ def main(argv=None):
         bad = [k for k, v in loss_vals.items() if not (v == v and abs(v) != float("inf"))]
         if bad:
             out["error"] = "non-finite losses after the timed window: %s -- the timed workload is degenerate, the number is void" % bad
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         if world > 1:
             dist.barrier()

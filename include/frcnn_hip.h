@@ -332,6 +332,11 @@ int frcnn_maxpool3x3s2_fwd(const frcnn_bf16* x, frcnn_bf16* y, uint8_t* argmax, 
                            int ho, int wo, frcnn_stream_t stream);
 int frcnn_maxpool3x3s2_bwd(const frcnn_bf16* gy, const uint8_t* argmax, frcnn_bf16* gx, int n, int h, int w, int c,
                            int ho, int wo, frcnn_stream_t stream);
+/* frcnn_maxpool3x3s2_bwd fused with the BatchNorm-backward reduce of the layer whose (ReLU) activation the pool read -- the ResNet
+ * stem (models/feature_extractor.py:8-10: conv1_bn -> conv1_relu -> pool1_pool): gx is written as by frcnn_maxpool3x3s2_bwd, and
+ * red->partial receives what frcnn_bn_bwd_reduce(gout = gx, relu_mask = red->relu_mask, z = red->z, ...) would add (c = 64). */
+int frcnn_maxpool3x3s2_bwd_bnreduce(const frcnn_bf16* gy, const uint8_t* argmax, frcnn_bf16* gx, int n, int h, int w, int c,
+                                    int ho, int wo, const struct frcnn_bn_reduce* red, frcnn_stream_t stream);
 
 /* Keras SGD(momentum) step on a flat parameter range (train_faster_rcnn.py:109-112,
  * models/faster_rcnn.py:104) fused with the L2 kernel regulariser gradient 2*l2*w

@@ -167,6 +167,40 @@ def test_maxpool(ops):
     _close(gx.float().cpu()[mask], ref[mask], 2 ** -7, 1e-2, "maxpool bwd")
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 19, 23), (4, 188, 621), (1, 5, 7)])
+def test_maxpool_bwd_bnreduce_equals_two_launches(ops, n, h, w):
+    """frcnn_maxpool3x3s2_bwd_bnreduce == frcnn_maxpool3x3s2_bwd (the activation gradient: bit for bit) + frcnn_bn_bwd_reduce on it
+    (the stem BatchNorm's masked backward sums: equal up to the order of the float additions; (4, 188, 621) is the benchmark's stem)."""
+    g = torch.Generator().manual_seed(n * 100 + h)
+    c, dev = 64, "cuda"
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    z = torch.randn(n * h * w, c, generator=g).to(BF).to(dev)
+    act = torch.relu(z.float()).to(BF)
+    mask_bits = (act.float() > 0).view(n * h * w, c // 8, 8).to(torch.int32)
+    relu_mask = (mask_bits * (2 ** torch.arange(8, device=dev, dtype=torch.int32))).sum(-1).to(torch.uint8).contiguous()
+    y = torch.empty(n, ho, wo, c, dtype=BF, device=dev)
+    am = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=dev)
+    ops.maxpool_fwd(act.view(n, h, w, c), y, am, n, h, w, c, ho, wo)
+    gy = torch.randn(n, ho, wo, c, generator=g).to(BF).to(dev)
+    mean, invstd = (torch.randn(c, generator=g) * 0.1).to(dev), (torch.rand(c, generator=g) + 0.5).to(dev)
+    gx_a, gx_b = torch.empty(n, h, w, c, dtype=BF, device=dev), torch.empty(n, h, w, c, dtype=BF, device=dev)
+    part_a, part_b = torch.zeros(16, 2, c, device=dev), torch.zeros(16, 2, c, device=dev)
+    ops.maxpool_bwd(gy, am, gx_a, n, h, w, c, ho, wo)
+    ops.bn_bwd_reduce(gx_a, None, z, mean, invstd, part_a, n * h * w, c, relu_mask=relu_mask)
+    red = ops.bn_reduce_args(z, relu_mask, mean, invstd, part_b)
+    ops.maxpool_bwd_bnreduce(gy, am, gx_b, n, h, w, c, ho, wo, red)
+    torch.cuda.synchronize()
+    assert torch.equal(gx_a.view(torch.int16), gx_b.view(torch.int16)), "activation gradient"
+    sa, sb = part_a.sum(0).cpu(), part_b.sum(0).cpu()
+    assert float(sa.abs().max()) > 0
+    scale = float(gx_a.float().abs().sum(0).max().cpu())            # the sums are compared relative to the sum of magnitudes they cancel from
+    assert float((sa - sb).abs().max()) <= 2e-6 * scale + 1e-6, (float((sa - sb).abs().max()), scale)
+    m = (act.float() > 0).float()
+    xhat = (z.float() - mean) * invstd
+    ref = torch.stack([(gx_a.float().view(-1, c) * m).double().sum(0), (gx_a.float().view(-1, c) * m * xhat).double().sum(0)]).float().cpu()
+    assert float((sb - ref).abs().max()) <= 1e-5 * scale * 4 + 1e-5, float((sb - ref).abs().max())
+
+
 @pytest.mark.parametrize("n,h,w,c", [(2, 21, 30, 64), (1, 8, 9, 64), (3, 13, 16, 128), (1, 7, 5, 8)])
 def test_stem_bn_relu_maxpool_fused(ops, n, h, w, c):
     """frcnn_bn_train_apply_maxpool == bn_train_apply(ReLU, bit mask) + maxpool_fwd bit for bit: pooled values, arg-max bytes, ReLU
