@@ -8,7 +8,7 @@ TAG=${1:-r04_x}
 OUT=gpurun_out/stalls_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
-PCMD="bench.py --steps 3 --warmup 1 --windows 1 --no-graphs --profile-steps 0 --no-cpu-baseline --no-segmented $BENCH_ARGS"
+PCMD="bench.py --steps 3 --warmup 1 --windows 1 --no-graphs --profile-steps 0 --no-cpu-baseline --no-segmented --no-other-configs $BENCH_ARGS"
 rocprofv3 -L > $OUT/counters_list.txt 2>&1 || true
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES \
   -d $OUT/sq -o p --output-format csv -- python3 $PCMD > $OUT/bench_sq.json 2> $OUT/sq.err

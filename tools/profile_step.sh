@@ -7,7 +7,7 @@ set -e -o pipefail
 TAG=${1:-r02_x}
 OUT=gpurun_out/prof_$TAG
 # 1 eager warm-up run (plan build) + 4 warm-up steps + 25 timed steps = 30 executions of the step's kernels
-CMD="bench.py --steps 25 --warmup 4 --windows 1 --profile-steps 0 --no-cpu-baseline --no-segmented $BENCH_ARGS"
+CMD="bench.py --steps 25 --warmup 4 --windows 1 --profile-steps 0 --no-cpu-baseline --no-segmented --no-other-configs $BENCH_ARGS"
 STEPS=30
 export TMPDIR=/tmp
 mkdir -p $OUT
@@ -27,7 +27,7 @@ cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_summary.txt profiles/${TAG}_
 head -12 profiles/${TAG}_summary.txt
 # optional 4th pass (PMC_TABLE=1): SQ counters of an eager run -> profiles/<tag>_pmc_counters.txt (matrix-pipe / LDS busy per kernel)
 if [ -n "$PMC_TABLE" ]; then
-  PCMD="bench.py --steps 3 --warmup 1 --windows 1 --no-graphs --profile-steps 0 --no-cpu-baseline --no-segmented $BENCH_ARGS"
+  PCMD="bench.py --steps 3 --warmup 1 --windows 1 --no-graphs --profile-steps 0 --no-cpu-baseline --no-segmented --no-other-configs $BENCH_ARGS"
   rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU -d $OUT/sq -o p --output-format csv -- python3 $PCMD > $OUT/bench_sq.json 2> $OUT/sq.err
   python3 profiles/pmc_table.py $(find $OUT/sq -name '*counter_collection.csv' | head -1) "python3 $PCMD" > profiles/${TAG}_pmc_counters.txt
   cp profiles/${TAG}_pmc_counters.txt $OUT/
