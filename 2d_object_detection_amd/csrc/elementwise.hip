@@ -1010,6 +1010,11 @@ __global__ void sgd_fused_kernel(float* __restrict__ w, const float* __restrict_
     const float l2x2 = 2.f * f.l2;
     const int64_t stem_end = f.stem_begin >= 0 ? f.stem_begin + (int64_t)f.stem_cout * 147 : -1;
     bf16_t* wp = reinterpret_cast<bf16_t*>(f.stem_packed);
+    // A thread owns at most ONE element of the stem kernel (the grid has at least as many threads as the stem has elements: checked by
+    // the host): it is only remembered inside the streaming loop and re-laid-out after it.  (With the index arithmetic -- four integer
+    // divisions -- inside the loop the compiler computed it for every element, speculatively: the launch took 130 us instead of 52.)
+    int stem_j = -1;
+    float stem_v = 0.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float wi = w[i];
         const float gi = g[i] * gscale + (i < f.decay_end ? l2x2 : 0.f) * wi;
@@ -1018,16 +1023,18 @@ __global__ void sgd_fused_kernel(float* __restrict__ w, const float* __restrict_
         v[i] = vi;
         w[i] = wn;
         if (wb) wb[i] = (bf16_t)wn;
-        if (i >= f.stem_begin && i < stem_end) {     // [co][kh][kw][c] of the 7x7x3 kernel -> [co][kh][8][4]
-            const int j = (int)(i - f.stem_begin);
-            const int c = j % 3, kw = (j / 3) % 7, kh = (j / 21) % 7, co = j / 147;
-            wp[((co * 7 + kh) * 8 + kw) * 4 + c] = (bf16_t)wn;
-        }
+        const bool in_stem = i >= f.stem_begin && i < stem_end;
+        stem_j = in_stem ? (int)(i - f.stem_begin) : stem_j;
+        stem_v = in_stem ? wn : stem_v;
     }
-    // every workgroup has read *step before it arrives here: the last arriver may move it
+    if (stem_j >= 0) {                               // [co][kh][kw][c] of the 7x7x3 kernel -> [co][kh][8][4]
+        const int c = stem_j % 3, kw = (stem_j / 3) % 7, kh = (stem_j / 21) % 7, co = stem_j / 147;
+        wp[((co * 7 + kh) * 8 + kw) * 4 + c] = (bf16_t)stem_v;
+    }
+    // every wave of every workgroup has read *step (it used the rate) before its workgroup arrives here: the last arriver may move it.
+    // (No fence: nothing but the counter itself is handed over, and a fence would hold the workgroup until its stores have landed.)
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         if (atomicAdd(f.arrive, 1u) == gridDim.x - 1) {
             *f.arrive = 0u;
             *step = st + 1;
@@ -1407,6 +1414,8 @@ extern "C" int frcnn_sgd_momentum_fused(float* w, const float* g, float* v, frcn
     FRCNN_CHECK_ARG(f->decay_end >= 0 && f->decay_end <= n, "sgd_momentum_fused: decay_end outside [0, n]");
     FRCNN_CHECK_ARG(f->stem_begin < 0 || (f->stem_packed && f->stem_cout > 0 && f->stem_begin + (int64_t)f->stem_cout * 147 <= n),
                     "sgd_momentum_fused: stem range outside the buffer or no packed destination");
+    // (one stem element per thread at most: the grid is min(n, 2048 * 256) threads)
+    FRCNN_CHECK_ARG(f->stem_begin < 0 || (int64_t)f->stem_cout * 147 <= (int64_t)grid_for(n, 256) * 256, "sgd_momentum_fused: stem kernel larger than the grid");
     hipLaunchKernelGGL(sgd_fused_kernel, dim3(grid_for(n, 256)), dim3(256), 0, S_(stream), w, g, v, BF(w_bf16), n, momentum, grad_scale, step,
                        boundaries, values, nb, *f);
     FRCNN_CHECK_LAUNCH("sgd_momentum_fused");

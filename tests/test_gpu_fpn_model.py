@@ -419,7 +419,10 @@ def test_configs4_workload_fpn_fp8_batch8_full_size():
         # changes which RoIs are pooled and sampled -- rcnn_reg, a SUM of un-normalised box terms dominated by a few rows, moved by
         # 53 % between two runs of the same fp8 step on MI355X (round 4), rpn_cls by 0.2 %, rpn_reg and rcnn_cls by 2 %.
         assert rel_b[k][1] <= FP8_RERUN_BOUND[k], (k, 1, h_graph[1][k], h_eager[1][k])
-    assert e_w < 1e-5, e_w
+    # the weights after the first update: two runs of ONE configuration differ by 9.2e-5 (fp8; 5.3e-6 in bf16) whether replayed or not
+    # -- tools/probes/diag_configs4.py, profiles/r04_run_to_run_noise.txt: the forward pass and the heads' gradients are reproducible
+    # (1e-6), the random-init backbone's backward pass amplifies the order of the RoI / BatchNorm float sums by 10^4 on its way down
+    assert e_w < 3e-4, e_w
     # (c) fp8 against bf16 on the FIRST step (same weights, nothing discrete has diverged yet: the difference is the fp8 forward pass)
     for k in ("rpn_cls", "rcnn_cls"):
         assert diff[k][0] < FP8_LOSS_BOUND[k], (k, diff[k])
@@ -427,9 +430,10 @@ def test_configs4_workload_fpn_fp8_batch8_full_size():
         assert diff[k][0] < FP8_LOSS_BOUND[k] * max(abs(h_ref[0][k]), 1e-3), (k, diff[k], h_ref[0][k])
 
 
-# bounds of the fp8-vs-bf16 loss difference at configs[4]'s full size after two steps: 1.3x .. 2x what was measured on MI355X
-# (round 4; values in DESIGN.md 5): absolute for the mean classification losses, relative for the summed regression losses
-FP8_LOSS_BOUND = {"rpn_cls": 0.02, "rcnn_cls": 1.0, "rpn_reg": 0.25, "rcnn_reg": 1.0}
+# bounds of the fp8-vs-bf16 loss difference of the FIRST step at configs[4]'s full size: 2x what MI355X measures (round 4: rpn_cls
+# 0.00064, rcnn_cls 0.0128 absolute; rpn_reg 0.178 of 3.66, rcnn_reg 11.3 of 56.7 -- sums of un-normalised box terms of an untrained
+# head): absolute for the mean classification losses, relative for the summed regression losses
+FP8_LOSS_BOUND = {"rpn_cls": 0.002, "rcnn_cls": 0.03, "rpn_reg": 0.1, "rcnn_reg": 0.4}
 # ... and of the relative difference between two fp8 runs of the same second step (eager vs replayed)
 FP8_RERUN_BOUND = {"rpn_cls": 1e-2, "rcnn_cls": 0.1, "rpn_reg": 0.1, "rcnn_reg": 2.0}
 
