@@ -51,6 +51,7 @@ _SIGNATURES = {
     # name: (restype, [argtypes])
     "frcnn_abi_version": (c_int, []),
     "frcnn_last_error": (c_char_p, []),
+    "frcnn_source_hash": (c_char_p, []),
     "frcnn_last_conv_instantiation": (c_char_p, []),
     "frcnn_conv2d_workspace_bytes": (ctypes.c_size_t, [P]),
     "frcnn_conv2d_workspace_counter_bytes": (ctypes.c_size_t, [P]),

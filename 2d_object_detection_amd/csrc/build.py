@@ -3,6 +3,7 @@
 In-tree build: the .so lands next to the package so that it travels with a repo snapshot.
 hipcc cross-compiles without a GPU.  Usage: python 2d_object_detection_amd/csrc/build.py [--force]
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -33,6 +34,17 @@ if VARIANT:
     LIB = os.path.join(PKG, "lib2dod_hip%s.so" % VARIANT)
 
 
+def source_hash():
+    """sha1 over the HIP sources, their headers and the C-ABI header (12 hex digits): what frcnn_source_hash() returns and what
+    bench.py keys its committed rocprof profiles with (bench.kernel_source_hash is this function)."""
+    h = hashlib.sha1()
+    for name in sorted(os.listdir(HERE)):
+        if name.endswith((".hip", ".h")):
+            h.update(open(os.path.join(HERE, name), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "..", "include", "frcnn_hip.h"), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -47,12 +59,18 @@ def build(force=False, verbose=True):
     hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
     jobs = []
     objs = []
+    digest = source_hash()
+    stamp = os.path.join(objdir, "source_hash.txt")
+    stale_hash = not os.path.exists(stamp) or open(stamp).read().strip() != digest
     for s in SOURCES:
         src = os.path.join(HERE, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+        extra = []
+        if s == "host_io.hip":                   # carries frcnn_source_hash(): rebuilt whenever any source changed
+            extra = ['-DFRCNN_SOURCE_HASH="%s"' % digest]
+        if force or _newer(obj, [src] + hdrs) or (extra and stale_hash):
+            jobs.append([hipcc] + FLAGS + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -63,6 +81,8 @@ def build(force=False, verbose=True):
         list(ex.map(run, jobs))
     if force or jobs or _newer(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(stamp, "w") as fh:
+        fh.write(digest + "\n")
     return LIB
 
 

@@ -36,3 +36,11 @@ extern "C" uint32_t frcnn_crc32c(uint32_t crc, const void* data, size_t n) {
     while (n--) c = (c >> 8) ^ tb.t[0][(c ^ *p++) & 0xFFu];
     return ~c;
 }
+
+// Hash of the kernel sources this library was built from (csrc/build.py passes it: sha1 over csrc/*.hip, csrc/*.h and the header, first
+// 12 hex digits -- the same hash bench.py stamps its profiles with).  __graft_entry__.build() rebuilds with --force when it differs
+// from the tree's: a pushed tree can never run stale objects.
+#ifndef FRCNN_SOURCE_HASH
+#define FRCNN_SOURCE_HASH "unknown"
+#endif
+extern "C" const char* frcnn_source_hash(void) { return FRCNN_SOURCE_HASH; }

@@ -48,14 +48,13 @@ FAM_WGRAD = "conv wgrad (wgrad_kernel, wgrad_group_kernel)"
 
 
 def kernel_source_hash():
-    """sha1 over the HIP sources + headers: ties an offline profile (profiles/*.json) to the code it was taken from."""
-    h = hashlib.sha1()
-    src = os.path.join(ROOT, "2d_object_detection_amd", "csrc")
-    for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h")):
-            h.update(open(os.path.join(src, name), "rb").read())
-    h.update(open(os.path.join(ROOT, "include", "frcnn_hip.h"), "rb").read())
-    return h.hexdigest()[:12]
+    """sha1 over the HIP sources + headers: ties an offline profile (profiles/*.json) to the code it was taken from -- the hash the
+    library itself reports (frcnn_source_hash(), csrc/build.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_frcnn_build", os.path.join(ROOT, "2d_object_detection_amd", "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_hash()
 
 
 def conv_flops(d, true_cin=None, true_cout=None):

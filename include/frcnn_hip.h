@@ -40,6 +40,9 @@ typedef uint8_t frcnn_fp8;     /* OCP e4m3fn (gfx950's fp8: 4 exponent bits, bia
 #define FRCNN_ABI_VERSION 5
 int frcnn_abi_version(void);
 const char* frcnn_last_error(void);
+/* sha1 (12 hex digits) over the kernel sources and this header the library was built from, or "unknown" (csrc/build.py passes it):
+ * the build entry point rebuilds a library whose hash is not the tree's, and bench.py stamps its rocprof profiles with the same hash */
+const char* frcnn_source_hash(void);
 
 /* ------------------------------------------------------------------ dense tensor ops */
 

@@ -71,3 +71,17 @@ def test_library_of_another_abi_version_is_refused(monkeypatch):
         assert False, "expected HipLibraryError"
     except lib_mod.HipLibraryError as e:
         assert "ABI version" in str(e)
+
+
+def test_library_reports_the_sources_it_was_built_from():
+    """frcnn_source_hash() == the hash of this tree's kernel sources (csrc/build.py: source_hash): __graft_entry__.build() rebuilds a
+    library that says anything else, and bench.py keys its committed rocprof profiles (profiles/r*_offline*.json) with the same hash."""
+    import sys
+    sys.path.insert(0, ROOT)
+    try:
+        bench = importlib.import_module("bench")
+    finally:
+        sys.path.remove(ROOT)
+    lib_mod = importlib.import_module("2d_object_detection_amd._lib")
+    have = lib_mod.load().frcnn_source_hash().decode()
+    assert len(have) == 12 and have == bench.kernel_source_hash()
