@@ -416,8 +416,15 @@ struct WgradGroup {
 template <int BM, int BN, int S, int MODE, int OCC, bool F8 = false>
 __global__ __launch_bounds__(512, 2 * OCC) void wgrad_group_kernel(const WgradGroup* __restrict__ g) {
     const int id = xcd_chunk(blockIdx.x, gridDim.x);
+    // layer = number of layers whose first workgroup is <= id (first[] is non-decreasing).  Constant indices: the whole table comes
+    // in with a few wide scalar loads issued together -- as a search loop it was up to n - 1 DEPENDENT scalar round trips per workgroup
     int layer = 0;
-    while (layer + 1 < g->n && id >= g->first[layer + 1]) ++layer;             // (uniform: scalar loads)
+    const int n = g->n;
+#pragma unroll
+    for (int i = 1; i < kGroupMax; ++i) {
+        const int f = g->first[i];               // (unconditional: the whole array lies inside the table; entries beyond n are masked)
+        layer += (int)(i < n) & (int)(id >= f);
+    }
     const WgradParams p = g->p[layer];
     wgrad_body<BM, BN, S, MODE, OCC, F8>(p, id - g->first[layer]);
 }
