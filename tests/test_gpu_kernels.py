@@ -512,9 +512,9 @@ def test_roi_fwd_wave_uniform_form_equals_generic_kernel(ops, B, C):
     rois = torch.stack([x0, y0, x0 + wh[..., 0] + 0.004, y0 + wh[..., 1] + 0.01], -1)
     rois[0, 0] = 0.0
     rois[0, 1] = torch.tensor([0.0, 0.0, 1.0, 1.0])
-    rois[1, 0] = torch.tensor([0.9, 0.9, 1.3, 1.2])
-    rois[1, 1] = torch.tensor([1.1, 0.2, 1.4, 0.6])
-    rois[1, 2] = torch.tensor([-0.2, -0.1, 0.3, 0.4])
+    rois[-1, 3] = torch.tensor([0.9, 0.9, 1.3, 1.2])
+    rois[-1, 4] = torch.tensor([1.1, 0.2, 1.4, 0.6])
+    rois[-1, 5] = torch.tensor([-0.2, -0.1, 0.3, 0.4])
     rois[0, 2] = torch.tensor([0.25, 0.5, 0.25 + 1.0 / 77, 0.5 + 1.0 / 23])           # exactly one cell: integer sample coordinates at the corners
     exp = oroi.roi_pooling(feat.clone(), rois, 7, 2)
     dev = "cuda"
