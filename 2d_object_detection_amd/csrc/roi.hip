@@ -360,7 +360,7 @@ template <int CS>
 __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(const bf16_t* __restrict__ gpooled, const uint8_t* __restrict__ amax,
                                                            const float* __restrict__ rois, const int* __restrict__ rows, int nrows, int P,
                                                            int Hf, int Wf, int C, int ps, int ks, bf16_t* __restrict__ gfeat,
-                                                           const int* __restrict__ levels, int level) {
+                                                           const int* __restrict__ levels, int level, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float racc[];              // [Wf][CS]
     constexpr int LANES = CS / 2, GROUPS = 256 / LANES;                        // channel pairs per slab, RoI rows in flight
     const int slabs = C / CS;
@@ -368,7 +368,18 @@ __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(const bf16_t* __restr
     const int slab = bid % slabs;
     bid /= slabs;
     const int y = bid % Hf, b = bid / Hf;
-    for (int i = threadIdx.x; i < Wf * CS; i += 256) racc[i] = 0.f;
+    if (accumulate) {
+        // gfeat already holds another branch's gradient of this map (the RPN's data gradient): the row starts from it
+        const bf16_t* in = gfeat + ((int64_t)(b * Hf + y) * Wf) * C + slab * CS;
+        for (int i = threadIdx.x; i < Wf * (CS / 2); i += 256) {
+            const int x = i / (CS / 2), cp = (i - x * (CS / 2)) * 2;
+            const unsigned int v = *reinterpret_cast<const unsigned int*>(in + (int64_t)x * C + cp);
+            racc[x * CS + cp] = bf16_bits_to_f32((unsigned short)(v & 0xFFFFu));
+            racc[x * CS + cp + 1] = bf16_bits_to_f32((unsigned short)(v >> 16));
+        }
+    } else {
+        for (int i = threadIdx.x; i < Wf * CS; i += 256) racc[i] = 0.f;
+    }
     __syncthreads();
 
     const int cl = (threadIdx.x % LANES) * 2, grp = threadIdx.x / LANES;
@@ -550,7 +561,7 @@ extern "C" int frcnn_roi_crop_pool_bwd(const frcnn_bf16* gpooled, const uint8_t*
 
 static int roi_bwd_bf16_impl(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,
                              int nrows, int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat, const int32_t* levels, int level,
-                             frcnn_stream_t stream) {
+                             frcnn_stream_t stream, int accumulate = 0) {
     FRCNN_CHECK_ARG(gpooled && argmax && rois && rows && gfeat && nrows > 0 && b > 0, "roi_crop_pool_bwd_bf16: bad arguments");
     FRCNN_CHECK_ARG(c % 64 == 0 && ps >= 1 && ks >= 1 && ks * ks <= 255 && hf > 1 && wf > 1, "roi_crop_pool_bwd_bf16: bad sizes");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -561,14 +572,19 @@ static int roi_bwd_bf16_impl(const frcnn_bf16* gpooled, const uint8_t* argmax, c
         const size_t smem32 = (size_t)wf * 32 * 4;
         FRCNN_CHECK_ARG(smem32 <= 64 * 1024 && c % 32 == 0, "roi_crop_pool_bwd_bf16: feature map too wide (wf=%d)", wf);
         hipLaunchKernelGGL(roi_bwd_rows_kernel<32>, dim3(b * hf * (c / 32)), dim3(256), smem32, s, reinterpret_cast<const bf16_t*>(gpooled),
-                           argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat), levels, level);
+                           argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat), levels, level, accumulate);
         FRCNN_CHECK_LAUNCH("roi_crop_pool_bwd_bf16");
         return FRCNN_OK;
     }
     hipLaunchKernelGGL(roi_bwd_rows_kernel<64>, dim3(b * hf * (c / 64)), dim3(256), smem, s, reinterpret_cast<const bf16_t*>(gpooled),
-                       argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat), levels, level);
+                       argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat), levels, level, accumulate);
     FRCNN_CHECK_LAUNCH("roi_crop_pool_bwd_bf16");
     return FRCNN_OK;
+}
+
+extern "C" int frcnn_roi_crop_pool_bwd_bf16_add(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows, int nrows,
+                                                int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat, frcnn_stream_t stream) {
+    return roi_bwd_bf16_impl(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, ps, ks, gfeat, nullptr, 0, stream, 1);
 }
 
 extern "C" int frcnn_roi_crop_pool_bwd_bf16(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,

@@ -446,10 +446,17 @@ __global__ __launch_bounds__(1024) void losses_kernel(const LossParams p) {
         for (int r0 = 0; r0 < rows; r0 += 256) {
             const int r1 = min(rows, r0 + 256);
             for (int rl = part; rl < 32; rl += (int)(blockDim.x >> 6)) {
+                // the (at most 8) rows of this partial sum: loads issued together, added in the loop's order (+0 for a missing row
+                // leaves the sum's bits alone)
+                float vv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = r0 + rl + 32 * k;
+                    vv[k] = (col < p.ld && r < r1) ? bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(p.dhead + (int64_t)r * p.ld + col)) : 0.f;
+                }
                 float s = 0.f;
-                if (col < p.ld)
-                    for (int r = r0 + rl; r < r1; r += 32)
-                        s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(p.dhead + (int64_t)r * p.ld + col));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += vv[k];
                 cs[rl][col] = s;
             }
             __syncthreads();

@@ -157,7 +157,8 @@ class FastRCNNDetector:
             self.regions_plan(plan, rois)
         return {"regions": self.regions_abs, "pred_scores": self.scores, "pred_boxes": self.deltas}
 
-    def backward_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, rois, g_feat_bf16, head_grad_done=False, bias_grad_done=False):
+    def backward_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, rois, g_feat_bf16, head_grad_done=False, bias_grad_done=False,
+                      add_to_g_feat_after=None):
         """Per-sample loss gradients -> head parameter gradients and the RoI-branch feature-map
         gradient, written (bf16) to g_feat_bf16 [B*hf*wf, C].  head_grad_done: self.dhead_s / self.rows were already written
         by the loss launch (ops.losses_head_grad)."""
@@ -169,8 +170,14 @@ class FastRCNNDetector:
         # needs before the update, after it.  (As a side branch they measured 0.015 ms SLOWER than in line: see faster_rcnn.py.)
         plan.add(ops.conv2d_fprop, self.d_dgrad, self.dhead_s, self.w_t, self.dpooled_s)
         # gather form: every element of g_feat is written once, in bf16, without global atomics (no memset / cast passes)
-        plan.add(ops.roi_crop_pool_bwd_bf16, self.dpooled_s, self.argmax, rois, self.rows, self.rs, self.batch, self.p, self.hf, self.wf,
-                 self.cf, self.ps, self.ks, g_feat_bf16)
+        if add_to_g_feat_after is not None:
+            # g_feat already receives another branch's gradient (the RPN's, on the side stream named here): wait for it, then add
+            plan.join(add_to_g_feat_after)
+            plan.add(ops.roi_crop_pool_bwd_bf16_add, self.dpooled_s, self.argmax, rois, self.rows, self.rs, self.batch, self.p, self.hf, self.wf,
+                     self.cf, self.ps, self.ks, g_feat_bf16)
+        else:
+            plan.add(ops.roi_crop_pool_bwd_bf16, self.dpooled_s, self.argmax, rois, self.rows, self.rs, self.batch, self.p, self.hf, self.wf,
+                     self.cf, self.ps, self.ks, g_feat_bf16)
         if not bias_grad_done:                      # (the fused loss launch adds the bias gradient itself: ops.losses_head_grad(bias_grad=...))
             plan.add(ops.colsum_bf16, self.dhead_s, self.rs, HEAD_LD, HEAD_LD, st.grad("fast_rcnn_heads/bias"))
         plan.add(ops.conv2d_wgrad, self.d_wgrad, self.pooled, self.dhead_s, st.grad("fast_rcnn_heads/kernel"), HEAD_LD, self.rows)

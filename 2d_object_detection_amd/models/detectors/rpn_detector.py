@@ -140,6 +140,9 @@ class RPNDetector:
             self.d_heads_bwd = ops.conv_desc(batch, gh, gw, HEAD_LD, 1, 1, 1, 0, 0, gh, gw, 256)
             self.d_inter_bwd = ops.conv_desc(batch, gh, gw, 256, self.ws, self.ws, 1, p, p, gh, gw, cf, flags=ops.CONV_ADD_RES)
             self._conv_ws.append(ops.conv_attach_workspace(self.d_inter_bwd, dev))
+            # the same data gradient WRITTEN (not added): the form that runs on the RPN's side stream before the RoI backward pass
+            self.d_inter_bwd_plain = ops.conv_desc(batch, gh, gw, 256, self.ws, self.ws, 1, p, p, gh, gw, cf)
+            self._conv_ws.append(ops.conv_attach_workspace(self.d_inter_bwd_plain, dev))
             from ..feature_extractor import FP8_BWD
             if self.w_inter8 is not None and f8_scales is not None and FP8_BWD:
                 # fp8 data gradient of the 3x3 convolution: e5m2 twin of dz_f (written by a quantise pass behind the ReLU backward),
@@ -238,9 +241,18 @@ class RPNDetector:
         else:
             plan.add(ops.conv2d_wgrad, self.d_inter, feature_maps, self.dz_f, st.grad("rpn_intermediate_layer/kernel"))
 
-    def backward_data_plan(self, plan, g_feat, consumer=None):
+    def backward_data_plan(self, plan, g_feat, consumer=None, plain=False):
         """consumer: the backbone's last conv unit -- g_feat is complete after this kernel, so it also runs that unit's
-        BatchNorm-backward reduce."""
+        BatchNorm-backward reduce.  plain: g_feat = the RPN's data gradient alone (written, not added: the RoI backward pass adds its
+        own afterwards, ops.roi_crop_pool_bwd_bf16_add) -- the kernel then needs nothing from the RoI branch."""
+        if plain:
+            assert consumer is None
+            ops.conv_zero_counters(plan, self.d_inter_bwd_plain)
+            if self.dz_f8 is not None:
+                plan.add(ops.conv2d_dgrad_fp8, self.d_inter_bwd_plain, self.dz_f8.data, self.w_inter_t8, self.dz_f8.scale, self.w_inter_t8_scale, g_feat)
+            else:
+                plan.add(ops.conv2d_fprop, self.d_inter_bwd_plain, self.dz_f, self.w_inter_t, g_feat)
+            return
         ops.conv_zero_counters(plan, self.d_inter_bwd)
         red = None
         if consumer is not None:

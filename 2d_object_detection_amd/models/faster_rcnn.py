@@ -11,6 +11,8 @@ as hipGraphs: no host synchronisation inside a step, ~zero launch overhead.  The
 computed once per step (the reference computes them twice with identical inputs,
 faster_rcnn.py:53,106).
 """
+import os
+
 import torch
 
 from .. import ops
@@ -25,6 +27,10 @@ from .fpn import FastRCNNDetectorFPN, FPNNeck, RPNDetectorFPN
 
 BF16 = torch.bfloat16
 LOSS_NAMES = ("rpn_cls", "rpn_reg", "rcnn_cls", "rcnn_reg")
+
+
+# measuring aid (tools/ab_lib.sh): 1 = the RPN's 3x3 data gradient runs on the RPN's side stream and the RoI backward pass adds to its result
+RPN_DGRAD_ON_SIDE_STREAM = os.environ.get("FRCNN_RPN_DGRAD_SIDE", "0") != "0"
 
 
 class _Modules:
@@ -262,6 +268,10 @@ class FasterRCNN:
                 rpn_targets(rpn_out["regions"])
                 rpn_losses()
                 mods.rpn.backward_params_plan(plan, None, None, t["rpn_idx"], S_rpn, feat2d, head_grad_done=True)
+                if RPN_DGRAD_ON_SIDE_STREAM:
+                    # the RPN's data gradient needs nothing from the RoI branch either: it WRITES g_feat here, beside the proposal NMS /
+                    # RoI pooling / heads, and the RoI backward pass adds to it
+                    mods.rpn.backward_data_plan(plan, g_feat, plain=True)
         else:
             rpn_targets(rpn_out["regions"])
             rpn_losses()
@@ -288,12 +298,16 @@ class FasterRCNN:
         rcnn_losses()
 
         if training:
-            mods.rcnn.backward_plan(plan, None, None, t["rcnn_idx"], S_rcnn, rois, g_feat, head_grad_done=True, bias_grad_done=True)
-            plan.join("rpn_side")
-            mods.rpn.backward_data_plan(plan, g_feat, consumer=mods.fe.last_unit())
+            if RPN_DGRAD_ON_SIDE_STREAM:
+                mods.rcnn.backward_plan(plan, None, None, t["rcnn_idx"], S_rcnn, rois, g_feat, head_grad_done=True, bias_grad_done=True,
+                                        add_to_g_feat_after="rpn_side")
+            else:
+                mods.rcnn.backward_plan(plan, None, None, t["rcnn_idx"], S_rcnn, rois, g_feat, head_grad_done=True, bias_grad_done=True)
+                plan.join("rpn_side")
+                mods.rpn.backward_data_plan(plan, g_feat, consumer=mods.fe.last_unit())
             plan.join("detections")
             plan.cut("bwd_conv4")
-            mods.fe.backward_plan(plan, g_feat, g_feat_reduced=True)
+            mods.fe.backward_plan(plan, g_feat, g_feat_reduced=not RPN_DGRAD_ON_SIDE_STREAM)
             plan.cut("update")
             optimizer.apply_plan(plan, stem=mods.fe.stem)     # SGD + the stem's packed taps + the step counter: one launch
             if mods.fe.f8 is not None:

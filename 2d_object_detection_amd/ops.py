@@ -469,6 +469,11 @@ def roi_crop_pool_bwd_bf16(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, 
     call("frcnn_roi_crop_pool_bwd_bf16", _p(gpooled), _p(argmax), _p(rois), _p(rows), nrows, b, p, hf, wf, c, ps, ks, _p(gfeat), _stream())
 
 
+def roi_crop_pool_bwd_bf16_add(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, ps, ks, gfeat):
+    """gfeat += the RoI-branch gradient (gfeat holds another consumer's gradient of the same map)"""
+    call("frcnn_roi_crop_pool_bwd_bf16_add", _p(gpooled), _p(argmax), _p(rois), _p(rows), nrows, b, p, hf, wf, c, ps, ks, _p(gfeat), _stream())
+
+
 # ---------------------------------------------------------------- feature pyramid (BASELINE.json configs[4])
 def upsample_add(top, ht, wt, lat, out, b, h, w, c):
     call("frcnn_upsample_add", _p(top), ht, wt, _p(lat), _p(out), b, h, w, c, _stream())
