@@ -120,7 +120,7 @@ _SIGNATURES = {
     "frcnn_roi_crop_pool_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "frcnn_roi_crop_pool_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "frcnn_roi_crop_pool_bwd_bf16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
-    "frcnn_roi_crop_pool_bwd_bf16_add": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "frcnn_roi_crop_pool_bwd_bf16_add": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, POINTER(BnReduce), P]),
     "frcnn_rcnn_head_post": (c_int, [P, c_int, P, c_int, c_int, P, P, P]),
     "frcnn_boxes_scale": (c_int, [P, P, c_int64, c_float, c_float, P]),
     "frcnn_assign_targets": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float,

@@ -360,7 +360,7 @@ template <int CS>
 __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(const bf16_t* __restrict__ gpooled, const uint8_t* __restrict__ amax,
                                                            const float* __restrict__ rois, const int* __restrict__ rows, int nrows, int P,
                                                            int Hf, int Wf, int C, int ps, int ks, bf16_t* __restrict__ gfeat,
-                                                           const int* __restrict__ levels, int level, int accumulate) {
+                                                           const int* __restrict__ levels, int level, int accumulate, const frcnn_bn_reduce red) {
     extern __shared__ __attribute__((aligned(16))) float racc[];              // [Wf][CS]
     constexpr int LANES = CS / 2, GROUPS = 256 / LANES;                        // channel pairs per slab, RoI rows in flight
     const int slabs = C / CS;
@@ -494,10 +494,55 @@ __global__ __launch_bounds__(256) void roi_bwd_rows_kernel(const bf16_t* __restr
     }
     __syncthreads();
     bf16_t* out = gfeat + ((int64_t)(b * Hf + y) * Wf) * C + slab * CS;
+    // red.partial != NULL: gfeat is complete with this launch and is the gradient arriving at a BatchNorm(+ReLU) layer whose raw input
+    // was red.z -- the row's contribution to that layer's backward sums (sum g*m, sum g*m*xhat; g as stored, m = the ReLU mask bit) is
+    // accumulated while the row is written: what frcnn_bn_bwd_reduce(gout = gfeat, ...) would add after re-reading gfeat, z and the mask
+    float sg[2] = {0.f, 0.f}, sgx[2] = {0.f, 0.f};
+    const int cp_fixed = (threadIdx.x % (CS / 2)) * 2;                        // (256 % (CS / 2) == 0: a thread keeps its channel pair)
+    float mu[2] = {0.f, 0.f}, is[2] = {0.f, 0.f};
+    if (red.partial) {
+        mu[0] = red.mean[slab * CS + cp_fixed]; mu[1] = red.mean[slab * CS + cp_fixed + 1];
+        is[0] = red.invstd[slab * CS + cp_fixed]; is[1] = red.invstd[slab * CS + cp_fixed + 1];
+    }
     for (int i = threadIdx.x; i < Wf * (CS / 2); i += 256) {
         const int x = i / (CS / 2), cp = (i - x * (CS / 2)) * 2;
         const unsigned int v = (unsigned int)f32_to_bf16_bits(racc[x * CS + cp]) | ((unsigned int)f32_to_bf16_bits(racc[x * CS + cp + 1]) << 16);
         *reinterpret_cast<unsigned int*>(out + (int64_t)x * C + cp) = v;
+        if (red.partial) {
+            const int64_t pix = (int64_t)(b * Hf + y) * Wf + x;
+            const int c = slab * CS + cp;
+            const unsigned int zz = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const bf16_t*>(red.z) + pix * C + c);
+            const unsigned int mb = red.relu_mask ? red.relu_mask[pix * (C / 8) + (c >> 3)] : 0xFFu;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float g = bf16_bits_to_f32((unsigned short)(e ? (v >> 16) : (v & 0xFFFFu)));
+                const float z = bf16_bits_to_f32((unsigned short)(e ? (zz >> 16) : (zz & 0xFFFFu)));
+                const float gm = ((mb >> ((c + e) & 7)) & 1u) ? g : 0.f;
+                sg[e] += gm;
+                sgx[e] += gm * ((z - mu[e]) * is[e]);
+            }
+        }
+    }
+    if (red.partial) {
+        // the 256 / (CS / 2) threads that share a channel pair meet in LDS (the row accumulator is free now), then one atomic per
+        // (statistic, channel) and workgroup
+        __syncthreads();
+        constexpr int SH = 256 / (CS / 2);
+        float* sc = racc;                                                     // [SH][CS][2]
+        const int grp2 = threadIdx.x / (CS / 2);
+        sc[(grp2 * CS + cp_fixed) * 2] = sg[0];
+        sc[(grp2 * CS + cp_fixed) * 2 + 1] = sgx[0];
+        sc[(grp2 * CS + cp_fixed + 1) * 2] = sg[1];
+        sc[(grp2 * CS + cp_fixed + 1) * 2 + 1] = sgx[1];
+        __syncthreads();
+        if (threadIdx.x < 2 * CS) {
+            const int stat = threadIdx.x / CS, cl2 = threadIdx.x - stat * CS;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < SH; ++k) t += sc[(k * CS + cl2) * 2 + stat];
+            const int slot = blockIdx.x & (FRCNN_STAT_SLOTS - 1);
+            atomicAdd(red.partial + ((int64_t)slot * 2 + stat) * C + slab * CS + cl2, t);
+        }
     }
 }
 
@@ -561,10 +606,16 @@ extern "C" int frcnn_roi_crop_pool_bwd(const frcnn_bf16* gpooled, const uint8_t*
 
 static int roi_bwd_bf16_impl(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,
                              int nrows, int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat, const int32_t* levels, int level,
-                             frcnn_stream_t stream, int accumulate = 0) {
+                             frcnn_stream_t stream, int accumulate = 0, const frcnn_bn_reduce* red = nullptr) {
     FRCNN_CHECK_ARG(gpooled && argmax && rois && rows && gfeat && nrows > 0 && b > 0, "roi_crop_pool_bwd_bf16: bad arguments");
     FRCNN_CHECK_ARG(c % 64 == 0 && ps >= 1 && ks >= 1 && ks * ks <= 255 && hf > 1 && wf > 1, "roi_crop_pool_bwd_bf16: bad sizes");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    frcnn_bn_reduce rd{};
+    if (red) {
+        FRCNN_CHECK_ARG(red->z && red->mean && red->invstd && red->partial, "roi_crop_pool_bwd_bf16_add: incomplete BatchNorm-reduce arguments");
+        FRCNN_CHECK_ARG((size_t)wf * 64 * 4 >= 8 * 64 * 2 * 4, "roi_crop_pool_bwd_bf16_add: feature row too short for the reduce scratch");
+        rd = *red;
+    }
     // 64-channel slabs: 8 RoI rows in flight per workgroup, 8 workgroups per CU (measured: 118 us; 128 channels 129, 32 channels 127);
     // 32-channel slabs where a row of 64 channels does not fit 64 KB of LDS (the stride-4 level of a feature pyramid: 311 pixels)
     const size_t smem = (size_t)wf * 64 * 4;
@@ -572,19 +623,20 @@ static int roi_bwd_bf16_impl(const frcnn_bf16* gpooled, const uint8_t* argmax, c
         const size_t smem32 = (size_t)wf * 32 * 4;
         FRCNN_CHECK_ARG(smem32 <= 64 * 1024 && c % 32 == 0, "roi_crop_pool_bwd_bf16: feature map too wide (wf=%d)", wf);
         hipLaunchKernelGGL(roi_bwd_rows_kernel<32>, dim3(b * hf * (c / 32)), dim3(256), smem32, s, reinterpret_cast<const bf16_t*>(gpooled),
-                           argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat), levels, level, accumulate);
+                           argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat), levels, level, accumulate, rd);
         FRCNN_CHECK_LAUNCH("roi_crop_pool_bwd_bf16");
         return FRCNN_OK;
     }
     hipLaunchKernelGGL(roi_bwd_rows_kernel<64>, dim3(b * hf * (c / 64)), dim3(256), smem, s, reinterpret_cast<const bf16_t*>(gpooled),
-                       argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat), levels, level, accumulate);
+                       argmax, rois, rows, nrows, p, hf, wf, c, ps, ks, reinterpret_cast<bf16_t*>(gfeat), levels, level, accumulate, rd);
     FRCNN_CHECK_LAUNCH("roi_crop_pool_bwd_bf16");
     return FRCNN_OK;
 }
 
 extern "C" int frcnn_roi_crop_pool_bwd_bf16_add(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows, int nrows,
-                                                int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat, frcnn_stream_t stream) {
-    return roi_bwd_bf16_impl(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, ps, ks, gfeat, nullptr, 0, stream, 1);
+                                                int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat,
+                                                const struct frcnn_bn_reduce* red, frcnn_stream_t stream) {
+    return roi_bwd_bf16_impl(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, ps, ks, gfeat, nullptr, 0, stream, 1, red);
 }
 
 extern "C" int frcnn_roi_crop_pool_bwd_bf16(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,

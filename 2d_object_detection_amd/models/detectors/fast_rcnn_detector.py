@@ -158,7 +158,7 @@ class FastRCNNDetector:
         return {"regions": self.regions_abs, "pred_scores": self.scores, "pred_boxes": self.deltas}
 
     def backward_plan(self, plan, dlogits_s, ddeltas_s, indices, num_samples, rois, g_feat_bf16, head_grad_done=False, bias_grad_done=False,
-                      add_to_g_feat_after=None):
+                      add_to_g_feat_after=None, consumer=None):
         """Per-sample loss gradients -> head parameter gradients and the RoI-branch feature-map
         gradient, written (bf16) to g_feat_bf16 [B*hf*wf, C].  head_grad_done: self.dhead_s / self.rows were already written
         by the loss launch (ops.losses_head_grad)."""
@@ -172,9 +172,15 @@ class FastRCNNDetector:
         # gather form: every element of g_feat is written once, in bf16, without global atomics (no memset / cast passes)
         if add_to_g_feat_after is not None:
             # g_feat already receives another branch's gradient (the RPN's, on the side stream named here): wait for it, then add
+            # (consumer: the backbone's last conv unit -- g_feat is complete after this kernel, so it also runs that unit's
+            # BatchNorm-backward reduce)
             plan.join(add_to_g_feat_after)
+            red = None
+            if consumer is not None:
+                red = consumer.reduce_args(relu=True)
+                plan.hold(red)
             plan.add(ops.roi_crop_pool_bwd_bf16_add, self.dpooled_s, self.argmax, rois, self.rows, self.rs, self.batch, self.p, self.hf, self.wf,
-                     self.cf, self.ps, self.ks, g_feat_bf16)
+                     self.cf, self.ps, self.ks, g_feat_bf16, red=red)
         else:
             plan.add(ops.roi_crop_pool_bwd_bf16, self.dpooled_s, self.argmax, rois, self.rows, self.rs, self.batch, self.p, self.hf, self.wf,
                      self.cf, self.ps, self.ks, g_feat_bf16)

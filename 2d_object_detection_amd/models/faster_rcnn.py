@@ -300,14 +300,14 @@ class FasterRCNN:
         if training:
             if RPN_DGRAD_ON_SIDE_STREAM:
                 mods.rcnn.backward_plan(plan, None, None, t["rcnn_idx"], S_rcnn, rois, g_feat, head_grad_done=True, bias_grad_done=True,
-                                        add_to_g_feat_after="rpn_side")
+                                        add_to_g_feat_after="rpn_side", consumer=mods.fe.last_unit())
             else:
                 mods.rcnn.backward_plan(plan, None, None, t["rcnn_idx"], S_rcnn, rois, g_feat, head_grad_done=True, bias_grad_done=True)
                 plan.join("rpn_side")
                 mods.rpn.backward_data_plan(plan, g_feat, consumer=mods.fe.last_unit())
             plan.join("detections")
             plan.cut("bwd_conv4")
-            mods.fe.backward_plan(plan, g_feat, g_feat_reduced=not RPN_DGRAD_ON_SIDE_STREAM)
+            mods.fe.backward_plan(plan, g_feat, g_feat_reduced=True)
             plan.cut("update")
             optimizer.apply_plan(plan, stem=mods.fe.stem)     # SGD + the stem's packed taps + the step counter: one launch
             if mods.fe.f8 is not None:

@@ -469,9 +469,11 @@ def roi_crop_pool_bwd_bf16(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, 
     call("frcnn_roi_crop_pool_bwd_bf16", _p(gpooled), _p(argmax), _p(rois), _p(rows), nrows, b, p, hf, wf, c, ps, ks, _p(gfeat), _stream())
 
 
-def roi_crop_pool_bwd_bf16_add(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, ps, ks, gfeat):
-    """gfeat += the RoI-branch gradient (gfeat holds another consumer's gradient of the same map)"""
-    call("frcnn_roi_crop_pool_bwd_bf16_add", _p(gpooled), _p(argmax), _p(rois), _p(rows), nrows, b, p, hf, wf, c, ps, ks, _p(gfeat), _stream())
+def roi_crop_pool_bwd_bf16_add(gpooled, argmax, rois, rows, nrows, b, p, hf, wf, c, ps, ks, gfeat, red=None):
+    """gfeat += the RoI-branch gradient (gfeat holds another consumer's gradient of the same map); red (bn_reduce_args): also the
+    BatchNorm-backward sums of the layer gfeat arrives at"""
+    call("frcnn_roi_crop_pool_bwd_bf16_add", _p(gpooled), _p(argmax), _p(rois), _p(rows), nrows, b, p, hf, wf, c, ps, ks, _p(gfeat),
+         byref(red) if red is not None else None, _stream())
 
 
 # ---------------------------------------------------------------- feature pyramid (BASELINE.json configs[4])

@@ -439,10 +439,11 @@ int frcnn_roi_crop_pool_bwd_bf16(const frcnn_bf16* gpooled, const uint8_t* argma
                                  frcnn_stream_t stream);
 /* The same gradient ADDED to what gfeat already holds (every element read once, written once): gfeat = bf16(gfeat + RoI-branch gradient).
  * For a map whose other consumer wrote its gradient first -- the RPN's data gradient, which then can run beside the proposal NMS
- * instead of after the RoI backward pass. */
+ * instead of after the RoI backward pass.  red (optional): gfeat is complete with this launch and arrives at a BatchNorm(+ReLU) layer;
+ * its backward sums are accumulated while the rows are written, exactly what frcnn_bn_bwd_reduce(gout = gfeat, ...) would add. */
 int frcnn_roi_crop_pool_bwd_bf16_add(const frcnn_bf16* gpooled, const uint8_t* argmax, const float* rois, const int32_t* rows,
                                      int nrows, int b, int p, int hf, int wf, int c, int ps, int ks, frcnn_bf16* gfeat,
-                                     frcnn_stream_t stream);
+                                     const struct frcnn_bn_reduce* red, frcnn_stream_t stream);
 /* fast_rcnn_detector.py:62-65 after the GEMM: logits [R, ld] fp32 (+bias): softmax over the first
  * nc1 columns -> scores [R,nc1]; columns [nc1, nc1+4*(nc1-1)) -> deltas. */
 int frcnn_rcnn_head_post(const float* logits, int ld, const float* bias, int r, int nc1, float* scores, float* deltas,

@@ -569,6 +569,45 @@ def test_roi_bwd_with_mostly_padding_rois(ops):
     assert float(fr.grad[0, 0, 0].abs().max()) > 20.0
 
 
+def test_roi_bwd_add_form_with_fused_reduce(ops):
+    """frcnn_roi_crop_pool_bwd_bf16_add: gfeat = bf16(existing + RoI-branch gradient) -- against the plain gather form added in fp32 --
+    and, with `red`, the BatchNorm-backward sums of the layer gfeat arrives at, against frcnn_bn_bwd_reduce on the stored result."""
+    g = torch.Generator().manual_seed(26)
+    B, P, Hf, Wf, C, dev = 2, 24, 24, 78, 128, "cuda"
+    feat = _rt(torch.randn(B, Hf, Wf, C, generator=g))
+    x0, y0 = torch.rand(B, P, generator=g) * 0.7, torch.rand(B, P, generator=g) * 0.7
+    rois = torch.stack([x0, y0, x0 + torch.rand(B, P, generator=g) * 0.3 + 0.02, y0 + torch.rand(B, P, generator=g) * 0.3 + 0.02], -1)
+    rois[0, :3] = 0.0
+    pooled = torch.empty(B * P, 49 * C, dtype=BF, device=dev)
+    am = torch.empty(B * P, 49 * C, dtype=torch.uint8, device=dev)
+    ops.roi_crop_pool_fwd(feat.to(BF).to(dev), rois.to(dev), B, P, Hf, Wf, C, 7, 2, pooled, am)
+    rows = torch.cat([torch.arange(0, 16), torch.arange(24, 24 + 20)]).to(torch.int32).to(dev)
+    gp = _rt(torch.randn(len(rows), 49 * C, generator=g)).to(BF).to(dev)
+    existing = (torch.randn(B, Hf, Wf, C, generator=g) * 0.5).to(BF).to(dev)
+    plain = torch.empty(B, Hf, Wf, C, dtype=BF, device=dev)
+    ops.roi_crop_pool_bwd_bf16(gp, am, rois.to(dev), rows, len(rows), B, P, Hf, Wf, C, 7, 2, plain)
+    z = torch.randn(B * Hf * Wf, C, generator=g).to(BF).to(dev)
+    relu_mask = torch.randint(0, 256, (B * Hf * Wf, C // 8), generator=g, dtype=torch.uint8).to(dev)
+    mean, invstd = (torch.randn(C, generator=g) * 0.1).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev)
+    part_a, part_b = torch.zeros(16, 2, C, device=dev), torch.zeros(16, 2, C, device=dev)
+    out = existing.clone()
+    red = ops.bn_reduce_args(z, relu_mask, mean, invstd, part_b)
+    ops.roi_crop_pool_bwd_bf16_add(gp, am, rois.to(dev), rows, len(rows), B, P, Hf, Wf, C, 7, 2, out, red=red)
+    ops.bn_bwd_reduce(out, None, z, mean, invstd, part_a, B * Hf * Wf, C, relu_mask=relu_mask)
+    torch.cuda.synchronize()
+    # the add form rounds existing + fp32 row sum once; the reference here adds two bf16 tensors: one bf16 ulp of the larger term apart
+    ref = existing.float() + plain.float()
+    _close(out, ref.cpu(), 2 ** -7, 2e-2, "RoI backward, add form")
+    sa, sb = part_a.sum(0).cpu(), part_b.sum(0).cpu()
+    scale = float(out.float().view(-1, C).abs().sum(0).max().cpu())
+    assert float(sa.abs().max()) > 0 and float((sa - sb).abs().max()) <= 4e-6 * scale + 1e-5, (float((sa - sb).abs().max()), scale)
+    # without `red` nothing but gfeat is touched
+    out2 = existing.clone()
+    ops.roi_crop_pool_bwd_bf16_add(gp, am, rois.to(dev), rows, len(rows), B, P, Hf, Wf, C, 7, 2, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
+
+
 # ------------------------------------------------------------------ targets / sampling / losses
 def _targets_case(seed, B, R, rpn):
     g = torch.Generator().manual_seed(seed)
