@@ -613,12 +613,12 @@ static int roi_bwd_bf16_impl(const frcnn_bf16* gpooled, const uint8_t* argmax, c
     frcnn_bn_reduce rd{};
     if (red) {
         FRCNN_CHECK_ARG(red->z && red->mean && red->invstd && red->partial, "roi_crop_pool_bwd_bf16_add: incomplete BatchNorm-reduce arguments");
-        FRCNN_CHECK_ARG((size_t)wf * 64 * 4 >= 8 * 64 * 2 * 4, "roi_crop_pool_bwd_bf16_add: feature row too short for the reduce scratch");
         rd = *red;
     }
     // 64-channel slabs: 8 RoI rows in flight per workgroup, 8 workgroups per CU (measured: 118 us; 128 channels 129, 32 channels 127);
     // 32-channel slabs where a row of 64 channels does not fit 64 KB of LDS (the stride-4 level of a feature pyramid: 311 pixels)
-    const size_t smem = (size_t)wf * 64 * 4;
+    // (LDS: one feature row of the slab in fp32; with a fused reduce at least its 4 KB of scratch)
+    const size_t smem = (size_t)wf * 64 * 4 < 4096 ? 4096 : (size_t)wf * 64 * 4;
     if (smem > 64 * 1024) {
         const size_t smem32 = (size_t)wf * 32 * 4;
         FRCNN_CHECK_ARG(smem32 <= 64 * 1024 && c % 32 == 0, "roi_crop_pool_bwd_bf16: feature map too wide (wf=%d)", wf);

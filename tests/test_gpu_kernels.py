@@ -969,8 +969,8 @@ def test_cast_and_relu_colsum_fused_equal_two_launches(ops, m, c):
     assert torch.equal(d_a.view(torch.int16), d_b.view(torch.int16)) and torch.equal(r_a.view(torch.int16), r_b.view(torch.int16))
     if m <= 256:
         assert torch.equal(s_a, s_b) and torch.equal(t_a, t_b)
-    _close(s_b, s_a.cpu(), 1e-6, 1e-6, "cast + column sums")
-    _close(t_b, t_a.cpu(), 1e-6, 1e-5, "ReLU backward + column sums")
+    _close(s_b, s_a.cpu(), 1e-5, 1e-4, "cast + column sums")                   # (one float atomic per column and 256-row chunk: arrival order)
+    _close(t_b, t_a.cpu(), 1e-5, 1e-4, "ReLU backward + column sums")
     _close(t_b, r_a.double().sum(0).float().cpu(), 1e-5, 1e-3, "column sums against torch")
 
 
