@@ -29,8 +29,11 @@ BF16 = torch.bfloat16
 LOSS_NAMES = ("rpn_cls", "rpn_reg", "rcnn_cls", "rcnn_reg")
 
 
-# measuring aid (tools/ab_lib.sh): 1 = the RPN's 3x3 data gradient runs on the RPN's side stream and the RoI backward pass adds to its result
-RPN_DGRAD_ON_SIDE_STREAM = os.environ.get("FRCNN_RPN_DGRAD_SIDE", "0") != "0"
+# The RPN's 3x3 data gradient (a 50 us launch that needs nothing from the RoI branch) runs on the RPN's side stream, beside proposal NMS /
+# RoI pooling / heads, and WRITES g_feat; the RoI backward pass then ADDS its gradient and runs the last backbone unit's BatchNorm-backward
+# reduce (ops.roi_crop_pool_bwd_bf16_add).  Round 3 had it on the main chain after the RoI backward pass.  Same-box A/B (tools/ab_lib.sh,
+# FRCNN_RPN_DGRAD_SIDE=0 / 1, twice): 4.107 -> 4.071, 4.104 -> 4.089 ms.  (C4 plan; the pyramid plan keeps the old order.)
+RPN_DGRAD_ON_SIDE_STREAM = os.environ.get("FRCNN_RPN_DGRAD_SIDE", "1") != "0"
 
 
 class _Modules:
