@@ -34,6 +34,8 @@ LOSS_NAMES = ("rpn_cls", "rpn_reg", "rcnn_cls", "rcnn_reg")
 # reduce (ops.roi_crop_pool_bwd_bf16_add).  Round 3 had it on the main chain after the RoI backward pass.  Same-box A/B (tools/ab_lib.sh,
 # FRCNN_RPN_DGRAD_SIDE=0 / 1, twice): 4.107 -> 4.071, 4.104 -> 4.089 ms.  (C4 plan; the pyramid plan keeps the old order.)
 RPN_DGRAD_ON_SIDE_STREAM = os.environ.get("FRCNN_RPN_DGRAD_SIDE", "1") != "0"
+# measuring aid: 1 = RPN target assignment + sampling run on the weight re-layout side stream, under the forward pass
+RPN_TARGETS_UNDER_FORWARD = os.environ.get("FRCNN_RPN_TARGETS_EARLY", "0") != "0"
 
 
 class _Modules:
@@ -195,6 +197,7 @@ class FasterRCNN:
         mods.rcnn.setup(batch, P, gh, gw, training, S_rcnn)
         step = optimizer.iterations if training else self._eval_step
 
+        rpn_targets_early = False
         if training:
             plan.zero(self.store.g)
             # derived weights for the backward pass: all tap-flipped transposes (backbone, RPN, heads) in ONE launch, on a
@@ -205,6 +208,7 @@ class FasterRCNN:
                 plan.add(ops.weights_transpose_flip_batched, table, total)
                 if mods.fe.f8 is not None:           # fp8 mode: e4m3 twins of the transposes, for the fp8 data gradients
                     mods.fe.quantize_bwd_weights_plan(plan, extra=mods.rpn.quant_entries_bwd())
+                rpn_targets_early = RPN_TARGETS_UNDER_FORWARD
         # ---- targets, sampling, losses (+ per-sample gradients)
         n = mods.rpn.n
         f32 = dict(dtype=torch.float32, device=dev)
@@ -256,6 +260,12 @@ class FasterRCNN:
                 plan.add(ops.losses, rcnn_out["pred_scores"], rcnn_out["pred_boxes"], t["rcnn_tl"], t["rcnn_tb"], t["rcnn_idx"], batch, P,
                          nc1, S_rcnn, cls_scale, 1.0, losses[2:4], None, None)
 
+        if rpn_targets_early:
+            # The RPN's targets and sample indices depend on the anchors and the ground truth, not on the predictions: they join the
+            # side stream that already runs under the forward pass (no new fork), so that the RPN's own side stream -- since round 4
+            # the longer of the two chains between the proposals and the backbone's backward pass -- starts with the loss launch
+            with plan.branch("weight_flips"):
+                rpn_targets(mods.rpn.regions(True))
         feat = mods.fe.forward_plan(plan, training)
         feat2d = feat.view(batch * gh * gw, cf)
         nms_cfg = self._rpn_config["nms"]
@@ -268,7 +278,8 @@ class FasterRCNN:
             t["g_feat"] = g_feat
             plan.join("weight_flips")
             with plan.branch("rpn_side"):
-                rpn_targets(rpn_out["regions"])
+                if not rpn_targets_early:
+                    rpn_targets(rpn_out["regions"])
                 rpn_losses()
                 mods.rpn.backward_params_plan(plan, None, None, t["rpn_idx"], S_rpn, feat2d, head_grad_done=True)
                 if RPN_DGRAD_ON_SIDE_STREAM:
@@ -367,6 +378,16 @@ class FasterRCNN:
                 plan.add(ops.weights_transpose_flip_batched, table, total)
                 if fe.f8 is not None:                # precision "fp8": the backbone + the pyramid's 3x3 convolutions
                     fe.quantize_bwd_weights_plan(plan, extra=neck.quant_entries()[1] + rpn.quant_entries()[1])
+        rpn_targets_early = training and RPN_TARGETS_UNDER_FORWARD
+
+        def rpn_targets():
+            plan.add(ops.assign_targets, rpn.regions_all, io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
+                     rs["foreground_iou_interval"], rs["background_iou_interval"], t["rpn_tl"], t["rpn_tb"])
+            plan.add(ops.sample_indices, t["rpn_tl"], batch, n, 2, S_rpn, rs["foreground_proportion"], self.sampling_seed, step, 0,
+                     t["rpn_idx"], t["rpn_ws"], self.status, image_base=self.sampling_image_base)
+        if rpn_targets_early:                        # (as in the C4 plan: on the side stream that runs under the forward pass)
+            with plan.branch("weight_flips"):
+                rpn_targets()
         fe.forward_plan(plan, training)
         stage_maps = {l: fe.acts[last[l]]["out"] for l in FPN_LEVELS}
         pyramid = neck.forward_plan(plan, stage_maps, {l: fe.acts[last[l]].get("out_8") for l in FPN_LEVELS} if training else None)
@@ -378,10 +399,8 @@ class FasterRCNN:
         if training:
             plan.join("weight_flips")                # (the RPN's parameter gradients below read the transposed head weights)
         with plan.branch("rpn_side"):
-            plan.add(ops.assign_targets, rpn_out["regions"], io["gt_labels"], io["gt_boxes"], batch, n, G, nc1, True, W, H,
-                     rs["foreground_iou_interval"], rs["background_iou_interval"], t["rpn_tl"], t["rpn_tb"])
-            plan.add(ops.sample_indices, t["rpn_tl"], batch, n, 2, S_rpn, rs["foreground_proportion"], self.sampling_seed, step, 0,
-                     t["rpn_idx"], t["rpn_ws"], self.status, image_base=self.sampling_image_base)
+            if not rpn_targets_early:
+                rpn_targets()
             plan.add(ops.losses, rpn_out["pred_scores"], rpn_out["pred_boxes"], t["rpn_tl"], t["rpn_tb"], t["rpn_idx"], batch, n, 2, S_rpn,
                      cls_scale, 1.0, losses[0:2], t.get("rpn_dl"), t.get("rpn_dd"))
             if training:
