@@ -34,8 +34,11 @@ LOSS_NAMES = ("rpn_cls", "rpn_reg", "rcnn_cls", "rcnn_reg")
 # reduce (ops.roi_crop_pool_bwd_bf16_add).  Round 3 had it on the main chain after the RoI backward pass.  Same-box A/B (tools/ab_lib.sh,
 # FRCNN_RPN_DGRAD_SIDE=0 / 1, twice): 4.107 -> 4.071, 4.104 -> 4.089 ms.  (C4 plan; the pyramid plan keeps the old order.)
 RPN_DGRAD_ON_SIDE_STREAM = os.environ.get("FRCNN_RPN_DGRAD_SIDE", "1") != "0"
-# measuring aid: 1 = RPN target assignment + sampling run on the weight re-layout side stream, under the forward pass
-RPN_TARGETS_UNDER_FORWARD = os.environ.get("FRCNN_RPN_TARGETS_EARLY", "0") != "0"
+# RPN target assignment + sampling (anchors and ground truth only: no prediction) run on the weight re-layout side stream, under the
+# forward pass, instead of at the head of the RPN's side stream behind the RPN convolutions.  Same-box A/B (FRCNN_RPN_TARGETS_EARLY=0 / 1,
+# twice each): pyramid + fp8 + batch 8 (82 k regions per image: 53 + 83 us of one-workgroup-per-image kernels) 8.697 -> 8.605 ms; C4 batch 4
+# 4.087 -> 4.089 (neutral: that chain is not the critical one there).
+RPN_TARGETS_UNDER_FORWARD = os.environ.get("FRCNN_RPN_TARGETS_EARLY", "1") != "0"
 
 
 class _Modules:
