@@ -307,6 +307,7 @@ struct LossParams {
     bf16_t* dhead; int ld; int* rows_out;          // optional fused Fast-RCNN head-gradient rows (what rcnn_head_grad_kernel writes)
     float* rpn_dhead; const int* keep; int locs, apl, rpn_ld;   // optional fused RPN scatter-add (what rpn_head_grad_kernel does; C1 == 2)
     float* bias_grad;                              // optional (with dhead, ld <= 64): += column sums of the dhead rows (colsum_kernel's sums)
+    int stage;                                     // dhead rows are assembled in (dynamic) LDS and leave as 16-byte vectors
 };
 
 // One workgroup, one thread per sampled row (rows beyond 1024: strided).  MAXC bounds C1 at compile time (2 / 8 / 32): the row's
@@ -316,6 +317,7 @@ template <int MAXC>
 __global__ __launch_bounds__(1024) void losses_kernel(const LossParams p) {
     __shared__ float red[2][16];
     __shared__ float cs[32][65];
+    extern __shared__ __attribute__((aligned(16))) unsigned char hstage[];     // [rows][ld] bf16 when p.stage
     const int C = p.C1 - 1;
     const int rows = p.B * p.S;
     const float inv_rows = 1.0f / (float)rows;
@@ -341,7 +343,9 @@ __global__ __launch_bounds__(1024) void losses_kernel(const LossParams p) {
             tv[c] = c < C ? *reinterpret_cast<const f32x4*>(tbr + c * 4) : z4;
             pv[c] = c < C ? *reinterpret_cast<const f32x4*>(pvr + c * 4) : z4;
         }
-        bf16_t* hrow = p.dhead ? p.dhead + (int64_t)i * p.ld : nullptr;
+        // the head-gradient row of this sample: 64 two-byte values.  Written straight to global memory they are 64 store instructions
+        // per wave, each touching 64 different 128-byte rows; staged (p.stage) they go to LDS and leave below as whole 16-byte vectors
+        bf16_t* hrow = p.dhead ? (p.stage ? reinterpret_cast<bf16_t*>(hstage) + (int64_t)i * p.ld : p.dhead + (int64_t)i * p.ld) : nullptr;
         float* arow = nullptr;                       // RPN: the dense head-gradient row of this sample's location, and its anchor slot
         int ak = 0;
         if (p.rpn_dhead) {
@@ -436,10 +440,17 @@ __global__ __launch_bounds__(1024) void losses_kernel(const LossParams p) {
         p.losses[0] = a * inv_rows;
         p.losses[1] = c2;
     }
+    if (p.stage) {
+        __syncthreads();
+        const int nvec = rows * p.ld / 8;                         // (ld % 8 == 0: checked by the host)
+        for (int v = threadIdx.x; v < nvec; v += blockDim.x)
+            *reinterpret_cast<u32x4*>(p.dhead + (int64_t)v * 8) = *reinterpret_cast<const u32x4*>(hstage + (int64_t)v * 16);
+    }
     if (p.bias_grad) {
         // The head's bias gradient = column sums of the bf16 gradient rows written above, in colsum_kernel's order (row chunks of 256;
         // per column 32 partial sums over rows rl, rl + 32, ..., added in ascending rl; one atomic per column and chunk): the bits
         // frcnn_colsum_bf16(dhead_s, B*S, ld, ld, bias_grad) produces, without its launch.
+        const bf16_t* hsrc = p.stage ? reinterpret_cast<const bf16_t*>(hstage) : p.dhead;
         __threadfence_block();
         __syncthreads();
         const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(1024) void losses_kernel(const LossParams p) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int r = r0 + rl + 32 * k;
-                    vv[k] = (col < p.ld && r < r1) ? bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(p.dhead + (int64_t)r * p.ld + col)) : 0.f;
+                    vv[k] = (col < p.ld && r < r1) ? bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(hsrc + (int64_t)r * p.ld + col)) : 0.f;
                 }
                 float s = 0.f;
 #pragma unroll
@@ -471,10 +482,15 @@ __global__ __launch_bounds__(1024) void losses_kernel(const LossParams p) {
     }
 }
 
-static void launch_losses(const LossParams& p, hipStream_t stream) {
-    if (p.C1 <= 2) hipLaunchKernelGGL(losses_kernel<2>, dim3(1), dim3(1024), 0, stream, p);
-    else if (p.C1 <= 8) hipLaunchKernelGGL(losses_kernel<8>, dim3(1), dim3(1024), 0, stream, p);
-    else hipLaunchKernelGGL(losses_kernel<kMaxC1>, dim3(1), dim3(1024), 0, stream, p);
+static void launch_losses(LossParams p, hipStream_t stream) {
+    // head-gradient rows through LDS when they fit beside the static arrays (48 KB: 384 rows of 64 columns) and every row is owned by one
+    // thread of the single pass (rows <= 1024)
+    const size_t bytes = p.dhead ? (size_t)p.B * p.S * p.ld * 2 : 0;
+    p.stage = (p.dhead && p.ld % 8 == 0 && bytes <= 48 * 1024 && p.B * p.S <= 1024) ? 1 : 0;
+    const size_t smem = p.stage ? bytes : 0;
+    if (p.C1 <= 2) hipLaunchKernelGGL(losses_kernel<2>, dim3(1), dim3(1024), smem, stream, p);
+    else if (p.C1 <= 8) hipLaunchKernelGGL(losses_kernel<8>, dim3(1), dim3(1024), smem, stream, p);
+    else hipLaunchKernelGGL(losses_kernel<kMaxC1>, dim3(1), dim3(1024), smem, stream, p);
 }
 
 // RPN: scatter-add per-sample gradients into the dense fp32 head-gradient matrix
