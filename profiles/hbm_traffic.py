@@ -29,14 +29,18 @@ def family(name):
         return "conv fprop/dgrad (conv_tile_kernel)"
     if "wgrad_kernel" in name or "wgrad_group_kernel" in name:
         return "conv wgrad (wgrad_kernel, wgrad_group_kernel)"
-    if "bn_" in name:
-        return "batchnorm apply / reduce (bn_*_kernel)"
+    # (kernel NAMES, not argument types: roi_bwd_rows_kernel and maxpool_bwd_bnreduce_kernel take a frcnn_bn_reduce argument, which
+    # appears in their mangled names)
     if "roi_fwd" in name:
         return "RoI crop+pool forward (roi_fwd_kernel)"
     if "roi_bwd" in name:
         return "RoI crop+pool backward (roi_bwd_rows_kernel)"
     if "nms_" in name:
         return "combined NMS (nms_class_kernel + nms_merge_kernel)"
+    if "maxpool_bwd_bnreduce" in name:
+        return "other"
+    if "bn_train" in name or "bn_bwd" in name or "bn_apply" in name:
+        return "batchnorm apply / reduce (bn_*_kernel)"
     return "other"
 
 
