@@ -845,6 +845,136 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------- the ResNet stem, on its own
+// conv1 of the backbone (7x7 / 2 on the 4-channel padded image, K = 7 rows x (8 pixels x 4 channels), 64 output channels;
+// models/feature_extractor.py:8) through the general kernel is INGEST-bound: every 128-pixel tile re-fetches its 7 x 8 KB of
+// overlapping A rows (adjacent output pixels share 6 of their 8 input pixels) and the whole 28 KB filter bank -- 100 KB through the CU's
+// load path per 16 KB of output, 57 us for a layer whose HBM roofline is 12.  Here a WAVE owns 16 consecutive output pixels x all 64
+// channels and needs no LDS for its operands at all:
+//   * the filter bank lives in REGISTERS for the whole launch (7 x 4 fragments of 16 bytes per lane = 112 VGPRs: lane (c, q) holds
+//     K chunk q of output channel 16 j + c of every tap row kh);
+//   * the pixel operand of tap row kh is ONE 16-byte load per lane straight from the image (lane (p, q): pixels 2p + 2q, 2p + 2q + 1 of
+//     input row 2 oy + kh -- 16-byte aligned because the stride is 2 pixels of 4 bf16 channels); neighbouring lanes overlap, which
+//     the vector L1 absorbs; the next unit's 7 loads are in flight under this unit's 28 MFMAs;
+//   * the epilogue (bias, bf16 rounding, the BatchNorm statistics of the rounded values) stages the wave's 16 x 64 outputs in 2 KB of
+//     wave-private LDS and stores them as one contiguous 2 KB run.
+// No barrier until the statistics flush at the very end.
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvParams p, const int units_per_row, const int total_units) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PITCH = 144;                   // staging row pitch (128 B of channels + 16: the 16 pixel rows spread over the banks)
+    __shared__ __attribute__((aligned(16))) unsigned char stage_all[4][16 * PITCH];
+    __shared__ float wsum[4][2][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pl = lane & 15, q = lane >> 4;
+    unsigned char* stage = stage_all[wave];
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+
+    bf16x8 wf[7][4];                             // the filter bank: [tap row][16-channel block], K chunk q of channel 16 j + pl
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[kh][j] = *reinterpret_cast<const bf16x8*>(p.w + ((16 * j + pl) * 7 + kh) * 32 + q * 8);
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.flags & FRCNN_CONV_BIAS) b = *reinterpret_cast<const f32x4*>(p.bias + 16 * j + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[j][e] = b[e];
+    }
+    float ssum[4][4], ssq[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssum[j][e] = ssq[j][e] = 0.f;
+
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const unsigned row_pitch = (unsigned)p.Wi * 8u;          // bytes per input row (4 bf16 channels per pixel)
+    auto issue = [&](const int u, u32x4 (&a)[7]) {
+        const int row = u / units_per_row;                    // n * Ho + oy
+        const int ox0 = (u - row * units_per_row) * 16;
+        const int n = row / p.Ho, oy = row - n * p.Ho;
+        const unsigned base = (unsigned)(((n * p.Hi + 2 * oy) * p.Wi + 2 * (ox0 + pl) + 2 * q) * 8);
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) a[kh] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, base + (unsigned)kh * row_pitch, 0, 0);
+    };
+    u32x4 cur[7], nxt[7];
+    int u = gw;
+    if (u < total_units) issue(u, cur);
+    for (; u < total_units; u += nw) {
+        if (u + nw < total_units) issue(u + nw, nxt);
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][j], __builtin_bit_cast(bf16x8, cur[kh]), acc[j], 0, 0, 0);
+        // ---- epilogue of the unit: lane (pl, q) holds channels 16 j + 4 q + {0..3} of pixel ox0 + pl
+        const int row = u / units_per_row;
+        const int ox0 = (u - row * units_per_row) * 16;
+        const bool valid = ox0 + pl < p.Wo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x2 pk;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x2 v;
+                v[0] = acc[j][2 * h] + bv[j][2 * h];
+                v[1] = acc[j][2 * h + 1] + bv[j][2 * h + 1];
+                const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
+                pk[h] = bits;
+                if (STATS) {                     // sums of the ROUNDED outputs (what the BatchNorm kernel reads)
+                    const float q0 = valid ? __uint_as_float(bits << 16) : 0.f, q1 = valid ? __uint_as_float(bits & 0xFFFF0000u) : 0.f;
+                    ssum[j][2 * h] += q0;
+                    ssq[j][2 * h] += q0 * q0;
+                    ssum[j][2 * h + 1] += q1;
+                    ssq[j][2 * h + 1] += q1 * q1;
+                }
+            }
+            *reinterpret_cast<u32x2*>(stage + pl * PITCH + (16 * j + 4 * q) * 2) = pk;
+        }
+        // (same wave writes and reads: LDS operations of a wave complete in order, no barrier)
+        bf16_t* out = reinterpret_cast<bf16_t*>(p.y) + ((long long)row * p.Wo + ox0) * 64;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int L = lane + 64 * half, pix = L >> 3, c = L & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stage + pix * PITCH + c * 16);
+            if (ox0 + pix < p.Wo) *reinterpret_cast<u32x4*>(out + pix * 64 + c * 8) = v;
+        }
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) cur[kh] = nxt[kh];
+    }
+    if (STATS) {
+        // the 16 pixel lanes of a wave meet by butterflies, the four waves in LDS, then one f64 atomic per (statistic, channel) and
+        // workgroup into one of the pre-zeroed slots (as conv_tile_kernel's statistics flush)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = ssum[j][e], b = ssq[j][e];
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) {
+                    a += __shfl_xor(a, sh);
+                    b += __shfl_xor(b, sh);
+                }
+                if (pl == 0) {
+                    wsum[wave][0][16 * j + 4 * q + e] = a;
+                    wsum[wave][1][16 * j + 4 * q + e] = b;
+                }
+            }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int st = threadIdx.x >> 6, c = threadIdx.x & 63;
+            const float v = (wsum[0][st][c] + wsum[1][st][c]) + (wsum[2][st][c] + wsum[3][st][c]);
+            atomicAdd(p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * 64 + c, (double)v);
+        }
+    }
+#endif
+}
+
 // Name of the instantiation the calling thread launched last (frcnn_last_conv_instantiation): lets the parity tests assert
 // WHICH kernel a shape dispatched to, so that their coverage cannot rot silently when the heuristics below move.
 thread_local char g_last_inst[512] = "";
@@ -1201,6 +1331,29 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
         const long long yb = M * d->cout * 2;
         p.direct_out = (d->out_scatter == 1 && d->out_h == d->ho && d->out_w == d->wo && yb < 0xFFFF0000ll) ? 1 : 0;
         p.y_bytes = p.direct_out ? (unsigned)yb : 0u;
+    }
+    // the ResNet stem's packed descriptor (7 tap rows of 8 pixels x 4 channels, stride 2, 64 output channels, plain bf16 output):
+    // its own kernel (conv_stem_kernel)
+    bool stem = d->kh == 7 && d->kw == 1 && d->cin == 32 && d->in_pix_stride == 4 && d->stride == 2 && d->pad_h == 0 && d->pad_w == 0 && d->cout == 64 &&
+                p.direct_out && !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_STATS | FRCNN_CONV_WGRAD_ACCUMULATE | FRCNN_CONV_WGRAD_STEM_UNPACK)) && !res && !red &&
+                !f8_x_scale && !d->workspace && d->wi % 2 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_STEM_OLD")) { if (atoi(e)) stem = false; }
+#endif
+    if (stem) {
+        const int units_per_row = (d->wo + 15) / 16;
+        const long long total = (long long)d->n * d->ho * units_per_row;
+        FRCNN_CHECK_ARG(total < (1ll << 30), "conv2d_fprop: stem grid too large");
+        // two workgroups of four waves per CU (the filter bank in registers: ~190 VGPRs per lane), every wave walks its share of units
+        int grid = 2 * num_cus();
+        if ((long long)grid * 4 > total) grid = (int)((total + 3) / 4);
+        snprintf(g_last_inst, sizeof(g_last_inst), "conv_stem<STATS=%d> grid=%dx1 tpb=1", (flags & FRCNN_CONV_STATS) ? 1 : 0, grid);
+        if (dry_run) return FRCNN_OK;
+        hipStream_t s_ = reinterpret_cast<hipStream_t>(stream);
+        if (flags & FRCNN_CONV_STATS) hipLaunchKernelGGL(conv_stem_kernel<true>, dim3(grid), dim3(256), 0, s_, p, units_per_row, (int)total);
+        else hipLaunchKernelGGL(conv_stem_kernel<false>, dim3(grid), dim3(256), 0, s_, p, units_per_row, (int)total);
+        FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop(stem)");
+        return FRCNN_OK;
     }
     return conv_tile_dispatch(p, d, reinterpret_cast<hipStream_t>(stream));
 }

@@ -174,8 +174,21 @@ def test_conv_stem(ops):
     d = ops.conv_desc(n, hp, wp, 32, 7, 1, 2, 0, 0, ho, wo, 64, in_pix_stride=4, flags=ops.CONV_BIAS)
     y = torch.empty(n, ho, wo, 64, dtype=BF, device="cuda")
     ops.conv2d_fprop(d, xpad, w_packed, y, bias=bias.cuda())
+    assert ops.last_conv_instantiation().startswith("conv_stem<STATS=0>"), ops.last_conv_instantiation()
     torch.cuda.synchronize()
     _close(y, ref, 2 ** -7, 0.5, "stem conv")          # |x| up to 150 -> outputs O(100)
+    # training form: the same outputs + the BatchNorm statistics of the ROUNDED outputs (column sums / sums of squares, f64 slots)
+    ds = ops.conv_desc(n, hp, wp, 32, 7, 1, 2, 0, 0, ho, wo, 64, in_pix_stride=4, flags=ops.CONV_BIAS | ops.CONV_STATS)
+    y2 = torch.full((n, ho, wo, 64), 7.0, dtype=BF, device="cuda")
+    stats = torch.zeros(16, 2, 64, dtype=torch.float64, device="cuda")
+    ops.conv2d_fprop(ds, xpad, w_packed, y2, bias=bias.cuda(), stats=stats)
+    assert ops.last_conv_instantiation().startswith("conv_stem<STATS=1>"), ops.last_conv_instantiation()
+    torch.cuda.synchronize()
+    assert torch.equal(y2.view(torch.int16), y.view(torch.int16)), "the statistics form must not change the outputs"
+    yd = y2.double().view(-1, 64).cpu()
+    got = stats.sum(0).cpu()
+    assert float((got[0] - yd.sum(0)).abs().max()) <= 1e-4 * float(yd.abs().sum(0).max()), "column sums"
+    assert float((got[1] - (yd * yd).sum(0)).abs().max()) <= 1e-4 * float((yd * yd).sum(0).max()), "column sums of squares"
 
 
 def test_conv_dgrad_3x3_with_residual(ops):
