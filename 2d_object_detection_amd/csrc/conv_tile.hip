@@ -975,9 +975,148 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvParams p, c
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------- short-K 1x1 layers, streamed
+// The expansion layers of conv2 / conv3 (1x1, stride 1, 64 -> 256 and 128 -> 512; also conv2's 64 -> 64) have ONE or TWO K slices: in
+// the tile kernel they are all prologue and epilogue (19-22 us against an HBM roofline of 9.4 at 64 -> 256: input once, output once).
+// The stem kernel's scheme fits them as well: a wave owns 16 consecutive pixels x NC output channels, its slice of the filter bank
+// (NC x K bf16 = 16 KB) stays in REGISTERS for the whole launch, the pixel operand is K / 32 16-byte loads per lane straight from the
+// activation tensor (a pixel row is K * 2 contiguous bytes: lanes (p, q) and K step kk read bytes [64 kk + 16 q, +16) of row p --
+// 16 rows x 128 / 256 contiguous bytes per unit), the next unit's loads fly under this unit's MFMAs, and the epilogue (bias, bf16
+// rounding, BatchNorm statistics of the rounded values) goes through wave-private LDS to contiguous 16-byte stores.  The Cout / NC
+// channel parts of a pixel group are taken by neighbouring waves (same A rows: vector-L1 hits).
+template <int K, int NC, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvParams p, const int parts, const int total_units) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KK = K / 32, NJ = NC / 16;
+    constexpr int PITCH = NC * 2 + 16;           // staging row pitch
+    __shared__ __attribute__((aligned(16))) unsigned char stage_all[4][16 * PITCH];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pl = lane & 15, q = lane >> 4;
+    unsigned char* stage = stage_all[wave];
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    // a wave keeps ONE channel part for the whole launch: global wave g takes part g % parts and the pixel groups g / parts, + stride
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;         // (the host makes nw a multiple of parts)
+    const int part = gw % parts;
+    const int n0 = part * NC;
+    bf16x8 wf[KK][NJ];                           // K chunk q of channel n0 + 16 j + pl, K step kk
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wf[kk][j] = *reinterpret_cast<const bf16x8*>(p.w + (long long)(n0 + 16 * j + pl) * K + kk * 32 + q * 8);
+    float bv[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.flags & FRCNN_CONV_BIAS) b = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * j + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[j][e] = b[e];
+    }
+    float ssum[STATS ? NJ : 1][4], ssq[STATS ? NJ : 1][4];
+#pragma unroll
+    for (int j = 0; j < (STATS ? NJ : 1); ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssum[j][e] = ssq[j][e] = 0.f;
+    const float lo = (p.flags & FRCNN_CONV_RELU) ? 0.f : -__builtin_inff();
+
+    auto issue = [&](const int grp, u32x4 (&a)[KK]) {
+        const unsigned base = (unsigned)(grp * 16 + pl) * (unsigned)(p.in_pix_stride * 2) + (unsigned)q * 16u;      // (rows beyond M: beyond the descriptor, zeros)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) a[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (grp * 16 + pl) < p.M ? base + kk * 64u : kOob, 0, 0);
+    };
+    const int groups = total_units;              // 16-pixel groups
+    const int gstride = nw / parts;
+    u32x4 cur[KK], nxt[KK];
+    int grp = gw / parts;
+    if (grp < groups) issue(grp, cur);
+    for (; grp < groups; grp += gstride) {
+        if (grp + gstride < groups) issue(grp + gstride, nxt);
+        f32x4 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], __builtin_bit_cast(bf16x8, cur[kk]), acc[j], 0, 0, 0);
+        const int m0 = grp * 16;
+        const bool valid = m0 + pl < p.M;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            u32x2 pk;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x2 v;
+                v[0] = __builtin_amdgcn_fmed3f(acc[j][2 * h] + bv[j][2 * h], lo, __builtin_inff());
+                v[1] = __builtin_amdgcn_fmed3f(acc[j][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
+                const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+                pk[h] = bits;
+                if (STATS) {
+                    const float q0 = valid ? __uint_as_float(bits << 16) : 0.f, q1 = valid ? __uint_as_float(bits & 0xFFFF0000u) : 0.f;
+                    ssum[STATS ? j : 0][2 * h] += q0;
+                    ssq[STATS ? j : 0][2 * h] += q0 * q0;
+                    ssum[STATS ? j : 0][2 * h + 1] += q1;
+                    ssq[STATS ? j : 0][2 * h + 1] += q1 * q1;
+                }
+            }
+            *reinterpret_cast<u32x2*>(stage + pl * PITCH + (16 * j + 4 * q) * 2) = pk;
+        }
+        // 16 rows x NC * 2 bytes staged: NC / 8 16-byte vectors per row, NC * 2 / 64 per lane
+        bf16_t* out = reinterpret_cast<bf16_t*>(p.y) + (long long)m0 * p.Cout + n0;
+        constexpr int VPR = NC / 8;              // vectors per row
+#pragma unroll
+        for (int it = 0; it < (16 * VPR) / 64; ++it) {
+            const int L = lane + 64 * it, pix = L / VPR, c = L - pix * VPR;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stage + pix * PITCH + c * 16);
+            if (m0 + pix < p.M) *reinterpret_cast<u32x4*>(out + (long long)pix * p.Cout + c * 8) = v;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) cur[kk] = nxt[kk];
+    }
+    if (STATS) {
+        // the 16 pixel lanes meet by butterflies; one f64 atomic per (statistic, channel) and WAVE (every wave has its own channel part)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = ssum[STATS ? j : 0][e], b = ssq[STATS ? j : 0][e];
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) {
+                    a += __shfl_xor(a, sh);
+                    b += __shfl_xor(b, sh);
+                }
+                if (pl == 0) {
+                    const int c = n0 + 16 * j + 4 * q + e;
+                    const long long slot = (long long)(gw & (FRCNN_STAT_SLOTS - 1)) * 2;
+                    atomicAdd(p.stats + slot * p.Cout + c, (double)a);
+                    atomicAdd(p.stats + (slot + 1) * p.Cout + c, (double)b);
+                }
+            }
+    }
+#endif
+}
+
 // Name of the instantiation the calling thread launched last (frcnn_last_conv_instantiation): lets the parity tests assert
 // WHICH kernel a shape dispatched to, so that their coverage cannot rot silently when the heuristics below move.
 thread_local char g_last_inst[512] = "";
+
+template <int K, int NC>
+int launch_stream_1x1(const ConvParams& p, hipStream_t s) {
+    const int parts = p.Cout / NC;
+    const int groups = (p.M + 15) / 16;
+    // two workgroups of four waves per CU; the number of waves a multiple of the channel parts (a wave keeps its part)
+    long long waves = 2ll * num_cus() * 4;
+    if (waves > (long long)groups * parts) waves = (long long)groups * parts;
+    waves = (waves + 4ll * parts - 1) / (4ll * parts) * (4ll * parts);
+    const int grid = (int)(waves / 4);
+    const bool stats = (p.flags & FRCNN_CONV_STATS) != 0;
+    snprintf(g_last_inst, sizeof(g_last_inst), "conv1x1_stream<K=%d,NC=%d,STATS=%d> grid=%dx1 tpb=1", K, NC, stats ? 1 : 0, grid);
+    if (p.dry_run) return FRCNN_OK;
+    if (stats) hipLaunchKernelGGL((conv1x1_stream_kernel<K, NC, true>), dim3(grid), dim3(256), 0, s, p, parts, groups);
+    else hipLaunchKernelGGL((conv1x1_stream_kernel<K, NC, false>), dim3(grid), dim3(256), 0, s, p, parts, groups);
+    FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop(stream 1x1)");
+    return FRCNN_OK;
+}
+
 unsigned long long* g_stamp_buffer = nullptr;    // FRCNN_STAMPS builds: set through frcnn_debug_set_stamp_buffer (tools/conv_stamps.py)
 
 template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false, bool FIX = false, int F8 = 0>
@@ -1336,7 +1475,7 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     // its own kernel (conv_stem_kernel)
     bool stem = d->kh == 7 && d->kw == 1 && d->cin == 32 && d->in_pix_stride == 4 && d->stride == 2 && d->pad_h == 0 && d->pad_w == 0 && d->cout == 64 &&
                 p.direct_out && !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_STATS | FRCNN_CONV_WGRAD_ACCUMULATE | FRCNN_CONV_WGRAD_STEM_UNPACK)) && !res && !red &&
-                !f8_x_scale && !d->workspace && d->wi % 2 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+                !f8_x_scale && !d->workspace && d->wi % 2 == 0;
 #ifdef FRCNN_SWEEP
     if (const char* e = getenv("FRCNN_STEM_OLD")) { if (atoi(e)) stem = false; }
 #endif
@@ -1349,11 +1488,29 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
         if ((long long)grid * 4 > total) grid = (int)((total + 3) / 4);
         snprintf(g_last_inst, sizeof(g_last_inst), "conv_stem<STATS=%d> grid=%dx1 tpb=1", (flags & FRCNN_CONV_STATS) ? 1 : 0, grid);
         if (dry_run) return FRCNN_OK;
+        FRCNN_CHECK_ARG((reinterpret_cast<size_t>(x) & 15) == 0 && (reinterpret_cast<size_t>(w) & 15) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0,
+                        "conv2d_fprop(stem): operands must be 16-byte aligned");
         hipStream_t s_ = reinterpret_cast<hipStream_t>(stream);
         if (flags & FRCNN_CONV_STATS) hipLaunchKernelGGL(conv_stem_kernel<true>, dim3(grid), dim3(256), 0, s_, p, units_per_row, (int)total);
         else hipLaunchKernelGGL(conv_stem_kernel<false>, dim3(grid), dim3(256), 0, s_, p, units_per_row, (int)total);
         FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop(stem)");
         return FRCNN_OK;
+    }
+    // short-K 1x1 / stride-1 layers with a plain bf16 output (bias / ReLU / statistics epilogues): the streaming kernel
+    bool use_stream = p.linear_a && p.direct_out && (d->cin == 64 || d->cin == 128) && d->in_pix_stride == d->cin &&
+                  !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_RELU | FRCNN_CONV_STATS | FRCNN_CONV_WGRAD_ACCUMULATE)) && !res && !red && !f8_x_scale &&
+                  !d->workspace && M >= 4096;
+    if (use_stream) use_stream = d->cin == 64 ? d->cout % 128 == 0 || d->cout == 64 : d->cout % 64 == 0;
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_STREAM_1X1_OLD")) { if (atoi(e)) use_stream = false; }
+#endif
+    if (use_stream) {
+        hipStream_t s_ = reinterpret_cast<hipStream_t>(stream);
+        FRCNN_CHECK_ARG(dry_run || ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(y)) & 15) == 0,
+                        "conv2d_fprop(stream 1x1): operands must be 16-byte aligned");
+        p.dry_run = dry_run ? 1 : 0;
+        if (d->cin == 64) return d->cout == 64 ? launch_stream_1x1<64, 64>(p, s_) : launch_stream_1x1<64, 128>(p, s_);
+        return launch_stream_1x1<128, 64>(p, s_);
     }
     return conv_tile_dispatch(p, d, reinterpret_cast<hipStream_t>(stream));
 }
