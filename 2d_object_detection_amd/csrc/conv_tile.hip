@@ -995,9 +995,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvParams
     const int pl = lane & 15, q = lane >> 4;
     unsigned char* stage = stage_all[wave];
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-    // a wave keeps ONE channel part for the whole launch: global wave g takes part g % parts and the pixel groups g / parts, + stride
-    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;         // (the host makes nw a multiple of parts)
-    const int part = gw % parts;
+    // a WORKGROUP keeps one channel part for the whole launch (its four waves meet in LDS for the statistics: one atomic per channel
+    // and workgroup); workgroup b takes part b % parts, its waves the pixel groups (b / parts) * 4 + wave, + stride
+    const int part = blockIdx.x % parts;         // (the host makes gridDim.x a multiple of parts)
+    const int gw = (blockIdx.x / parts) * 4 + wave, nw = (gridDim.x / parts) * 4;
     const int n0 = part * NC;
     bf16x8 wf[KK][NJ];                           // K chunk q of channel n0 + 16 j + pl, K step kk
 #pragma unroll
@@ -1025,9 +1026,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvParams
         for (int kk = 0; kk < KK; ++kk) a[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (grp * 16 + pl) < p.M ? base + kk * 64u : kOob, 0, 0);
     };
     const int groups = total_units;              // 16-pixel groups
-    const int gstride = nw / parts;
+    const int gstride = nw;
     u32x4 cur[KK], nxt[KK];
-    int grp = gw / parts;
+    int grp = gw;
     if (grp < groups) issue(grp, cur);
     for (; grp < groups; grp += gstride) {
         if (grp + gstride < groups) issue(grp + gstride, nxt);
@@ -1073,7 +1074,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvParams
         for (int kk = 0; kk < KK; ++kk) cur[kk] = nxt[kk];
     }
     if (STATS) {
-        // the 16 pixel lanes meet by butterflies; one f64 atomic per (statistic, channel) and WAVE (every wave has its own channel part)
+        // the 16 pixel lanes meet by butterflies, the four waves in LDS (the staging area is free now), then one f64 atomic per
+        // (statistic, channel) and workgroup
+        __syncthreads();
+        float* wsum = reinterpret_cast<float*>(&stage_all[0][0]);      // [4 waves][2][NC]
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -1085,12 +1089,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvParams
                     b += __shfl_xor(b, sh);
                 }
                 if (pl == 0) {
-                    const int c = n0 + 16 * j + 4 * q + e;
-                    const long long slot = (long long)(gw & (FRCNN_STAT_SLOTS - 1)) * 2;
-                    atomicAdd(p.stats + slot * p.Cout + c, (double)a);
-                    atomicAdd(p.stats + (slot + 1) * p.Cout + c, (double)b);
+                    wsum[(wave * 2 + 0) * NC + 16 * j + 4 * q + e] = a;
+                    wsum[(wave * 2 + 1) * NC + 16 * j + 4 * q + e] = b;
                 }
             }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * NC; t += 256) {
+            const int st = t / NC, c = t - st * NC;
+            const float v = (wsum[(0 * 2 + st) * NC + c] + wsum[(1 * 2 + st) * NC + c]) + (wsum[(2 * 2 + st) * NC + c] + wsum[(3 * 2 + st) * NC + c]);
+            atomicAdd(p.stats + ((long long)((blockIdx.x / parts) & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + n0 + c, (double)v);
+        }
     }
 #endif
 }
@@ -1103,11 +1111,11 @@ template <int K, int NC>
 int launch_stream_1x1(const ConvParams& p, hipStream_t s) {
     const int parts = p.Cout / NC;
     const int groups = (p.M + 15) / 16;
-    // two workgroups of four waves per CU; the number of waves a multiple of the channel parts (a wave keeps its part)
-    long long waves = 2ll * num_cus() * 4;
-    if (waves > (long long)groups * parts) waves = (long long)groups * parts;
-    waves = (waves + 4ll * parts - 1) / (4ll * parts) * (4ll * parts);
-    const int grid = (int)(waves / 4);
+    // two workgroups of four waves per CU; the number of workgroups a multiple of the channel parts (a workgroup keeps its part)
+    long long wgs = 2ll * num_cus();
+    if (wgs * 4 > (long long)groups * parts) wgs = ((long long)groups * parts + 3) / 4;
+    wgs = (wgs + parts - 1) / parts * parts;
+    const int grid = (int)wgs;
     const bool stats = (p.flags & FRCNN_CONV_STATS) != 0;
     snprintf(g_last_inst, sizeof(g_last_inst), "conv1x1_stream<K=%d,NC=%d,STATS=%d> grid=%dx1 tpb=1", K, NC, stats ? 1 : 0, grid);
     if (p.dry_run) return FRCNN_OK;
@@ -1474,8 +1482,8 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     // the ResNet stem's packed descriptor (7 tap rows of 8 pixels x 4 channels, stride 2, 64 output channels, plain bf16 output):
     // its own kernel (conv_stem_kernel)
     bool stem = d->kh == 7 && d->kw == 1 && d->cin == 32 && d->in_pix_stride == 4 && d->stride == 2 && d->pad_h == 0 && d->pad_w == 0 && d->cout == 64 &&
-                p.direct_out && !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_STATS | FRCNN_CONV_WGRAD_ACCUMULATE | FRCNN_CONV_WGRAD_STEM_UNPACK)) && !res && !red &&
-                !f8_x_scale && !d->workspace && d->wi % 2 == 0;
+                p.direct_out && !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_STATS | FRCNN_CONV_WGRAD_ACCUMULATE | FRCNN_CONV_WGRAD_STEM_UNPACK)) && !red &&
+                !f8_x_scale && !d->workspace && d->wi % 2 == 0;       // (no ADD_RES among the flags: `res` is unused, whatever it points to)
 #ifdef FRCNN_SWEEP
     if (const char* e = getenv("FRCNN_STEM_OLD")) { if (atoi(e)) stem = false; }
 #endif
@@ -1498,7 +1506,7 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     }
     // short-K 1x1 / stride-1 layers with a plain bf16 output (bias / ReLU / statistics epilogues): the streaming kernel
     bool use_stream = p.linear_a && p.direct_out && (d->cin == 64 || d->cin == 128) && d->in_pix_stride == d->cin &&
-                  !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_RELU | FRCNN_CONV_STATS | FRCNN_CONV_WGRAD_ACCUMULATE)) && !res && !red && !f8_x_scale &&
+                  !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_RELU | FRCNN_CONV_STATS | FRCNN_CONV_WGRAD_ACCUMULATE)) && !red && !f8_x_scale &&
                   !d->workspace && M >= 4096;
     if (use_stream) use_stream = d->cin == 64 ? d->cout % 128 == 0 || d->cout == 64 : d->cout % 64 == 0;
 #ifdef FRCNN_SWEEP
