@@ -1504,13 +1504,23 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
         FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop(stem)");
         return FRCNN_OK;
     }
-    // short-K 1x1 / stride-1 layers with a plain bf16 output (bias / ReLU / statistics epilogues): the streaming kernel
-    bool use_stream = p.linear_a && p.direct_out && (d->cin == 64 || d->cin == 128) && d->in_pix_stride == d->cin &&
+    // short-K 1x1 / stride-1 layers with a plain bf16 output and NO statistics (inference-mode convolutions, the RPN heads' data
+    // gradient): the streaming kernel.  Measured per layer at 375x1242, batch 4 (round 4, gpurun_out/r4_layer_table3.txt, tile kernel in
+    // brackets): without statistics 64 -> 64 6.3 us (7.3), 128 -> 256 at M = 7,488 4.6 (5.2); WITH the BatchNorm statistics epilogue it
+    // loses -- 64 -> 256 24.2 (21.3), 128 -> 512 19.5 (16.4), 64 -> 64 10.8 (9.9): its eight waves per CU finish together and their
+    // per-workgroup f64 atomics queue up on the 16 slots, and 2 waves per SIMD do not hide the per-element epilogue arithmetic; in the step
+    // 4.053 -> 4.105 ms.  The statistics form stays compiled (FRCNN_SWEEP builds: FRCNN_STREAM_1X1_STATS=1) for the record.
+    bool use_stream = p.linear_a && p.direct_out && (d->cin == 64 || d->cin == 128) && d->in_pix_stride == d->cin && !(flags & FRCNN_CONV_STATS) &&
                   !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_RELU | FRCNN_CONV_STATS | FRCNN_CONV_WGRAD_ACCUMULATE)) && !red && !f8_x_scale &&
                   !d->workspace && M >= 4096;
     if (use_stream) use_stream = d->cin == 64 ? d->cout % 128 == 0 || d->cout == 64 : d->cout % 64 == 0;
 #ifdef FRCNN_SWEEP
     if (const char* e = getenv("FRCNN_STREAM_1X1_OLD")) { if (atoi(e)) use_stream = false; }
+    if (const char* e = getenv("FRCNN_STREAM_1X1_STATS")) {
+        if (atoi(e) && (flags & FRCNN_CONV_STATS))
+            use_stream = p.linear_a && p.direct_out && d->in_pix_stride == d->cin && !(flags & FRCNN_CONV_ADD_RES) && !red && !f8_x_scale && !d->workspace &&
+                         M >= 4096 && (d->cin == 64 ? d->cout % 128 == 0 || d->cout == 64 : d->cin == 128 && d->cout % 64 == 0);
+    }
 #endif
     if (use_stream) {
         hipStream_t s_ = reinterpret_cast<hipStream_t>(stream);

@@ -30,9 +30,10 @@ FPROP = [
     dict(id="fpn_lateral3_1x1_512_256_bias", n=4, h=47, w=156, cin=512, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=False),       # 460 tiles: 128 x 128
     dict(id="fpn_p2_3x3_256_256_bias_relu", n=1, h=94, w=311, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),        # 256 output channels: plain 128 x 128 tiles, no kw sharing
     dict(id="fpn_output4_3x3_256_256_bias_b8", n=8, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=False),
-    # short-K 1x1 layers on the streaming kernel (conv1x1_stream: K = 64 / 128, M >= 4096)
-    dict(id="c3_1x1_128_512_stats_stream", n=4, h=47, w=156, cin=128, cout=512, k=1, s=1, p=0, bias=True, relu=False, stats=True),
-    dict(id="c2_1x1_64_64_stats_stream", n=4, h=94, w=311, cin=64, cout=64, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    # short-K 1x1 layers without statistics on the streaming kernel (conv1x1_stream: K = 64 / 128, M >= 4096)
+    dict(id="stream_64_64_bias", n=4, h=94, w=311, cin=64, cout=64, k=1, s=1, p=0, bias=True, relu=False, stats=False),
+    dict(id="stream_128_512_bias", n=4, h=47, w=156, cin=128, cout=512, k=1, s=1, p=0, bias=True, relu=False, stats=False),
+    dict(id="c3_1x1_128_512_stats", n=4, h=47, w=156, cin=128, cout=512, k=1, s=1, p=0, bias=True, relu=False, stats=True),
     dict(id="stream_64_256_relu_tail", n=1, h=67, w=63, cin=64, cout=256, k=1, s=1, p=0, bias=True, relu=True, stats=False),      # M = 4221: 13-pixel tail group
     dict(id="stream_128_64_nobias", n=1, h=65, w=64, cin=128, cout=64, k=1, s=1, p=0, bias=False, relu=False, stats=False),
     # small shapes (tails, odd grids)
