@@ -109,7 +109,7 @@ def classify(ops, fn, args, kwargs):
         return "batchnorm apply / reduce (bn_*_kernel)", 0.0, _tensor_bytes(args, kwargs)
     if name in ("roi_crop_pool_fwd", "roi_crop_pool_fwd_level"):
         return "RoI crop+pool forward (roi_fwd_kernel)", 0.0, _tensor_bytes(args, kwargs)
-    if name in ("roi_crop_pool_bwd_bf16", "roi_crop_pool_bwd_bf16_level"):
+    if name in ("roi_crop_pool_bwd_bf16", "roi_crop_pool_bwd_bf16_level", "roi_crop_pool_bwd_bf16_add"):
         return "RoI crop+pool backward (roi_bwd_rows_kernel)", 0.0, _tensor_bytes(args, kwargs)
     if name == "nms_combined":
         # boxes [B,N,q,4] + scores [B,N,*] in, padded outputs out (the workspace is scratch)

@@ -21,6 +21,8 @@ sys.path.insert(0, ROOT)
 
 
 def family(name):
+    if "conv_stem_kernel" in name or "conv1x1_stream_kernel" in name:      # (round 4: the stem's own kernel, the streaming 1x1 kernel -- bf16)
+        return "conv fprop/dgrad (conv_tile_kernel)"
     if "conv_tile_kernel" in name:
         # the last template argument is F8 (fp8 operands): conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8>
         args = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",") if "<" in name and ">" in name else []
