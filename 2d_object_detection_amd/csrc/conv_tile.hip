@@ -1103,6 +1103,337 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvParams
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------- 3x3 / stride 1 / pad 1, patch-resident
+// The tile kernel above walks a 3x3 filter as nine GEMM slices per 64-channel chunk and fetches the A rows of every tap again: a 128-pixel
+// tile takes in 9 x 16 KB of activations per chunk, although the nine taps read the SAME pixels shifted (kw sharing brings that to 3 x).
+// On the M = 7,488 layers (conv4, the RPN) that is most of what a CU's load path carries (~37 GB/s per CU whatever
+// the schedule), and the load path, not the matrix pipe, is what bounds them.  Here the workgroup owns a SPATIAL tile of 8 x 16 output
+// pixels x 64 output channels and keeps the 10 x 18 input patch of one 64-channel chunk in LDS (180 pixel rows of 128 B, double
+// buffered): all nine taps read it at shifted rows -- tap (kh, kw) of output pixel (ty, tx) is patch row (ty + kh) * 18 + tx + kw -- and
+// pixels outside the image are zero-filled once by the buffer range check, so the K loop carries no validity masks.  Per chunk the CU
+// takes in 23 KB of activations instead of 144 (kw sharing: 50), and the filter slab (9 x 8 KB) becomes most of the traffic.
+//   * K order: (64-channel chunk, kh, kw).  One STEP = one (chunk, kh) = three taps = 192 K values = 24 KB of weights in one ring slot;
+//     a barrier per step (a third of the tile kernel's), 24 MFMAs per wave between barriers;
+//   * DMA per wave and step: 3 weight pieces of step k + SB - 1, and at kh == 0 the 3 patch pieces of the NEXT chunk (they are older than
+//     the weights of the step that first reads them, so one counted vmcnt wait covers both);
+//   * 8 waves as 4 (tile row pairs) x 2 (32 output channels): 2 + 2 fragment reads per 4 MFMAs;
+//   * epilogue as the tile kernel's (bias / ReLU, bf16 rounding, BatchNorm statistics of the rounded values or the fused
+//     BatchNorm-backward reduce of the consumer layer), rows of the staging tile mapped back to (oy, ox).
+template <int SB, int SMODE, int OCCW>
+__global__ __launch_bounds__(512, OCCW) void conv3x3_patch_kernel(const ConvParams p, const int tiles_x, const int tiles_y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool STATS = SMODE == 1, RED = SMODE == 2;
+    constexpr bool INTERLEAVE = false;          // a step's DMA pieces spread between its MFMA groups: measured slower (c4 3x3 17.4 -> 18.7 us)
+    constexpr int NW = 8, T = 512, BM = 128, BN = 64, TW = 16, TH = 8, PW = TW + 2;
+    constexpr int MI = 2, NI = 2;
+    constexpr int A_BUF = 24 * 1024, B_STEP = 3 * 8 * 1024, B_BASE = 2 * A_BUF, PB = SB - 1;
+    constexpr int ROWB = BN * 2 + 16, C8 = BN / 8, ST_IT = (BM * C8) / T, STG = BM * ROWB;
+    static_assert(SB >= 2 && SB <= 4, "weight ring: 2..4 steps");
+    static_assert(STG + NW * 2 * BN * 4 <= B_BASE + SB * B_STEP, "staging tile + flush scratch alias the drained buffers");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int flags = p.flags;
+
+    // workgroup -> (spatial tile, 64-channel part), channel part fastest; every XCD takes a contiguous chunk of that list, so the
+    // workgroups that share an L2 read the same patches and neighbouring ones
+    int unit;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, local = bid >> 3;
+        const int q = nb >> 3, r = nb & 7;
+        unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int tmi = unit / p.tiles_n, tn = unit - tmi * p.tiles_n;
+    const int per_img = tiles_x * tiles_y;
+    const int img = tmi / per_img;
+    const int trem = tmi - img * per_img;
+    const int tyt = trem / tiles_x;
+    const int oy0 = tyt * TH, ox0 = (trem - tyt * tiles_x) * TW, n0 = tn * BN;
+
+    float bv[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (flags & FRCNN_CONV_BIAS) b = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 32 + j * 16 + fchunk * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[j][e] = b[e];
+    }
+
+    // ------------------------------------------------------------------ loader state
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const unsigned dma_swz = (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);      // piece rows start at multiples of 8: row & 7 == lane >> 3
+    unsigned a_voff[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int q = (wave + NW * t) * 8 + (lane >> 3);                          // patch row = patch pixel
+        const int py = q / PW, px = q - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool ok = q < (TH + 2) * PW && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        a_voff[t] = ok ? (unsigned)((img * p.Hi + iy) * p.Wi + ix) * (unsigned)(p.in_pix_stride * 2) + dma_swz : kOob;
+    }
+    const unsigned b_voff = (unsigned)(n0 + wave * 8 + (lane >> 3)) * (unsigned)(p.Ktot * 2) + dma_swz;
+    const int nsub = p.Cin >> 6, K = nsub * 3;
+    int ld_k = 0, ld_s = 0, ld_kh = 0, ld_slot = 0;                               // next weight step to issue
+    // one weight piece (tap kw of the loader's step) / one patch piece (t) per call: the K loop spreads a step's pieces between its MFMA
+    // groups -- an LDS-DMA instruction issued into a backed-up load path stalls its wave (75 - 100 ns per piece when the eight waves issue
+    // theirs back to back), one per ~130 cycles of MFMA does not
+    auto issue_b_piece = [&](const int kw) {
+        unsigned char* dst = smem + B_BASE + ld_slot * B_STEP + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(dst + kw * 8192), 16, b_voff, (unsigned)((((ld_kh * 3 + kw) * p.Cin) + ld_s * 64) * 2), 0, 0);
+    };
+    auto advance_b = [&]() {
+        ++ld_k;
+        ld_slot = ld_slot + 1 == SB ? 0 : ld_slot + 1;
+        if (++ld_kh == 3) { ld_kh = 0; ++ld_s; }
+    };
+    auto issue_b = [&]() {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) issue_b_piece(kw);
+        advance_b();
+    };
+    auto issue_a_piece = [&](const int s, const int t) {
+        unsigned char* dst = smem + (s & 1) * A_BUF + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(dst + t * NW * 1024), 16, a_voff[t], (unsigned)(s * 128), 0, 0);
+    };
+    auto issue_a = [&](const int s) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) issue_a_piece(s, t);
+    };
+    // pieces a wave issues in consumer step j: the next chunk's patch at kh == 0, the weights of step j + PB
+    auto issued_in = [&](const int j) { return ((j % 3 == 0 && j / 3 + 1 < nsub) ? 3 : 0) + (j + PB < K ? 3 : 0); };
+
+    // ------------------------------------------------------------------ consumer state
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned a_q0[MI], b_foff[2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a_q0[i] = (unsigned)((2 * wm + i) * PW + frow);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) b_foff[kk] = (unsigned)((wn * 32 + frow) * 128 + (((kk * 4 + fchunk) ^ (frow & 7)) << 4));
+    auto mfma_step = [&](const int abuf, const int slot, const int kh, const bool do_a, const bool do_b, const int s_next) {
+        const unsigned char* cA = smem + abuf * A_BUF;
+        const unsigned char* cB = smem + B_BASE + slot * B_STEP;
+        unsigned qrow[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) qrow[i] = a_q0[i] + (unsigned)(kh * PW);
+        bf16x8 af[2][MI], bfr[2][NI];
+        auto fetch = [&](const int st, const int buf) {      // fragments of K step st = kw * 2 + kk of this step
+            const int kw = st >> 1, kk = st & 1;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const unsigned q = qrow[i] + (unsigned)kw;
+                af[buf][i] = *reinterpret_cast<const bf16x8*>(cA + (q << 7) + ((((unsigned)(kk * 4 + fchunk)) ^ (q & 7u)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[buf][j] = *reinterpret_cast<const bf16x8*>(cB + kw * 8192 + j * 2048 + b_foff[kk]);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+            const int cur = st & 1;
+            if (st + 1 < 6) fetch(st + 1, cur ^ 1);
+            // this step's DMA, one piece per MFMA group; a patch piece always BEFORE the weight piece that follows it: the step's last piece is
+            // a weight piece, so "weight step k has landed" implies "every older patch piece has landed" (the counted wait below)
+            if (INTERLEAVE) {
+                if ((st & 1) == 0) { if (do_a) issue_a_piece(s_next, st >> 1); }
+                else if (do_b) issue_b_piece(st >> 1);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+        }
+        if (INTERLEAVE && do_b) advance_b();
+    };
+
+    // ------------------------------------------------------------------ K loop
+    issue_a(0);
+    for (int k = 0; k < PB && k < K; ++k) issue_b();
+    int pend = 3 * ((PB < K ? PB : K) - 1);      // pieces this wave issued after the last piece of weight step 0
+    int s = 0, kh = 0, slot = 0;
+    for (int k = 0; k < K; ++k) {
+        // wait until only the `pend` youngest pieces are outstanding: weight step k (and, older than it, this chunk's patch) have landed
+        switch (pend) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads of the buffers refilled next have completed
+        __builtin_amdgcn_s_barrier();
+        const bool do_a = kh == 0 && s + 1 < nsub, do_b = ld_k < K;
+        if (!INTERLEAVE) {
+            if (do_a) issue_a(s + 1);
+            if (do_b) issue_b();
+        }
+        mfma_step(s & 1, slot, kh, do_a, do_b, s + 1);
+        // pieces younger than weight step k + 1: what was younger than step k, plus this step's, minus the group that ends with step k + 1
+        pend += issued_in(k) - (k + 1 < PB ? 3 : issued_in(k + 1 - PB));
+        slot = slot + 1 == SB ? 0 : slot + 1;
+        if (++kh == 3) { kh = 0; ++s; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // every wave is done with the patch and the ring: the staging tile may overwrite them
+
+    // ------------------------------------------------------------------ epilogue
+    // lane holds, for fragment (i, j): pixel (ty = 2 wm + i, tx = lane & 15); couts n0 + 32 wn + 16 j + 4 (lane >> 4) + 0..3
+    unsigned char* stage = smem;
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_rz = __builtin_amdgcn_make_buffer_rsrc((void*)p.red_z, 0, p.y_bytes, 0x00020000);
+    const int lrow_o = tid / C8, lc8 = tid - lrow_o * C8;
+    unsigned vo_out[ST_IT];
+#pragma unroll
+    for (int it = 0; it < ST_IT; ++it) {
+        const int r = lrow_o + it * (T / C8);
+        const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+        vo_out[it] = (oy < p.Ho && ox < p.Wo) ? (unsigned)((img * p.Ho + oy) * p.Wo + ox) * (unsigned)(p.Cout * 2) + (unsigned)((n0 + lc8 * 8) * 2) : kOob;
+    }
+    u32x4 redz[ST_IT];
+    unsigned redm[ST_IT];
+    if (RED) {                                   // consumer layer's z rows and mask bytes: in flight under the convert phase
+#pragma unroll
+        for (int it = 0; it < ST_IT; ++it) {
+            redz[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rz, vo_out[it], 0, 0);
+            redm[it] = (p.red_mask && vo_out[it] != kOob) ? p.red_mask[vo_out[it] >> 4] : 0xFFu;
+        }
+    }
+    const float lo = (flags & FRCNN_CONV_RELU) ? 0.f : -__builtin_inff();
+    float ssum[NI][4], ssq[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssum[j][e] = ssq[j][e] = 0.f;
+    const bool col_in = ox0 + frow < p.Wo;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int r = (2 * wm + i) * 16 + frow;
+        const bool row_ok = col_in && oy0 + 2 * wm + i < p.Ho;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int cl = wn * 32 + j * 16 + fchunk * 4;
+            u32x2 pk;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x2 v;
+                v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] + bv[j][2 * h], lo, __builtin_inff());
+                v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
+                const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32 (RNE)
+                pk[h] = bits;
+                if (STATS) {                     // sums of the ROUNDED outputs (what the next layer reads), pixels inside the image only
+                    const float q0 = row_ok ? __uint_as_float(bits << 16) : 0.f, q1 = row_ok ? __uint_as_float(bits & 0xFFFF0000u) : 0.f;
+                    ssum[j][2 * h] += q0;
+                    ssq[j][2 * h] += q0 * q0;
+                    ssum[j][2 * h + 1] += q1;
+                    ssq[j][2 * h + 1] += q1 * q1;
+                }
+            }
+            *reinterpret_cast<u32x2*>(stage + r * ROWB + cl * 2) = pk;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float rsg[8], rsgz[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rsg[e] = rsgz[e] = 0.f;
+#pragma unroll
+    for (int it = 0; it < ST_IT; ++it) {
+        const int r = lrow_o + it * (T / C8);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + lc8 * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo_out[it], 0, 0);      // (the offset travels in the VGPR: see conv_tile_kernel)
+        if (RED) {
+            float g[8], zz[8];
+            unpack8(v, g);
+            unpack8(redz[it], zz);
+            const bool ok = vo_out[it] != kOob;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float gm = (ok && ((redm[it] >> e) & 1u)) ? g[e] : 0.f;
+                rsg[e] += gm;
+                rsgz[e] += gm * zz[e];
+            }
+        }
+    }
+    // ---- flushes (as conv_tile_kernel's: nothing here waits for the global stores above)
+    float* fl = reinterpret_cast<float*>(smem + STG);            // [NW][2][BN]
+    const unsigned fl_a = lds_addr(fl);
+    if (RED) {
+#pragma unroll
+        for (int sh = C8; sh < 64; sh <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                rsg[e] += __shfl_xor(rsg[e], sh);
+                rsgz[e] += __shfl_xor(rsgz[e], sh);
+            }
+        }
+        if (lane < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                lds_write_b64(fl_a + ((wave * 2 + 0) * BN + lane * 8 + e) * 4, u32x2{__float_as_uint(rsg[e]), __float_as_uint(rsg[e + 1])});
+                lds_write_b64(fl_a + ((wave * 2 + 1) * BN + lane * 8 + e) * 4, u32x2{__float_as_uint(rsgz[e]), __float_as_uint(rsgz[e + 1])});
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 2 * BN) {
+            const int st = tid / BN, cl = tid - st * BN;
+            const int c = n0 + cl;
+            float sg = 0.f, sgz = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                sg += fl[(w * 2 + 0) * BN + cl];
+                sgz += fl[(w * 2 + 1) * BN + cl];
+            }
+            const float v = st == 0 ? sg : p.red_invstd[c] * (sgz - p.red_mean[c] * sg);
+            atomicAdd(p.red_part + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + c, v);
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = ssum[j][e], b = ssq[j][e];
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) {
+                    a += __shfl_xor(a, sh);
+                    b += __shfl_xor(b, sh);
+                }
+                ssum[j][e] = a;
+                ssq[j][e] = b;
+            }
+        if (frow == 0) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int cl = wn * 32 + j * 16 + fchunk * 4;
+                lds_write_b64(fl_a + ((wm * 2 + 0) * BN + cl) * 4, u32x2{__float_as_uint(ssum[j][0]), __float_as_uint(ssum[j][1])});
+                lds_write_b64(fl_a + ((wm * 2 + 0) * BN + cl + 2) * 4, u32x2{__float_as_uint(ssum[j][2]), __float_as_uint(ssum[j][3])});
+                lds_write_b64(fl_a + ((wm * 2 + 1) * BN + cl) * 4, u32x2{__float_as_uint(ssq[j][0]), __float_as_uint(ssq[j][1])});
+                lds_write_b64(fl_a + ((wm * 2 + 1) * BN + cl + 2) * 4, u32x2{__float_as_uint(ssq[j][2]), __float_as_uint(ssq[j][3])});
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 2 * BN) {
+            const int st = tid / BN, cl = tid - st * BN;
+            const float v = (fl[(0 * 2 + st) * BN + cl] + fl[(1 * 2 + st) * BN + cl]) + (fl[(2 * 2 + st) * BN + cl] + fl[(3 * 2 + st) * BN + cl]);
+            atomicAdd(p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + n0 + cl, (double)v);
+        }
+    }
+#endif
+}
+
 // Name of the instantiation the calling thread launched last (frcnn_last_conv_instantiation): lets the parity tests assert
 // WHICH kernel a shape dispatched to, so that their coverage cannot rot silently when the heuristics below move.
 thread_local char g_last_inst[512] = "";
@@ -1123,6 +1454,44 @@ int launch_stream_1x1(const ConvParams& p, hipStream_t s) {
     else hipLaunchKernelGGL((conv1x1_stream_kernel<K, NC, false>), dim3(grid), dim3(256), 0, s, p, parts, groups);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop(stream 1x1)");
     return FRCNN_OK;
+}
+
+template <int SB, int SMODE>
+int launch_patch_sm(const ConvParams& p, hipStream_t s, const int tiles_x, const int tiles_y, const int grid) {
+    constexpr int smem = 2 * 24 * 1024 + SB * 24 * 1024;
+    static_assert(smem <= 163840, "LDS budget");
+    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv3x3_patch_kernel<SB, SMODE, 2>), smem) != 0) {
+        frcnn_set_error("frcnn_conv2d_fprop(patch 3x3): cannot reserve %d B of LDS", smem);
+        return FRCNN_EINVAL;
+    }
+    snprintf(g_last_inst, sizeof(g_last_inst), "conv3x3_patch<SB=%d,SMODE=%d> grid=%dx1 tpb=1", SB, SMODE, grid);
+    if (p.dry_run) return FRCNN_OK;
+    hipLaunchKernelGGL((conv3x3_patch_kernel<SB, SMODE, 2>), dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y);
+    FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop(patch 3x3)");
+    return FRCNN_OK;
+}
+
+// 3x3 / stride 1 / pad 1 on the patch-resident kernel: 8 x 16 pixel tiles x 64 output channels, one workgroup per CU
+int launch_patch(ConvParams p, hipStream_t s, const int n_img, int sb) {
+    const int tiles_x = (p.Wo + 15) / 16, tiles_y = (p.Ho + 7) / 8;
+    p.tiles_m = n_img * tiles_x * tiles_y;
+    p.tiles_n = p.Cout / 64;
+    p.items = p.tiles_m * p.tiles_n;
+    const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
+#define FRCNN_PATCH_CASE(SB_)                                                                           \
+    if (sb == SB_) {                                                                                    \
+        if (smode == 1) return launch_patch_sm<SB_, 1>(p, s, tiles_x, tiles_y, p.items);              \
+        if (smode == 2) return launch_patch_sm<SB_, 2>(p, s, tiles_x, tiles_y, p.items);              \
+        return launch_patch_sm<SB_, 0>(p, s, tiles_x, tiles_y, p.items);                              \
+    }
+    FRCNN_PATCH_CASE(4)
+#ifdef FRCNN_SWEEP
+    FRCNN_PATCH_CASE(3)
+    FRCNN_PATCH_CASE(2)
+#endif
+#undef FRCNN_PATCH_CASE
+    frcnn_set_error("conv2d_fprop(patch 3x3): no instantiation with a %d-step weight ring", sb);
+    return FRCNN_EINVAL;
 }
 
 unsigned long long* g_stamp_buffer = nullptr;    // FRCNN_STAMPS builds: set through frcnn_debug_set_stamp_buffer (tools/conv_stamps.py)
@@ -1192,6 +1561,7 @@ int launch_tile_flags(const ConvParams& p, hipStream_t s) {
     return launch_tile<BM, BN, BK, S, false, 0, OCC, MULTI, false, false, FIX>(p, s);
 }
 
+thread_local bool g_ws_query = false;             // inside frcnn_conv2d_workspace_bytes: answer for the tile kernel's forms (see there)
 thread_local size_t g_last_ws_bytes = 0;          // workspace the last dispatch decision would use (frcnn_conv2d_workspace_bytes)
 thread_local size_t g_last_ws_counter_bytes = 0;  // ... and the size of its arrival-counter tail
 
@@ -1530,6 +1900,30 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
         if (d->cin == 64) return d->cout == 64 ? launch_stream_1x1<64, 64>(p, s_) : launch_stream_1x1<64, 128>(p, s_);
         return launch_stream_1x1<128, 64>(p, s_);
     }
+    // 3x3 / stride 1 / pad 1 with the input patch of a spatial tile resident in LDS (conv3x3_patch_kernel): from two 64-channel chunks on
+    // (a one-chunk layer -- conv2's 64 -> 64 -- is three steps long: all prologue and epilogue, the kw-sharing tile kernel keeps it)
+    bool patch = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->hi == d->ho && d->wi == d->wo && d->cin % 64 == 0 &&
+                 d->cout % 64 == 0 && d->in_pix_stride % 8 == 0 && p.direct_out && !f8_x_scale && d->wo >= 16 && d->ho >= 4 &&
+                 !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_RELU | FRCNN_CONV_STATS | FRCNN_CONV_WGRAD_ACCUMULATE | FRCNN_CONV_WGRAD_STEM_UNPACK)) &&
+                 !((flags & FRCNN_CONV_STATS) && red) && (long long)d->n * d->hi * d->wi * d->in_pix_stride * 2 < 0xFFFF0000ll;
+    // measured per layer (tools/patch_bench.py, graph replays, us, tile kernel -> this one): conv4 3x3 256 -> 256 at M = 7,488 20.7 -> 18.1, its
+    // data gradient with the fused reduce 21.5 -> 17.0, at M = 3,744 (ResNet-101, batch 2) 18.3 -> 16.4, the RPN's 3x3 1024 -> 256 (against the
+    // split-K pair form) 55.9 -> 48.7; it LOSES where the tile kernel has two workgroups per CU or 128-wide tiles: conv3 128 -> 128 at
+    // M = 29,328 18.8 -> 21.2 (480 workgroups, one per CU: two rounds), conv2 64 -> 64 22.7 -> 26.5, the RPN's data gradient 256 -> 1024
+    // 40.7 -> 52.4.  Hence: from four channel chunks on and only where every workgroup gets a CU of its own in ONE round.
+    const long long patch_wgs = (long long)d->n * ((d->wo + 15) / 16) * ((d->ho + 7) / 8) * (d->cout / 64);
+    bool patch_on = patch && d->cin >= 256 && patch_wgs <= num_cus() && !g_ws_query;
+    int patch_sb = 4;
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_PATCH")) patch_on = patch && atoi(e) != 0;
+    if (const char* e = getenv("FRCNN_PATCH_SB")) patch_sb = atoi(e);
+#endif
+    if (patch_on) {
+        FRCNN_CHECK_ARG(dry_run || ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(y)) & 15) == 0,
+                        "conv2d_fprop(patch 3x3): operands must be 16-byte aligned");
+        g_last_ws_bytes = g_last_ws_counter_bytes = 0;
+        return launch_patch(p, reinterpret_cast<hipStream_t>(stream), d->n, patch_sb);
+    }
     return conv_tile_dispatch(p, d, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1557,16 +1951,23 @@ extern "C" const char* frcnn_conv2d_describe(const frcnn_conv_desc* d, int with_
     return rc == FRCNN_OK ? g_last_inst : nullptr;
 }
 
+// One descriptor serves the bf16 and the fp8 entry points (the models pass the same frcnn_conv_desc to either), and only the tile kernel
+// has a workspace form: the answer is what THAT kernel would use -- the patch-resident 3x3 kernel, which takes some of these layers in
+// bf16, ignores the workspace it is handed.
 extern "C" size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d) {
     g_last_ws_bytes = g_last_ws_counter_bytes = 0;
-    if (!d || !frcnn_conv2d_describe(d, 0)) return 0;
-    return g_last_ws_bytes;
+    g_ws_query = true;
+    const bool ok = d && frcnn_conv2d_describe(d, 0);
+    g_ws_query = false;
+    return ok ? g_last_ws_bytes : 0;
 }
 
 extern "C" size_t frcnn_conv2d_workspace_counter_bytes(const frcnn_conv_desc* d) {
     g_last_ws_bytes = g_last_ws_counter_bytes = 0;
-    if (!d || !frcnn_conv2d_describe(d, 0)) return 0;
-    return g_last_ws_counter_bytes;
+    g_ws_query = true;
+    const bool ok = d && frcnn_conv2d_describe(d, 0);
+    g_ws_query = false;
+    return ok ? g_last_ws_counter_bytes : 0;
 }
 
 extern "C" int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d) {

@@ -117,7 +117,9 @@ const char* frcnn_conv2d_describe(const frcnn_conv_desc* d, int with_bn_reduce);
 const char* frcnn_conv2d_wgrad_describe(const frcnn_conv_desc* d, int with_row_index, const void* group_table_host);
 /* rows of the stats_partial buffer [rows][2][cout] (== FRCNN_STAT_SLOTS) */
 /* Bytes of frcnn_conv_desc.workspace with which frcnn_conv2d_fprop / frcnn_conv2d_dgrad_bnreduce run this descriptor in the split-K
- * fix-up form; 0 when the dispatcher would not use it (the answer does not depend on d->workspace).  No device needed. */
+ * fix-up form; 0 when the dispatcher would not use it (the answer does not depend on d->workspace).  No device needed.  The answer is
+ * the tile kernel's, which serves the bf16 AND the fp8 entry points of one descriptor: a 3x3 layer that the bf16 entry points run on the
+ * patch-resident kernel (frcnn_conv2d_describe says "conv3x3_patch") simply ignores the workspace. */
 size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d);
 /* The arrival counters are the LAST frcnn_conv2d_workspace_counter_bytes(d) bytes of that workspace (a multiple of 16).  The kernel
  * leaves them zero after a completed launch; a caller that may abort launches (or replays captured graphs after an error) zeroes

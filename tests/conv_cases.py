@@ -25,6 +25,12 @@ FPROP = [
     dict(id="c4_1x1_1024_256_stats", n=4, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
     dict(id="c4_3x3_256_256_stats", n=4, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     dict(id="rpn_3x3_1024_256_relu", n=1, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False),
+    # patch-resident 3x3 kernel (conv3x3_patch: cin >= 256, every 8 x 16 pixel x 64 channel workgroup on a CU of its own): the plans' conv4 /
+    # RPN launches (c4_3x3_256_256_stats, c4_3x3_256_256_b2 and rpn_3x3_1024_256_relu above), 16 channel chunks at batch 4, and grids that end
+    # inside tiles in both directions (13 x 21: one full and one 5-wide tile column, rows 8..12 of the second tile row)
+    dict(id="rpn_3x3_1024_256_relu_patch_b4", n=4, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),   # the plan's launch: 240 workgroups (the workspace the model attaches is ignored)
+    dict(id="patch_3x3_256_128_stats_ragged", n=3, h=13, w=21, cin=256, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+    dict(id="patch_3x3_320_64_nobias_ragged", n=1, h=9, w=33, cin=320, cout=64, k=3, s=1, p=1, bias=False, relu=False, stats=False),     # five chunks: odd count
     # feature-pyramid neck (BASELINE configs[4]): bias-only epilogues on shapes the C4 plans run with statistics
     dict(id="fpn_lateral4_1x1_1024_256_bias", n=4, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=False),
     dict(id="fpn_lateral3_1x1_512_256_bias", n=4, h=47, w=156, cin=512, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=False),       # 460 tiles: 128 x 128
@@ -44,8 +50,7 @@ FPROP = [
     dict(id="small_3x3_128_stats", n=1, h=9, w=11, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     dict(id="c4_3x3_256_256_b2", n=2, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     # split-K fix-up form (ws: the descriptor carries a workspace): fewer tiles than CUs, >= 64 K slices
-    dict(id="rpn_3x3_1024_256_relu_fix_b4", n=4, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),   # the plan's launch: 236 tiles
-    dict(id="rpn_3x3_1024_256_relu_fix", n=1, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),
+    dict(id="rpn_like_3x3_1024_256_relu_fix_w15", n=4, h=24, w=15, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),   # (rows narrower than a 16-pixel patch tile: the tile kernel's pair form)
     dict(id="k4096_1x1_stats_fix", n=1, h=24, w=78, cin=4096, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True, ws=True),
     dict(id="k4096_1x1_relu_fix", n=1, h=12, w=10, cin=4096, cout=64, k=1, s=1, p=0, bias=True, relu=True, stats=False, ws=True),
     dict(id="small_3x3_576_oddk_stats_fix", n=1, h=12, w=10, cin=576, cout=64, k=3, s=1, p=1, bias=True, relu=False, stats=True, ws=True),   # 81 slices: 41 + 40, one tile, 14 idle workgroups
@@ -130,6 +135,9 @@ DGRAD = [
     # small shapes
     dict(id="small_dg_run", n=2, h=12, w=39, cin=256, cout=64, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
     dict(id="small_dg_3x3", n=2, h=13, w=17, cin=128, cout=128, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="patch_dg_3x3_256_256_red_ragged", n=2, h=13, w=21, cin=256, cout=256, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),   # conv3x3_patch, SMODE 2, partial tiles
+    dict(id="patch_dg_3x3_256_64_red_nomask", n=1, h=24, w=78, cin=256, cout=64, k=3, res=False, res_mask=False, red=True, mask=False, scatter=1),
+    dict(id="patch_dg_3x3_512_128_plain", n=1, h=17, w=40, cin=512, cout=128, k=3, res=False, res_mask=False, red=False, mask=False, scatter=1),
     dict(id="small_dg_nomask", n=1, h=24, w=78, cin=1024, cout=256, k=1, res=False, res_mask=False, red=True, mask=False, scatter=1),
     dict(id="small_dg_scatter", n=2, h=12, w=39, cin=512, cout=256, k=1, res=True, res_mask=False, red=True, mask=True, scatter=2),
     # split-K fix-up form (>= 64 K slices on fewer tiles than CUs)

@@ -96,18 +96,24 @@ def test_describe_reports_errors(ops):
 def test_workspace_query_matches_the_dispatch_rule(ops):
     """frcnn_conv2d_workspace_bytes: > 0 exactly where the dispatcher takes the split-K fix-up form (fewer 128 x 64 tiles than CUs,
     >= 64 K slices); a descriptor without workspace keeps the one-workgroup-per-tile kernel."""
-    rpn = ops.conv_desc(4, 24, 78, 1024, 3, 3, 1, 1, 1, 24, 78, 256, flags=ops.CONV_BIAS | ops.CONV_RELU)        # 236 tiles, 144 slices
-    tiles = ((4 * 24 * 78 + 127) // 128) * (256 // 64)
+    rpn = ops.conv_desc(4, 24, 15, 1024, 3, 3, 1, 1, 1, 24, 15, 256, flags=ops.CONV_BIAS | ops.CONV_RELU)        # 48 tiles, 144 slices
+    tiles = ((4 * 24 * 15 + 127) // 128) * (256 // 64)
     assert ops.conv_workspace_bytes(rpn) == tiles * 2 * 128 * 64 * 4 + tiles * 4
     assert "FIX" not in ops.conv2d_describe(rpn)
     assert ops.conv_attach_workspace(rpn, "cpu") is not None and "FIX=1" in ops.conv2d_describe(rpn)
+    # the RPN's own 3x3 (rows of 78 pixels) runs on the patch-resident kernel in bf16 since round 4 and ignores the workspace; the query
+    # still answers for the tile kernel, which the fp8 entry points use with the same descriptor
+    real = ops.conv_desc(4, 24, 78, 1024, 3, 3, 1, 1, 1, 24, 78, 256, flags=ops.CONV_BIAS | ops.CONV_RELU)
+    assert ops.conv_workspace_bytes(real) > 0 and ops.conv_attach_workspace(real, "cpu") is not None
+    assert ops.conv2d_describe(real).startswith("conv3x3_patch<SB=4,SMODE=0> grid=240x1")
+    assert "FIX=1" in ops.conv2d_describe_fp8(real)
     for d in (ops.conv_desc(4, 24, 78, 1024, 1, 1, 1, 0, 0, 24, 78, 256, flags=ops.CONV_BIAS | ops.CONV_STATS),       # 16 slices
-              ops.conv_desc(4, 24, 78, 256, 3, 3, 1, 1, 1, 24, 78, 256, flags=ops.CONV_BIAS | ops.CONV_STATS),        # 36 slices
+              ops.conv_desc(4, 24, 78, 256, 3, 3, 1, 1, 1, 24, 78, 256, flags=ops.CONV_BIAS | ops.CONV_STATS),        # patch-resident kernel
               ops.conv_desc(4, 94, 311, 64, 3, 3, 1, 1, 1, 94, 311, 64),                                              # kw-shared, 914 tiles
               ops.conv_desc(4, 24, 78, 256, 3, 3, 1, 1, 1, 24, 78, 1024)):                                            # 128 x 128 tiles
         assert ops.conv_workspace_bytes(d) == 0
         assert ops.conv_attach_workspace(d, "cpu") is None
-    small = ops.conv_desc(4, 24, 78, 1024, 3, 3, 1, 1, 1, 24, 78, 256)
+    small = ops.conv_desc(4, 24, 15, 1024, 3, 3, 1, 1, 1, 24, 15, 256)
     ops.conv_attach_workspace(small, "cpu")
     small.workspace_bytes = 1000
     with pytest.raises(Exception):

@@ -45,7 +45,7 @@ def test_head_stages_at_benchmark_size(depth, batch, proposals):
     feat = aux["feature_maps"].float().cpu()
     assert bool(torch.isfinite(feat).all())
 
-    # RPN on the HIP feature maps (3x3 conv in the fix-up form at batch 4, merged heads, softmax, in-image anchors)
+    # RPN on the HIP feature maps (3x3 conv on the patch-resident kernel, merged heads, softmax, in-image anchors)
     anchors = O.generate_anchors(feat.shape[1:3], **cfg["rpn"]["anchors"])
     rpn_ref = O.rpn_forward(p, feat, anchors, ishape, True, quant=oresnet.bf16_storage)
     assert torch.equal(aux["rpn_out"]["regions"].cpu(), rpn_ref["regions"])
@@ -83,7 +83,7 @@ def test_head_stages_at_benchmark_size(depth, batch, proposals):
     nms2 = O.postprocess_output(ishape, **hip_rcnn, **cfg["rcnn"]["nms"])
     assert torch.equal(preds["rcnn_classes"].cpu(), nms2["pred_classes"])
     assert torch.equal(preds["rcnn_scores"].cpu(), nms2["pred_scores"])
-    # which conv kernel carried the RPN's 3x3 layer: the fix-up form wherever the dispatcher offers a workspace (both configurations
-    # have fewer than 256 tiles of 128 x 64 and 144 K slices)
+    # which conv kernel carried the RPN's 3x3 layer: the patch-resident kernel (rounds 2-3: the tile kernel's split-K pair form) -- both
+    # configurations have at most 240 workgroups of 8 x 16 pixels x 64 channels
     ops = importlib.import_module("2d_object_detection_amd.ops")
-    assert "FIX=1" in ops.conv2d_describe(model._train.rpn.d_inter)
+    assert ops.conv2d_describe(model._train.rpn.d_inter).startswith("conv3x3_patch<SB=4,SMODE=0>")
