@@ -1434,6 +1434,272 @@ __global__ __launch_bounds__(512, OCCW) void conv3x3_patch_kernel(const ConvPara
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------- 3x3 / stride 1 / pad 1, 64 input channels: weights resident
+// conv2's 3x3 layers (64 -> 64 at M = 116,936) have ONE channel chunk: the whole filter slab of a 64-channel output part is 9 x 8 KB and
+// fits LDS beside two input patches.  A persistent workgroup loads it ONCE and walks its share of the 8 x 16 pixel tiles: per tile it
+// takes in one 23 KB patch (DMA'd a tile ahead) and nothing else, runs 18 K steps of MFMA between two barriers and stores 16 KB.  The
+// tile kernel's kw-sharing form fetches 74 KB of weights and 50 KB of activations per 128-pixel tile and pays a barrier per tap
+// (23 - 26 us per launch against an HBM roofline of 3.8); here the CU's load path carries a third of that and the statistics /
+// reduce flushes (and their atomics) happen once per workgroup instead of once per tile.
+template <int SMODE>
+__global__ __launch_bounds__(512, 2) void conv3x3_wres_kernel(const ConvParams p, const int tiles_x, const int tiles_y, const int tiles_total) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool STATS = SMODE == 1, RED = SMODE == 2;
+    constexpr int NW = 8, T = 512, BM = 128, BN = 64, TW = 16, TH = 8, PW = TW + 2;
+    constexpr int MI = 2, NI = 2;
+    constexpr int W_BYTES = 9 * 8 * 1024, A_BUF = 24 * 1024, A_BASE = W_BYTES, STG_BASE = A_BASE + 2 * A_BUF;
+    constexpr int ROWB = BN * 2 + 16, C8 = BN / 8, ST_IT = (BM * C8) / T, STG = BM * ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int flags = p.flags;
+    // workgroup b: channel part b % tiles_n, spatial tiles b / tiles_n, + gridDim.x / tiles_n, ... (the host makes the grid a multiple of tiles_n)
+    const int tn = blockIdx.x % p.tiles_n, n0 = tn * BN;
+    const int t_first = blockIdx.x / p.tiles_n, t_stride = gridDim.x / p.tiles_n;
+    const int per_img = tiles_x * tiles_y;
+
+    float bv[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (flags & FRCNN_CONV_BIAS) b = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 32 + j * 16 + fchunk * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[j][e] = b[e];
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_rz = __builtin_amdgcn_make_buffer_rsrc((void*)p.red_z, 0, p.y_bytes, 0x00020000);
+    const unsigned dma_swz = (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
+    // the filter slab of this channel part: [tap][64 output channels][128 B], 9 pieces per wave, once
+    {
+        const unsigned b_voff = (unsigned)(n0 + wave * 8 + (lane >> 3)) * (unsigned)(p.Ktot * 2) + dma_swz;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(smem + tap * 8192 + wave * 1024), 16, b_voff, (unsigned)(tap * 128), 0, 0);
+    }
+    // patch rows of this lane's three DMA pieces (tile-independent part)
+    int a_py[3], a_px[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int q = (wave + NW * t) * 8 + (lane >> 3);
+        a_py[t] = q < (TH + 2) * PW ? q / PW : -100000;          // rows beyond the patch: never inside an image
+        a_px[t] = q - (q / PW) * PW;
+    }
+    auto issue_patch = [&](const int tile, const int buf) {
+        const int img = tile / per_img, trem = tile - img * per_img;
+        const int tyt = trem / tiles_x;
+        const int oy0 = tyt * TH, ox0 = (trem - tyt * tiles_x) * TW;
+        unsigned char* dst = smem + A_BASE + buf * A_BUF + wave * 1024;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int iy = oy0 - 1 + a_py[t], ix = ox0 - 1 + a_px[t];
+            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const unsigned vo = ok ? (unsigned)((img * p.Hi + iy) * p.Wi + ix) * (unsigned)(p.in_pix_stride * 2) + dma_swz : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(dst + t * NW * 1024), 16, vo, 0, 0, 0);
+        }
+    };
+    unsigned a_q0[MI], b_foff[2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a_q0[i] = (unsigned)((2 * wm + i) * PW + frow);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) b_foff[kk] = (unsigned)((wn * 32 + frow) * 128 + (((kk * 4 + fchunk) ^ (frow & 7)) << 4));
+
+    const int lrow_o = tid / C8, lc8 = tid - lrow_o * C8;
+    const float lo = (flags & FRCNN_CONV_RELU) ? 0.f : -__builtin_inff();
+    float ssum[NI][4], ssq[NI][4];               // BatchNorm partial sums over ALL tiles of this workgroup
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssum[j][e] = ssq[j][e] = 0.f;
+    float rsg[8], rsgz[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rsg[e] = rsgz[e] = 0.f;
+    unsigned char* stage = smem + STG_BASE;
+
+    int tile = t_first, buf = 0;
+    if (tile < tiles_total) issue_patch(tile, 0);
+    bool first = true;
+    for (; tile < tiles_total; tile += t_stride, buf ^= 1) {
+        // this tile's patch (and, the first time, the filter slab) has landed; younger than its pieces are only the previous tile's ST_IT stores
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_IT) : "memory");
+        first = false;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave is done with the other patch buffer and the staging tile
+        __builtin_amdgcn_s_barrier();
+        if (tile + t_stride < tiles_total) issue_patch(tile + t_stride, buf ^ 1);
+
+        f32x4 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const unsigned char* cA = smem + A_BASE + buf * A_BUF;
+            bf16x8 af[2][MI], bfr[2][NI];
+            auto fetch = [&](const int st, const int b) {       // K step st = (kh * 3 + kw) * 2 + kk
+                const int tap = st >> 1, kk = st & 1, kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const unsigned q = a_q0[i] + (unsigned)(kh * PW + kw);
+                    af[b][i] = *reinterpret_cast<const bf16x8*>(cA + (q << 7) + ((((unsigned)(kk * 4 + fchunk)) ^ (q & 7u)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bfr[b][j] = *reinterpret_cast<const bf16x8*>(smem + tap * 8192 + j * 2048 + b_foff[kk]);
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int st = 0; st < 18; ++st) {
+                const int cur = st & 1;
+                if (st + 1 < 18) fetch(st + 1, cur ^ 1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+            }
+        }
+        // ---- epilogue of this tile (as conv3x3_patch_kernel's)
+        const int img = tile / per_img, trem = tile - img * per_img;
+        const int tyt = trem / tiles_x;
+        const int oy0 = tyt * TH, ox0 = (trem - tyt * tiles_x) * TW;
+        unsigned vo_out[ST_IT];
+#pragma unroll
+        for (int it = 0; it < ST_IT; ++it) {
+            const int r = lrow_o + it * (T / C8);
+            const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+            vo_out[it] = (oy < p.Ho && ox < p.Wo) ? (unsigned)((img * p.Ho + oy) * p.Wo + ox) * (unsigned)(p.Cout * 2) + (unsigned)((n0 + lc8 * 8) * 2) : kOob;
+        }
+        u32x4 redz[ST_IT];
+        unsigned redm[ST_IT];
+        if (RED) {
+#pragma unroll
+            for (int it = 0; it < ST_IT; ++it) {
+                redz[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rz, vo_out[it], 0, 0);
+                redm[it] = (p.red_mask && vo_out[it] != kOob) ? p.red_mask[vo_out[it] >> 4] : 0xFFu;
+            }
+        }
+        const bool col_in = ox0 + frow < p.Wo;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = (2 * wm + i) * 16 + frow;
+            const bool row_ok = col_in && oy0 + 2 * wm + i < p.Ho;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int cl = wn * 32 + j * 16 + fchunk * 4;
+                u32x2 pk;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x2 v;
+                    v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] + bv[j][2 * h], lo, __builtin_inff());
+                    v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
+                    const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+                    pk[h] = bits;
+                    if (STATS) {
+                        const float q0 = row_ok ? __uint_as_float(bits << 16) : 0.f, q1 = row_ok ? __uint_as_float(bits & 0xFFFF0000u) : 0.f;
+                        ssum[j][2 * h] += q0;
+                        ssq[j][2 * h] += q0 * q0;
+                        ssum[j][2 * h + 1] += q1;
+                        ssq[j][2 * h + 1] += q1 * q1;
+                    }
+                }
+                // (asm form: hipcc would order a DS write it emits itself behind the next patch's pending LDS-DMA -- vmcnt(0))
+                lds_write_b64(lds_addr(stage) + r * ROWB + cl * 2, pk);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int it = 0; it < ST_IT; ++it) {
+            const int r = lrow_o + it * (T / C8);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * ROWB + lc8 * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, vo_out[it], 0, 0);
+            if (RED) {
+                float g[8], zz[8];
+                unpack8(v, g);
+                unpack8(redz[it], zz);
+                const bool ok = vo_out[it] != kOob;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gm = (ok && ((redm[it] >> e) & 1u)) ? g[e] : 0.f;
+                    rsg[e] += gm;
+                    rsgz[e] += gm * zz[e];
+                }
+            }
+        }
+    }
+    // ---- flushes, once per workgroup (scratch behind the staging tile)
+    float* fl = reinterpret_cast<float*>(smem + STG_BASE + STG);            // [NW][2][BN]
+    const unsigned fl_a = lds_addr(fl);
+    if (RED) {
+#pragma unroll
+        for (int sh = C8; sh < 64; sh <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                rsg[e] += __shfl_xor(rsg[e], sh);
+                rsgz[e] += __shfl_xor(rsgz[e], sh);
+            }
+        }
+        if (lane < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                lds_write_b64(fl_a + ((wave * 2 + 0) * BN + lane * 8 + e) * 4, u32x2{__float_as_uint(rsg[e]), __float_as_uint(rsg[e + 1])});
+                lds_write_b64(fl_a + ((wave * 2 + 1) * BN + lane * 8 + e) * 4, u32x2{__float_as_uint(rsgz[e]), __float_as_uint(rsgz[e + 1])});
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 2 * BN) {
+            const int st = tid / BN, cl = tid - st * BN;
+            const int c = n0 + cl;
+            float sg = 0.f, sgz = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                sg += fl[(w * 2 + 0) * BN + cl];
+                sgz += fl[(w * 2 + 1) * BN + cl];
+            }
+            const float v = st == 0 ? sg : p.red_invstd[c] * (sgz - p.red_mean[c] * sg);
+            atomicAdd(p.red_part + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + c, v);
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = ssum[j][e], b = ssq[j][e];
+#pragma unroll
+                for (int sh = 1; sh < 16; sh <<= 1) {
+                    a += __shfl_xor(a, sh);
+                    b += __shfl_xor(b, sh);
+                }
+                ssum[j][e] = a;
+                ssq[j][e] = b;
+            }
+        if (frow == 0) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int cl = wn * 32 + j * 16 + fchunk * 4;
+                lds_write_b64(fl_a + ((wm * 2 + 0) * BN + cl) * 4, u32x2{__float_as_uint(ssum[j][0]), __float_as_uint(ssum[j][1])});
+                lds_write_b64(fl_a + ((wm * 2 + 0) * BN + cl + 2) * 4, u32x2{__float_as_uint(ssum[j][2]), __float_as_uint(ssum[j][3])});
+                lds_write_b64(fl_a + ((wm * 2 + 1) * BN + cl) * 4, u32x2{__float_as_uint(ssq[j][0]), __float_as_uint(ssq[j][1])});
+                lds_write_b64(fl_a + ((wm * 2 + 1) * BN + cl + 2) * 4, u32x2{__float_as_uint(ssq[j][2]), __float_as_uint(ssq[j][3])});
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 2 * BN) {
+            const int st = tid / BN, cl = tid - st * BN;
+            const float v = (fl[(0 * 2 + st) * BN + cl] + fl[(1 * 2 + st) * BN + cl]) + (fl[(2 * 2 + st) * BN + cl] + fl[(3 * 2 + st) * BN + cl]);
+            atomicAdd(p.stats + ((long long)(blockIdx.x & (FRCNN_STAT_SLOTS - 1)) * 2 + st) * p.Cout + n0 + cl, (double)v);
+        }
+    }
+#endif
+}
+
 // Name of the instantiation the calling thread launched last (frcnn_last_conv_instantiation): lets the parity tests assert
 // WHICH kernel a shape dispatched to, so that their coverage cannot rot silently when the heuristics below move.
 thread_local char g_last_inst[512] = "";
@@ -1492,6 +1758,35 @@ int launch_patch(ConvParams p, hipStream_t s, const int n_img, int sb) {
 #undef FRCNN_PATCH_CASE
     frcnn_set_error("conv2d_fprop(patch 3x3): no instantiation with a %d-step weight ring", sb);
     return FRCNN_EINVAL;
+}
+
+// 3x3 / stride 1 / pad 1 with 64 input channels on the weights-resident kernel: persistent workgroups, equal shares of the 8 x 16 pixel tiles
+int launch_wres(ConvParams p, hipStream_t s, const int n_img) {
+    const int tiles_x = (p.Wo + 15) / 16, tiles_y = (p.Ho + 7) / 8;
+    const int tiles_total = n_img * tiles_x * tiles_y;
+    p.tiles_m = tiles_total;
+    p.tiles_n = p.Cout / 64;
+    p.items = p.tiles_m * p.tiles_n;
+    int wg_sp = num_cus() / p.tiles_n;                           // workgroups per channel part: one workgroup per CU in all
+    if (wg_sp < 1) wg_sp = 1;
+    const int per = (tiles_total + wg_sp - 1) / wg_sp;           // tiles per workgroup, the same for all but the last few
+    const int grid = ((tiles_total + per - 1) / per) * p.tiles_n;
+    constexpr int smem = 9 * 8 * 1024 + 2 * 24 * 1024 + 128 * (64 * 2 + 16) + 8 * 2 * 64 * 4;
+    static_assert(smem <= 163840, "LDS budget");
+    const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
+    const void* fn = smode == 1 ? reinterpret_cast<const void*>(&conv3x3_wres_kernel<1>)
+                   : smode == 2 ? reinterpret_cast<const void*>(&conv3x3_wres_kernel<2>) : reinterpret_cast<const void*>(&conv3x3_wres_kernel<0>);
+    if (!p.dry_run && frcnn_allow_big_lds(fn, smem) != 0) {
+        frcnn_set_error("frcnn_conv2d_fprop(3x3, weights resident): cannot reserve %d B of LDS", smem);
+        return FRCNN_EINVAL;
+    }
+    snprintf(g_last_inst, sizeof(g_last_inst), "conv3x3_wres<SMODE=%d> grid=%dx1 tpb=%d", smode, grid, per);
+    if (p.dry_run) return FRCNN_OK;
+    if (smode == 1) hipLaunchKernelGGL(conv3x3_wres_kernel<1>, dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y, tiles_total);
+    else if (smode == 2) hipLaunchKernelGGL(conv3x3_wres_kernel<2>, dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y, tiles_total);
+    else hipLaunchKernelGGL(conv3x3_wres_kernel<0>, dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y, tiles_total);
+    FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop(3x3, weights resident)");
+    return FRCNN_OK;
 }
 
 unsigned long long* g_stamp_buffer = nullptr;    // FRCNN_STAMPS builds: set through frcnn_debug_set_stamp_buffer (tools/conv_stamps.py)
@@ -1918,6 +2213,17 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     if (const char* e = getenv("FRCNN_PATCH")) patch_on = patch && atoi(e) != 0;
     if (const char* e = getenv("FRCNN_PATCH_SB")) patch_sb = atoi(e);
 #endif
+    // ... and the one-chunk layers (64 input channels: conv2) on the weights-resident form of the same tiling (conv3x3_wres_kernel)
+    bool wres_on = patch && d->cin == 64 && d->in_pix_stride % 8 == 0 && (long long)d->n * ((d->wo + 15) / 16) * ((d->ho + 7) / 8) >= 2ll * num_cus() / (d->cout / 64);
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_WRES")) wres_on = patch && d->cin == 64 && atoi(e) != 0;
+#endif
+    if (wres_on) {
+        FRCNN_CHECK_ARG(dry_run || ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(y)) & 15) == 0,
+                        "conv2d_fprop(3x3, weights resident): operands must be 16-byte aligned");
+        g_last_ws_bytes = g_last_ws_counter_bytes = 0;
+        return launch_wres(p, reinterpret_cast<hipStream_t>(stream), d->n);
+    }
     if (patch_on) {
         FRCNN_CHECK_ARG(dry_run || ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(y)) & 15) == 0,
                         "conv2d_fprop(patch 3x3): operands must be 16-byte aligned");

@@ -31,6 +31,11 @@ FPROP = [
     dict(id="rpn_3x3_1024_256_relu_patch_b4", n=4, h=24, w=78, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),   # the plan's launch: 240 workgroups (the workspace the model attaches is ignored)
     dict(id="patch_3x3_256_128_stats_ragged", n=3, h=13, w=21, cin=256, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     dict(id="patch_3x3_320_64_nobias_ragged", n=1, h=9, w=33, cin=320, cout=64, k=3, s=1, p=1, bias=False, relu=False, stats=False),     # five chunks: odd count
+    # weights-resident 3x3 kernel (conv3x3_wres: 64 input channels, at least two 8 x 16 pixel tiles per CU): conv2's layers at the
+    # benchmark's batch (240 workgroups x 4 tiles), two channel parts with a ragged grid and an uneven share (270 tiles on 128 x 2 workgroups)
+    dict(id="wres_3x3_64_64_stats_b4", n=4, h=94, w=311, cin=64, cout=64, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+    dict(id="wres_3x3_64_128_relu_ragged", n=9, h=45, w=70, cin=64, cout=128, k=3, s=1, p=1, bias=True, relu=True, stats=False),
+    dict(id="wres_3x3_64_128_stats_ragged", n=9, h=45, w=70, cin=64, cout=128, k=3, s=1, p=1, bias=False, relu=False, stats=True),
     # feature-pyramid neck (BASELINE configs[4]): bias-only epilogues on shapes the C4 plans run with statistics
     dict(id="fpn_lateral4_1x1_1024_256_bias", n=4, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=False),
     dict(id="fpn_lateral3_1x1_512_256_bias", n=4, h=47, w=156, cin=512, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=False),       # 460 tiles: 128 x 128
@@ -135,6 +140,9 @@ DGRAD = [
     # small shapes
     dict(id="small_dg_run", n=2, h=12, w=39, cin=256, cout=64, k=1, res=True, res_mask=True, red=True, mask=True, scatter=1),
     dict(id="small_dg_3x3", n=2, h=13, w=17, cin=128, cout=128, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="wres_dg_3x3_64_64_red_b4", n=4, h=94, w=311, cin=64, cout=64, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),                # conv3x3_wres, SMODE 2
+    dict(id="wres_dg_3x3_64_64_plain_ragged", n=7, h=90, w=100, cin=64, cout=64, k=3, res=False, res_mask=False, red=False, mask=False, scatter=1),   # 588 tiles: shares of 3 and 2
+    dict(id="wres_dg_3x3_64_64_red_nomask_ragged", n=7, h=90, w=100, cin=64, cout=64, k=3, res=False, res_mask=False, red=True, mask=False, scatter=1),
     dict(id="patch_dg_3x3_256_256_red_ragged", n=2, h=13, w=21, cin=256, cout=256, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),   # conv3x3_patch, SMODE 2, partial tiles
     dict(id="patch_dg_3x3_256_64_red_nomask", n=1, h=24, w=78, cin=256, cout=64, k=3, res=False, res_mask=False, red=True, mask=False, scatter=1),
     dict(id="patch_dg_3x3_512_128_plain", n=1, h=17, w=40, cin=512, cout=128, k=3, res=False, res_mask=False, red=False, mask=False, scatter=1),

@@ -34,6 +34,7 @@ def main():
         for var in VARIANTS:
             on, sb = (var.split(":") + [""])[:2]
             os.environ["FRCNN_PATCH"] = on
+            os.environ["FRCNN_WRES"] = on                    # (64-channel layers: the weights-resident form)
             os.environ["FRCNN_PATCH_SB"] = sb or "4"
             d = ops.conv_desc(n, h, w, cin, 3, 3, 1, 1, 1, h, w, cout, flags=flags)
             ws = ops.conv_attach_workspace(d, "cuda")
