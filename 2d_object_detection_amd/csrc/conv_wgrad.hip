@@ -26,6 +26,8 @@ struct WgradParams {
     int Ho, Wo, Cout, taps, dz_stride;
     int M, p_tiles, p_tiles_per_split;
     int tiles_co, tiles_ci, linear_x;
+    int dev;                                    // FRCNN_SWEEP builds: timing experiments (wrong results), else 0
+    int sp_tx, sp_ty;                           // wgrad3_body: spatial tiles (4 x 32 pixels) per image row / column; p_tiles = all of them
     int in_row_stride32;
     unsigned x_bytes, dz_bytes;
     int plain_store;                            // one pixel split: every dw element is written once -> plain stores, no float atomics
@@ -429,6 +431,268 @@ __global__ __launch_bounds__(512, 2 * OCC) void wgrad_group_kernel(const WgradGr
     wgrad_body<BM, BN, S, MODE, OCC, F8>(p, id - g->first[layer]);
 }
 
+#ifdef FRCNN_SWEEP
+// ---------------------------------------------------------------------------------------------------- 3x3 / stride 1 / pad 1: all nine taps per workgroup
+// wgrad_body gives every (cout tile, TAP, cin tile) its own workgroup: a 3x3 layer streams its dz and x pixels through the CUs' load path
+// nine times per tile pair (conv4's 256 -> 256: 207 MB through L2 -> LDS for 7.7 MB of operands), and that path -- ~37 GB/s per CU,
+// DESIGN.md 4.3 -- is what bounds it.  Here ONE workgroup owns all nine taps of a 64 (cout) x 64 (cin) block: 9 x 16 accumulator blocks of
+// 16 x 16 spread over 8 waves (72 VGPRs per lane), and walks SPATIAL tiles of 4 x 32 output pixels.  Per tile it takes in the 6 x 34 input
+// patch of its 64 input channels (26 KB) and the 128 dz pixels of its 64 output channels (16 KB) ONCE -- 42 KB for 9.4 MFLOP instead of
+// 9 x 32 KB -- both staged pixel-major exactly as they lie in HBM (fragments by ds_read_b64_tr_b16, as wgrad_body).
+//   * a K step is one tile row of 32 pixels, so the x fragment of (patch row R, kw) serves the taps kh = 0, 1, 2 of the tile rows R, R - 1,
+//     R - 2: the tile is walked by PATCH row -- 12 x reads feed up to 18 MFMAs per wave; the four dz fragments of a tile are read once;
+//   * the patch rows sit at a pitch of 48 pixel slots (34 used): a multiple of 16, so the swizzle term of a fragment address depends on
+//     (kw, lane) only and the row is a ds_read immediate;
+//   * pixels outside the image are zero-filled by the buffer range check -- in the patch (the padding) and in dz (tiles that overhang the
+//     image contribute nothing), so the loop has no masks;
+//   * three stages of (patch, dz tile) in LDS: tiles t + 1 and t + 2 are in flight while tile t is multiplied; one barrier per tile;
+//   * epilogue: three passes of three taps through LDS, whole 256-byte rows of dw stored (one pixel range) or added with float atomics.
+// MEASURED AND NOT USED (round 4; compiled in FRCNN_SWEEP builds only, FRCNN_WGRAD3=1 selects it; parity-green: tests/test_gpu_conv.py passed
+// with it as the default).  Isolated, graph replays, us (tools/wgrad3_bench.py), per-tap kernel -> this one: conv4 256 -> 256 30.2 -> 41.1,
+// conv3 128 -> 128 35.8 -> 43.4, conv2 64 -> 64 27.8 -> 46.5, RPN 1024 -> 256 71.0 -> 72.4; in the step 4.00 -> 4.055 ms.  Why: (1) a tile
+// takes 2.07 us, not the 1.1 us of its 72 MFMAs per wave -- 0.52 us of that is the six LDS-DMA pieces every wave issues per tile (the
+// instruction stalls its wave while the CU's load path is backed up; without them 1.55 us), and the rest is the read -> wait -> MFMA chain
+// of a row; (2) a layer has only (cout / 64) x (cin / 64) blocks -- 16 for conv4, 4 for conv3, 1 for conv2 -- so filling 256 CUs needs
+// pixel splits, and every split costs 9 x 64 x 64 x 4 bytes of float atomics per workgroup at the memory side's 1.3 TB/s: the per-tap
+// kernel has nine times the tiles and needs no split in the grouped launches at all.  What would make it win is in DESIGN.md 0.2
+// (dedicated loader waves; 32-wide cin blocks).
+constexpr int kW3_TH = 4, kW3_TW = 32, kW3_PITCH = 48;
+constexpr int kW3_XBUF = 6 * kW3_PITCH * 128, kW3_ZBUF = 16 * 1024, kW3_STAGE = kW3_XBUF + kW3_ZBUF, kW3_STAGES = 3;
+
+__device__ __forceinline__ void wgrad3_body(const WgradParams& p, int bid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = 8, T = 512, TH = kW3_TH, TW = kW3_TW, PW = TW + 2, PITCH = kW3_PITCH;
+    constexpr int SROW = 64 * 4 + 16;            // staging pitch (bytes) of one tap's [64 cout][64 cin] fp32 block
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave >> 1, jb0 = (wave & 1) * 2;              // this wave's cout block and its two cin blocks (of 16)
+
+    const int tiles_all = p.tiles_co * p.tiles_ci;
+    const int split_idx = bid / tiles_all;
+    bid -= split_idx * tiles_all;
+    const int tile_ci = bid % p.tiles_ci, tile_co = bid / p.tiles_ci;
+    const int co0 = tile_co * 64, ci0 = tile_ci * 64;
+    const int t_begin = split_idx * p.p_tiles_per_split;
+    const int t_end = min(p.p_tiles, t_begin + p.p_tiles_per_split);
+    const int per_img = p.sp_tx * p.sp_ty;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.dz_bytes, 0x00020000);
+
+    // ---- DMA pieces of this lane: 4 of the patch (piece i = wave + 8 k: patch row i / 5, pixel slots 8 (i % 5) .. + 7; 30 real pieces),
+    // 2 of the dz tile (piece j = wave + 8 k: tile pixels 8 j .. 8 j + 7).  Lane l of a piece: pixel l / 8, 16-byte slot l % 8.
+    int x_pr[4], x_pc[4];
+    unsigned x_col[4], z_col[2];
+    int z_ty[2], z_tx[2];
+    {
+        const int pl = lane >> 3, s16 = lane & 7;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = wave + NW * k;
+            const int pr = i / 5, pc = (i - pr * 5) * 8 + pl;
+            const bool ok = i < 30 && pc < PW;
+            x_pr[k] = ok ? pr : -100000;                         // (never inside an image)
+            x_pc[k] = pc;
+            x_col[k] = (unsigned)(((((s16 >> 1) ^ fsw<64>(pc)) << 4) + (s16 & 1) * 8) * 2);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = (wave + NW * k) * 8 + pl;
+            z_ty[k] = r >> 5;
+            z_tx[k] = r & 31;
+            z_col[k] = (unsigned)(((((s16 >> 1) ^ fsw<64>(r)) << 4) + (s16 & 1) * 8) * 2);
+        }
+    }
+    auto issue_tile = [&](const int tile, const int stage) {
+        const int img = tile / per_img, trem = tile - img * per_img;
+        const int tyt = trem / p.sp_tx;
+        const int oy0 = tyt * TH, ox0 = (trem - tyt * p.sp_tx) * TW;
+        unsigned char* sx = smem + stage * kW3_STAGE;
+        unsigned char* sz = sx + kW3_XBUF;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = wave + NW * k;
+            const int iy = oy0 - 1 + x_pr[k], ix = ox0 - 1 + x_pc[k];
+            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const unsigned vo = ok ? (unsigned)((img * p.Hi + iy) * p.Wi + ix) * (unsigned)(p.in_pix_stride * 2) + (unsigned)(ci0 * 2) + x_col[k] : kOob;
+            const int pr = i / 5;
+            if (i < 30) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(sx + (pr * PITCH + (i - pr * 5) * 8) * 128), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int oy = oy0 + z_ty[k], ox = ox0 + z_tx[k];
+            const bool ok = oy < p.Ho && ox < p.Wo;
+            const unsigned vo = ok ? (unsigned)((img * p.Ho + oy) * p.Wo + ox) * (unsigned)(p.dz_stride * 2) + (unsigned)(co0 * 2) + z_col[k] : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_z, (lds_ptr_t)(sz + (wave + NW * k) * 1024), 16, vo, 0, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses (stage 0; + stage * kW3_STAGE per tile).  Lane (g, q, pp) of a transposing read points at pixel row
+    // base + 8 g + q (+ 4 for the second half) and channels 16 blk + 4 pp of a pixel-major tile (load_frag_tr)
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int rb = 8 * g + q;
+    const unsigned lds0 = lds_addr(smem);
+    unsigned x_off[3][2][2], z_off[2];           // [kw][half][cin block], [half]
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = kw + rb + 4 * h;
+                x_off[kw][h][j] = lds0 + (unsigned)(r * 128 + ((((jb0 + j) ^ fsw<64>(r)) << 5) | (pp << 3)));
+            }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = rb + 4 * h;
+        z_off[h] = lds0 + (unsigned)(kW3_XBUF + r * 128 + (((cb ^ fsw<64>(r)) << 5) | (pp << 3)));
+    }
+
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto frag = [](const u32x2 lo, const u32x2 hi) -> bf16x8 {
+        const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    int stage = 0;
+    if (t_begin < t_end) issue_tile(t_begin, 0);
+    if (t_begin + 1 < t_end) issue_tile(t_begin + 1, 1);
+    for (int tile = t_begin; tile < t_end; ++tile, stage = stage + 1 == kW3_STAGES ? 0 : stage + 1) {
+        // this tile's pieces have landed; younger than them are only the next tile's (6 per wave; 5 for the two waves without a 4th patch piece)
+        if (tile + 1 < t_end) {
+            if (wave < 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // the tile is complete for everyone; everyone's reads of the stage refilled next are done
+#ifdef FRCNN_SWEEP
+        if (!(p.dev & 1))
+#endif
+        if (tile + 2 < t_end) issue_tile(tile + 2, stage >= 1 ? stage - 1 : kW3_STAGES - 1);      // (stage + 2) % 3
+        const unsigned sb = (unsigned)(stage * kW3_STAGE);
+        // the transposing reads go through inline asm (hipcc would order its own behind the DMA just issued: vmcnt(0)); completion by
+        // counted lgkmcnt waits + register pins, as wgrad_body
+        u32x2 zl[4], zh[4];
+#define FRCNN_W3_READ(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+        {
+            const unsigned a0 = z_off[0] + sb, a1 = z_off[1] + sb;
+            FRCNN_W3_READ(zl[0], a0, 0 * 4096); FRCNN_W3_READ(zh[0], a1, 0 * 4096);
+            FRCNN_W3_READ(zl[1], a0, 1 * 4096); FRCNN_W3_READ(zh[1], a1, 1 * 4096);
+            FRCNN_W3_READ(zl[2], a0, 2 * 4096); FRCNN_W3_READ(zh[2], a1, 2 * 4096);
+            FRCNN_W3_READ(zl[3], a0, 3 * 4096); FRCNN_W3_READ(zh[3], a1, 3 * 4096);
+        }
+        unsigned xa[3][2][2];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xa[kw][h][j] = x_off[kw][h][j] + sb;
+        u32x2 xl[2][3][2], xh[2][3][2];          // [buffer][kw][cin block]
+        // (asm operands cannot name a captured variable of a generic lambda: the destination arrays travel as reference parameters)
+        auto read_row = [&](auto r_c, u32x2 (&dl)[3][2], u32x2 (&dh)[3][2], const unsigned (&ad)[3][2][2]) {     // the 12 reads of patch row R
+            constexpr int R = decltype(r_c)::value;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned al = ad[kw][0][j], ah = ad[kw][1][j];
+                    FRCNN_W3_READ(dl[kw][j], al, R * PITCH * 128);
+                    FRCNN_W3_READ(dh[kw][j], ah, R * PITCH * 128);
+                }
+        };
+        auto pin_row = [](u32x2 (&dl)[3][2], u32x2 (&dh)[3][2]) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(dl[kw][j]), "+v"(dh[kw][j]));
+        };
+        read_row(std::integral_constant<int, 0>{}, xl[0], xh[0], xa);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(zl[i]), "+v"(zh[i]));
+        pin_row(xl[0], xh[0]);
+        auto row_step = [&](auto r_c, u32x2 (&cl)[3][2], u32x2 (&ch)[3][2], u32x2 (&nl)[3][2], u32x2 (&nh)[3][2]) {
+            // patch row R (fragments in cl / ch): fetch row R + 1 into nl / nh, multiply row R into the taps kh = R - ty of the tile rows ty
+            constexpr int R = decltype(r_c)::value;
+            if constexpr (R + 1 < TH + 2) read_row(std::integral_constant<int, R + 1>{}, nl, nh, xa);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ty = R - kh;
+                if (ty < 0 || ty >= TH) continue;
+                const bf16x8 zf = frag(zl[ty], zh[ty]);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[kh * 3 + kw][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(cl[kw][j], ch[kw][j]), zf, acc[kh * 3 + kw][j], 0, 0, 0);
+            }
+            if constexpr (R + 1 < TH + 2) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                pin_row(nl, nh);
+            }
+        };
+        row_step(std::integral_constant<int, 0>{}, xl[0], xh[0], xl[1], xh[1]);
+        row_step(std::integral_constant<int, 1>{}, xl[1], xh[1], xl[0], xh[0]);
+        row_step(std::integral_constant<int, 2>{}, xl[0], xh[0], xl[1], xh[1]);
+        row_step(std::integral_constant<int, 3>{}, xl[1], xh[1], xl[0], xh[0]);
+        row_step(std::integral_constant<int, 4>{}, xl[0], xh[0], xl[1], xh[1]);
+        row_step(std::integral_constant<int, 5>{}, xl[1], xh[1], xl[0], xh[0]);
+#undef FRCNN_W3_READ
+    }
+
+    // ---- epilogue: D rows = cin (4 consecutive per lane), cols = cout (lane & 15); three taps per pass through the idle stages
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            unsigned char* stg = smem + tt * (64 * SROW);
+            const int co_l = cb * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ci_l = (jb0 + j) * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<f32x4*>(stg + co_l * SROW + ci_l * 4) = acc[pass * 3 + tt][j];
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 3 * 64 * 64; idx += T) {
+            const int tt = idx >> 12, r = (idx >> 6) & 63, c = idx & 63;
+            const float v = *reinterpret_cast<const float*>(smem + tt * (64 * SROW) + r * SROW + c * 4);
+            float* dst = p.dw + ((long long)(co0 + r) * 9 + pass * 3 + tt) * p.Cin + ci0 + c;
+            if (p.plain_store) *dst = v;
+            else atomicAdd(dst, v);
+        }
+        __syncthreads();
+    }
+#endif
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad3_kernel(const WgradParams p) { wgrad3_body(p, xcd_chunk(blockIdx.x, gridDim.x)); }
+
+__global__ __launch_bounds__(512, 2) void wgrad3_group_kernel(const WgradGroup* __restrict__ g) {
+    const int id = xcd_chunk(blockIdx.x, gridDim.x);
+    int layer = 0;
+    const int n = g->n;
+#pragma unroll
+    for (int i = 1; i < kGroupMax; ++i) {
+        const int f = g->first[i];
+        layer += (int)(i < n) & (int)(id >= f);
+    }
+    const WgradParams p = g->p[layer];
+    wgrad3_body(p, id - g->first[layer]);
+}
+
+#endif  // FRCNN_SWEEP (wgrad3_body)
+
 thread_local bool t_dry_run = false;            // frcnn_conv2d_wgrad*_describe: stop before the launch
 
 template <int BM, int BN, int S, int MODE, int OCC, bool F8 = false>
@@ -520,10 +784,92 @@ static int wgrad_fill(const frcnn_conv_desc* d, const void* x, const void* dz, i
     return FRCNN_OK;
 }
 
+// ---- the all-taps kernel for 3x3 / stride 1 / pad 1 (wgrad3_body): which layers, and how their pixels are split over workgroups
+#ifdef FRCNN_SWEEP
+static bool wgrad3_eligible(const frcnn_conv_desc* d, const int es, const int32_t* row_index) {
+    bool on = es == 2 && !row_index && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->hi == d->ho && d->wi == d->wo &&
+              d->cin % 64 == 0 && d->cout % 64 == 0 && d->in_pix_stride % 8 == 0 && !(d->flags & FRCNN_CONV_WGRAD_STEM_UNPACK);
+    const char* e = getenv("FRCNN_WGRAD3");
+    return on && e && atoi(e) != 0;
+}
+
+// One split count per LAYER (layers of one launch differ in pixels per block: conv3's blocks have 240 spatial tiles, conv4's 72), all derived
+// from one target T of tiles per workgroup, chosen by a cost model: rounds of workgroups x (T tiles at ~1.1 us + ~6 us of prologue and
+// epilogue) + the float atomics of the split layers at the memory side's ~1.3 TB/s (9 x 64 x 64 x 4 bytes per workgroup).
+static void wgrad3_plan(WgradParams* ps, const int n, const bool* accumulate, int* first) {
+    int max_sp = 1;
+    for (int i = 0; i < n; ++i) {
+        WgradParams& p = ps[i];
+        p.sp_tx = (p.Wo + kW3_TW - 1) / kW3_TW;
+        p.sp_ty = (p.Ho + kW3_TH - 1) / kW3_TH;
+        p.p_tiles = (p.M / (p.Ho * p.Wo)) * p.sp_tx * p.sp_ty;
+        p.tiles_co = p.Cout / 64;
+        p.tiles_ci = p.Cin / 64;
+        if (p.p_tiles > max_sp) max_sp = p.p_tiles;
+    }
+    double tile_us = 2.1, fixed_us = 6.0, atom_bpus = 1.3e6;
+    if (const char* e = getenv("FRCNN_WGRAD3_MODEL")) sscanf(e, "%lf,%lf,%lf", &tile_us, &fixed_us, &atom_bpus);
+    const int cus = num_cus();
+    double best = 1e30;
+    int best_t = max_sp;
+    for (int t = 1; t <= max_sp; ++t) {
+        long long wgs = 0;
+        double atom = 0.0;
+        int t_eff = 0;
+        for (int i = 0; i < n; ++i) {
+            const int sp = ps[i].p_tiles, blocks = ps[i].tiles_co * ps[i].tiles_ci;
+            const int splits = (sp + t - 1) / t, per = (sp + splits - 1) / splits;
+            wgs += (long long)blocks * splits;
+            if (splits > 1 || accumulate[i]) atom += (double)blocks * splits * (9.0 * 64 * 64 * 4);
+            if (per > t_eff) t_eff = per;
+        }
+        const double rounds = (double)((wgs + cus - 1) / cus);
+        const double cost = rounds * (t_eff * tile_us + fixed_us) + atom / atom_bpus;
+        if (cost < best) { best = cost; best_t = t; }
+    }
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        WgradParams& p = ps[i];
+        const int splits = (p.p_tiles + best_t - 1) / best_t;
+        p.p_tiles_per_split = (p.p_tiles + splits - 1) / splits;
+        const int eff = (p.p_tiles + p.p_tiles_per_split - 1) / p.p_tiles_per_split;
+        p.plain_store = eff == 1 && !accumulate[i] ? 1 : 0;
+        first[i] = total;
+        total += p.tiles_co * p.tiles_ci * eff;
+    }
+    first[n] = total;
+}
+
+constexpr int kW3_SMEM = kW3_STAGES * kW3_STAGE;
+static_assert(kW3_SMEM <= 163840 && 3 * 64 * (64 * 4 + 16) <= kW3_SMEM, "LDS budget of wgrad3_body");
+#else
+static bool wgrad3_eligible(const frcnn_conv_desc*, int, const int32_t*) { return false; }
+#endif
+
 static int wgrad_one(const frcnn_conv_desc* d, const void* x, const void* dz, int dz_stride, const int32_t* row_index, float* dw,
                      int es, const float* x_scale, const float* dz_scale, frcnn_stream_t stream) {
     WgradParams p;
     if (const int rc = wgrad_fill(d, x, dz, dz_stride, row_index, dw, p, es, x_scale, dz_scale)) return rc;
+    p.dev = 0;
+#ifdef FRCNN_SWEEP
+    if (const char* e = getenv("FRCNN_W3_DEV")) p.dev = atoi(e);
+    if (wgrad3_eligible(d, es, row_index)) {
+        const bool accumulate = (d->flags & FRCNN_CONV_WGRAD_ACCUMULATE) != 0;
+        int first[2];
+        wgrad3_plan(&p, 1, &accumulate, first);
+        if (!t_dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad3_kernel), kW3_SMEM) != 0) {
+            frcnn_set_error("frcnn_conv2d_wgrad(3x3): cannot reserve %d B of LDS", kW3_SMEM);
+            return FRCNN_EINVAL;
+        }
+        char name[160];
+        snprintf(name, sizeof(name), "wgrad3x3_patch grid=%d split=%d", first[1], first[1] / (p.tiles_co * p.tiles_ci));
+        frcnn_note_instantiation(name);
+        if (t_dry_run) return FRCNN_OK;
+        hipLaunchKernelGGL(wgrad3_kernel, dim3(first[1]), dim3(512), kW3_SMEM, reinterpret_cast<hipStream_t>(stream), p);
+        FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad(3x3)");
+        return FRCNN_OK;
+    }
+#endif
     const long long M = p.M;
     const int BKP = es == 1 ? 128 : 64;          // pixels per slice
 
@@ -597,7 +943,7 @@ extern "C" int frcnn_conv2d_wgrad_fp8(const frcnn_conv_desc* d, const frcnn_fp8*
 
 // ---------------------------------------------------------------------------------------------------- grouped launches
 constexpr int kWideGroupDefault = 0;             // (see frcnn_conv2d_wgrad_group_plan)
-constexpr int kGroups = 4;                      // {bf16, fp8} x {x rows linear in the pixel index, general addressing}
+constexpr int kGroups = 5;                      // {bf16, fp8} x {x rows linear in the pixel index, general addressing}; 4: bf16 3x3 on wgrad3_body
 extern "C" size_t frcnn_wgrad_group_bytes(void) { return kGroups * sizeof(WgradGroup); }
 
 // Fill `table_host` (frcnn_wgrad_group_bytes() bytes: one group of 1x1 / stride-1 layers whose x rows are the GEMM rows, one
@@ -618,6 +964,7 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
     }
 #endif
     int tiles[kGroups], min_p_tiles[kGroups];
+    bool acc3[kGroupMax];
     for (int m = 0; m < kGroups; ++m) {
         g[m].n = g[m].total = tiles[m] = 0;
         min_p_tiles[m] = 1 << 30;
@@ -628,13 +975,23 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
         if (const int rc = wgrad_fill(items[i].desc, items[i].x, items[i].dz, items[i].dz_stride, nullptr, items[i].dw, p, f8 ? 1 : 2,
                                       items[i].x_scale, items[i].dz_scale)) return rc;
         FRCNN_CHECK_ARG(p.Cin % 64 == 0 && p.Cout % 64 == 0, "conv2d_wgrad_group_plan: layer %d: channels must be multiples of 64", i);
+        p.dev = 0;
         p.p_tiles = f8 ? (p.M + 127) / 128 : (p.M + 63) / 64;
-        const int m = (f8 ? 2 : 0) + (p.linear_x ? 0 : 1);
+        const int m = wgrad3_eligible(items[i].desc, f8 ? 1 : 2, nullptr) ? 4 : (f8 ? 2 : 0) + (p.linear_x ? 0 : 1);
         FRCNN_CHECK_ARG(g[m].n < kGroupMax, "conv2d_wgrad_group_plan: more than %d layers in one group", kGroupMax);
+        if (m == 4) acc3[g[m].n] = (items[i].desc->flags & FRCNN_CONV_WGRAD_ACCUMULATE) != 0;
         g[m].p[g[m].n++] = p;
         if (p.p_tiles < min_p_tiles[m]) min_p_tiles[m] = p.p_tiles;
     }
-    for (int m = 0; m < kGroups; ++m) {
+#ifdef FRCNN_SWEEP
+    if (g[4].n > 0) {
+        wgrad3_plan(g[4].p, g[4].n, acc3, g[4].first);
+        g[4].total = g[4].first[g[4].n];
+        g[4].bm = g[4].bn = 64;
+        g[4].stages = 2;
+    }
+#endif
+    for (int m = 0; m < 4; ++m) {
         // measured (train step, batch 4): 128 x 64 tiles 0.73 ms of weight-gradient time per step, 64 x 64 0.82, 64 x 128 0.77,
         // 128 x 128 0.83 -- twice the MFMA work per barrier for 1.5x the staged bytes; not for 64-channel outputs (half a tile idle)
         int min_cout = 1 << 30;
@@ -663,7 +1020,7 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
     // one pixel split for the whole group: just enough workgroups for ~4 per CU.  The float atomics of a split cost
     // split x |dw| bytes at the memory side's 1.3 TB/s; launched alone, a layer with few tiles needs a far larger split to fill
     // the chip (conv2: 64-128) than the group does (~10)
-    for (int m = 0; m < kGroups; ++m) {
+    for (int m = 0; m < 4; ++m) {
         if (g[m].n == 0) continue;
         // (same-box A/B of the workgroups-per-CU target in the step, ms: batch 4: 2 4.215, 4 4.19, 6 4.19, 8 4.215, 12 4.275; fp8 batch 8
         // 6.79 -> 6.74; pyramid 9.64 -> 9.56: more, shorter pixel ranges even out the tail; the extra float atomics cost less)
@@ -747,6 +1104,16 @@ extern "C" int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* ta
 #endif
 #undef FRCNN_GROUP_LAUNCH
 #undef FRCNN_GROUP_LAUNCH1
+#ifdef FRCNN_SWEEP
+    if (h[4].n > 0) {
+        FRCNN_CHECK_ARG(t_dry_run || frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad3_group_kernel), kW3_SMEM) == 0,
+                        "conv2d_wgrad_grouped: cannot reserve %d B of LDS", kW3_SMEM);
+        if (!t_dry_run) hipLaunchKernelGGL(wgrad3_group_kernel, dim3(h[4].total), dim3(512), kW3_SMEM, s, dv + 4);
+        snprintf(name + strlen(name), sizeof(name) - strlen(name), "wgrad3x3_patch_group grid=%d layers=%d; ", h[4].total, h[4].n);
+        if (!t_dry_run) FRCNN_CHECK_LAUNCH("frcnn_conv2d_wgrad_grouped");
+        launched |= 1 << 4;
+    }
+#endif
     frcnn_note_instantiation(name);
     for (int m = 0; m < kGroups; ++m)
         FRCNN_CHECK_ARG(h[m].n == 0 || (launched & (1 << m)), "conv2d_wgrad_grouped: no kernel for tile %dx%d, %d slots", h[m].bm, h[m].bn, h[m].stages);

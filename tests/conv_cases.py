@@ -174,6 +174,12 @@ WGRAD = [
     dict(id="c4_3x3", n=3, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1),
     dict(id="c2_1x1", n=2, h=30, w=40, cin=64, cout=256, k=1, s=1, p=0),
     dict(id="fpn_p2_3x3_wide", n=1, h=94, w=311, cin=256, cout=256, k=3, s=1, p=1),             # M >= 24576, multi-tap: 128 x 128 tiles
+    # more 3x3 shapes (added with the all-taps kernel of round 4, a sweep-build variant that was measured slower and is not dispatched):
+    # ragged grids, conv2's shape at the benchmark's batch, conv3's
+    dict(id="w3_ragged_64_128", n=2, h=13, w=37, cin=64, cout=128, k=3, s=1, p=1),
+    dict(id="w3_c2_64_64_b4", n=4, h=94, w=311, cin=64, cout=64, k=3, s=1, p=1),
+    dict(id="w3_c3_128_128", n=2, h=47, w=156, cin=128, cout=128, k=3, s=1, p=1),
+    dict(id="small_3x3_general_cin32", n=2, h=12, w=10, cin=32, cout=64, k=3, s=1, p=1),       # (cin % 64 != 0: the per-tap kernel, general addressing)
 ]
 
 # ---- fp8 weight gradients (x8: e4m3, dz8: e5m2; 128-pixel slices through ds_read_b64_tr_b8): both addressing modes, the pixel
