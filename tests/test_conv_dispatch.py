@@ -105,7 +105,7 @@ def test_workspace_query_matches_the_dispatch_rule(ops):
     # still answers for the tile kernel, which the fp8 entry points use with the same descriptor
     real = ops.conv_desc(4, 24, 78, 1024, 3, 3, 1, 1, 1, 24, 78, 256, flags=ops.CONV_BIAS | ops.CONV_RELU)
     assert ops.conv_workspace_bytes(real) > 0 and ops.conv_attach_workspace(real, "cpu") is not None
-    assert ops.conv2d_describe(real).startswith("conv3x3_patch<SB=4,SMODE=0> grid=240x1")
+    assert ops.conv2d_describe(real).startswith("conv3x3_patch<SB=4,SMODE=0,LW=4> grid=240x1")
     assert "FIX=1" in ops.conv2d_describe_fp8(real)
     for d in (ops.conv_desc(4, 24, 78, 1024, 1, 1, 1, 0, 0, 24, 78, 256, flags=ops.CONV_BIAS | ops.CONV_STATS),       # 16 slices
               ops.conv_desc(4, 24, 78, 256, 3, 3, 1, 1, 1, 24, 78, 256, flags=ops.CONV_BIAS | ops.CONV_STATS),        # patch-resident kernel

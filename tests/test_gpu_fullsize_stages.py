@@ -86,4 +86,4 @@ def test_head_stages_at_benchmark_size(depth, batch, proposals):
     # which conv kernel carried the RPN's 3x3 layer: the patch-resident kernel (rounds 2-3: the tile kernel's split-K pair form) -- both
     # configurations have at most 240 workgroups of 8 x 16 pixels x 64 channels
     ops = importlib.import_module("2d_object_detection_amd.ops")
-    assert ops.conv2d_describe(model._train.rpn.d_inter).startswith("conv3x3_patch<SB=4,SMODE=0>")
+    assert ops.conv2d_describe(model._train.rpn.d_inter).startswith("conv3x3_patch<SB=4,SMODE=0,LW=4>")

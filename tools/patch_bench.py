@@ -32,7 +32,8 @@ def main():
         mean, invstd = torch.randn(cout, device="cuda", generator=g), torch.rand(cout, device="cuda", generator=g) + 0.5
         out, ys = [], []
         for var in VARIANTS:
-            on, sb = (var.split(":") + [""])[:2]
+            on, sb, lw = (var.split(":") + ["", ""])[:3]
+            os.environ["FRCNN_PATCH_LW"] = lw or "0"         # (4: dedicated loader waves)
             os.environ["FRCNN_PATCH"] = on
             os.environ["FRCNN_WRES"] = on                    # (64-channel layers: the weights-resident form)
             os.environ["FRCNN_PATCH_SB"] = sb or "4"
