@@ -39,7 +39,6 @@ struct ConvParams {
     const float* f8_w_scale;                //   output channel's weight row (device [Cout]); NULL: bf16 operands
     int f8_fmt;                             // 1: x is e4m3 (activations), 2: x is e5m2 (gradients); the weights are always e4m3
     int dry_run;                            // host only: stop before the launch (frcnn_conv2d_describe)
-    int loader_waves;                       // host only: the dispatcher's choice of the LW = 4 instantiation (conv_tile_kernel)
     unsigned long long* dbg;                // FRCNN_STAMPS builds: per-workgroup phase stamps (NULL otherwise)
 };
 

@@ -16,8 +16,8 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, bool KWS, bool FIX, int F8, int LW>
-__global__ __launch_bounds__(512 + 64 * LW, (8 + LW) * OCC / 4) void conv_tile_kernel(const ConvParams p) {
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, bool KWS, bool FIX, int F8>
+__global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // SMODE 0: plain, 1: BatchNorm statistics of the output (forward), 2: BatchNorm-backward reduce of the consumer layer
     constexpr bool STATS = SMODE == 1, RED = SMODE == 2;
@@ -62,11 +62,6 @@ __global__ __launch_bounds__(512 + 64 * LW, (8 + LW) * OCC / 4) void conv_tile_k
     // matrix-pipe cycles per slice as the two bf16 MFMAs it replaces, at twice the K.  Dequantisation (activation scale x weight
     // scale of the output channel) is one multiply in the epilogue.
     static_assert(!F8 || (BK == 64 && !F32), "fp8 operands: 128-byte slices, bf16 output");
-    // LW = 4 (one-tile kernel): four more waves that only issue the LDS-DMA and wait for it -- each the pieces of two of the eight
-    // "virtual" loader waves (the instruction stalls its wave while the CU's load path is backed up: 120 - 265 ns of a 510 - 820 ns slice
-    // step in the stamps of DESIGN.md 4.3); the eight MFMA waves never execute one.  Same barriers for all twelve waves.
-    static_assert(!LW || (LW == 4 && !MULTI && !F32 && !KWS && !FIX && A_UNI && B_UNI), "loader waves: plain one-tile kernel, uniform DMA split");
-    constexpr int NV = LW ? 2 : 1;
     constexpr int B_BASE = KWS ? 2 * AK_BYTES : S * A_BYTES;
     constexpr int RING = KWS ? 2 * AK_BYTES + S * B_BYTES : S * (A_BYTES + B_BYTES), STG = BM * ROWB;
     // one tile per workgroup: the staging tile aliases the drained ring.  Tile runs (MULTI): the ring keeps prefetching the
@@ -102,8 +97,6 @@ __global__ __launch_bounds__(512 + 64 * LW, (8 + LW) * OCC / 4) void conv_tile_k
     const int wm = wave / WN, wn = wave - wm * WN;
     const int frow = lane & 15, fchunk = lane >> 4;
     const int flags = p.flags;
-    const bool is_loader = LW && wave >= NW;
-    const int vw0 = is_loader ? wave - NW : wave;                // first virtual loader wave of this wave (LW: + 4 is the second)
 
     // workgroup -> run of tiles_per_block consecutive m-tiles of one n-tile (one tile unless MULTI).  Workgroups b, b+8, ...
     // run on one XCD: each XCD takes a contiguous chunk of the unit list (n fastest), so the workgroups that share an L2
@@ -158,9 +151,7 @@ __global__ __launch_bounds__(512 + 64 * LW, (8 + LW) * OCC / 4) void conv_tile_k
     const long long halo = (long long)p.pad_h * p.in_row_stride + (long long)p.pad_w * p.in_pix_stride;
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - halo), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-    unsigned a_voff_[NV][KWS ? AK_IT : A_IT], a_mask_[NV][KWS ? AK_IT : A_IT], b_voff_[NV][B_IT];
-    auto& a_voff = a_voff_[0];                   // (the kw-sharing and tile-run forms have no loader waves: one set)
-    auto& a_mask = a_mask_[0];
+    unsigned a_voff[KWS ? AK_IT : A_IT], a_mask[KWS ? AK_IT : A_IT], b_voff[B_IT];
     unsigned edge_l[MI], edge_r[MI];            // KWS: all-ones, or zero where the lane's pixel has no left / right neighbour in its image row
     const int lrow = lane / CPR, lslot = lane % CPR;
     auto setup_tile = [&](const int m0) {        // per-lane source offsets (and tap validity masks) of the A rows of tile m0
@@ -188,24 +179,18 @@ __global__ __launch_bounds__(512 + 64 * LW, (8 + LW) * OCC / 4) void conv_tile_k
             }
         } else if (LIN) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                const int r = (vw0 + 4 * v + NW * i) * RPI + lrow;
+                const int r = (wave + NW * i) * RPI + lrow;
                 const int m = m0 + r;
-                a_voff_[v][i] = (m < p.M && r < BM) ? (unsigned)m * (unsigned)(p.in_pix_stride * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
-                a_mask_[v][i] = 1u;
+                a_voff[i] = (m < p.M && r < BM) ? (unsigned)m * (unsigned)(p.in_pix_stride * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
+                a_mask[i] = 1u;
             }
         } else {
-#pragma unroll
-          for (int v = 0; v < NV; ++v) {
-            auto& a_voff = a_voff_[v];
-            auto& a_mask = a_mask_[v];
             const int hw = p.Ho * p.Wo;
             int iy0[A_IT], ix0[A_IT];
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                const int r = (vw0 + 4 * v + NW * i) * RPI + lrow;
+                const int r = (wave + NW * i) * RPI + lrow;
                 const int m = m0 + r;
                 const int n = m / hw;            // rows beyond M compute harmless garbage, masked below
                 const int rem = m - n * hw;
@@ -224,19 +209,15 @@ __global__ __launch_bounds__(512 + 64 * LW, (8 + LW) * OCC / 4) void conv_tile_k
                     for (int i = 0; i < A_IT; ++i)
                         a_mask[i] |= ((unsigned)(iy0[i] + kh) < (unsigned)p.Hi && (unsigned)(ix0[i] + kw) < (unsigned)p.Wi) ? (1u << t) : 0u;
                 }
-          }
         }
     };
     setup_tile(tm_begin * BM);
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int r = (vw0 + 4 * v + NW * i) * RPI + lrow;
+        const int r = (wave + NW * i) * RPI + lrow;
         const int n = n0 + r;
-        b_voff_[v][i] = (n < p.Cout && r < BN) ? (unsigned)n * (unsigned)(p.Ktot * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
+        b_voff[i] = (n < p.Cout && r < BN) ? (unsigned)n * (unsigned)(p.Ktot * 2) + (unsigned)swz<BK>(lslot, r) * 16u : kOob;
     }
-    auto& b_voff = b_voff_[0];
     // F32: blockIdx.y selects a K range of k_tiles_per_split slices (split-K, 1x1 filters only)
     const int kt0 = F32 ? blockIdx.y * p.k_tiles_per_split : FIX ? fix_split * p.k_tiles_per_split : 0;
     const int nk = (F32 || FIX) ? min(p.k_tiles, kt0 + p.k_tiles_per_split) - kt0 : p.k_tiles;
@@ -255,23 +236,17 @@ __global__ __launch_bounds__(512 + 64 * LW, (8 + LW) * OCC / 4) void conv_tile_k
     auto issue_slice = [&](const int slot) {     // DMA the loader's next K slice into ring slot
         unsigned char* sa = ring + slot * A_BYTES;
         unsigned char* sb = ring + B_BASE + slot * B_BYTES;
-        if (!LW || is_loader) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int vw = vw0 + 4 * v;
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                if (A_UNI || vw + NW * i < A_INSTR) {
-                    const unsigned vo = LIN ? a_voff_[v][i] : (((a_mask_[v][i] >> ld_tap) & 1u) ? a_voff_[v][i] : kOob);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(sa + (vw + NW * i) * 1024), 16, vo, ld_soff_a, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) {
-                if (B_UNI || vw + NW * i < B_INSTR)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (vw + NW * i) * 1024), 16, b_voff_[v][i], ld_soff_b, 0, 0);
+        for (int i = 0; i < A_IT; ++i) {
+            if (A_UNI || wave + NW * i < A_INSTR) {
+                const unsigned vo = LIN ? a_voff[i] : (((a_mask[i] >> ld_tap) & 1u) ? a_voff[i] : kOob);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(sa + (wave + NW * i) * 1024), 16, vo, ld_soff_a, 0, 0);
             }
         }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            if (B_UNI || wave + NW * i < B_INSTR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (wave + NW * i) * 1024), 16, b_voff[i], ld_soff_b, 0, 0);
         }
         ld_soff_b += BK * 2;
         ld_soff_a += BK * 2;
@@ -472,32 +447,9 @@ __global__ __launch_bounds__(512 + 64 * LW, (8 + LW) * OCC / 4) void conv_tile_k
     for (int e = 0; e < 8; ++e) rsg[e] = rsgz[e] = 0.f;
 
     // ------------------------------------------------------------------ K loops of the run's tiles
-#define FRCNN_WAIT_IMM(n) do { if (!LW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); } while (0)
+#define FRCNN_WAIT_IMM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
     FRCNN_STAMP(1);
     const int total_slices = tile_count * nk;
-    if (is_loader) {
-        // loader waves: the ring's prologue, then per slice: wait for the slice's pieces (two virtual waves' worth), meet the MFMA waves at
-        // the slice's barrier, refill the slot they have just left.  Then the MFMA waves' remaining barriers (ring drained, staging tile
-        // complete, flushes) and out.
-        const int pre = total_slices < S - 1 ? total_slices : S - 1;
-        for (int s_ = 0; s_ < pre; ++s_) issue_slice(s_);
-        int to_issue_l = total_slices - pre, slot_l = 0;
-        for (int left_l = nk; left_l > 0; --left_l) {
-            if (to_issue_l > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LC * NV) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (to_issue_l > 0) {
-                issue_slice(slot_l == 0 ? S - 1 : slot_l - 1);
-                --to_issue_l;
-            }
-            slot_l = slot_l + 1 == S ? 0 : slot_l + 1;
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
-        if (RED) __builtin_amdgcn_s_barrier();
-        if (STATS) __builtin_amdgcn_s_barrier();
-        return;
-    }
     if (KWS) {
         issue_slice_kws(0);                      // (nk = 9 * Cin / 64 >= 9)
         issue_slice_kws(1);
@@ -1898,22 +1850,22 @@ int launch_wres(ConvParams p, hipStream_t s, const int n_img) {
 
 unsigned long long* g_stamp_buffer = nullptr;    // FRCNN_STAMPS builds: set through frcnn_debug_set_stamp_buffer (tools/conv_stamps.py)
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false, bool FIX = false, int F8 = 0, int LW = 0>
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false, bool FIX = false, int F8 = 0>
 int launch_tile(const ConvParams& p, hipStream_t s) {
     constexpr int ring = KWS ? 2 * 3 * 8 * 1024 + S * BN * BK * 2 : S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
     constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4;
     static_assert(smem <= 163840, "LDS budget");
     static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
-    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8, LW>), smem) != 0) {
+    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
     const int grid_x = FIX ? ((2 * p.items + 15) / 16) * 16 : p.items;      // FIX: two halves per tile, whole pairs per XCD
-    snprintf(g_last_inst, sizeof(g_last_inst), "conv_tile<BM=%d,BN=%d,BK=%d,S=%d,LIN=%d,SMODE=%d,OCC=%d,MULTI=%d,F32=%d,KWS=%d%s%s%s> grid=%dx%d tpb=%d",
-             BM, BN, BK, S, (int)LIN, SMODE, OCC, (int)MULTI, (int)F32, (int)KWS, FIX ? ",FIX=1" : "", F8 == 1 ? ",F8=1" : F8 == 2 ? ",F8=2" : "", LW ? ",LW=4" : "",
-             grid_x, F32 ? p.split : 1, p.tiles_per_block);
+    snprintf(g_last_inst, sizeof(g_last_inst), "conv_tile<BM=%d,BN=%d,BK=%d,S=%d,LIN=%d,SMODE=%d,OCC=%d,MULTI=%d,F32=%d,KWS=%d%s%s> grid=%dx%d tpb=%d",
+             BM, BN, BK, S, (int)LIN, SMODE, OCC, (int)MULTI, (int)F32, (int)KWS, FIX ? ",FIX=1" : "", F8 == 1 ? ",F8=1" : F8 == 2 ? ",F8=2" : "", grid_x, F32 ? p.split : 1,
+             p.tiles_per_block);
     if (p.dry_run) return FRCNN_OK;              // frcnn_conv2d_describe: the dispatch decision only
-    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8, LW>), dim3(grid_x, F32 ? p.split : 1), dim3(512 + 64 * LW), smem, s, p);
+    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8>), dim3(grid_x, F32 ? p.split : 1), dim3(512), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
     return FRCNN_OK;
 }
@@ -1950,19 +1902,6 @@ int launch_tile_flags(const ConvParams& p, hipStream_t s) {
         } else {
             frcnn_set_error("conv2d fp8: needs 128-byte K slices (cin %% 128 == 0)");
             return FRCNN_EINVAL;
-        }
-    }
-    if constexpr (BK == 64 && !MULTI && !FIX && BM == 128 && S * (BM + BN) * 128 <= 80000 && BM * (BN * 2 + 16) <= 80000) {
-        if (p.loader_waves) {                    // four dedicated loader waves, two workgroups per CU
-            if (smode == 2)
-                return p.linear_a ? launch_tile<BM, BN, BK, S, true, 2, 2, false, false, false, false, 0, 4>(p, s)
-                                  : launch_tile<BM, BN, BK, S, false, 2, 2, false, false, false, false, 0, 4>(p, s);
-            if (p.linear_a) {
-                if (smode == 1) return launch_tile<BM, BN, BK, S, true, 1, 2, false, false, false, false, 0, 4>(p, s);
-                return launch_tile<BM, BN, BK, S, true, 0, 2, false, false, false, false, 0, 4>(p, s);
-            }
-            if (smode == 1) return launch_tile<BM, BN, BK, S, false, 1, 2, false, false, false, false, 0, 4>(p, s);
-            return launch_tile<BM, BN, BK, S, false, 0, 2, false, false, false, false, 0, 4>(p, s);
         }
     }
     if (smode == 2)
@@ -2145,10 +2084,6 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
             return launch_tile_flags<128, 64, 64, 3, 2, false, true>(p, s);
         }
     }
-    p.loader_waves = 0;
-#ifdef FRCNN_SWEEP
-    if (const char* e = getenv("FRCNN_TILE_LW")) p.loader_waves = atoi(e) != 0 && tpb == 1 && bk == 64 && !p.f8_x_scale ? 1 : 0;
-#endif
     int rc = FRCNN_ENOTSUP;
 #define FRCNN_TILE(BM_, BN_, BK_, S_, OCC_) \
     if (rc == FRCNN_ENOTSUP && tpb == 1 && bm == BM_ && bn == BN_ && bk == BK_ && stages == S_) rc = launch_tile_flags<BM_, BN_, BK_, S_, OCC_, false>(p, s);
@@ -2232,7 +2167,6 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     p.red_part = red ? red->partial : nullptr;
     p.res_mask = res_mask;
     p.dry_run = dry_run ? 1 : 0;
-    p.loader_waves = 0;
     p.f8_x_scale = f8_x_scale;
     p.f8_w_scale = f8_w_scale;
     p.f8_fmt = f8_fmt;
