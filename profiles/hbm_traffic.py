@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 
 def family(name):
-    if "conv_stem_kernel" in name or "conv1x1_stream_kernel" in name:      # (round 4: the stem's own kernel, the streaming 1x1 kernel -- bf16)
+    if "conv_stem_kernel" in name or "conv1x1_stream_kernel" in name or "conv3x3_patch_kernel" in name or "conv3x3_wres_kernel" in name:      # (round 4: the stem's own kernel, the streaming 1x1 kernel -- bf16)
         return "conv fprop/dgrad (conv_tile_kernel)"
     if "conv_tile_kernel" in name:
         # the last template argument is F8 (fp8 operands): conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8>
