@@ -884,7 +884,10 @@ static int wgrad_one(const frcnn_conv_desc* d, const void* x, const void* dz, in
 #ifdef FRCNN_SWEEP
     if (const char* e = getenv("FRCNN_WG_WIDE_M")) wide_m = atoll(e);
 #endif
-    const bool wide = d->kh * d->kw > 1 && d->cin % 128 == 0 && d->cout % 128 == 0 && M >= wide_m;
+    // ... or when the layer alone has >= 128 tiles of 128 x 128 (the RPN's 3x3 1024 -> 256 at M = 7,488: 144; same-box A/B in the step
+    // 3.970 -> 3.948 ms): enough workgroups with a pixel split of 3, half the staged bytes per FLOP
+    const bool wide = d->kh * d->kw > 1 && d->cin % 128 == 0 && d->cout % 128 == 0 &&
+                      (M >= wide_m || (long long)(d->cout / 128) * d->kh * d->kw * (d->cin / 128) >= 128);
     int bm = wide ? 128 : 64;
     int bn = wide ? 128 : d->cin >= 64 ? 64 : 32;
     int stages = wide || bn == 32 ? 2 : 3, want_split = 0;
