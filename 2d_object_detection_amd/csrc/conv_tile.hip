@@ -1121,14 +1121,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvParams
 //     BatchNorm-backward reduce of the consumer layer), rows of the staging tile mapped back to (oy, ox).
 //   * LW = 4: four more waves per workgroup that do nothing but issue the DMA (each the pieces of two of the eight "virtual" loader waves)
 //     and wait for it; the eight MFMA waves never execute an LDS-DMA instruction (it stalls its wave while the CU's load path is backed up)
-template <int SB, int SMODE, int OCCW, int LW>
+//   * BNT = 128: 128 output channels per workgroup (wave tiles 32 pixels x 64 channels: 2 + 4 fragment reads per 8 MFMAs), 48 KB of weights
+//     per step in a 2-slot ring -- for layers with 128 output channels and few chunks (conv3), where it halves the workgroups to one round
+template <int SB, int SMODE, int OCCW, int LW, int BNT>
 __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(const ConvParams p, const int tiles_x, const int tiles_y) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr bool STATS = SMODE == 1, RED = SMODE == 2;
     constexpr bool INTERLEAVE = false;          // a step's DMA pieces spread between its MFMA groups: measured slower (c4 3x3 17.4 -> 18.7 us)
-    constexpr int NW = 8, T = 512, BM = 128, BN = 64, TW = 16, TH = 8, PW = TW + 2;
-    constexpr int MI = 2, NI = 2;
-    constexpr int A_BUF = 24 * 1024, B_STEP = 3 * 8 * 1024, B_BASE = 2 * A_BUF, PB = SB - 1;
+    constexpr int NW = 8, T = 512, BM = 128, BN = BNT, TW = 16, TH = 8, PW = TW + 2;
+    constexpr int MI = 2, NI = BN / 32, BPV = BN / 64;            // BPV: weight pieces per (virtual) wave and tap
+    constexpr int TAPB = BN * 128;                               // bytes of one tap's weights in a ring slot
+    constexpr int A_BUF = 24 * 1024, B_STEP = 3 * TAPB, B_BASE = 2 * A_BUF, PB = SB - 1;
+    static_assert(BN == 64 || BN == 128, "64 or 128 output channels per workgroup");
     constexpr int ROWB = BN * 2 + 16, C8 = BN / 8, ST_IT = (BM * C8) / T, STG = BM * ROWB;
     static_assert(SB >= 2 && SB <= 4, "weight ring: 2..4 steps");
     static_assert(STG + NW * 2 * BN * 4 <= B_BASE + SB * B_STEP, "staging tile + flush scratch alias the drained buffers");
@@ -1161,7 +1165,7 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (flags & FRCNN_CONV_BIAS) b = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 32 + j * 16 + fchunk * 4);
+        if (flags & FRCNN_CONV_BIAS) b = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * (BN / 2) + j * 16 + fchunk * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[j][e] = b[e];
     }
@@ -1174,7 +1178,7 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
     constexpr int NV = LW ? 2 : 1;
     const bool is_loader = LW && wave >= NW;
     const int vw0 = is_loader ? wave - NW : (wave & 7);
-    unsigned a_voff[NV][3], b_voff[NV];
+    unsigned a_voff[NV][3], b_voff[NV][BPV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int vw = vw0 + 4 * v;
@@ -1186,7 +1190,8 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
             const bool ok = q < (TH + 2) * PW && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             a_voff[v][t] = ok ? (unsigned)((img * p.Hi + iy) * p.Wi + ix) * (unsigned)(p.in_pix_stride * 2) + dma_swz : kOob;
         }
-        b_voff[v] = (unsigned)(n0 + vw * 8 + (lane >> 3)) * (unsigned)(p.Ktot * 2) + dma_swz;
+#pragma unroll
+        for (int u = 0; u < BPV; ++u) b_voff[v][u] = (unsigned)(n0 + (vw + NW * u) * 8 + (lane >> 3)) * (unsigned)(p.Ktot * 2) + dma_swz;
     }
     const int nsub = p.Cin >> 6, K = nsub * 3;
     int ld_k = 0, ld_s = 0, ld_kh = 0, ld_slot = 0;                               // next weight step to issue
@@ -1195,10 +1200,12 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
     // theirs back to back), one per ~130 cycles of MFMA does not
     auto issue_b_piece = [&](const int kw) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            unsigned char* dst = smem + B_BASE + ld_slot * B_STEP + (vw0 + 4 * v) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(dst + kw * 8192), 16, b_voff[v], (unsigned)((((ld_kh * 3 + kw) * p.Cin) + ld_s * 64) * 2), 0, 0);
-        }
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int u = 0; u < BPV; ++u) {
+                unsigned char* dst = smem + B_BASE + ld_slot * B_STEP + (vw0 + 4 * v + NW * u) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(dst + kw * TAPB), 16, b_voff[v][u], (unsigned)((((ld_kh * 3 + kw) * p.Cin) + ld_s * 64) * 2), 0, 0);
+            }
     };
     auto advance_b = [&]() {
         ++ld_k;
@@ -1222,7 +1229,7 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
         for (int t = 0; t < 3; ++t) issue_a_piece(s, t);
     };
     // pieces a wave issues in consumer step j: the next chunk's patch at kh == 0, the weights of step j + PB
-    auto issued_in = [&](const int j) { return ((j % 3 == 0 && j / 3 + 1 < nsub) ? 3 : 0) + (j + PB < K ? 3 : 0); };
+    auto issued_in = [&](const int j) { return ((j % 3 == 0 && j / 3 + 1 < nsub) ? 3 : 0) + (j + PB < K ? 3 * BPV : 0); };
 
     // ------------------------------------------------------------------ consumer state
     f32x4 acc[MI][NI];
@@ -1234,7 +1241,7 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
 #pragma unroll
     for (int i = 0; i < MI; ++i) a_q0[i] = (unsigned)((2 * wm + i) * PW + frow);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) b_foff[kk] = (unsigned)((wn * 32 + frow) * 128 + (((kk * 4 + fchunk) ^ (frow & 7)) << 4));
+    for (int kk = 0; kk < 2; ++kk) b_foff[kk] = (unsigned)((wn * (BN / 2) + frow) * 128 + (((kk * 4 + fchunk) ^ (frow & 7)) << 4));
     auto mfma_step = [&](const int abuf, const int slot, const int kh, const bool do_a, const bool do_b, const int s_next) {
         const unsigned char* cA = smem + abuf * A_BUF;
         const unsigned char* cB = smem + B_BASE + slot * B_STEP;
@@ -1250,7 +1257,7 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
                 af[buf][i] = *reinterpret_cast<const bf16x8*>(cA + (q << 7) + ((((unsigned)(kk * 4 + fchunk)) ^ (q & 7u)) << 4));
             }
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[buf][j] = *reinterpret_cast<const bf16x8*>(cB + kw * 8192 + j * 2048 + b_foff[kk]);
+            for (int j = 0; j < NI; ++j) bfr[buf][j] = *reinterpret_cast<const bf16x8*>(cB + kw * TAPB + j * 2048 + b_foff[kk]);
         };
         fetch(0, 0);
 #pragma unroll
@@ -1271,8 +1278,18 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
         if (INTERLEAVE && do_b) advance_b();
     };
 
+    // wait until at most n of this wave's DMA pieces are outstanding (n: a multiple of 3 up to 60; the immediate must be a constant)
+    auto wait_pending = [&](const int n) {
+        switch (n) {
+#define FRCNN_WP(c) case c: asm volatile("s_waitcnt vmcnt(" #c ")" ::: "memory"); break;
+            FRCNN_WP(0) FRCNN_WP(3) FRCNN_WP(6) FRCNN_WP(9) FRCNN_WP(12) FRCNN_WP(15) FRCNN_WP(18) FRCNN_WP(21) FRCNN_WP(24) FRCNN_WP(27) FRCNN_WP(30)
+            FRCNN_WP(36) FRCNN_WP(42) FRCNN_WP(48) FRCNN_WP(54) FRCNN_WP(60)
+#undef FRCNN_WP
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
     // ------------------------------------------------------------------ K loop
-    int pend = 3 * ((PB < K ? PB : K) - 1);      // pieces (per virtual wave) issued after the last piece of weight step 0
+    int pend = 3 * BPV * ((PB < K ? PB : K) - 1);      // pieces (per virtual wave) issued after the last piece of weight step 0
     int s = 0, kh = 0, slot = 0;
     if (is_loader) {
         // loader waves: prologue, then per step: wait for the step's pieces (twice the per-virtual-wave count), meet the MFMA waves at the
@@ -1280,19 +1297,11 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
         issue_a(0);
         for (int k = 0; k < PB && k < K; ++k) issue_b();
         for (int k = 0; k < K; ++k) {
-            switch (pend) {
-                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-                case 9: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-                case 12: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-                case 15: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            }
+            wait_pending(2 * pend);
             __builtin_amdgcn_s_barrier();
             if (kh == 0 && s + 1 < nsub) issue_a(s + 1);
             if (ld_k < K) issue_b();
-            pend += issued_in(k) - (k + 1 < PB ? 3 : issued_in(k + 1 - PB));
+            pend += issued_in(k) - (k + 1 < PB ? 3 * BPV : issued_in(k + 1 - PB));
             if (++kh == 3) { kh = 0; ++s; }
         }
         __builtin_amdgcn_s_barrier();            // (the MFMA waves' barriers: ring drained, staging tile complete, flushes)
@@ -1308,15 +1317,7 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
     for (int k = 0; k < K; ++k) {
         // wait until only the `pend` youngest pieces are outstanding: weight step k (and, older than it, this chunk's patch) have landed
         if (!LW) {
-            switch (pend) {
-                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-                case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-                case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            }
+            wait_pending(pend);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads of the buffers refilled next have completed
         __builtin_amdgcn_s_barrier();
@@ -1327,7 +1328,7 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
         }
         mfma_step(s & 1, slot, kh, do_a, do_b, s + 1);
         // pieces younger than weight step k + 1: what was younger than step k, plus this step's, minus the group that ends with step k + 1
-        pend += issued_in(k) - (k + 1 < PB ? 3 : issued_in(k + 1 - PB));
+        pend += issued_in(k) - (k + 1 < PB ? 3 * BPV : issued_in(k + 1 - PB));
         slot = slot + 1 == SB ? 0 : slot + 1;
         if (++kh == 3) { kh = 0; ++s; }
     }
@@ -1369,7 +1370,7 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
         const bool row_ok = col_in && oy0 + 2 * wm + i < p.Ho;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int cl = wn * 32 + j * 16 + fchunk * 4;
+            const int cl = wn * (BN / 2) + j * 16 + fchunk * 4;
             u32x2 pk;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1463,7 +1464,7 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
         if (frow == 0) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const int cl = wn * 32 + j * 16 + fchunk * 4;
+                const int cl = wn * (BN / 2) + j * 16 + fchunk * 4;
                 lds_write_b64(fl_a + ((wm * 2 + 0) * BN + cl) * 4, u32x2{__float_as_uint(ssum[j][0]), __float_as_uint(ssum[j][1])});
                 lds_write_b64(fl_a + ((wm * 2 + 0) * BN + cl + 2) * 4, u32x2{__float_as_uint(ssum[j][2]), __float_as_uint(ssum[j][3])});
                 lds_write_b64(fl_a + ((wm * 2 + 1) * BN + cl) * 4, u32x2{__float_as_uint(ssq[j][0]), __float_as_uint(ssq[j][1])});
@@ -1769,29 +1770,34 @@ int launch_stream_1x1(const ConvParams& p, hipStream_t s) {
     return FRCNN_OK;
 }
 
-template <int SB, int SMODE, int LW = 0>
+template <int SB, int SMODE, int LW = 0, int BNT = 64>
 int launch_patch_sm(const ConvParams& p, hipStream_t s, const int tiles_x, const int tiles_y, const int grid) {
-    constexpr int smem = 2 * 24 * 1024 + SB * 24 * 1024;
+    constexpr int smem = 2 * 24 * 1024 + SB * 3 * BNT * 128;
     static_assert(smem <= 163840, "LDS budget");
     constexpr int occw = LW ? 3 : 2;             // waves per SIMD of the one workgroup a CU holds
-    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv3x3_patch_kernel<SB, SMODE, occw, LW>), smem) != 0) {
+    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv3x3_patch_kernel<SB, SMODE, occw, LW, BNT>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop(patch 3x3): cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
-    snprintf(g_last_inst, sizeof(g_last_inst), "conv3x3_patch<SB=%d,SMODE=%d%s> grid=%dx1 tpb=1", SB, SMODE, LW ? ",LW=4" : "", grid);
+    snprintf(g_last_inst, sizeof(g_last_inst), "conv3x3_patch<SB=%d,SMODE=%d%s%s> grid=%dx1 tpb=1", SB, SMODE, LW ? ",LW=4" : "", BNT == 128 ? ",BN=128" : "", grid);
     if (p.dry_run) return FRCNN_OK;
-    hipLaunchKernelGGL((conv3x3_patch_kernel<SB, SMODE, occw, LW>), dim3(grid), dim3(512 + 64 * LW), smem, s, p, tiles_x, tiles_y);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<SB, SMODE, occw, LW, BNT>), dim3(grid), dim3(512 + 64 * LW), smem, s, p, tiles_x, tiles_y);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop(patch 3x3)");
     return FRCNN_OK;
 }
 
 // 3x3 / stride 1 / pad 1 on the patch-resident kernel: 8 x 16 pixel tiles x 64 output channels, one workgroup per CU
-int launch_patch(ConvParams p, hipStream_t s, const int n_img, int sb) {
+int launch_patch(ConvParams p, hipStream_t s, const int n_img, int sb, const int bn = 64) {
     const int tiles_x = (p.Wo + 15) / 16, tiles_y = (p.Ho + 7) / 8;
     p.tiles_m = n_img * tiles_x * tiles_y;
-    p.tiles_n = p.Cout / 64;
+    p.tiles_n = p.Cout / bn;
     p.items = p.tiles_m * p.tiles_n;
     const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
+    if (bn == 128) {                             // 128 output channels per workgroup: 2-slot weight ring (144 KB of LDS), loader waves
+        if (smode == 1) return launch_patch_sm<2, 1, 4, 128>(p, s, tiles_x, tiles_y, p.items);
+        if (smode == 2) return launch_patch_sm<2, 2, 4, 128>(p, s, tiles_x, tiles_y, p.items);
+        return launch_patch_sm<2, 0, 4, 128>(p, s, tiles_x, tiles_y, p.items);
+    }
 #define FRCNN_PATCH_CASE(SB_)                                                                           \
     if (sb == SB_) {                                                                                    \
         if (smode == 1) return launch_patch_sm<SB_, 1>(p, s, tiles_x, tiles_y, p.items);              \
@@ -2260,16 +2266,24 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
                  d->cout % 64 == 0 && d->in_pix_stride % 8 == 0 && p.direct_out && !f8_x_scale && d->wo >= 16 && d->ho >= 4 &&
                  !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_RELU | FRCNN_CONV_STATS | FRCNN_CONV_WGRAD_ACCUMULATE | FRCNN_CONV_WGRAD_STEM_UNPACK)) &&
                  !((flags & FRCNN_CONV_STATS) && red) && (long long)d->n * d->hi * d->wi * d->in_pix_stride * 2 < 0xFFFF0000ll;
-    // measured per layer (tools/patch_bench.py, graph replays, us, tile kernel -> this one): conv4 3x3 256 -> 256 at M = 7,488 20.7 -> 18.1, its
-    // data gradient with the fused reduce 21.5 -> 17.0, at M = 3,744 (ResNet-101, batch 2) 18.3 -> 16.4, the RPN's 3x3 1024 -> 256 (against the
-    // split-K pair form) 55.9 -> 48.7; it LOSES where the tile kernel has two workgroups per CU or 128-wide tiles: conv3 128 -> 128 at
-    // M = 29,328 18.8 -> 21.2 (480 workgroups, one per CU: two rounds), conv2 64 -> 64 22.7 -> 26.5, the RPN's data gradient 256 -> 1024
-    // 40.7 -> 52.4.  Hence: from four channel chunks on and only where every workgroup gets a CU of its own in ONE round.
-    const long long patch_wgs = (long long)d->n * ((d->wo + 15) / 16) * ((d->ho + 7) / 8) * (d->cout / 64);
-    bool patch_on = patch && d->cin >= 256 && patch_wgs <= num_cus() && !g_ws_query;
-    int patch_sb = 4;
+    // measured per layer (tools/patch_bench.py, graph replays, us, tile kernel -> this one with loader waves): 64 output channels per
+    // workgroup where that gives every workgroup a CU in ONE round -- conv4 3x3 256 -> 256 at M = 7,488 20.7 -> 15.4, its data gradient with
+    // the fused reduce 21.5 -> 15.2, at M = 3,744 (ResNet-101, batch 2) 18.3 -> 13.6, conv3 128 -> 128 at batch 2 13.9 -> 11.7, the RPN's
+    // 1024 -> 256 (against the split-K pair form) 55.9 -> 38.0; else 128 output channels per workgroup where that fits two rounds -- conv3
+    // 128 -> 128 at batch 4 19.6 -> 16.4 (data gradient 20.6 -> 14.8), at batch 8 35.5 -> 30.0 / 36.6 -> 28.5, 256 -> 256 at M = 14,976
+    // 28.1 -> 22.3, the RPN's data gradient 256 -> 1024 41.8 -> 38.0.  It LOSES with more workgroups than that (64-wide parts in two rounds:
+    // conv3 at batch 4 18.8 -> 20.2) and with one chunk (conv2 64 -> 64 22.7 -> 26.5: the weights-resident form below).
+    const long long patch_tiles = (long long)d->n * ((d->wo + 15) / 16) * ((d->ho + 7) / 8);
+    const long long patch_wgs = patch_tiles * (d->cout / 64);
+    bool patch_on = patch && d->cin >= 128 && patch_wgs <= num_cus() && !g_ws_query;
+    int patch_sb = 4, patch_bn = 64;
+    if (patch && !patch_on && d->cin >= 128 && d->cout % 128 == 0 && patch_tiles * (d->cout / 128) <= 2 * num_cus() && !g_ws_query) {
+        patch_on = true;
+        patch_bn = 128;
+    }
 #ifdef FRCNN_SWEEP
-    if (const char* e = getenv("FRCNN_PATCH")) patch_on = patch && atoi(e) != 0;
+    if (const char* e = getenv("FRCNN_PATCH")) { patch_on = patch && atoi(e) != 0; if (atoi(e) == 2) patch_on = patch_on && (d->cin >= 256 && patch_wgs <= num_cus()); }
+    if (const char* e = getenv("FRCNN_PATCH_BN")) { if (d->cout % 128 == 0 && atoi(e)) patch_bn = atoi(e) == 128 ? 128 : 64; }
     if (const char* e = getenv("FRCNN_PATCH_SB")) patch_sb = atoi(e);
 #endif
     // ... and the one-chunk layers (64 input channels: conv2) on the weights-resident form of the same tiling (conv3x3_wres_kernel)
@@ -2287,7 +2301,7 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
         FRCNN_CHECK_ARG(dry_run || ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(y)) & 15) == 0,
                         "conv2d_fprop(patch 3x3): operands must be 16-byte aligned");
         g_last_ws_bytes = g_last_ws_counter_bytes = 0;
-        return launch_patch(p, reinterpret_cast<hipStream_t>(stream), d->n, patch_sb);
+        return launch_patch(p, reinterpret_cast<hipStream_t>(stream), d->n, patch_sb, patch_bn);
     }
     return conv_tile_dispatch(p, d, reinterpret_cast<hipStream_t>(stream));
 }

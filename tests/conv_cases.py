@@ -143,6 +143,8 @@ DGRAD = [
     dict(id="wres_dg_3x3_64_64_red_b4", n=4, h=94, w=311, cin=64, cout=64, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),                # conv3x3_wres, SMODE 2
     dict(id="wres_dg_3x3_64_64_plain_ragged", n=7, h=90, w=100, cin=64, cout=64, k=3, res=False, res_mask=False, red=False, mask=False, scatter=1),   # 588 tiles: shares of 3 and 2
     dict(id="wres_dg_3x3_64_64_red_nomask_ragged", n=7, h=90, w=100, cin=64, cout=64, k=3, res=False, res_mask=False, red=True, mask=False, scatter=1),
+    dict(id="patch128_rpn_dg_3x3_256_1024_plain_b4", n=4, h=24, w=78, cin=256, cout=1024, k=3, res=False, res_mask=False, red=False, mask=False, scatter=1),   # conv3x3_patch, 128 channels per workgroup: the plan's RPN data gradient (480 workgroups)
+    dict(id="patch128_dg_3x3_128_512_red_ragged", n=12, h=13, w=21, cin=128, cout=512, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),   # 48 ragged tiles x 4 parts of 128
     dict(id="patch_dg_3x3_256_256_red_ragged", n=2, h=13, w=21, cin=256, cout=256, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),   # conv3x3_patch, SMODE 2, partial tiles
     dict(id="patch_dg_3x3_256_64_red_nomask", n=1, h=24, w=78, cin=256, cout=64, k=3, res=False, res_mask=False, red=True, mask=False, scatter=1),
     dict(id="patch_dg_3x3_512_128_plain", n=1, h=17, w=40, cin=512, cout=128, k=3, res=False, res_mask=False, red=False, mask=False, scatter=1),

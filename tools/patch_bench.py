@@ -14,7 +14,9 @@ ALL = [("c4 3x3 256->256 stats", 4, 24, 78, 256, 256, "stats"), ("c4 dgrad 3x3 2
           ("rpn 3x3 1024->256 relu", 4, 24, 78, 1024, 256, "plain"), ("rpn dgrad 3x3 256->1024", 4, 24, 78, 256, 1024, "none"),
           ("c3 3x3 128->128 stats", 4, 47, 156, 128, 128, "stats"), ("c3 dgrad 3x3 128->128 red", 4, 47, 156, 128, 128, "red"),
           ("c2 3x3 64->64 stats", 4, 94, 311, 64, 64, "stats"), ("c2 dgrad 3x3 64->64 red", 4, 94, 311, 64, 64, "red"),
-          ("r101 c4 3x3 b2 stats", 2, 24, 78, 256, 256, "stats")]
+          ("r101 c4 3x3 b2 stats", 2, 24, 78, 256, 256, "stats"), ("r101 c3 3x3 b2 stats", 2, 47, 156, 128, 128, "stats"),
+          ("b8 c3 3x3 stats", 8, 47, 156, 128, 128, "stats"), ("b8 c3 dgrad red", 8, 47, 156, 128, 128, "red"), ("b8 fpn p4 256->256", 8, 24, 78, 256, 256, "plain"),
+          ("b8 c4 3x3 stats", 8, 24, 78, 256, 256, "stats")]
 LAYERS = [l for l in ALL if not os.environ.get("PATCH_LAYERS") or any(t in l[0] for t in os.environ["PATCH_LAYERS"].split(","))]
 VARIANTS = [v for v in os.environ.get("PATCH_VARIANTS", "0 1:4 1:3").split()]
 
@@ -32,7 +34,8 @@ def main():
         mean, invstd = torch.randn(cout, device="cuda", generator=g), torch.rand(cout, device="cuda", generator=g) + 0.5
         out, ys = [], []
         for var in VARIANTS:
-            on, sb, lw = (var.split(":") + ["", ""])[:3]
+            on, sb, lw, bn = (var.split(":") + ["", "", ""])[:4]
+            os.environ["FRCNN_PATCH_BN"] = bn or "64"        # (128: 128 output channels per workgroup)
             os.environ["FRCNN_PATCH_LW"] = lw or "0"         # (4: dedicated loader waves)
             os.environ["FRCNN_PATCH"] = on
             os.environ["FRCNN_WRES"] = on                    # (64-channel layers: the weights-resident form)
