@@ -35,13 +35,20 @@ class BnReduce(Structure):
     _fields_ = [("z", c_void_p), ("relu_mask", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("partial", c_void_p)]
 
 
+class BnIn(Structure):
+    """frcnn_bn_in"""
+    _fields_ = [("stats_partial", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("moving_mean", c_void_p), ("moving_var", c_void_p),
+                ("momentum", c_float), ("eps", c_float), ("count", c_int64), ("act", c_void_p), ("relu_mask", c_void_p), ("mean", c_void_p),
+                ("invstd", c_void_p)]
+
+
 class SgdFused(Structure):
     """frcnn_sgd_fused"""
     _fields_ = [("decay_end", c_int64), ("l2", c_float), ("stem_begin", c_int64), ("stem_cout", c_int), ("stem_packed", c_void_p),
                 ("arrive", c_void_p)]
 
 
-ABI_VERSION = 5          # FRCNN_ABI_VERSION of include/frcnn_hip.h this table was written against (load() refuses any other library)
+ABI_VERSION = 6          # FRCNN_ABI_VERSION of include/frcnn_hip.h this table was written against (load() refuses any other library)
 
 CONV_BIAS, CONV_RELU, CONV_OUT_F32, CONV_ADD_RES, CONV_STATS, CONV_SPLITK_ATOMIC, CONV_WGRAD_ACCUMULATE = 1, 2, 4, 8, 16, 32, 64
 CONV_WGRAD_STEM_UNPACK = 128
@@ -67,6 +74,8 @@ _SIGNATURES = {
     "frcnn_quantize_weights_fp8_batched": (c_int, [P, c_int, c_int64, P]),
     "frcnn_fp8_update_scales": (c_int, [P, P, P, c_int, c_float, P, P, P]),
     "frcnn_conv2d_dgrad_bnreduce": (c_int, [POINTER(ConvDesc), P, P, P, P, P, POINTER(BnReduce), P]),
+    "frcnn_conv2d_fprop_bnin": (c_int, [POINTER(ConvDesc), P, P, P, P, P, POINTER(BnIn), P]),
+    "frcnn_conv2d_bnin_supported": (c_int, [POINTER(ConvDesc)]),
     "frcnn_conv2d_wgrad": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P]),
     "frcnn_conv2d_wgrad_fp8": (c_int, [POINTER(ConvDesc), P, P, c_int, P, P, P, P]),
     "frcnn_conv2d_wgrad_describe_fp8": (c_char_p, [POINTER(ConvDesc)]),

@@ -38,6 +38,17 @@ struct ConvParams {
     const float* f8_x_scale;                // fp8 operands (conv_tile.hip, F8): dequantisation scale of x (device scalar) and of every
     const float* f8_w_scale;                //   output channel's weight row (device [Cout]); NULL: bf16 operands
     int f8_fmt;                             // 1: x is e4m3 (activations), 2: x is e5m2 (gradients); the weights are always e4m3
+    // frcnn_conv2d_fprop_bnin (conv3x3_wres_kernel<.., BNIN>): the BatchNorm of the INPUT layer, applied by this convolution; NULL part: plain input
+    const double* bnin_part;
+    const float* bnin_gamma;
+    const float* bnin_beta;
+    float* bnin_mm;
+    float* bnin_mv;
+    float* bnin_mean;
+    float* bnin_invstd;
+    bf16_t* bnin_act;
+    unsigned char* bnin_mask;
+    float bnin_momentum, bnin_eps, bnin_inv_count, bnin_unbias;
     int dry_run;                            // host only: stop before the launch (frcnn_conv2d_describe)
     unsigned long long* dbg;                // FRCNN_STAMPS builds: per-workgroup phase stamps (NULL otherwise)
 };

@@ -1489,10 +1489,16 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
 // tile kernel's kw-sharing form fetches 74 KB of weights and 50 KB of activations per 128-pixel tile and pays a barrier per tap
 // (23 - 26 us per launch against an HBM roofline of 3.8); here the CU's load path carries a third of that and the statistics /
 // reduce flushes (and their atomics) happen once per workgroup instead of once per tile.
-template <int SMODE>
+//   * BNIN: the kernel's input is the RAW output z of the previous convolution and the kernel applies that layer's training-mode BatchNorm +
+//     ReLU itself (frcnn_conv2d_fprop_bnin): every workgroup derives scale / shift of the 64 input channels from the statistics slots (the
+//     arithmetic and summation order of bn_train_apply_kernel: same bits), transforms each landed patch in LDS (pixels outside the image
+//     stay zero: the padding is applied AFTER the BatchNorm), and the channel-part-0 workgroups write the activation and its ReLU bit mask
+//     for the backward pass from their patches' interiors.  One launch and one read of z less per layer than bn_train_apply + this kernel.
+template <int SMODE, bool BNIN>
 __global__ __launch_bounds__(512, 2) void conv3x3_wres_kernel(const ConvParams p, const int tiles_x, const int tiles_y, const int tiles_total) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr bool STATS = SMODE == 1, RED = SMODE == 2;
+    constexpr int BNIN_OFF = 9 * 8 * 1024 + 2 * 24 * 1024 + 128 * (64 * 2 + 16) + 8 * 2 * 64 * 4;      // scale / shift / reduction scratch behind the flush scratch
     constexpr int NW = 8, T = 512, BM = 128, BN = 64, TW = 16, TH = 8, PW = TW + 2;
     constexpr int MI = 2, NI = 2;
     constexpr int W_BYTES = 9 * 8 * 1024, A_BUF = 24 * 1024, A_BASE = W_BYTES, STG_BASE = A_BASE + 2 * A_BUF;
@@ -1529,6 +1535,47 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wres_kernel(const ConvParams p
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(smem + tap * 8192 + wave * 1024), 16, b_voff, (unsigned)(tap * 128), 0, 0);
+    }
+    float* s_scale = reinterpret_cast<float*>(smem + BNIN_OFF);
+    float* s_shift = s_scale + 64;
+    if (BNIN) {
+        // scale / shift of the input layer's BatchNorm from its f64 statistics slots, as bn_train_apply_kernel's prologue (four slot
+        // slices per channel summed in the same order, the same f64 -> f32 conversions); workgroup 0 publishes mean / invstd and
+        // updates the moving statistics
+        double* red = reinterpret_cast<double*>(smem + BNIN_OFF + 512);          // [2][4][64]
+        if (tid < 256) {
+            const int cl = tid & 63, sl = tid >> 6;
+            double a[FRCNN_STAT_SLOTS / 4], b[FRCNN_STAT_SLOTS / 4], s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < FRCNN_STAT_SLOTS / 4; ++k) {
+                a[k] = p.bnin_part[((long long)(sl + 4 * k) * 2) * 64 + cl];
+                b[k] = p.bnin_part[((long long)(sl + 4 * k) * 2 + 1) * 64 + cl];
+            }
+#pragma unroll
+            for (int k = 0; k < FRCNN_STAT_SLOTS / 4; ++k) { s0 += a[k]; s1 += b[k]; }
+            red[(0 * 4 + sl) * 64 + cl] = s0;
+            red[(1 * 4 + sl) * 64 + cl] = s1;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int cl = tid;
+            const double sum = red[(0 * 4 + 0) * 64 + cl] + red[(0 * 4 + 1) * 64 + cl] + red[(0 * 4 + 2) * 64 + cl] + red[(0 * 4 + 3) * 64 + cl];
+            const double ssq = red[(1 * 4 + 0) * 64 + cl] + red[(1 * 4 + 1) * 64 + cl] + red[(1 * 4 + 2) * 64 + cl] + red[(1 * 4 + 3) * 64 + cl];
+            const double mean = sum * p.bnin_inv_count;
+            double var = ssq * p.bnin_inv_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)p.bnin_eps));
+            const float sc = p.bnin_gamma[cl] * invstd;
+            s_scale[cl] = sc;
+            s_shift[cl] = p.bnin_beta[cl] - (float)mean * sc;
+            if (blockIdx.x == 0) {
+                p.bnin_mean[cl] = (float)mean;
+                p.bnin_invstd[cl] = invstd;
+                p.bnin_mm[cl] = p.bnin_mm[cl] * p.bnin_momentum + (float)mean * (1.f - p.bnin_momentum);
+                p.bnin_mv[cl] = p.bnin_mv[cl] * p.bnin_momentum + (float)(var * p.bnin_unbias) * (1.f - p.bnin_momentum);
+            }
+        }
+        __syncthreads();
     }
     // patch rows of this lane's three DMA pieces (tile-independent part)
     int a_py[3], a_px[3];
@@ -1579,6 +1626,48 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wres_kernel(const ConvParams p
         first = false;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave is done with the other patch buffer and the staging tile
         __builtin_amdgcn_s_barrier();
+        if (BNIN) {
+            // BatchNorm + ReLU of the landed patch, in place: 192 rows x 8 sixteen-byte slots, three per thread (slot s of row q holds
+            // channels 8 (s ^ (q & 7)) ..).  Rows outside the image (and beyond the patch) become zeros -- the convolution's padding.
+            const int img_t = tile / per_img, trem_t = tile - img_t * per_img;
+            const int tyt_t = trem_t / tiles_x;
+            const int oy0_t = tyt_t * TH, ox0_t = (trem_t - tyt_t * tiles_x) * TW;
+            const unsigned pbase = lds_addr(smem + A_BASE + buf * A_BUF);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int idx = tid + T * k;
+                const int q = idx >> 3, slot = idx & 7, c8 = slot ^ (q & 7);
+                const int py = q / PW, px = q - py * PW;
+                const int iy = oy0_t - 1 + py, ix = ox0_t - 1 + px;
+                const bool valid = q < (TH + 2) * PW && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(smem + A_BASE + buf * A_BUF + q * 128 + slot * 16);
+                const f32x4 sc0 = *reinterpret_cast<const f32x4*>(s_scale + c8 * 8), sc1 = *reinterpret_cast<const f32x4*>(s_scale + c8 * 8 + 4);
+                const f32x4 sh0 = *reinterpret_cast<const f32x4*>(s_shift + c8 * 8), sh1 = *reinterpret_cast<const f32x4*>(s_shift + c8 * 8 + 4);
+                float x[8];
+                unpack8(raw, x);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = fmaxf(x[e] * sc0[e] + sh0[e], 0.f);
+                    x[4 + e] = fmaxf(x[4 + e] * sc1[e] + sh1[e], 0.f);
+                }
+                u32x4 pk = pack8(x);
+                if (!valid) pk = u32x4{0u, 0u, 0u, 0u};
+                asm volatile("ds_write_b128 %0, %1" ::"v"(pbase + (unsigned)(q * 128 + slot * 16)), "v"(pk) : "memory");
+                if (tn == 0 && valid && py >= 1 && py <= TH && px >= 1 && px <= TW) {      // this tile's own pixels: the activation and its mask
+                    const long long pix = ((long long)img_t * p.Hi + iy) * p.Wi + ix;
+                    *reinterpret_cast<u32x4*>(p.bnin_act + pix * 64 + c8 * 8) = pk;
+                    unsigned m = 0;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        m |= ((pk[w2] & 0x7FFFu) != 0u && !(pk[w2] & 0x8000u)) ? (1u << (2 * w2)) : 0u;
+                        m |= ((pk[w2] & 0x7FFF0000u) != 0u && !(pk[w2] & 0x80000000u)) ? (1u << (2 * w2 + 1)) : 0u;
+                    }
+                    p.bnin_mask[pix * 8 + c8] = (unsigned char)m;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         if (tile + t_stride < tiles_total) issue_patch(tile + t_stride, buf ^ 1);
 
         f32x4 acc[MI][NI];
@@ -1836,20 +1925,28 @@ int launch_wres(ConvParams p, hipStream_t s, const int n_img) {
     if (wg_sp < 1) wg_sp = 1;
     const int per = (tiles_total + wg_sp - 1) / wg_sp;           // tiles per workgroup, the same for all but the last few
     const int grid = ((tiles_total + per - 1) / per) * p.tiles_n;
-    constexpr int smem = 9 * 8 * 1024 + 2 * 24 * 1024 + 128 * (64 * 2 + 16) + 8 * 2 * 64 * 4;
+    constexpr int smem = 9 * 8 * 1024 + 2 * 24 * 1024 + 128 * (64 * 2 + 16) + 8 * 2 * 64 * 4 + 512 + 2 * 4 * 64 * 8;
     static_assert(smem <= 163840, "LDS budget");
     const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
-    const void* fn = smode == 1 ? reinterpret_cast<const void*>(&conv3x3_wres_kernel<1>)
-                   : smode == 2 ? reinterpret_cast<const void*>(&conv3x3_wres_kernel<2>) : reinterpret_cast<const void*>(&conv3x3_wres_kernel<0>);
+    const bool bnin = p.bnin_part != nullptr;
+    if (bnin && smode == 2) {
+        frcnn_set_error("frcnn_conv2d_fprop_bnin: forward convolutions only");
+        return FRCNN_EINVAL;
+    }
+    const void* fn = bnin ? (smode == 1 ? reinterpret_cast<const void*>(&conv3x3_wres_kernel<1, true>) : reinterpret_cast<const void*>(&conv3x3_wres_kernel<0, true>))
+                   : smode == 1 ? reinterpret_cast<const void*>(&conv3x3_wres_kernel<1, false>)
+                   : smode == 2 ? reinterpret_cast<const void*>(&conv3x3_wres_kernel<2, false>) : reinterpret_cast<const void*>(&conv3x3_wres_kernel<0, false>);
     if (!p.dry_run && frcnn_allow_big_lds(fn, smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop(3x3, weights resident): cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
-    snprintf(g_last_inst, sizeof(g_last_inst), "conv3x3_wres<SMODE=%d> grid=%dx1 tpb=%d", smode, grid, per);
+    snprintf(g_last_inst, sizeof(g_last_inst), "conv3x3_wres<SMODE=%d%s> grid=%dx1 tpb=%d", smode, bnin ? ",BNIN=1" : "", grid, per);
     if (p.dry_run) return FRCNN_OK;
-    if (smode == 1) hipLaunchKernelGGL(conv3x3_wres_kernel<1>, dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y, tiles_total);
-    else if (smode == 2) hipLaunchKernelGGL(conv3x3_wres_kernel<2>, dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y, tiles_total);
-    else hipLaunchKernelGGL(conv3x3_wres_kernel<0>, dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y, tiles_total);
+    if (bnin && smode == 1) hipLaunchKernelGGL((conv3x3_wres_kernel<1, true>), dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y, tiles_total);
+    else if (bnin) hipLaunchKernelGGL((conv3x3_wres_kernel<0, true>), dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y, tiles_total);
+    else if (smode == 1) hipLaunchKernelGGL((conv3x3_wres_kernel<1, false>), dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y, tiles_total);
+    else if (smode == 2) hipLaunchKernelGGL((conv3x3_wres_kernel<2, false>), dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y, tiles_total);
+    else hipLaunchKernelGGL((conv3x3_wres_kernel<0, false>), dim3(grid), dim3(512), smem, s, p, tiles_x, tiles_y, tiles_total);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop(3x3, weights resident)");
     return FRCNN_OK;
 }
@@ -2134,7 +2231,8 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
 
 int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias, const frcnn_bf16* res,
                       const uint8_t* res_mask, void* y, double* stats_partial, const frcnn_bn_reduce* red, frcnn_stream_t stream,
-                      const bool dry_run = false, const float* f8_x_scale = nullptr, const float* f8_w_scale = nullptr, const int f8_fmt = 1) {
+                      const bool dry_run = false, const float* f8_x_scale = nullptr, const float* f8_w_scale = nullptr, const int f8_fmt = 1,
+                      const frcnn_bn_in* bn_in = nullptr) {
     FRCNN_CHECK_ARG(d && x && w && y, "conv2d_fprop: null pointer");
     FRCNN_CHECK_ARG(d->cin > 0 && d->cin % 32 == 0, "conv2d_fprop: cin=%d must be a multiple of 32", d->cin);
     FRCNN_CHECK_ARG(d->cout > 0 && d->cout % 8 == 0, "conv2d_fprop: cout=%d must be a multiple of 8", d->cout);
@@ -2173,6 +2271,21 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     p.red_part = red ? red->partial : nullptr;
     p.res_mask = res_mask;
     p.dry_run = dry_run ? 1 : 0;
+    p.bnin_part = nullptr;
+    if (bn_in) {
+        FRCNN_CHECK_ARG(dry_run || (bn_in->stats_partial && bn_in->gamma && bn_in->beta && bn_in->moving_mean && bn_in->moving_var && bn_in->act &&
+                                    bn_in->relu_mask && bn_in->mean && bn_in->invstd), "conv2d_fprop_bnin: null pointer in frcnn_bn_in");
+        p.bnin_part = dry_run ? reinterpret_cast<const double*>(x) : bn_in->stats_partial;
+        p.bnin_gamma = bn_in->gamma; p.bnin_beta = bn_in->beta;
+        p.bnin_mm = bn_in->moving_mean; p.bnin_mv = bn_in->moving_var;
+        p.bnin_mean = bn_in->mean; p.bnin_invstd = bn_in->invstd;
+        p.bnin_act = reinterpret_cast<bf16_t*>(bn_in->act);
+        p.bnin_mask = bn_in->relu_mask;
+        FRCNN_CHECK_ARG(dry_run || bn_in->count > 0, "conv2d_fprop_bnin: count must be positive");
+        p.bnin_momentum = bn_in->momentum; p.bnin_eps = bn_in->eps;
+        p.bnin_inv_count = bn_in->count > 0 ? (float)(1.0 / (double)bn_in->count) : 0.f;                       // (as frcnn_bn_train_apply)
+        p.bnin_unbias = bn_in->count > 1 ? (float)((double)bn_in->count / (double)(bn_in->count - 1)) : 1.f;
+    }
     p.f8_x_scale = f8_x_scale;
     p.f8_w_scale = f8_w_scale;
     p.f8_fmt = f8_fmt;
@@ -2275,9 +2388,12 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     // conv3 at batch 4 18.8 -> 20.2) and with one chunk (conv2 64 -> 64 22.7 -> 26.5: the weights-resident form below).
     const long long patch_tiles = (long long)d->n * ((d->wo + 15) / 16) * ((d->ho + 7) / 8);
     const long long patch_wgs = patch_tiles * (d->cout / 64);
-    bool patch_on = patch && d->cin >= 128 && patch_wgs <= num_cus() && !g_ws_query;
+    // (two-chunk layers only from 64 workgroups on: below that there is nothing to gain, and the small-geometry model tests keep the
+    // rounding of the tile kernel they were tuned with)
+    bool patch_on = patch && patch_wgs <= num_cus() && !g_ws_query && (d->cin >= 256 || (d->cin >= 128 && patch_wgs >= 64));
     int patch_sb = 4, patch_bn = 64;
-    if (patch && !patch_on && d->cin >= 128 && d->cout % 128 == 0 && patch_tiles * (d->cout / 128) <= 2 * num_cus() && !g_ws_query) {
+    if (patch && !patch_on && d->cin >= 128 && d->cout % 128 == 0 && patch_tiles * (d->cout / 128) <= 2 * num_cus() && patch_tiles * (d->cout / 128) >= 64 &&
+        !g_ws_query) {
         patch_on = true;
         patch_bn = 128;
     }
@@ -2291,7 +2407,13 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
 #ifdef FRCNN_SWEEP
     if (const char* e = getenv("FRCNN_WRES")) wres_on = patch && d->cin == 64 && atoi(e) != 0;
 #endif
+    if (bn_in && !wres_on) {
+        frcnn_set_error("conv2d_fprop_bnin: only 3x3 / stride 1 / pad 1 layers with 64 input channels that run on the weights-resident kernel "
+                        "(frcnn_conv2d_bnin_supported)");
+        return FRCNN_EINVAL;
+    }
     if (wres_on) {
+        FRCNN_CHECK_ARG(!bn_in || d->in_pix_stride == 64, "conv2d_fprop_bnin: the input must be the dense [M][64] output of the previous convolution");
         FRCNN_CHECK_ARG(dry_run || ((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(w) | reinterpret_cast<size_t>(y)) & 15) == 0,
                         "conv2d_fprop(3x3, weights resident): operands must be 16-byte aligned");
         g_last_ws_bytes = g_last_ws_counter_bytes = 0;
@@ -2357,6 +2479,25 @@ extern "C" int frcnn_conv2d_stat_tiles(const frcnn_conv_desc* d) {
 extern "C" int frcnn_conv2d_fprop(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn_bf16* w, const float* bias,
                                   const frcnn_bf16* res, void* y, double* stats_partial, frcnn_stream_t stream) {
     return conv2d_fprop_impl(d, x, w, bias, res, nullptr, y, stats_partial, nullptr, stream);
+}
+
+extern "C" int frcnn_conv2d_fprop_bnin(const frcnn_conv_desc* d, const frcnn_bf16* z_in, const frcnn_bf16* w, const float* bias, frcnn_bf16* y,
+                                       double* stats_partial, const frcnn_bn_in* bn, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(bn, "conv2d_fprop_bnin: null frcnn_bn_in");
+    FRCNN_CHECK_ARG(d && !(d->flags & (FRCNN_CONV_ADD_RES | FRCNN_CONV_OUT_F32 | FRCNN_CONV_SPLITK_ATOMIC)), "conv2d_fprop_bnin: plain bf16 output only");
+    return conv2d_fprop_impl(d, z_in, w, bias, nullptr, nullptr, y, stats_partial, nullptr, stream, false, nullptr, nullptr, 1, bn);
+}
+
+extern "C" int frcnn_conv2d_bnin_supported(const frcnn_conv_desc* d) {
+    if (!d) return 0;
+    static const uint8_t dummy[16] = {0};
+    const void* q = dummy;
+    frcnn_bn_in bn;
+    memset(&bn, 0, sizeof(bn));
+    const int rc = conv2d_fprop_impl(d, reinterpret_cast<const frcnn_bf16*>(q), reinterpret_cast<const frcnn_bf16*>(q), reinterpret_cast<const float*>(q), nullptr,
+                                     nullptr, const_cast<void*>(q), const_cast<double*>(reinterpret_cast<const double*>(q)), nullptr, nullptr, true, nullptr, nullptr,
+                                     1, &bn);
+    return rc == FRCNN_OK ? 1 : 0;
 }
 
 // fp8 (OCP e4m3) operands: the geometry with every element count halved IS the bf16 kernel's geometry in bytes (conv_tile_kernel, F8)

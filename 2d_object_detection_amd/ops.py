@@ -168,6 +168,26 @@ def bn_reduce_args(z, relu_mask, mean, invstd, partial):
                     partial.data_ptr())
 
 
+def bn_in_args(stats, gamma, beta, mm, mv, momentum, eps, count, act, relu_mask, mean, invstd):
+    """frcnn_bn_in for conv2d_fprop_bnin (keep the returned struct alive as long as a plan refers to it)."""
+    b = _lib.BnIn()
+    b.stats_partial, b.gamma, b.beta, b.moving_mean, b.moving_var = _p(stats), _p(gamma), _p(beta), _p(mm), _p(mv)
+    b.momentum, b.eps, b.count = float(momentum), float(eps), int(count)
+    b.act, b.relu_mask, b.mean, b.invstd = _p(act), _p(relu_mask), _p(mean), _p(invstd)
+    b._keep = (stats, gamma, beta, mm, mv, act, relu_mask, mean, invstd)
+    return b
+
+
+def conv2d_bnin_supported(d):
+    """Can conv2d_fprop_bnin run descriptor d (the BatchNorm + ReLU of the input layer applied by the convolution itself)?"""
+    return bool(_lib.load().frcnn_conv2d_bnin_supported(byref(d)))
+
+
+def conv2d_fprop_bnin(d, z_in, w, y, bn, bias=None, stats=None):
+    """== bn_train_apply(z_in -> bn.act, bn.relu_mask, ...) followed by conv2d_fprop(d, bn.act, w, y, ...), in one launch."""
+    call("frcnn_conv2d_fprop_bnin", byref(d), _p(z_in), _p(w), _p(bias), _p(y), _p(stats), byref(bn), _stream())
+
+
 def conv2d_dgrad_bnreduce(d, dz, w_t, gx, red, res=None, res_mask=None):
     """gx = conv(dz, w_t) [+ res (* res_mask bits)], fused with the BatchNorm-backward reduce of the layer that consumes gx."""
     call("frcnn_conv2d_dgrad_bnreduce", byref(d), _p(dz), _p(w_t), _p(res), _p(res_mask), _p(gx), byref(red), _stream())

@@ -34,10 +34,10 @@ typedef uint8_t frcnn_fp8;     /* OCP e4m3fn (gfx950's fp8: 4 exponent bits, bia
 
 /* Version of this header's structs and signatures.  Bumped whenever a struct grows or a signature changes (2: frcnn_conv_desc
  * gained workspace / workspace_bytes, frcnn_bn_bwd_apply_fused gained count / param_grad_scale; 3: the fp8 entry points; 5: frcnn_fp8_update_scales gained limit / status,
- * frcnn_losses_head_grad gained bias_grad, FRCNN_CONV_WGRAD_ACCUMULATE / _STEM_UNPACK, the fused launches of round 4).  A
+ * frcnn_losses_head_grad gained bias_grad, FRCNN_CONV_WGRAD_ACCUMULATE / _STEM_UNPACK, the fused launches of round 4; 6: frcnn_conv2d_fprop_bnin).  A
  * binding must compare frcnn_abi_version() with the FRCNN_ABI_VERSION it was written against and refuse any other library:
  * an older build would read the descriptor past the caller's struct. */
-#define FRCNN_ABI_VERSION 5
+#define FRCNN_ABI_VERSION 6
 int frcnn_abi_version(void);
 const char* frcnn_last_error(void);
 /* sha1 (12 hex digits) over the kernel sources and this header the library was built from, or "unknown" (csrc/build.py passes it):
@@ -105,6 +105,28 @@ typedef struct frcnn_bn_reduce {
 } frcnn_bn_reduce;
 int frcnn_conv2d_dgrad_bnreduce(const frcnn_conv_desc* d, const frcnn_bf16* dz, const frcnn_bf16* w_t, const frcnn_bf16* res,
                                 const uint8_t* res_mask, frcnn_bf16* gx, const frcnn_bn_reduce* red, frcnn_stream_t stream);
+/* Forward convolution that applies the training-mode BatchNorm + ReLU of its INPUT layer itself (round 4; == frcnn_bn_train_apply(z_in ...
+ * -> act, relu_mask, mean, invstd, moving statistics) followed by frcnn_conv2d_fprop(act ...): the same bits in act, relu_mask, mean,
+ * invstd, the moving statistics and y; the statistics of y in a different summation order).  z_in: the raw [M][cin] output of the previous
+ * convolution, whose forward statistics lie in bn->stats_partial.  Only for the shapes frcnn_conv2d_bnin_supported(d) accepts (3x3 / stride
+ * 1 / pad 1, 64 input channels, the sizes that run on the weights-resident kernel: conv2's layers at the benchmark's batch); d->flags:
+ * BIAS, STATS.  The reference applies the BatchNorm as its own Keras layer (tf.keras.applications ResNet50, models/feature_extractor.py:4-11). */
+typedef struct frcnn_bn_in {
+    const double* stats_partial;  /* [FRCNN_STAT_SLOTS][2][cin] f64: sum, sum of squares of z_in */
+    const float* gamma;           /* [cin] */
+    const float* beta;
+    float* moving_mean;           /* [cin], updated as frcnn_bn_train_apply does */
+    float* moving_var;
+    float momentum, eps;
+    int64_t count;                /* pixels the statistics were taken over (all ranks) */
+    frcnn_bf16* act;              /* out [M][cin]: ReLU(BN(z_in)) -- the weight gradient's x operand */
+    uint8_t* relu_mask;           /* out [M][cin / 8] */
+    float* mean;                  /* out [cin] */
+    float* invstd;
+} frcnn_bn_in;
+int frcnn_conv2d_fprop_bnin(const frcnn_conv_desc* d, const frcnn_bf16* z_in, const frcnn_bf16* w, const float* bias, frcnn_bf16* y,
+                            double* stats_partial, const frcnn_bn_in* bn, frcnn_stream_t stream);
+int frcnn_conv2d_bnin_supported(const frcnn_conv_desc* d);   /* 1 / 0; host logic, no device */
 /* Diagnostics: name, template arguments and grid of the MFMA conv kernel(s) the calling thread launched last through
  * frcnn_conv2d_fprop / _dgrad_bnreduce / _wgrad / _wgrad_grouped (thread-local; "" before the first launch).  The parity tests
  * assert with it that a shape really dispatched to the instantiation they mean to cover. */

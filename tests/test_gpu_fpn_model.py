@@ -294,9 +294,16 @@ def test_backbone_gradient_injection_is_additive():
         assert float(fa.acts[n]["gin"].float().cpu()[untouched].abs().max()) == 0.0
     ga = fa.store.grad("conv3_block4_3_bn/gamma").cpu()
     gb_ = fb.store.grad("conv3_block4_3_bn/gamma").cpu()
-    assert _rel(gb_, ga) > 1e-2, "parameter gradients upstream of the injection point did not change"
-    # (the grouped weight gradients split their pixel range at this small size: float atomics, equal up to the order of the sums)
-    assert _rel(fa.store.grad("conv4_block2_1_conv/kernel"), fb.store.grad("conv4_block2_1_conv/kernel")) < 1e-5, "downstream gradients must not"
+    print("upstream change %.3g, downstream: top %.3g, four blocks below %.3g" % (
+        _rel(gb_, ga), _rel(fa.store.grad("conv4_block6_3_conv/kernel"), fb.store.grad("conv4_block6_3_conv/kernel")),
+        _rel(fa.store.grad("conv4_block2_1_conv/kernel"), fb.store.grad("conv4_block2_1_conv/kernel"))))
+    assert _rel(gb_, ga) > 5e-2, "parameter gradients upstream of the injection point did not change"
+    # Downstream of the injection point nothing may change -- up to what two runs of ONE plan differ by: the BatchNorm-backward sums are
+    # float atomics, a different arrival order flips last bits of the top layer's dz (1e-6 of its norm), and every layer below amplifies
+    # that about tenfold at this geometry (192 pixels per BatchNorm, random initialisation): tools/probes/diag_fe_repeat.py measures
+    # 2e-6 at conv4_block6_3, 4e-4 at conv4_block6_1, 7e-3 at conv4_block2_1, 1e-2 at the stem between identical runs.
+    assert _rel(fa.store.grad("conv4_block6_3_conv/kernel"), fb.store.grad("conv4_block6_3_conv/kernel")) < 1e-4, "downstream gradients must not"
+    assert _rel(fa.store.grad("conv4_block2_1_conv/kernel"), fb.store.grad("conv4_block2_1_conv/kernel")) < 5e-2, "downstream gradients must not"
 
 
 def _full_size_discrete_checks(model, cfg, gl, gb, losses, step, seed):
@@ -432,8 +439,11 @@ def test_configs4_workload_fpn_fp8_batch8_full_size():
 
 # bounds of the fp8-vs-bf16 loss difference of the FIRST step at configs[4]'s full size: 2x what MI355X measures (round 4: rpn_cls
 # 0.00064, rcnn_cls 0.0128 absolute; rpn_reg 0.178 of 3.66, rcnn_reg 11.3 of 56.7 -- sums of un-normalised box terms of an untrained
-# head): absolute for the mean classification losses, relative for the summed regression losses
-FP8_LOSS_BOUND = {"rpn_cls": 0.002, "rcnn_cls": 0.03, "rpn_reg": 0.1, "rcnn_reg": 0.4}
+# head): absolute for the mean classification losses, relative for the summed regression losses.  rcnn_cls is a mean over the RoIs that
+# the proposal NMS happened to keep: when the bf16 twin's 3x3 layers moved to the patch-resident kernels (another summation order of
+# the same products) the twin's proposals changed at near-ties and the same fp8 run measured 0.088 of 6.35 against it (rpn_cls 0.00057,
+# rpn_reg 0.19 of 3.67, rcnn_reg 8.5 of 59.5) -- its bound covers both readings with the same factor
+FP8_LOSS_BOUND = {"rpn_cls": 0.002, "rcnn_cls": 0.2, "rpn_reg": 0.1, "rcnn_reg": 0.4}
 # ... and of the relative difference between two fp8 runs of the same second step (eager vs replayed)
 FP8_RERUN_BOUND = {"rpn_cls": 1e-2, "rcnn_cls": 0.1, "rpn_reg": 0.1, "rcnn_reg": 2.0}
 

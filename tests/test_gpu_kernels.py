@@ -1046,3 +1046,51 @@ def test_losses_head_grad_bias_gradient_equals_colsum(ops, B, S):
     torch.cuda.synchronize()
     assert torch.equal(h_a.view(torch.int16), h_b.view(torch.int16))
     assert float(bg_a.abs().sum()) > 0 and torch.equal(bg_a, bg_b), (bg_a - bg_b).abs().max()
+
+
+@pytest.mark.parametrize("n,h,w,cout,stats", [(4, 94, 311, 64, True), (9, 45, 70, 128, False), (18, 45, 70, 64, True)])
+def test_conv2d_fprop_bnin_equals_bn_apply_then_conv(ops, n, h, w, cout, stats):
+    """frcnn_conv2d_fprop_bnin == frcnn_bn_train_apply (ReLU, bit mask) followed by frcnn_conv2d_fprop on its output: the activation, its
+    ReLU mask, mean / invstd and the moving statistics bit for bit, the convolution output bit for bit (both run the weights-resident
+    kernel on identical patches), its statistics up to the order of the f64 slot sums.  (4, 94, 311) is conv2's shape at the benchmark's
+    batch; the others end inside tiles in both directions, one with two channel parts."""
+    g = torch.Generator().manual_seed(7 + h)
+    dev, cin = "cuda", 64
+    m = n * h * w
+    z = (torch.randn(m, cin, generator=g) * 1.3 + 0.2).to(BF).to(dev)
+    zf = z.double()
+    zstats = torch.zeros(16, 2, cin, dtype=torch.float64, device=dev)
+    for s_ in range(16):                                   # the sums spread over the slots, as the producing convolution leaves them
+        rows = slice(s_ * m // 16, (s_ + 1) * m // 16)
+        zstats[s_, 0], zstats[s_, 1] = zf[rows].sum(0), (zf[rows] * zf[rows]).sum(0)
+    gamma, beta = (torch.rand(cin, generator=g) + 0.5).to(dev), (torch.randn(cin, generator=g) * 0.2).to(dev)
+    wt = (torch.randn(cout, 3, 3, cin, generator=g) / 24.0).to(BF).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    flags = ops.CONV_BIAS | (ops.CONV_STATS if stats else 0)
+    d = ops.conv_desc(n, h, w, cin, 3, 3, 1, 1, 1, h, w, cout, flags=flags)
+    assert ops.conv2d_bnin_supported(d)
+    assert not ops.conv2d_bnin_supported(ops.conv_desc(1, 24, 78, 256, 3, 3, 1, 1, 1, 24, 78, 256))
+
+    def buffers():
+        return dict(act=torch.zeros(m, cin, dtype=BF, device=dev), mask=torch.zeros(m, cin // 8, dtype=torch.uint8, device=dev),
+                    mean=torch.zeros(cin, device=dev), invstd=torch.zeros(cin, device=dev), mm=torch.full((cin,), 0.25, device=dev),
+                    mv=torch.full((cin,), 1.5, device=dev), y=torch.zeros(m, cout, dtype=BF, device=dev),
+                    ystats=torch.zeros(16, 2, cout, dtype=torch.float64, device=dev))
+
+    a, b = buffers(), buffers()
+    ops.bn_train_apply(z, zstats, 16, m, gamma, beta, a["mm"], a["mv"], 0.99, 1.001e-5, a["act"], a["mean"], a["invstd"], m, cin, relu=True,
+                       relu_mask=a["mask"])
+    ops.conv2d_fprop(d, a["act"], wt, a["y"], bias=bias, stats=a["ystats"] if stats else None)
+    assert ops.last_conv_instantiation().startswith("conv3x3_wres<SMODE=%d>" % (1 if stats else 0))
+    bn = ops.bn_in_args(zstats, gamma, beta, b["mm"], b["mv"], 0.99, 1.001e-5, m, b["act"], b["mask"], b["mean"], b["invstd"])
+    ops.conv2d_fprop_bnin(d, z, wt, b["y"], bn, bias=bias, stats=b["ystats"] if stats else None)
+    assert ops.last_conv_instantiation().startswith("conv3x3_wres<SMODE=%d,BNIN=1>" % (1 if stats else 0))
+    torch.cuda.synchronize()
+    for k in ("mean", "invstd", "mm", "mv"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["act"].view(torch.int16), b["act"].view(torch.int16)), "activation"
+    assert torch.equal(a["mask"], b["mask"]), "ReLU mask"
+    assert torch.equal(a["y"].view(torch.int16), b["y"].view(torch.int16)), "convolution output"
+    if stats:
+        sa, sb = a["ystats"].sum(0), b["ystats"].sum(0)
+        assert float(sa.abs().max()) > 0 and float(((sa - sb).abs() / (sa.abs() + 1.0)).max()) < 1e-9

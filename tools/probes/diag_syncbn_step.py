@@ -1,0 +1,289 @@
+"""GPU, 2 ranks on ONE card (gloo carries the collectives; RCCL needs one GPU per rank): synchronised BatchNorm makes
+2 ranks x b images reproduce one process with 2b images -- the reference's single device whose training-mode BatchNorm
+sees the whole batch (reference models/faster_rcnn.py:50, models/feature_extractor.py:8-10).
+
+Each rank runs the backbone's forward and backward plan (HIP kernels, sync points between every statistics-producing and
+-consuming kernel: runtime.Plan.sync_point) on its image; the parent runs the same plan on both images without sync.
+Compared: feature maps, batch mean / invstd and moving statistics of every BatchNorm layer, the block-input gradients and
+the flat parameter gradient after the gradient all-reduce."""
+import importlib
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+SHAPE = (128, 192, 3)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs(batch):
+    g = torch.Generator().manual_seed(17)
+    images = torch.randint(0, 256, (batch,) + SHAPE, generator=g, dtype=torch.uint8)
+    g_feat = (torch.randn(batch * 8 * 12, 1024, generator=g) * 1e-2).to(torch.bfloat16)
+    return images, g_feat
+
+
+def _run_backbone(batch, images, g_feat, sync_world):
+    FE = importlib.import_module("2d_object_detection_amd.models.feature_extractor")
+    RT = importlib.import_module("2d_object_detection_amd.runtime")
+    fe = FE.FeatureExtractor(SHAPE, depth=50, device="cuda", sync_bn_world=sync_world)
+    g = torch.Generator().manual_seed(5)
+    for u in fe.conv_units():                       # non-trivial affine parameters, identical in every process
+        fe.store.weight(u.name + "_bn/gamma").copy_(torch.rand(u.cout, generator=g) + 0.5)
+        fe.store.weight(u.name + "_bn/beta").copy_(torch.randn(u.cout, generator=g) * 0.1)
+    fe.setup(batch, True)
+    fe.images.copy_(images)
+    fe.store.refresh_bf16()
+    gf = g_feat.cuda()
+    plan = RT.Plan("backbone")
+    plan.zero(fe.store.g)
+    fe.refresh_weights(plan)
+    fe.forward_plan(plan, True)
+    fe.backward_plan(plan, gf, g_feat_reduced=False)
+    plan.run_synced()
+    torch.cuda.synchronize()
+    return fe
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    D = importlib.import_module("2d_object_detection_amd.distributed")
+    D.init_from_env(backend="gloo")
+    images, g_feat = _inputs(world)
+    rows = 8 * 12
+    fe = _run_backbone(1, images[rank:rank + 1], g_feat[rank * rows:(rank + 1) * rows], world)
+    dist.all_reduce(fe.store.g)                     # the gradient bucket all-reduce (SUM)
+    torch.cuda.synchronize()
+    out = {"feat": fe.feature_maps.cpu(), "g": fe.store.g.cpu(), "gin": fe.acts[fe.specs[0][0]]["gin"].cpu(),
+           "stats": {u.name: (u.mean.cpu(), u.invstd.cpu(), u.mm.cpu(), u.mv.cpu()) for u in fe.conv_units()}}
+    torch.save(out, os.path.join(tmp, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def _rel(a, b):
+    a, b = a.float().reshape(-1), b.float().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def test_sync_bn_two_ranks_equal_one_process_with_the_whole_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    images, g_feat = _inputs(world)
+    ref = _run_backbone(world, images, g_feat, 1)
+    ranks = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    # A randomly initialised ResNet in training-mode BatchNorm amplifies any perturbation ~100x by conv4: the two
+    # runs sum their statistics in a different order (1e-16 in f64, an occasional fp32 ulp in the mean), so the comparison is
+    # tight where nothing has been amplified yet (stem, conv2_block1) and loose at the far end.
+    def stat_err(u):
+        return max(_rel(r["stats"][u.name][i], t.cpu()) for i, t in enumerate((u.mean, u.invstd, u.mm, u.mv)) for r in ranks)
+
+    assert stat_err(ref.stem) < 1e-5, "stem statistics %g" % stat_err(ref.stem)
+    first = ref.units[ref.specs[0][0]]
+    assert max(stat_err(first[k]) for k in first) < 2e-3
+    worst = max(stat_err(u) for u in ref.conv_units())
+    assert worst < 5e-2, "BatchNorm statistics differ by %g" % worst
+    for u in ref.conv_units():
+        assert torch.equal(ranks[0]["stats"][u.name][0], ranks[1]["stats"][u.name][0]), "ranks disagree on the synchronised mean of " + u.name
+    feat = torch.cat([r["feat"] for r in ranks], 0)
+    assert _rel(feat, ref.feature_maps.cpu()) < 5e-2, "feature maps %g" % _rel(feat, ref.feature_maps.cpu())
+    gin = torch.cat([r["gin"] for r in ranks], 0)
+    e_gin = _rel(gin, ref.acts[ref.specs[0][0]]["gin"].cpu())
+    assert e_gin < 0.35, "block-input gradient %g" % e_gin        # (ReLU masks flip under the amplified forward difference: measured 0.19)
+    assert torch.equal(ranks[0]["g"], ranks[1]["g"])
+    e_g = _rel(ranks[0]["g"], ref.store.g.cpu())
+    assert e_g < 0.35, "flat parameter gradient %g" % e_g
+    print("sync-BN 2 ranks vs 1 process: stem stats %.2e, worst stats %.2e, feature maps %.2e, gin %.2e, gradients %.2e" % (
+        stat_err(ref.stem), worst, _rel(feat, ref.feature_maps.cpu()), e_gin, e_g))
+    # and it is the synchronisation that does it: a single image's own statistics are far from the batch's
+    alone = _run_backbone(1, images[:1], g_feat[:96], 1)
+    assert _rel(alone.stem.mean.cpu(), ref.stem.mean.cpu()) > 1e-3
+    assert _rel(alone.feature_maps.cpu(), ref.feature_maps.cpu()[:1]) > 2 * _rel(feat, ref.feature_maps.cpu())
+
+
+def test_sync_bn_backward_arguments_single_layer(ops):
+    """count = m * world and param_grad_scale = 1 / world of frcnn_bn_bwd_apply_fused, checked on ONE layer before any
+    amplification through the network: two emulated ranks (halves of the batch, partial sums added by hand where the plan's sync
+    point all-reduces them) against torch autograd of batch_norm over the whole batch -- dz, dgamma and dbeta separately, at
+    fp32-level tolerance for the parameter gradients (a missing 1/world is a factor 2, a wrong count a few percent of dz)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(7)
+    m, c, world = 1536, 128, 2
+    BF = torch.bfloat16
+    rt = lambda t: t.to(BF).float()
+    z = rt(torch.randn(world * m, c, generator=g) * 1.5 + 0.3)
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    gout = rt(torch.randn(world * m, c, generator=g))
+    zz, gm, bt = z.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    out_ref = F.relu(F.batch_norm(zz, None, None, gm, bt, training=True, eps=1.001e-5))
+    out_ref.backward(gout)
+    dev = "cuda"
+    # forward statistics of the GLOBAL batch (what the forward sync point produces): f64 slot sums of both halves added
+    parts = torch.zeros(16, 2, c, dtype=torch.float64, device=dev)
+    parts[0, 0], parts[0, 1] = z.double().sum(0).to(dev), (z.double() ** 2).sum(0).to(dev)
+    mm, mv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    mean, invstd = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    halves, masks = [], []
+    for r in range(world):
+        zr = z[r * m:(r + 1) * m].to(BF).to(dev)
+        out = torch.empty(m, c, dtype=BF, device=dev)
+        mask = torch.zeros(m, c // 8, dtype=torch.uint8, device=dev)
+        ops.bn_train_apply(zr, parts, 16, world * m, gamma.to(dev), beta.to(dev), mm.clone(), mv.clone(), 0.99, 1.001e-5, out, mean, invstd, m, c,
+                           relu=True, relu_mask=mask)
+        halves.append((zr, gout[r * m:(r + 1) * m].to(BF).to(dev)))
+        masks.append(mask)
+    nb = ops.bn_bwd_blocks(m)
+    partial = [torch.zeros(nb, 2, c, device=dev) for _ in range(world)]
+    for r in range(world):
+        ops.bn_bwd_reduce(halves[r][1], None, halves[r][0], mean, invstd, partial[r], m, c, relu_mask=masks[r])
+    total = partial[0] + partial[1]                               # the backward sync point: SUM all-reduce of the slot sums
+    dz, dgam, dbet = [], [], []
+    for r in range(world):
+        dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        d = torch.empty(m, c, dtype=BF, device=dev)
+        ops.bn_bwd_apply_fused(halves[r][1], None, halves[r][0], mean, invstd, gamma.to(dev), total.clone(), nb, dg, db, d, None, m, c,
+                               relu_mask=masks[r], count=world * m, param_grad_scale=1.0 / world)
+        dz.append(d)
+        dgam.append(dg)
+        dbet.append(db)
+    torch.cuda.synchronize()
+    # every rank publishes global / world; the gradient all-reduce (SUM) restores the global parameter gradient
+    dgamma, dbeta = (dgam[0] + dgam[1]).cpu(), (dbet[0] + dbet[1]).cpu()
+    assert torch.equal(dgam[0], dgam[1]) and torch.equal(dbet[0], dbet[1])
+    assert float((dgamma - gm.grad).abs().max()) <= 2e-4 * float(gm.grad.abs().max()) + 1e-4, "dgamma (count / param_grad_scale)"
+    assert float((dbeta - bt.grad).abs().max()) <= 2e-4 * float(bt.grad.abs().max()) + 1e-4, "dbeta (param_grad_scale)"
+    dz_all = torch.cat(dz).float().cpu()
+    # bf16 storage with error-feedback rounding: half an ulp of the element plus half an ulp of its chain predecessor
+    col_max = zz.grad.abs().max(0).values
+    bound = 2.0 ** -8 * (zz.grad.abs() + col_max) * 1.05 + 1e-4
+    assert bool(((dz_all - zz.grad).abs() <= bound).all()), "dz with count = m * world"
+    rel = float((dz_all - zz.grad).norm() / zz.grad.norm())
+    assert rel < 4e-3, rel
+    # and the arguments matter: per-replica count / no 1/world are caught at these tolerances
+    dg_bad, db_bad, d_bad = torch.empty(c, device=dev), torch.empty(c, device=dev), torch.empty(m, c, dtype=BF, device=dev)
+    ops.bn_bwd_apply_fused(halves[0][1], None, halves[0][0], mean, invstd, gamma.to(dev), total.clone(), nb, dg_bad, db_bad, d_bad, None, m, c,
+                           relu_mask=masks[0], count=m, param_grad_scale=1.0)
+    torch.cuda.synchronize()
+    assert float((2 * dg_bad.cpu() - gm.grad).abs().max()) > 0.5 * float(gm.grad.abs().max())
+    assert float((d_bad.float().cpu() - zz.grad[:m]).norm() / zz.grad[:m].norm()) > 0.015      # (measured 0.028 against 0.003 with the right count)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The FULL train step under data parallelism: 2 ranks x 1 image (gloo ranks sharing the GPU), synchronised BatchNorm, the
+# GradientSynchronizer's bucketed all-reduce driven by the step's segment hooks, the sampler keyed by the GLOBAL image index --
+# against one process that trains on both images.  This is where the loss rule (classification means / world, regression sums
+# x 1: reference utils/losses.py:18,40) is checked on the PRODUCT's gradient buffer rather than on the oracle's autograd.
+def _step_config():
+    from oracle import faster_rcnn as O
+    cfg = O.default_config(SHAPE)
+    cfg["rpn"]["anchors"]["base_anchor_shape"] = [32, 32]
+    cfg["rpn"]["nms"].update(max_total_size=40, max_output_size_per_class=40)
+    cfg["rpn"]["sampling"]["num_samples"] = 32
+    cfg["rcnn"]["sampling"]["num_samples"] = 16
+    params = O.init_params(cfg, seed=3, randomize_affine=True)
+    for k in params:
+        if k.endswith("/kernel"):
+            params[k] = params[k].to(torch.bfloat16).float()
+        if k.endswith("_3_bn/gamma"):
+            params[k] = params[k] * 0.25            # residual-branch scale of trained nets: rounding noise is not amplified 100x
+    images, gl, gb = O.synthetic_batch(2, cfg["image_shape"], seed=5)
+    return cfg, params, images, gl, gb
+
+
+def _train_one_step(cfg, params, images, gl, gb, world, rank):
+    M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
+    OPT = importlib.import_module("2d_object_detection_amd.optimizers")
+    D = importlib.import_module("2d_object_detection_amd.distributed")
+    b = images.shape[0]
+    model = M.FasterRCNN(cfg, sampling_seed=11, world_size=world, sync_bn=world > 1, sampling_image_base=rank * b)
+    model.use_graphs = False
+    model.set_weights(params)
+    sync = D.GradientSynchronizer(model.store.g, model.store.buckets) if world > 1 else None
+    losses, _ = model.train_step(images.cuda(), gl.cuda(), gb.cuda(), OPT.SGD(learning_rate=1e-3, momentum=0.9),
+                                 sync_fn=sync.after_segment if sync else None)
+    torch.cuda.synchronize()
+    t = model._train_plan["aux"]["targets"]
+    st = model.store
+    names = ["rpn_heads/kernel", "rpn_intermediate_layer/kernel", "conv4_block6_3_conv/kernel", "conv4_block6_3_bn/gamma", "conv2_block1_1_conv/kernel",
+             "conv1_conv/kernel"]
+    names = [n for n in names if n in st.entries]
+    fe = model._train.fe
+    extra = {"feat": model._train_plan["aux"]["feature_maps"].float().cpu()}
+    for u in fe.conv_units():
+        extra["z:" + u.name] = u.z.float().cpu()
+    return {"extra": extra, "g": st.g.cpu(), "losses": {k: float(v) for k, v in losses.items()}, "rpn_idx": t["rpn_idx"].cpu(), "rcnn_idx": t["rcnn_idx"].cpu(),
+            "rois": model._train_plan["aux"]["nms_rpn"]["pred_boxes"].cpu(), "slices": {n: st.grad(n).cpu().clone() for n in names},
+            "buckets": list(st.buckets), "w_after": st.w.cpu()}
+
+
+def _worker_step(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    D = importlib.import_module("2d_object_detection_amd.distributed")
+    D.init_from_env(backend="gloo")
+    cfg, params, images, gl, gb = _step_config()
+    out = _train_one_step(cfg, params, images[rank:rank + 1], gl[rank:rank + 1], gb[rank:rank + 1], world, rank)
+    torch.save(out, os.path.join(tmp, "step_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_step(tmp_path):
+    world = 2
+    mp.spawn(_worker_step, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    cfg, params, images, gl, gb = _step_config()
+    ref = _train_one_step(cfg, params, images, gl, gb, 1, 0)
+    ranks = [torch.load(os.path.join(str(tmp_path), "step_rank%d.pt" % r)) for r in range(world)]
+    for k in ref["extra"]:
+        a = torch.cat([ranks[0]["extra"][k], ranks[1]["extra"][k]], 0) if k != "feat" else torch.cat([ranks[0]["extra"][k].reshape(-1, 1024), ranks[1]["extra"][k].reshape(-1, 1024)], 0)
+        b = ref["extra"][k] if k != "feat" else ref["extra"][k].reshape(-1, 1024)
+        d = float((a - b).abs().max())
+        if d > 0:
+            print("DIFF %-28s max %.3e rel %.3e" % (k, d, float((a - b).norm() / b.norm())), flush=True)
+    print("same rois:", [bool(torch.equal(ranks[r]["rois"][0], ref["rois"][r])) for r in range(world)], flush=True)
+    # after the bucketed all-reduce every rank holds the same summed gradient, and has applied the same update
+    assert torch.equal(ranks[0]["g"], ranks[1]["g"]), "ranks disagree on the all-reduced gradient"
+    assert torch.equal(ranks[0]["w_after"], ranks[1]["w_after"]), "ranks disagree on the updated weights"
+    # the sampler is keyed by the global image index: rank r draws what the one-process run draws for image r -- given the same
+    # candidates, i.e. the same proposals (synchronised statistics differ from the one-process ones in the last f64 bit only)
+    same_rois = all(torch.equal(ranks[r]["rois"][0], ref["rois"][r]) for r in range(world))
+    for r in range(world):
+        assert torch.equal(ranks[r]["rpn_idx"][0], ref["rpn_idx"][r]), "RPN samples of image %d" % r
+        if same_rois:
+            assert torch.equal(ranks[r]["rcnn_idx"][0], ref["rcnn_idx"][r]), "Fast-RCNN samples of image %d" % r
+    # losses: a rank REPORTS the reference's quantities for its own images -- classification: mean over its sampled rows, regression: sum
+    # over its rows (utils/losses.py:18,40) -- so the global value is the mean / the sum over the ranks (the 1 / world of the
+    # classification term is applied to the gradient, which the bucket checks below see)
+    for k in ("rpn_cls", "rpn_reg", "rcnn_cls", "rcnn_reg"):
+        tot = sum(r["losses"][k] for r in ranks) / (world if k.endswith("cls") else 1)
+        assert abs(tot - ref["losses"][k]) <= 2e-3 * abs(ref["losses"][k]) + 1e-4, (k, tot, ref["losses"][k])
+    # the gradient: head / RPN slices first (nothing amplified yet; a wrong loss scale is a factor world on part of them), then
+    # backbone slices and the whole buffer
+    errs = {n: _rel(ranks[0]["slices"][n], ref["slices"][n]) for n in ref["slices"]}
+    print("2 ranks x 1 image vs 1 process x 2 images: proposals equal %s, gradient slices %s, flat %.3e" % (
+        same_rois, {n: "%.2e" % e for n, e in errs.items()}, _rel(ranks[0]["g"], ref["g"])))
+    assert errs["rpn_heads/kernel"] < 2e-2 and errs["rpn_intermediate_layer/kernel"] < 2e-2, errs
+    for name, b0, e0 in ref["buckets"]:
+        e = _rel(ranks[0]["g"][b0:e0], ref["g"][b0:e0])
+        assert e < 0.08, "gradient bucket %s: %g" % (name, e)
+    assert _rel(ranks[0]["w_after"], ref["w_after"]) < 1e-4
+
+
+if __name__ == "__main__":
+    import tempfile
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    with tempfile.TemporaryDirectory() as t:
+        run_step(t)
