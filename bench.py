@@ -96,7 +96,7 @@ def _tensor_bytes(args, kwargs, skip=()):
 
 def classify(ops, fn, args, kwargs):
     """(family name, algorithmic FLOP, algorithmic bytes) of one plan launch."""
-    if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce:
+    if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce or fn is ops.conv2d_fprop_bnin:      # (bnin: + the input layer's BatchNorm, not counted)
         return FAM_CONV, conv_flops(args[0], *_true_dims(args[0])), 0.0
     if fn is ops.conv2d_fprop_fp8 or fn is ops.conv2d_dgrad_fp8:
         return FAM_CONV_F8, conv_flops(args[0], *_true_dims(args[0])), 0.0
@@ -202,8 +202,8 @@ def profile_kernels(model, built, steps=3):
                     byts = 1.0 * (m * d.cin + d.cout * d.kh * d.kw * d.cin) + 2.0 * m * d.cout
                 roof = max(fl / pk, byts / 8e12) * 1e6
                 inst = ""
-                if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce:
-                    inst = ops.conv2d_describe(d, fn is ops.conv2d_dgrad_bnreduce)
+                if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce or fn is ops.conv2d_fprop_bnin:
+                    inst = ops.conv2d_describe(d, fn is ops.conv2d_dgrad_bnreduce) + (" +bnin" if fn is ops.conv2d_fprop_bnin else "")
                 if fn is ops.conv2d_fprop_fp8:
                     inst = ops.conv2d_describe_fp8(d)
                 if fn is ops.conv2d_dgrad_fp8:
