@@ -53,6 +53,15 @@ class EventFileWriter:
     def scalar(self, tag, value, step):
         self._write(_event(time.time(), step=step, tag=tag, value=value))
 
+    def image(self, tag, png_bytes, height, width, step):
+        """tf.summary.image(tag, one RGB image) as TensorBoard stores it: Summary.Value{1: tag, 4: Image{1: height, 2: width, 3: colorspace
+        (3 = RGB), 4: encoded_image_string}} (reference train_faster_rcnn.py:180,194)."""
+        img = (_enc_varint((1 << 3) | 0) + _enc_varint(int(height)) + _enc_varint((2 << 3) | 0) + _enc_varint(int(width)) +
+               _enc_varint((3 << 3) | 0) + _enc_varint(3) + _ld(4, bytes(png_bytes)))
+        val = _ld(1, tag.encode()) + _ld(4, img)
+        msg = _enc_varint((1 << 3) | 1) + struct.pack("<d", float(time.time())) + _enc_varint((2 << 3) | 0) + _enc_varint(int(step)) + _ld(5, _ld(1, val))
+        self._write(msg)
+
     def close(self):
         if self.fh:
             self.fh.close()
@@ -82,4 +91,40 @@ def read_scalars(path, verify=True):
                     simple = struct.unpack("<f", bytes(x))[0] if not isinstance(x, float) else x
             if tag is not None and simple is not None:
                 out.append((int(step), tag, float(simple)))
+    return out
+
+
+def read_images(path, verify=True):
+    """[(step, tag, height, width, png bytes)] of the image summaries of an event file."""
+    out = []
+    for rec in read_records(path, verify=verify):
+        step, summary = 0, None
+        for field, wire, v in _fields(rec):
+            if field == 2 and wire == 0:
+                step = v
+            elif field == 5 and wire == 2:
+                summary = v
+        if summary is None:
+            continue
+        for field, wire, val in _fields(summary):
+            if field != 1 or wire != 2:
+                continue
+            tag, img = None, None
+            for f2, w2, x in _fields(val):
+                if f2 == 1 and w2 == 2:
+                    tag = bytes(x).decode()
+                elif f2 == 4 and w2 == 2:
+                    img = x
+            if tag is None or img is None:
+                continue
+            h = w = 0
+            png = b""
+            for f3, w3, y in _fields(img):
+                if f3 == 1 and w3 == 0:
+                    h = y
+                elif f3 == 2 and w3 == 0:
+                    w = y
+                elif f3 == 4 and w3 == 2:
+                    png = bytes(y)
+            out.append((int(step), tag, int(h), int(w), png))
     return out

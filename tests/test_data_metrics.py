@@ -311,3 +311,59 @@ def test_tensorboard_event_file_round_trip(tmp_path):
     files = sorted(os.listdir(tmp_path / "valid"))
     assert files[0].startswith("events.out.tfevents.") and files[1] == "scalars.jsonl"
     assert EV.read_scalars(str(tmp_path / "valid" / files[0])) == [(7, "AP/Car", 0.5)]
+
+
+def test_image_summaries_of_the_driver(tmp_path):
+    """utils/images.py (reference utils/images.py:11-105) and the image summaries of the validation pass (train_faster_rcnn.py:169-195):
+    the seaborn "hls" palette restated from its definition (known first colour), boxes land where their relative coordinates say,
+    Summary.Value{tag, Image{height, width, colorspace 3, png}} records by hand and through the driver's helper."""
+    import io
+    import struct
+    from PIL import Image
+    IM = importlib.import_module("2d_object_detection_amd.utils.images")
+    EV = importlib.import_module("2d_object_detection_amd.data.tfevents")
+    pal = IM.hls_palette(7)
+    assert len(pal) == 7 and pal[0] == (219, 94, 86) and len(set(pal)) == 7          # seaborn: (0.86, 0.3712, 0.34) for hue 0.01
+    img = Image.new("RGB", (200, 100), (0, 0, 0))
+    IM.draw_box_on_image(img, [0.25, 0.5, 0.75, 0.9], relative=True, color=(255, 0, 0), thickness=2)
+    px = img.load()
+    assert px[100, 50] == (255, 0, 0) and px[50, 70] == (255, 0, 0) and px[150, 70] == (255, 0, 0) and px[100, 90] == (255, 0, 0)   # four sides
+    assert px[100, 70] == (0, 0, 0) and px[10, 10] == (0, 0, 0)                     # inside and outside stay untouched
+    img2 = Image.new("RGB", (200, 100), (0, 0, 0))
+    IM.draw_predictions_on_image(img2, [[50, 50, 150, 90]], scores=[0.87], class_indices=[3], class_names=["a", "b", "c", "d"], relative=False)
+    assert img2.load()[100, 50] == IM.hls_palette(4)[3]                             # class colour
+    assert any(img2.load()[x, 44] == IM.hls_palette(4)[3] for x in range(50, 80))   # the label's filled rectangle above the box
+    png = IM.to_png(img2)
+    assert png[:8] == b"\x89PNG\r\n\x1a\n" and Image.open(io.BytesIO(png)).size == (200, 100)
+    w = EV.EventFileWriter(str(tmp_path / "valid"))
+    w.image("Ground-truth", png, 100, 200, 0)
+    w.scalar("x", 1.0, 2)
+    w.close()
+    (step, tag, h, wd, back), = EV.read_images(w.path)
+    assert (step, tag, h, wd) == (0, "Ground-truth", 100, 200) and back == png
+    assert EV.read_scalars(w.path) == [(2, "x", 1.0)]
+    # by hand: Event{09 wall_time, 10 step, 2a Summary{0a Value{0a tag, 22 Image{08 h, 10 w, 18 03, 22 png}}}}
+    TFR = importlib.import_module("2d_object_detection_amd.data.tfrecord")
+    rec = bytes(list(TFR.read_records(w.path, verify=True))[1])
+    assert rec[0] == 0x09 and rec[9:11] == b"\x10\x00" and rec[11] == 0x2a
+    assert b"\x0a\x0cGround-truth\x22" in rec and b"\x08\x64\x10\xc8\x01\x18\x03\x22" in rec
+    # the driver's helper: ground truth at epoch 1 (padding rows skipped), detections above 0.5 every fifth epoch
+    drv = importlib.import_module("train_faster_rcnn")
+    sw = drv.ScalarWriter(str(tmp_path / "drv"))
+    images = torch.zeros(2, 60, 80, 3, dtype=torch.uint8)
+    gt_boxes = torch.zeros(2, 100, 4)
+    gt_boxes[0, 0] = torch.tensor([0.1, 0.2, 0.6, 0.8])
+    gt_classes = torch.zeros(2, 100, 8)
+    gt_classes[0, 0, 3] = 1.0                                                       # class id 2 + 1
+    preds = {"rcnn_boxes": torch.tensor([[[0.2, 0.2, 0.5, 0.5], [0.0, 0.0, 1.0, 1.0]]] * 2), "rcnn_scores": torch.tensor([[0.9, 0.3]] * 2),
+             "rcnn_classes": torch.tensor([[1, 2]] * 2)}
+    drv._image_summaries(sw, 1, 100, images, gt_classes, gt_boxes, preds)
+    drv._image_summaries(sw, 2, 200, images, gt_classes, gt_boxes, preds)            # neither epoch 1 nor a multiple of 5: nothing
+    drv._image_summaries(sw, 5, 500, images, gt_classes, gt_boxes, preds)
+    sw.events.close()
+    got = EV.read_images(sw.events.path)
+    assert [(s, t, h, w_) for s, t, h, w_, _ in got] == [(0, "Ground-truth", 60, 80), (500, "Predictions/pred@score=.50", 60, 80)]
+    gt_img = Image.open(io.BytesIO(got[0][4])).convert("RGB")
+    assert gt_img.load()[8, 30] == IM.hls_palette(7)[2]                             # left side of the ground-truth box in its class colour
+    pr_img = Image.open(io.BytesIO(got[1][4])).convert("RGB")
+    assert pr_img.load()[16, 20] == IM.hls_palette(7)[1] and pr_img.load()[0, 30] == (0, 0, 0)   # the 0.9 box drawn, the 0.3 box not

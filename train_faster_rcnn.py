@@ -96,6 +96,39 @@ class ScalarWriter:
             self.fh.flush()
             self.events.scalar(tag, value, step)
 
+    def image(self, tag, pil_image, step):
+        """tf.summary.image(tag, to_tensor(pil_image), step) (reference train_faster_rcnn.py:180,194): the PNG goes into the event file."""
+        if self.events:
+            images = importlib.import_module(PKG + ".utils.images")
+            self.events.image(tag, images.to_png(pil_image), pil_image.size[1], pil_image.size[0], step)
+
+
+def _image_summaries(writer, epoch, step, images, gt_classes, gt_boxes, preds):
+    """The first validation image with its ground-truth boxes (once, at epoch 1) and with the detections of score > 0.5 (every
+    5 epochs), as the reference logs them (train_faster_rcnn.py:169-195)."""
+    if not writer.events or not (epoch == 1 or epoch % 5 == 0):
+        return
+    from PIL import Image
+    draw = importlib.import_module(PKG + ".utils.images")
+    names = importlib.import_module(PKG + ".data.kitti_classes").class_names
+    frame = images[0].detach().to("cpu", torch.uint8).numpy()
+    if epoch == 1:
+        img = Image.fromarray(frame)
+        cls = gt_classes[0].detach().float().cpu()
+        real = cls.sum(-1) > 0                    # (padding rows are all-zero one-hot vectors: data/input_pipeline.py)
+        draw.draw_predictions_on_image(img, gt_boxes[0].detach().float().cpu()[real].tolist(), class_indices=cls[:, 1:].argmax(-1)[real].tolist(),
+                                       class_names=names, relative=True)
+        writer.image("Ground-truth", img, 0)
+        img.close()
+    if epoch % 5 == 0:
+        img = Image.fromarray(frame)
+        sc = preds["rcnn_scores"][0].detach().float().cpu()
+        keep = sc > 0.5
+        draw.draw_predictions_on_image(img, preds["rcnn_boxes"][0].detach().float().cpu()[keep].tolist(), scores=sc[keep].tolist(),
+                                       class_indices=preds["rcnn_classes"][0].detach().cpu().long()[keep].tolist(), class_names=names, relative=True)
+        writer.image("Predictions/pred@score=.50", img, step)
+        img.close()
+
 
 class CheckpointManager:
     """tf.train.CheckpointManager(max_to_keep=1) over {step, optimizer, model} (train_faster_rcnn.py:114-125)."""
@@ -235,8 +268,10 @@ def main(argv=None):
             if world > 1:
                 torch.distributed.barrier()
             if chief:
-                for vimages, vclasses, vboxes in dataset_valid():
+                for test_step, (vimages, vclasses, vboxes) in enumerate(dataset_valid()):
                     vlosses, vpreds = model.test_step(vimages, vclasses, vboxes)
+                    if test_step == 0:
+                        _image_summaries(valid_writer, epoch, step, vimages, vclasses, vboxes, vpreds)
                     valid_cls.update_state(vlosses["rcnn_cls"])
                     valid_reg.update_state(vlosses["rcnn_reg"])
                     valid_map.update_state(vboxes, vclasses, vpreds["rcnn_boxes"], vpreds["rcnn_scores"], vpreds["rcnn_classes"])
