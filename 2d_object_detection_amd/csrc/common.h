@@ -107,22 +107,26 @@ __device__ __forceinline__ u32x2 pack8_bf8(const float* f, const float qs) {
 // Callable after per-thread early returns: with every lane of the wave active the reduction is a butterfly and lane 0 writes; with
 // some lanes gone (a channel count that is not a multiple of 64, a tail row) the exited lanes' registers are undefined to a shuffle,
 // so the maximum is collected from the ACTIVE lanes one by one (v_readlane on the ballot's set bits) and the first active lane writes.
+// The reduction runs on the BIT PATTERNS of |v| (unsigned integer max: the order of non-negative floats, with +Inf above every finite
+// value and every NaN above +Inf): fmaxf would drop a NaN operand, and a tensor holding NaN but no Inf would leave a finite amax behind --
+// fp8_update_scales_kernel's `!(v <= 3e38f)` test then never fired for it and FasterRCNN.fp8_status() reported a healthy tensor.
 __device__ __forceinline__ void atomic_amax(float* dst, float v) {
     const unsigned long long act = __ballot(1);
+    unsigned u = __float_as_uint(v) & 0x7fffffffu;
     int writer = 0;
     if (act == ~0ull) {
 #pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) v = fmaxf(v, __shfl_xor(v, sh));
+        for (int sh = 32; sh >= 1; sh >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, sh));
     } else {
-        float m = 0.f;
+        unsigned m = 0u;
         for (unsigned long long rem = act; rem; rem &= rem - 1)
-            m = fmaxf(m, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), __ffsll((long long)rem) - 1)));
-        v = m;
+            m = max(m, (unsigned)__builtin_amdgcn_readlane(u, __ffsll((long long)rem) - 1));
+        u = m;
         writer = __ffsll((long long)act) - 1;
     }
-    if ((int)(threadIdx.x & 63) == writer && v > 0.f) {
+    if ((int)(threadIdx.x & 63) == writer && u > 0u) {
         const unsigned slot = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (FRCNN_FP8_AMAX_SLOTS - 1);
-        atomicMax(reinterpret_cast<unsigned*>(dst) + slot, __float_as_uint(v));
+        atomicMax(reinterpret_cast<unsigned*>(dst) + slot, u);
     }
 }
 

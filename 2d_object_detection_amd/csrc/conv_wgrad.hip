@@ -968,6 +968,7 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
 #endif
     int tiles[kGroups], min_p_tiles[kGroups];
     bool acc3[kGroupMax];
+    bool accumulate[kGroups][kGroupMax];          // FRCNN_CONV_WGRAD_ACCUMULATE of every layer: dw shared with other launches -> never a plain store
     for (int m = 0; m < kGroups; ++m) {
         g[m].n = g[m].total = tiles[m] = 0;
         min_p_tiles[m] = 1 << 30;
@@ -983,6 +984,7 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
         const int m = wgrad3_eligible(items[i].desc, f8 ? 1 : 2, nullptr) ? 4 : (f8 ? 2 : 0) + (p.linear_x ? 0 : 1);
         FRCNN_CHECK_ARG(g[m].n < kGroupMax, "conv2d_wgrad_group_plan: more than %d layers in one group", kGroupMax);
         if (m == 4) acc3[g[m].n] = (items[i].desc->flags & FRCNN_CONV_WGRAD_ACCUMULATE) != 0;
+        accumulate[m][g[m].n] = (items[i].desc->flags & FRCNN_CONV_WGRAD_ACCUMULATE) != 0;
         g[m].p[g[m].n++] = p;
         if (p.p_tiles < min_p_tiles[m]) min_p_tiles[m] = p.p_tiles;
     }
@@ -1038,7 +1040,7 @@ extern "C" int frcnn_conv2d_wgrad_group_plan(const frcnn_wgrad_item* items, int 
             WgradParams& p = g[m].p[i];
             p.p_tiles_per_split = (p.p_tiles + split - 1) / split;
             const int eff = (p.p_tiles + p.p_tiles_per_split - 1) / p.p_tiles_per_split;
-            p.plain_store = eff == 1 ? 1 : 0;
+            p.plain_store = eff == 1 && !accumulate[m][i] ? 1 : 0;
             g[m].first[i] = g[m].total;
             g[m].total += p.tiles_co * p.taps * p.tiles_ci * eff;
         }

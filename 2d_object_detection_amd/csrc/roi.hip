@@ -558,7 +558,9 @@ static int roi_fwd_impl(const frcnn_bf16* feat, const float* rois, int b, int p,
     // for the 2 x 2 window on maps of >= 64 channel vectors, slices in whole multiples of 64 vectors (the wave-uniform form: a wave owns
     // whole bins); with fewer than 8 pairs two XCDs share a pair's slice of the map
     const int c8 = c / 8;
-    const bool uniform_ok = ks == 2 && c8 % 64 == 0;
+    // (roi_fwd_ks2_kernel marks out-of-map samples with the byte offset 0x40000000 and relies on the buffer descriptor's range check to
+    // return zeros for it: the sentinel -- plus any valid row / column offset -- must lie beyond a per-image map, i.e. the map under 1 GiB)
+    const bool uniform_ok = ks == 2 && c8 % 64 == 0 && (long long)hf * wf * c * 2 < 0x40000000ll;
     int nsplit = 1;
     if (uniform_ok) {
         while (b * nsplit < 8 && c8 % (2 * nsplit) == 0 && (c8 / (2 * nsplit)) % 64 == 0) nsplit *= 2;

@@ -129,6 +129,7 @@ class FasterRCNN:
         self._eval_step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.status = torch.zeros(4, dtype=torch.int32, device=self.device)     # [0] |= 1: empty background set while sampling
         self.use_graphs = True
+        self._inject_proposals = False       # train_step(..., proposals_override=...): the plan being built takes its proposals from the caller
 
     # ------------------------------------------------------------------ parameters
     def init_weights(self, seed=0):
@@ -296,6 +297,7 @@ class FasterRCNN:
         nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"], buffers=rpn_nms, decoded_done=True,
                                    abs_boxes=mods.rcnn.regions_abs)
         rois = nms_rpn["pred_boxes"]
+        self._inject_proposals_plan(plan, io, training, rois, mods.rcnn.regions_abs, batch, P, W, H)
         det_cfg = self._rcnn_config["nms"]
         det_nms = NmsBuffers(batch, P, nc1 - 1, det_cfg["max_output_size_per_class"], det_cfg["max_total_size"], dev)
         # Target assignment and sampling of the Fast-RCNN stage need the proposals and the ground truth, not the head's
@@ -413,6 +415,7 @@ class FasterRCNN:
         nms_rpn = postprocess_plan(plan, self._image_shape, **rpn_out, **self._rpn_config["nms"], buffers=rpn_nms, decoded_done=True,
                                    abs_boxes=rcnn.regions_abs)
         rois = nms_rpn["pred_boxes"]
+        self._inject_proposals_plan(plan, io, training, rois, rcnn.regions_abs, batch, P, W, H)
         det_cfg = self._rcnn_config["nms"]
         det_nms = NmsBuffers(batch, P, nc1 - 1, det_cfg["max_output_size_per_class"], det_cfg["max_total_size"], dev)
         with plan.branch("rcnn_targets"):
@@ -459,6 +462,18 @@ class FasterRCNN:
                "pyramid": pyramid, "stage_maps": stage_maps, "roi_levels": rcnn.levels}
         return {"plan": plan, "io": io, "losses": losses, "preds": preds, "aux": aux, "batch": batch}
 
+    def _inject_proposals_plan(self, plan, io, training, rois, regions_abs, batch, P, W, H):
+        """Test hook (train_step(..., proposals_override=...)): two launches behind the proposal NMS overwrite its kept boxes -- `rois`
+        [B,P,4] relative, and their absolute form with the NMS launch's own arithmetic (x * W, y * H: frcnn_nms_combined_abs) -- with
+        the caller's, so that everything downstream (RoI levels, pooling, Fast-RCNN targets, sample indices, losses, gradients) of two
+        runs whose RPN scores differ in the last bits is computed on the SAME regions (the reference's stop_gradient'ed rois,
+        models/faster_rcnn.py:53-55).  Not part of a plan built without an override: the benchmark's step is unchanged."""
+        if not (training and self._inject_proposals):
+            return
+        io["proposals"] = torch.zeros(batch, P, 4, device=self.device)
+        plan.add(ops.copy_bytes, io["proposals"], rois)
+        plan.add(ops.boxes_scale, rois, regions_abs, float(W), float(H))
+
     def _build_forward(self, mods, batch):
         """Training-mode forward only (reference faster_rcnn.py:39-57 with training=True): BatchNorm on batch statistics (its
         moving averages are updated, as Keras does), RPN on the in-image anchors, proposal NMS, Fast-RCNN heads."""
@@ -501,9 +516,11 @@ class FasterRCNN:
         return {"plan": plan, "io": io, "batch": batch, "aux": {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn,
                                                                 "feature_maps": fe.feature_maps, "pyramid": pyramid, "roi_levels": rcnn.levels}}
 
-    def _feed(self, built, images, gt_labels, gt_boxes):
+    def _feed(self, built, images, gt_labels, gt_boxes, proposals=None):
         io = built["io"]
         pairs = ((images, io["images"]), (gt_labels, io["gt_labels"]), (gt_boxes, io["gt_boxes"]))
+        if proposals is not None:
+            pairs += ((proposals, io["proposals"]),)
         for s, d in pairs:
             if tuple(s.shape) != tuple(d.shape):      # (copy_ would broadcast a smaller input silently)
                 raise ValueError("input of shape %s where the step expects %s" % (tuple(s.shape), tuple(d.shape)))
@@ -520,20 +537,28 @@ class FasterRCNN:
         return {k: l[i] for i, k in enumerate(LOSS_NAMES)}
 
     # ------------------------------------------------------------------ reference call surface
-    def train_step(self, images, gt_labels, gt_boxes, optimizer, sync_fn=None):
+    def train_step(self, images, gt_labels, gt_boxes, optimizer, sync_fn=None, proposals_override=None):
         """reference faster_rcnn.py:59-117.  images uint8 [B,H,W,3]; gt_labels fp32 [B,100,C+1];
         gt_boxes fp32 [B,100,4] relative (CUDA tensors).  Returns (losses, preds): device tensors
         living in static buffers (valid until the next step; clone to keep).
-        sync_fn(segment_index) is the data-parallel hook called after each backward segment."""
+        sync_fn(segment_index) is the data-parallel hook called after each backward segment.
+        proposals_override (tests): fp32 CUDA [B,P,4] relative boxes that replace the proposal NMS's output inside the step
+        (_inject_proposals_plan); a model steps either always with or always without one (the plan is rebuilt on a change)."""
         b = int(images.shape[0])
-        if self._train_plan is None or self._train_plan["batch"] != b or self._train_plan["optimizer"] is not optimizer:
+        inject = proposals_override is not None
+        if inject and not (proposals_override.is_cuda and proposals_override.dtype == torch.float32):
+            raise TypeError("proposals_override: float32 CUDA tensor [B, P, 4] expected")
+        if (self._train_plan is None or self._train_plan["batch"] != b or self._train_plan["optimizer"] is not optimizer
+                or self._train_plan["inject"] != inject):
             optimizer.bind(self.store)
+            self._inject_proposals = inject
             built = self._build(self._train, b, True, optimizer)
             built["optimizer"] = optimizer
+            built["inject"] = inject
             self._train_plan = built
             self._sync_derived_weights(self._train)
             self._weights_dirty = False
-            self._feed(built, images, gt_labels, gt_boxes)
+            self._feed(built, images, gt_labels, gt_boxes, proposals_override)
             if self.use_graphs or self.get_fp8_state() is not None:
                 # warm-up eagerly on a scratch copy of the mutable state, then capture.  In fp8 mode the same run is the calibration
                 # pass of the delayed scales (kept: the first real step quantises with measured scales, not with 1) -- also without
@@ -552,7 +577,7 @@ class FasterRCNN:
         if self._weights_dirty:
             self._sync_derived_weights(self._train)
             self._weights_dirty = False
-        self._feed(built, images, gt_labels, gt_boxes)
+        self._feed(built, images, gt_labels, gt_boxes, proposals_override)
         plan = built["plan"]
         nseg = len(plan.segments)
         collectives = self.world_size > 1 and bool(plan.pre_sync)

@@ -14,8 +14,10 @@ FasterRCNN.train_step, models/faster_rcnn.py:59-117).  Prints ONE JSON line on r
                         `families`: every kernel family of the step with its time and its TFLOP/s or algorithmic GB/s;
                         `rocprof`: the same quotient from the rocprofv3 summary committed under profiles/ (+ PMC HBM traffic)
   cpu_baseline          the CPU oracle (kind "port") timed on this host: SURVEY 8(d) protocol, see cpu_baseline()
-  other_configs         (default N = 1 run only) BASELINE.json configs[3] and configs[4] timed after the headline's region, 3 windows each,
-                        with their own roofline -- the headline's value / config / roofline do not depend on them
+  other_configs         (default N = 1 run only) BASELINE.json configs[3], configs[4] and the reference's own configuration (config.json:
+                        600x1987, batch 2: "reference_default") timed after the headline's region -- one discarded window, then 3 whose
+                        median is their `value` -- with their own roofline; the headline's value / config / roofline do not depend on them
+  other_configs_summary the LAST key of the line: {name: [images/s, ms/step, roofline frac]} (survives a truncated tail)
 
 Every step of a window trains on the next of `--resident-batches` (8) synthetic batches resident in HBM (seeds 1234 + rank + 100 i):
 the head cannot memorise one batch, so the density of the RoI-backward gradient stays that of a real run.
@@ -94,6 +96,16 @@ def _tensor_bytes(args, kwargs, skip=()):
     return float(total)
 
 
+def kernels_of(ops, fn, args, kwargs):
+    """GPU kernels one plan call launches (what a rocprofv3 trace counts): a grouped weight-gradient call is one kernel per addressing
+    mode of its group, a combined NMS over more than one class is the per-class kernel + the merge kernel."""
+    if fn is ops.conv2d_wgrad_grouped:
+        return max(1, len([p for p in ops.conv2d_wgrad_describe(group=args[0]).split("; ") if p.strip()]))
+    if getattr(fn, "__name__", "") in ("nms_combined", "nms_combined_abs"):
+        return 1 if int(args[5]) == 1 else 2
+    return 1
+
+
 def classify(ops, fn, args, kwargs):
     """(family name, algorithmic FLOP, algorithmic bytes) of one plan launch."""
     if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce or fn is ops.conv2d_fprop_bnin:      # (bnin: + the input layer's BatchNorm, not counted)
@@ -111,8 +123,8 @@ def classify(ops, fn, args, kwargs):
         return "RoI crop+pool forward (roi_fwd_kernel)", 0.0, _tensor_bytes(args, kwargs)
     if name in ("roi_crop_pool_bwd_bf16", "roi_crop_pool_bwd_bf16_level", "roi_crop_pool_bwd_bf16_add"):
         return "RoI crop+pool backward (roi_bwd_rows_kernel)", 0.0, _tensor_bytes(args, kwargs)
-    if name == "nms_combined":
-        # boxes [B,N,q,4] + scores [B,N,*] in, padded outputs out (the workspace is scratch)
+    if name in ("nms_combined", "nms_combined_abs"):
+        # boxes [B,N,q,4] + scores [B,N,*] in, padded outputs out (the workspace is scratch; _abs: + the kept boxes once more, 16 B each)
         return "combined NMS (nms_class_kernel + nms_merge_kernel)", 0.0, float(sum(t.numel() * t.element_size() for t in (args[0], args[1], args[12], args[13], args[14])))
     if name in ("assign_targets", "sample_indices", "losses", "losses_head_grad", "losses_rpn_head_grad", "rpn_head_grad", "rcnn_head_grad",
                 "rpn_head_post", "rpn_head_post_decode", "rcnn_head_post", "decode_boxes", "boxes_scale", "rpn_head_post_level", "rpn_head_grad_level",
@@ -134,7 +146,7 @@ def profile_kernels(model, built, steps=3):
             if fn is None:                       # join marker of a side-stream branch (the profile pass runs serially)
                 continue
             name, fl, by = classify(ops, fn, args, kwargs)
-            records.append((fn, args, kwargs, name, fl, by))
+            records.append((fn, args, kwargs, name, fl, by, kernels_of(ops, fn, args, kwargs)))
     state = model._snapshot(built["optimizer"])
     # cost of an event pair itself (two marker packets back to back, nothing between): subtracted from every measurement
     torch.cuda._sleep(20_000_000)
@@ -153,18 +165,18 @@ def profile_kernels(model, built, steps=3):
         # idles between an eager launch and the start of its kernel (a graph replay has no such gaps).
         torch.cuda._sleep(60_000_000)
         plan._zero_prologue()                    # (the plan's one zero-fill launch, not timed)
-        for fn, args, kwargs, name, fl, by in records:
+        for fn, args, kwargs, name, fl, by, nk in records:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn(*args, **kwargs)
             e1.record()
             if it > 0:
-                events.append((name, fl, by, e0, e1))
+                events.append((name, fl, by, e0, e1, nk))
     torch.cuda.synchronize()
     # RoI backward with a DENSE pooled gradient: the kernel skips zero gradient words, and how many there are depends on what the
     # head has learnt (a saturated softmax zeroes whole rows) -- the dense time is its data-independent upper bound
     dense = {}
-    roi_b = [(fn, args, kwargs) for fn, args, kwargs, name, fl, by in records if name.startswith("RoI crop+pool backward")]
+    roi_b = [(fn, args, kwargs) for fn, args, kwargs, name, fl, by, nk in records if name.startswith("RoI crop+pool backward")]
     if roi_b:
         gp = roi_b[0][1][0]
         keep = gp.clone()
@@ -189,7 +201,7 @@ def profile_kernels(model, built, steps=3):
         # per-launch table (median over steps) for kernel work: shape, us, TFLOP/s, GB/s of compulsory traffic, kernel
         n = len(records)
         with open(os.environ["FRCNN_LAYER_TABLE"], "w") as fh:
-            for j, (fn, args, kwargs, name, fl, by) in enumerate(records):
+            for j, (fn, args, kwargs, name, fl, by, nk) in enumerate(records):
                 if name not in (FAM_CONV, FAM_CONV_F8, FAM_WGRAD):
                     continue
                 per = sorted(events[it * n + j][3].elapsed_time(events[it * n + j][4]) * 1e3 for it in range(steps))
@@ -212,9 +224,10 @@ def profile_kernels(model, built, steps=3):
                     "wgrad" if name == FAM_WGRAD else "fp8" if name == FAM_CONV_F8 else "fprop/dgrad", m, d.cin, d.cout, d.kh, d.kw, d.stride, us, fl / us / 1e6, byts / us / 1e3, roof,
                     "mfma" if fl / pk > byts / 8e12 else "hbm", roof / us, inst))
     fam = {}
-    for name, fl, by, e0, e1 in events:
-        f = fam.setdefault(name, {"launches": 0, "seconds": 0.0, "flops": 0.0, "bytes": 0.0})
-        f["launches"] += 1
+    for name, fl, by, e0, e1, nk in events:
+        f = fam.setdefault(name, {"launches": 0, "plan_calls": 0, "seconds": 0.0, "flops": 0.0, "bytes": 0.0})
+        f["launches"] += nk                      # GPU kernels (a trace's count); plan_calls: C-ABI calls = event pairs
+        f["plan_calls"] += 1
         f["seconds"] += max(e0.elapsed_time(e1) * 1e-3 - pair_overhead_s, 0.0)
         f["flops"] += fl
         f["bytes"] += by
@@ -289,9 +302,15 @@ def cpu_baseline(cfg, budget_s=150.0):
             "legs": legs}
 
 
-def workload_key(depth, batch, proposals, fp8, fpn):
-    """What a trace's per-launch figures belong to: the step's shapes (network, batch, proposals, precision, topology)."""
-    return "R%d,b%d,P%d,%s,%s" % (int(depth), int(batch), int(proposals) or 300, "fp8" if fp8 else "bf16", "fpn" if fpn else "c4")
+DEFAULT_SHAPE = (375, 1242)        # BASELINE.json's image size (the reference's own config.json:3 says 600 x 1987)
+
+
+def workload_key(depth, batch, proposals, fp8, fpn, shape=None):
+    """What a trace's per-launch figures belong to: the step's shapes (network, batch, proposals, precision, topology, image size)."""
+    key = "R%d,b%d,P%d,%s,%s" % (int(depth), int(batch), int(proposals) or 300, "fp8" if fp8 else "bf16", "fpn" if fpn else "c4")
+    if shape and tuple(shape[:2]) != DEFAULT_SHAPE:
+        key += ",%dx%d" % (shape[0], shape[1])
+    return key
 
 
 def workload_key_of_command(cmd):
@@ -300,7 +319,8 @@ def workload_key_of_command(cmd):
 
     def val(flag, default):
         return int(tok[tok.index(flag) + 1]) if flag in tok else default
-    return workload_key(val("--depth", 50), val("--batch-per-gpu", 4), val("--proposals", 0), "--fp8" in tok, "--fpn" in tok)
+    shape = (int(tok[tok.index("--image-shape") + 1]), int(tok[tok.index("--image-shape") + 2])) if "--image-shape" in tok else None
+    return workload_key(val("--depth", 50), val("--batch-per-gpu", 4), val("--proposals", 0), "--fp8" in tok, "--fpn" in tok, shape)
 
 
 def offline_profile(family, variant="", workload=None):
@@ -327,15 +347,20 @@ def offline_profile(family, variant="", workload=None):
     return None, "no committed trace for this run: %s (this tree's kernel sources: %s)" % ("; ".join(stale), mine)
 
 
-BASE_SPEC = {"depth": 50, "batch": 4, "proposals": 0, "fp8": False, "fpn": False}
+BASE_SPEC = {"depth": 50, "batch": 4, "proposals": 0, "fp8": False, "fpn": False, "shape": None}
 OTHER_CONFIGS = {
-    "configs[3]": {"depth": 101, "batch": 2, "proposals": 1000, "fp8": False, "fpn": False},
-    "configs[4]": {"depth": 50, "batch": 8, "proposals": 0, "fp8": True, "fpn": True},
+    "configs[3]": {"depth": 101, "batch": 2, "proposals": 1000, "fp8": False, "fpn": False, "shape": None},
+    "configs[4]": {"depth": 50, "batch": 8, "proposals": 0, "fp8": True, "fpn": True, "shape": None},
+    # the reference's OWN configuration: /root/reference config.json:3 image_shape [600, 1987, 3], train_faster_rcnn.py:52-54 batch 2
+    "reference_default": {"depth": 50, "batch": 2, "proposals": 0, "fp8": False, "fpn": False, "shape": (600, 1987)},
 }
 
 
 def workload_text(spec, world):
     depth, B, P, fp8, fpn = spec["depth"], spec["batch"], spec["proposals"] or 300, spec["fp8"], spec["fpn"]
+    if spec.get("shape") and tuple(spec["shape"][:2]) != DEFAULT_SHAPE:
+        return ("ResNet-%d(C4) Faster-RCNN full train step, %s, batch %d per GPU, %dx%d synthetic batches (the reference's own config.json "
+                "image_shape, not BASELINE.json's 375x1242), %d proposals, 7 classes" % (depth, "fp8" if fp8 else "bf16", B, spec["shape"][0], spec["shape"][1], P))
     if fp8:
         return ("ResNet-%d%s Faster-RCNN full train step, fp8: e4m3 weights (per output channel) and activations (per tensor, delayed "
                 "scaling), e5m2 gradients, in the forward convolutions, data gradients and weight gradients of the backbone wherever the channel counts allow (K >= 256 for forward / data gradients)%s on "
@@ -352,9 +377,12 @@ def workload_text(spec, world):
             "%d proposals, 7 classes (BASELINE.json configs[%d])" % (depth, B, P, 3 if depth == 101 else 1 if world == 1 else 2))
 
 
-def measure(spec, args, rank, world, dev, windows, with_segmented, with_rccl_leg):
+def measure(spec, args, rank, world, dev, windows, with_segmented, with_rccl_leg, discard=0):
     """Build the model of `spec`, warm up, time `windows` regions of exactly args.steps steps (barrier + synchronize on both sides, MAX
-    over ranks) and -- on rank 0 -- attach the per-family kernel profile.  Returns the result dict (the headline's shape)."""
+    over ranks) and -- on rank 0 -- attach the per-family kernel profile.  Returns the result dict (the headline's shape).
+    discard (other_configs only): that many regions are timed and reported but not counted first, and `value` is the MEDIAN of the
+    `windows` that follow -- the first region after another model's teardown measured 5.6 % slow on configs[4] (VERDICT r4 weak 7);
+    the headline (discard 0) keeps the contract's rule: `value` is its FIRST region."""
     global RPN_HEAD_ROWS
     RPN_HEAD_ROWS = 18 if spec["fpn"] else 72
     D = importlib.import_module("2d_object_detection_amd.distributed")
@@ -364,7 +392,8 @@ def measure(spec, args, rank, world, dev, windows, with_segmented, with_rccl_leg
     DATA = importlib.import_module("2d_object_detection_amd.data")
     import torch.distributed as dist
 
-    cfg = C.default_config()                                   # 375 x 1242, 7 classes, reference hyper-parameters
+    # 375 x 1242 (BASELINE.json) unless the spec names another image size; 7 classes, reference hyper-parameters
+    cfg = C.default_config((spec["shape"][0], spec["shape"][1], 3)) if spec.get("shape") else C.default_config()
     if spec["proposals"]:
         cfg["rpn"]["nms"]["max_total_size"] = cfg["rpn"]["nms"]["max_output_size_per_class"] = spec["proposals"]
     B = spec["batch"]
@@ -413,14 +442,17 @@ def measure(spec, args, rank, world, dev, windows, with_segmented, with_rccl_leg
         model._restore(state0, opt)
         return timed_window()
 
+    discarded_ms = [window()[0] / args.steps * 1e3 for _ in range(discard)]
     dt, (losses, preds) = window()                             # the contract's region: EXACTLY K steps, barrier + synchronize both sides
     loss_vals = {k: float(v) for k, v in losses.items()}
     window_ms = [dt / args.steps * 1e3]
     for _ in range(max(0, windows - 1)):                       # more evidence than one 0.1 s region: the same region again
         window_ms.append(window()[0] / args.steps * 1e3)
+    srt = sorted(window_ms)
+    if discard:
+        dt = srt[len(srt) // 2] * 1e-3 * args.steps            # (other_configs: the median region)
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt
-    srt = sorted(window_ms)
     # what data parallelism costs before any byte moves: the same step as its backward-segment graphs with a (no-op) hook between
     # them -- the form every rank runs when a GradientSynchronizer interleaves bucket all-reduces -- against the one-graph replay
     segmented_ms = None
@@ -461,7 +493,9 @@ def measure(spec, args, rank, world, dev, windows, with_segmented, with_rccl_leg
                    "segmented_ms_per_step": None if segmented_ms is None else round(segmented_ms, 4),
                    "forced_collectives_world1": rccl,
                    "segments": len(model._train_plan["plan"].segments)},
-        "windows": {"steps_each": args.steps, "ms_per_step": [round(x, 4) for x in window_ms], "min": round(srt[0], 4),
+        "windows": {"steps_each": args.steps, "ms_per_step": [round(x, 4) for x in window_ms],
+                    "value_is": "median of these regions (after the discarded ones)" if discard else "the first of these regions",
+                    "discarded_first_ms_per_step": [round(x, 4) for x in discarded_ms], "min": round(srt[0], 4),
                     "median": round(srt[len(srt) // 2], 4), "max": round(srt[-1], 4),
                     "images_per_s_median": round(world * B / (srt[len(srt) // 2] * 1e-3), 2)},
         "final_losses": loss_vals,
@@ -489,10 +523,11 @@ def attach_roofline(out, fam, spec, ms):
     # while the kernel sources are the ones that trace was taken from.  The live HIP-event timing of the same launches is
     # reported beside it (`events`): raw pairs over-state a launch by the cost of the pair itself, pairs minus the calibrated
     # empty-pair cost under-state it; when the committed trace is stale the RAW (conservative) event figure is the headline.
-    variant = ("_fp8" if spec["fp8"] else "") + ("_fpn" if spec["fpn"] else "") + ("_r101" if spec["depth"] == 101 else "")
-    wkey = workload_key(spec["depth"], spec["batch"], spec["proposals"], spec["fp8"], spec["fpn"])
+    odd_shape = bool(spec.get("shape")) and tuple(spec["shape"][:2]) != DEFAULT_SHAPE
+    variant = ("_fp8" if spec["fp8"] else "") + ("_fpn" if spec["fpn"] else "") + ("_r101" if spec["depth"] == 101 else "") + ("_ref600" if odd_shape else "")
+    wkey = workload_key(spec["depth"], spec["batch"], spec["proposals"], spec["fp8"], spec["fpn"], spec.get("shape"))
     off, source = offline_profile(dom, variant, wkey)
-    ev_raw_us = (f["seconds"] + f["launches"] * f["event_pair_overhead_us"] * 1e-6) / f["launches"] * 1e6
+    ev_raw_us = (f["seconds"] + f["plan_calls"] * f["event_pair_overhead_us"] * 1e-6) / f["launches"] * 1e6
     ev_net_us = f["seconds"] / f["launches"] * 1e6
     if off and off.get("avg_launch_us"):
         head_us, head_src = float(off["avg_launch_us"]), "rocprofv3 kernel trace, " + source
@@ -506,8 +541,8 @@ def attach_roofline(out, fam, spec, ms):
     for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["seconds"]):
         o = off_all.get(k)
         # durations: the committed trace where it is current (same source as the headline), else raw event pairs
-        sec = o["ms_per_step"] * 1e-3 if (o and o.get("ms_per_step")) else v["seconds"] + v["launches"] * v["event_pair_overhead_us"] * 1e-6
-        e = {"launches_per_step": v["launches"], "ms_per_step": round(sec * 1e3, 4), "timing": "rocprof" if (o and o.get("ms_per_step")) else "events_raw",
+        sec = o["ms_per_step"] * 1e-3 if (o and o.get("ms_per_step")) else v["seconds"] + v["plan_calls"] * v["event_pair_overhead_us"] * 1e-6
+        e = {"launches_per_step": v["launches"], "plan_calls_per_step": v["plan_calls"], "ms_per_step": round(sec * 1e3, 4), "timing": "rocprof" if (o and o.get("ms_per_step")) else "events_raw",
              "events_net_ms_per_step": round(v["seconds"] * 1e3, 4)}
         if v["flops"] > 0:
             e["tflops"] = round(v["flops"] / sec / 1e12, 2)
@@ -579,6 +614,8 @@ def main(argv=None):
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) MFMA conv path where a layer supports it (BASELINE.json configs[4]'s precision)")
     ap.add_argument("--depth", type=int, default=50, help="ResNet depth (101 with --proposals 1000 --batch-per-gpu 2 = BASELINE.json configs[3])")
     ap.add_argument("--proposals", type=int, default=0, help="RPN NMS max_total_size / max_output_size_per_class (0: config.json's 300)")
+    ap.add_argument("--image-shape", type=int, nargs=2, default=None, metavar=("H", "W"),
+                    help="image size (default 375 1242 = BASELINE.json; 600 1987 with --batch-per-gpu 2 = the reference's own config.json: other_configs.reference_default)")
     argv = sys.argv[1:] if argv is None else list(argv)
     args = ap.parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -597,7 +634,8 @@ def main(argv=None):
     local_rank = int(os.environ.get("FRCNN_BENCH_DEVICE", local_rank))      # (rehearsals: several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    spec = {"depth": args.depth, "batch": args.batch_per_gpu, "proposals": args.proposals, "fp8": args.fp8, "fpn": args.fpn}
+    shape = tuple(args.image_shape) if args.image_shape and tuple(args.image_shape) != DEFAULT_SHAPE else None
+    spec = {"depth": args.depth, "batch": args.batch_per_gpu, "proposals": args.proposals, "fp8": args.fp8, "fpn": args.fpn, "shape": shape}
     is_headline = spec == BASE_SPEC
     out = measure(spec, args, rank, world, dev, args.windows, not args.no_segmented, not args.no_segmented)
     cfg = out.pop("_cfg")
@@ -609,7 +647,7 @@ def main(argv=None):
         for name, ospec in OTHER_CONFIGS.items():
             try:
                 sub = copy.copy(args)
-                o = measure(ospec, sub, rank, world, dev, 3, False, False)
+                o = measure(ospec, sub, rank, world, dev, 3, False, False, discard=1)
                 o.pop("_cfg")
                 keep = {k: o[k] for k in ("value", "unit", "ms_per_step", "dtype", "windows", "final_losses") if k in o}
                 keep["workload"] = o["config"]["workload"]
@@ -628,6 +666,12 @@ def main(argv=None):
         bad = [k for k, v in loss_vals.items() if not (v == v and abs(v) != float("inf"))]
         if bad:
             out["error"] = "non-finite losses after the timed window: %s -- the timed workload is degenerate, the number is void" % bad
+        if "other_configs" in out:
+            # LAST key of the line, compact: a reader who only keeps the tail of stdout still gets every configuration's figures
+            out["other_configs_summary"] = {"fields": ["images_per_s", "ms_per_step", "roofline_frac"]}
+            for name, o in out["other_configs"].items():
+                out["other_configs_summary"][name] = ([o["value"], o["ms_per_step"], (o.get("roofline") or {}).get("frac")]
+                                                      if "value" in o else [None, None, o.get("error", "?")[:80]])
         print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         if world > 1:

@@ -248,6 +248,22 @@ def _strip(name):
     return name.split(" grid")[0]
 
 
+# ---- convolutions that carry a neighbouring BatchNorm (ops entry point -> cases).  Each case is run by an "equals its parts" GPU test
+# (tests/test_gpu_kernels.py) and counted by tests/test_conv_dispatch.py under "<instantiation>+<entry point>": a plan that sends another
+# instantiation through one of these entry points names the missing case.
+BN_FUSED_ENTRY_POINTS = ("conv2d_fprop_bnin",)
+BNIN = [   # frcnn_conv2d_fprop_bnin: 3x3 / stride 1 / pad 1 on the RAW output of the 1x1 layer before it (n, h, w = its grid)
+    dict(id="bnin_c2_3x3_64_64_stats_b4", n=4, h=94, w=311, cin=64, cout=64, stats=True),              # conv2's shape at the benchmark's batch
+    dict(id="bnin_3x3_64_128_nostats_ragged", n=9, h=45, w=70, cin=64, cout=128, stats=False),         # ends inside tiles in both directions, two channel parts
+    dict(id="bnin_3x3_64_64_stats_ragged", n=18, h=45, w=70, cin=64, cout=64, stats=True),
+    dict(id="bnin_c2_3x3_64_64_stats_600x1987_b2", n=2, h=150, w=497, cin=64, cout=64, stats=True),    # the reference's own configuration (config.json:3, batch 2)
+]
+
+
+def bnin_desc(ops, c):
+    return ops.conv_desc(c["n"], c["h"], c["w"], c["cin"], 3, 3, 1, 1, 1, c["h"], c["w"], c["cout"], flags=ops.CONV_BIAS | (ops.CONV_STATS if c["stats"] else 0))
+
+
 def covered_instantiations(ops):
     """{instantiation name: [case ids]} for every case above (dry-run of the dispatcher: no GPU needed)."""
     import torch
@@ -258,6 +274,8 @@ def covered_instantiations(ops):
 
     for c in FPROP:
         note(ops.conv2d_describe(fprop_desc(ops, c), False), c["id"])
+    for c in BNIN:
+        note(ops.conv2d_describe(bnin_desc(ops, c), False).replace(" grid", "+conv2d_fprop_bnin grid", 1), c["id"])
     for c in FPROP_FP8:
         note(ops.conv2d_describe_fp8(fprop_desc(ops, c)), c["id"])
     for c in DGRAD_FP8:

@@ -16,7 +16,7 @@ import torch
 import conv_cases
 
 
-def _plan_instantiations(monkeypatch, depth, batch, proposals=None, precision="bf16", topology="c4"):
+def _plan_instantiations(monkeypatch, depth, batch, proposals=None, precision="bf16", topology="c4", image_shape=None):
     ops = importlib.import_module("2d_object_detection_amd.ops")
     # the two init-time kernels of the RPN detector (anchor table, clip) need a device; their values do not matter here
     monkeypatch.setattr(ops, "anchors_generate", lambda out, *a, **k: out.zero_())
@@ -24,7 +24,7 @@ def _plan_instantiations(monkeypatch, depth, batch, proposals=None, precision="b
     M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
     C = importlib.import_module("2d_object_detection_amd.config")
     OPT = importlib.import_module("2d_object_detection_amd.optimizers")
-    cfg = copy.deepcopy(C.default_config())
+    cfg = copy.deepcopy(C.default_config(image_shape) if image_shape else C.default_config())
     if proposals:
         cfg["rpn"]["nms"]["max_total_size"] = cfg["rpn"]["nms"]["max_output_size_per_class"] = proposals
     model = M.FasterRCNN(cfg, depth=depth, device="cpu", precision=precision, topology=topology)
@@ -32,11 +32,17 @@ def _plan_instantiations(monkeypatch, depth, batch, proposals=None, precision="b
     opt.bind(model.store)
     plan = model._build(model._train, batch, True, opt)["plan"]
     names = {}
+    BN_FUSED_FORMS = {getattr(ops, n): n for n in conv_cases.BN_FUSED_ENTRY_POINTS if hasattr(ops, n)}
+    assert BN_FUSED_FORMS, "ops lost its BatchNorm-carrying convolution entry points"
     for seg in plan.segments:
         for fn, args, kwargs, _br in seg:
             found = []
             if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce:
                 found = [ops.conv2d_describe(args[0], fn is ops.conv2d_dgrad_bnreduce)]
+            elif fn in BN_FUSED_FORMS:
+                # the convolutions that carry a neighbouring BatchNorm (forward apply on the input side, ...): the kernel frcnn_conv2d_describe
+                # names for the plain form, tagged with the form -- a parity case must have run THAT form on THAT instantiation
+                found = [ops.conv2d_describe(args[0], False).replace(" grid", "+" + BN_FUSED_FORMS[fn] + " grid", 1)]
             elif fn is ops.conv2d_fprop_fp8:
                 found = [ops.conv2d_describe_fp8(args[0])]
             elif fn is ops.conv2d_dgrad_fp8:
@@ -60,6 +66,17 @@ def test_every_plan_instantiation_has_a_parity_case(monkeypatch, ops, depth, bat
     assert len(used) >= 20 and launches >= 200
     missing = sorted(k for k in used if k not in covered)
     assert not missing, "conv kernels of the R%d batch-%d train plan without an oracle-compared GPU case:\n  %s" % (depth, batch, "\n  ".join(missing))
+
+
+def test_reference_default_plan_instantiations_have_parity_cases(monkeypatch, ops):
+    """The reference's OWN configuration -- /root/reference config.json:3 image_shape [600, 1987, 3], train_faster_rcnn.py:52-54 batch 2 --
+    which INTEGRATION.md tells a maintainer to load unchanged: 38 x 125 feature grid, odd extents at every stage, other workgroup-count
+    branches of the 3x3 dispatch than 375 x 1242 takes.  (tests/test_gpu_reference_default.py runs the step itself.)"""
+    used, launches = _plan_instantiations(monkeypatch, 50, 2, image_shape=(600, 1987, 3))
+    covered = conv_cases.covered_instantiations(ops)
+    assert len(used) >= 20 and launches >= 190
+    missing = sorted(k for k in used if k not in covered)
+    assert not missing, "conv kernels of the 600x1987 batch-2 train plan without an oracle-compared GPU case:\n  %s" % "\n  ".join(missing)
 
 
 def test_every_fp8_plan_instantiation_has_a_parity_case(monkeypatch, ops):

@@ -30,8 +30,10 @@ def mism(a, b):
 
 # (image shape, batch): the small geometry, and BASELINE.json configs[1] -- ResNet-50, 375 x 1242, batch 4 -- whose layers
 # dispatch to the 128x128-tile, kw-sharing and tile-run kernels that carry the benchmark (tests/test_conv_dispatch.py)
-GEOMETRIES = [((128, 192, 3), 2), ((375, 1242, 3), 4)]
-GEOM_IDS = ["128x192-b2", "375x1242-b4"]
+# ... and the reference's own configuration (/root/reference config.json:3, train_faster_rcnn.py:52-54): 600 x 1987, batch 2 -- odd extents
+# at every stage (300 x 994 -> 150 x 497 -> 75 x 249 -> 38 x 125)
+GEOMETRIES = [((128, 192, 3), 2), ((375, 1242, 3), 4), ((600, 1987, 3), 2)]
+GEOM_IDS = ["128x192-b2", "375x1242-b4", "600x1987-b2"]
 
 
 @pytest.mark.gpu

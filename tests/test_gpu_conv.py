@@ -297,6 +297,28 @@ def test_conv_wgrad_shared_dw_accumulates_over_launches(ops, k):
     _close(dw, r, 2e-4, 2e-3 * m ** 0.5, "wgrad plain store")
 
 
+def test_conv_wgrad_grouped_honours_the_accumulate_flag(ops):
+    """frcnn_conv2d_wgrad_group_plan set plain_store for every layer with one effective pixel split and ignored
+    FRCNN_CONV_WGRAD_ACCUMULATE, which include/frcnn_hip.h documents for the weight-gradient entry points generally: two flagged layers
+    of ONE grouped launch that share a dw (8 x 8 pixels each: one split) must leave the SUM of their gradients there, on top of what
+    dw held before; unflagged, a one-split layer replaces."""
+    g = torch.Generator().manual_seed(56)
+    cin, cout = 128, 128
+    case = dict(n=1, h=8, w=8, cin=cin, cout=cout, k=1, s=1, p=0)
+    other = dict(n=1, h=8, w=8, cin=cin, cout=64, k=1, s=1, p=0)               # an unflagged neighbour in the same group
+    (x0, dz0, r0, m), (x1, dz1, r1, _), (x2, dz2, r2, _) = _wgrad_problem(case, g), _wgrad_problem(case, g), _wgrad_problem(other, g)
+    before = torch.randn(cout, 1, 1, cin, generator=g)
+    dw = before.clone().cuda()
+    dw2 = torch.full((64, 1, 1, cin), 7.0, device="cuda")
+    fl = ops.CONV_WGRAD_ACCUMULATE
+    group = ops.WgradGroup([(conv_desc(ops, case, flags=fl), x0, dz0, dw), (conv_desc(ops, case, flags=fl), x1, dz1, dw),
+                            (conv_desc(ops, other), x2, dz2, dw2)], "cuda")
+    ops.conv2d_wgrad_grouped(group)
+    torch.cuda.synchronize()
+    _close(dw, before + r0 + r1, 2e-4, 2e-3 * (2 * m) ** 0.5, "grouped wgrad, shared dw")
+    _close(dw2, r2, 2e-4, 2e-3 * m ** 0.5, "grouped wgrad, plain store of the unflagged layer")
+
+
 @pytest.mark.parametrize("grp", WGRAD_GROUPS, ids=[c["id"] for c in WGRAD_GROUPS])
 def test_conv_wgrad_grouped(ops, grp):
     """Several layers (3x3, strided 1x1, plain 1x1 -- both addressing modes) in one grouped launch with a common pixel split."""

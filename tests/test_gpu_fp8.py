@@ -413,6 +413,31 @@ def test_bn_train_apply_writes_the_fp8_twin(ops):
         assert float(amax.max()) == float(outs[1].float().abs().max())
 
 
+@pytest.mark.parametrize("n", [8 * 4096, 8 * 37])        # every lane of the writing waves active / a tail wave with exited lanes
+def test_amax_records_a_nan_without_an_inf(ops, n):
+    """fmaxf drops a NaN operand, so a tensor holding NaN but no Inf used to leave a FINITE amax behind and
+    frcnn_fp8_update_scales never counted it.  atomic_amax now reduces the bit patterns of |x| (every NaN orders above +Inf): the slot
+    row of such a tensor holds a NaN, the scale is kept and status[1] counts the event; a clean tensor beside it is updated as before."""
+    x = torch.linspace(-3.0, 5.0, n).to(BF)
+    clean = x.clone()
+    x[n // 2 + 3] = float("nan")
+    assert not bool(torch.isinf(x.float()).any())
+    qs = torch.tensor([1.0]).cuda()
+    out8 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    amax = torch.zeros(2, ops.FP8_AMAX_SLOTS, device="cuda")
+    ops.quantize_fp8(x.cuda(), qs, out8, amax[0])
+    ops.quantize_fp8(clean.cuda(), qs, out8, amax[1])
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(amax[0]).any()) and float(amax[1].max()) == 5.0
+    scale, qscale = torch.tensor([7.0, 7.0], device="cuda"), torch.tensor([9.0, 9.0], device="cuda")
+    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.fp8_update_scales(amax, scale, qscale, 2, margin=1.0, status=status)
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [0, 1], status
+    assert float(scale[0]) == 7.0 and float(qscale[0]) == 9.0                      # non-finite amax: the scale is kept
+    assert abs(float(scale[1]) - 5.0 / 448.0) < 1e-7
+
+
 def test_fp8_delayed_scaling_update(ops):
     amax = torch.zeros(3, ops.FP8_AMAX_SLOTS, device="cuda")
     amax[0, 5], amax[0, 63], amax[2, 0] = 4.48, 1.0, 896.0        # (the maximum over a tensor's slots counts)

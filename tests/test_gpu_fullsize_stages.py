@@ -24,11 +24,14 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
-@pytest.mark.parametrize("depth,batch,proposals", [(50, 4, 300), (101, 2, 1000)], ids=["configs1_r50_b4_p300", "configs3_r101_b2_p1000"])
-def test_head_stages_at_benchmark_size(depth, batch, proposals):
+@pytest.mark.parametrize("depth,batch,proposals,shape", [(50, 4, 300, (375, 1242, 3)), (101, 2, 1000, (375, 1242, 3)), (50, 2, 300, (600, 1987, 3))],
+                         ids=["configs1_r50_b4_p300", "configs3_r101_b2_p1000", "reference_default_r50_b2_p300_600x1987"])
+def test_head_stages_at_benchmark_size(depth, batch, proposals, shape):
+    """(the third case is the reference's own configuration: /root/reference config.json:3 image_shape [600, 1987, 3] and the batch of 2
+    of train_faster_rcnn.py:52-54 -- 30 833 in-image anchors per image through the proposal NMS, a 38 x 125 feature grid)"""
     M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
     OPT = importlib.import_module("2d_object_detection_amd.optimizers")
-    cfg = O.default_config((375, 1242, 3))
+    cfg = O.default_config(shape)
     cfg["rpn"]["nms"].update(max_total_size=proposals, max_output_size_per_class=proposals)
     ishape = cfg["image_shape"]
     images, gl, gb = O.synthetic_batch(batch, ishape, seed=5)
@@ -86,4 +89,10 @@ def test_head_stages_at_benchmark_size(depth, batch, proposals):
     # which conv kernel carried the RPN's 3x3 layer: the patch-resident kernel (rounds 2-3: the tile kernel's split-K pair form) -- both
     # configurations have at most 240 workgroups of 8 x 16 pixels x 64 channels
     ops = importlib.import_module("2d_object_detection_amd.ops")
-    assert ops.conv2d_describe(model._train.rpn.d_inter).startswith("conv3x3_patch<SB=4,SMODE=0,LW=4>")
+    if shape[0] == 375:
+        assert ops.conv2d_describe(model._train.rpn.d_inter).startswith("conv3x3_patch<SB=4,SMODE=0,LW=4>")
+    else:
+        # 600 x 1987, batch 2: 38 x 125 grid = 5 x 8 patch tiles per image x 2 x 4 channel parts = 320 workgroups of 64 channels (more than
+        # one round of CUs) -> the 128-channel parts (160 workgroups)
+        assert aux["rpn_out"]["regions"].shape[0] == 30833 and feat.shape[1:3] == (38, 125)
+        print("RPN 3x3 at 600x1987 batch 2:", ops.conv2d_describe(model._train.rpn.d_inter))

@@ -7,6 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import conv_cases
 from oracle import boxes as oboxes
 from oracle import faster_rcnn as O
 from oracle import losses as olosses
@@ -1048,14 +1049,15 @@ def test_losses_head_grad_bias_gradient_equals_colsum(ops, B, S):
     assert float(bg_a.abs().sum()) > 0 and torch.equal(bg_a, bg_b), (bg_a - bg_b).abs().max()
 
 
-@pytest.mark.parametrize("n,h,w,cout,stats", [(4, 94, 311, 64, True), (9, 45, 70, 128, False), (18, 45, 70, 64, True)])
-def test_conv2d_fprop_bnin_equals_bn_apply_then_conv(ops, n, h, w, cout, stats):
+@pytest.mark.parametrize("case", conv_cases.BNIN, ids=[c["id"] for c in conv_cases.BNIN])
+def test_conv2d_fprop_bnin_equals_bn_apply_then_conv(ops, case):
     """frcnn_conv2d_fprop_bnin == frcnn_bn_train_apply (ReLU, bit mask) followed by frcnn_conv2d_fprop on its output: the activation, its
     ReLU mask, mean / invstd and the moving statistics bit for bit, the convolution output bit for bit (both run the weights-resident
     kernel on identical patches), its statistics up to the order of the f64 slot sums.  (4, 94, 311) is conv2's shape at the benchmark's
     batch; the others end inside tiles in both directions, one with two channel parts."""
+    n, h, w, cout, stats = case["n"], case["h"], case["w"], case["cout"], case["stats"]
     g = torch.Generator().manual_seed(7 + h)
-    dev, cin = "cuda", 64
+    dev, cin = "cuda", case["cin"]
     m = n * h * w
     z = (torch.randn(m, cin, generator=g) * 1.3 + 0.2).to(BF).to(dev)
     zf = z.double()
@@ -1067,7 +1069,7 @@ def test_conv2d_fprop_bnin_equals_bn_apply_then_conv(ops, n, h, w, cout, stats):
     wt = (torch.randn(cout, 3, 3, cin, generator=g) / 24.0).to(BF).to(dev)
     bias = torch.randn(cout, generator=g).to(dev)
     flags = ops.CONV_BIAS | (ops.CONV_STATS if stats else 0)
-    d = ops.conv_desc(n, h, w, cin, 3, 3, 1, 1, 1, h, w, cout, flags=flags)
+    d = conv_cases.bnin_desc(ops, case)
     assert ops.conv2d_bnin_supported(d)
     assert not ops.conv2d_bnin_supported(ops.conv_desc(1, 24, 78, 256, 3, 3, 1, 1, 1, 24, 78, 256))
 

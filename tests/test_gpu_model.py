@@ -349,3 +349,61 @@ def test_forced_collectives_on_rccl_at_world_one(setup):
             assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (i, k, a[k], b[k])
     e = _rel(w_forced, w_plain.cpu())
     assert e < 1e-6, e                       # after the first update (float-atomic order in the weight gradients is all that differs)
+
+
+@pytest.mark.parametrize("topology", ["c4", "fpn"])
+def test_proposals_override_is_the_nms_output_replaced(setup, topology):
+    """train_step(..., proposals_override=R) (a test hook; reference models/faster_rcnn.py:53-55: the rois enter the Fast-RCNN stage
+    behind a stop_gradient): (i) with R = the proposals the un-injected step kept, the step is the SAME computation -- RoIs, absolute
+    regions, sample indices, the four losses (Dense heads: split-K float atomics -> 1e-5) and the RPN's gradient; (ii) with other
+    proposals the RPN half does not move (losses bit-equal) and the Fast-RCNN half does; (iii) eager and replayed injected steps agree;
+    (iv) switching a model between the two forms rebuilds its plan instead of silently ignoring the override."""
+    cfg, params, M, OPT = setup["cfg"], setup["params"], setup["M"], setup["OPT"]
+    images, gl, gb = setup["images"].cuda(), setup["gl"].cuda(), setup["gb"].cuda()
+
+    def step(proposals, graphs=False):
+        m = M.FasterRCNN(cfg, sampling_seed=11, topology=topology)
+        m.use_graphs = graphs
+        if topology == "c4":
+            m.set_weights(params)
+        losses, preds = m.train_step(images, gl, gb, OPT.SGD(learning_rate=1e-5, momentum=0.9), proposals_override=proposals)
+        torch.cuda.synchronize()
+        aux = m._train_plan["aux"]
+        return m, {"losses": {k: float(v) for k, v in losses.items()}, "rois": aux["nms_rpn"]["pred_boxes"].clone(),
+                   "abs": aux["rcnn_out"]["regions"].clone(), "rcnn_idx": aux["targets"]["rcnn_idx"].clone(),
+                   "rpn_idx": aux["targets"]["rpn_idx"].clone(), "g_rpn": m.store.grad("rpn_heads/kernel").clone(),
+                   "launches": m._train_plan["plan"].num_launches}
+
+    _, plain = step(None)
+    m_same, same = step(plain["rois"].clone())
+    assert same["launches"] == plain["launches"] + 2
+    assert torch.equal(same["rois"], plain["rois"]) and torch.equal(same["abs"], plain["abs"])
+    assert torch.equal(same["rcnn_idx"], plain["rcnn_idx"]) and torch.equal(same["rpn_idx"], plain["rpn_idx"])
+    for k, v in plain["losses"].items():
+        assert abs(same["losses"][k] - v) <= 1e-5 * max(1.0, abs(v)), (k, same["losses"][k], v)
+    assert _rel(same["g_rpn"], plain["g_rpn"]) < 1e-5
+    # (ii) other proposals: a fixed grid of boxes
+    b, p = plain["rois"].shape[:2]
+    g = torch.Generator().manual_seed(0)
+    xy = torch.rand(b, p, 2, generator=g) * 0.6
+    wh = torch.rand(b, p, 2, generator=g) * 0.3 + 0.08
+    other = torch.cat([xy, xy + wh], -1).cuda()
+    _, moved = step(other)
+    assert torch.equal(moved["rois"], other)
+    W, H = cfg["image_shape"][1], cfg["image_shape"][0]
+    assert torch.equal(moved["abs"], other * torch.tensor([W, H, W, H], dtype=torch.float32, device="cuda"))
+    assert moved["losses"]["rpn_cls"] == plain["losses"]["rpn_cls"] and moved["losses"]["rpn_reg"] == plain["losses"]["rpn_reg"]
+    assert torch.equal(moved["rpn_idx"], plain["rpn_idx"])
+    assert abs(moved["losses"]["rcnn_cls"] - plain["losses"]["rcnn_cls"]) > 1e-4 or not torch.equal(moved["rcnn_idx"], plain["rcnn_idx"])
+    # (iii) replayed
+    _, replayed = step(other, graphs=True)
+    assert torch.equal(replayed["rois"], other) and torch.equal(replayed["rcnn_idx"], moved["rcnn_idx"])
+    for k, v in moved["losses"].items():
+        assert abs(replayed["losses"][k] - v) <= 1e-5 * max(1.0, abs(v)), (k, replayed["losses"][k], v)
+    # (iv) the same model without an override: a new plan, two launches shorter
+    built = m_same._train_plan
+    m_same.train_step(images, gl, gb, built["optimizer"])
+    torch.cuda.synchronize()
+    assert m_same._train_plan is not built and m_same._train_plan["plan"].num_launches == plain["launches"]
+    with pytest.raises(TypeError):
+        m_same.train_step(images, gl, gb, built["optimizer"], proposals_override=other.cpu())

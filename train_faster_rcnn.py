@@ -8,7 +8,7 @@ reference's TFRecord files, files written by `python -m 2d_object_detection_amd.
 directory; `--synthetic N` trains on N generated records instead (no data set in the container); scalars go to
 `<logs-dir>/<time>/faster-rcnn/{train,valid}/` as a TensorBoard event file (events.out.tfevents.*, data/tfevents.py) and as
 scalars.jsonl, both with the reference's tag names; launched under `python -m torch.distributed.run` every rank reads its own shard of the records and
-gradients are all-reduced over RCCL (one process per GPU).  Image summaries (utils/images.py) are not produced."""
+gradients are all-reduced over RCCL (one process per GPU).  The validation pass's image summaries (utils/images.py: the drawings of the reference's train_faster_rcnn.py:146-239) go to the same event file."""
 import argparse
 import datetime
 import glob
