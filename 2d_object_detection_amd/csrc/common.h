@@ -107,6 +107,11 @@ __device__ __forceinline__ u32x2 pack8_bf8(const float* f, const float qs) {
 // Callable after per-thread early returns: with every lane of the wave active the reduction is a butterfly and lane 0 writes; with
 // some lanes gone (a channel count that is not a multiple of 64, a tail row) the exited lanes' registers are undefined to a shuffle,
 // so the maximum is collected from the ACTIVE lanes one by one (v_readlane on the ballot's set bits) and the first active lane writes.
+// per-thread accumulation for atomic_amax: m <- max(m, |v|) on bit patterns (m >= 0), so that a NaN stays visible (see below)
+__device__ __forceinline__ float amax_fold(float m, float v) {
+    const unsigned a = __float_as_uint(m), b = __float_as_uint(v) & 0x7fffffffu;
+    return __uint_as_float(a > b ? a : b);
+}
 // The reduction runs on the BIT PATTERNS of |v| (unsigned integer max: the order of non-negative floats, with +Inf above every finite
 // value and every NaN above +Inf): fmaxf would drop a NaN operand, and a tensor holding NaN but no Inf would leave a finite amax behind --
 // fp8_update_scales_kernel's `!(v <= 3e38f)` test then never fired for it and FasterRCNN.fp8_status() reported a healthy tensor.

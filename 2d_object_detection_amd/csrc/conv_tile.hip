@@ -1123,10 +1123,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvParams
 //     and wait for it; the eight MFMA waves never execute an LDS-DMA instruction (it stalls its wave while the CU's load path is backed up)
 //   * BNT = 128: 128 output channels per workgroup (wave tiles 32 pixels x 64 channels: 2 + 4 fragment reads per 8 MFMAs), 48 KB of weights
 //     per step in a 2-slot ring -- for layers with 128 output channels and few chunks (conv3), where it halves the workgroups to one round
-template <int SB, int SMODE, int OCCW, int LW, int BNT>
+//   * BNIN (frcnn_conv2d_fprop_bnin, loader-wave forms only): the input is the RAW output z of the previous convolution and this kernel
+//     applies that layer's training-mode BatchNorm + ReLU itself, as conv3x3_wres_kernel<., BNIN> does for the one-chunk layers: every MFMA
+//     thread below Cin derives scale / shift of one input channel from the f64 statistics slots (the additions of bn_train_apply_kernel in
+//     its order: same bits) into LDS behind the weight ring; when a chunk's patch has landed (the step with kh == 0) the eight MFMA waves
+//     transform it in place -- pixels outside the image stay zero: the padding applies AFTER the BatchNorm -- while the loader waves keep
+//     issuing, one more barrier per chunk; the workgroup whose channel part equals chunk mod parts writes the chunk's activation and ReLU
+//     bit mask for the backward pass from its patch interior.  One launch and one read of z less than bn_train_apply + this kernel.
+template <int SB, int SMODE, int OCCW, int LW, int BNT, bool BNIN = false>
 __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(const ConvParams p, const int tiles_x, const int tiles_y) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr bool STATS = SMODE == 1, RED = SMODE == 2;
+    static_assert(!BNIN || (LW == 4 && SMODE != 2), "BatchNorm on the input side: forward convolutions on the loader-wave forms");
     constexpr bool INTERLEAVE = false;          // a step's DMA pieces spread between its MFMA groups: measured slower (c4 3x3 17.4 -> 18.7 us)
     constexpr int NW = 8, T = 512, BM = 128, BN = BNT, TW = 16, TH = 8, PW = TW + 2;
     constexpr int MI = 2, NI = BN / 32, BPV = BN / 64;            // BPV: weight pieces per (virtual) wave and tap
@@ -1169,6 +1177,88 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[j][e] = b[e];
     }
+
+    // BNIN: scale / shift of the Cin input channels ([Cin] + [Cin] floats behind the weight ring), one channel per MFMA thread: the four slot
+    // slices of bn_train_apply_kernel's prologue (slot_sums) and their sum, in that order; workgroup 0 publishes mean / invstd and updates
+    // the moving statistics.  Published to the other waves by the first step's barrier.
+    float* s_scale = reinterpret_cast<float*>(smem + B_BASE + SB * B_STEP);
+    float* s_shift = s_scale + p.Cin;
+    if (BNIN && tid < p.Cin) {
+        const int c = tid;
+        double a[4][FRCNN_STAT_SLOTS / 4], b[4][FRCNN_STAT_SLOTS / 4];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+            for (int k = 0; k < FRCNN_STAT_SLOTS / 4; ++k) {
+                a[sl][k] = p.bnin_part[((long long)(sl + 4 * k) * 2) * p.Cin + c];
+                b[sl][k] = p.bnin_part[((long long)(sl + 4 * k) * 2 + 1) * p.Cin + c];
+            }
+        double ps[4], pq[4];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < FRCNN_STAT_SLOTS / 4; ++k) { s0 += a[sl][k]; s1 += b[sl][k]; }
+            ps[sl] = s0;
+            pq[sl] = s1;
+        }
+        const double sum = ps[0] + ps[1] + ps[2] + ps[3];
+        const double ssq_ = pq[0] + pq[1] + pq[2] + pq[3];
+        const double mean = sum * p.bnin_inv_count;
+        double var = ssq_ * p.bnin_inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)p.bnin_eps));
+        const float sc = p.bnin_gamma[c] * invstd;
+        s_scale[c] = sc;
+        s_shift[c] = p.bnin_beta[c] - (float)mean * sc;
+        if (blockIdx.x == 0) {
+            p.bnin_mean[c] = (float)mean;
+            p.bnin_invstd[c] = invstd;
+            p.bnin_mm[c] = p.bnin_mm[c] * p.bnin_momentum + (float)mean * (1.f - p.bnin_momentum);
+            p.bnin_mv[c] = p.bnin_mv[c] * p.bnin_momentum + (float)(var * p.bnin_unbias) * (1.f - p.bnin_momentum);
+        }
+    }
+    // BatchNorm + ReLU of the landed patch of chunk s, in place: 192 rows x 8 sixteen-byte slots, three per MFMA thread (slot sl of row q
+    // holds channels 8 (sl ^ (q & 7)) .. of the chunk).  Rows outside the image (and beyond the patch) become zeros.
+    auto bnin_transform = [&](const int s) {
+        unsigned char* buf = smem + (s & 1) * A_BUF;
+        const unsigned pbase = lds_addr(buf);
+        const bool mine = (s % p.tiles_n) == tn;                     // this workgroup writes chunk s of its tile's activation
+        const float* csc = s_scale + s * 64;
+        const float* csh = s_shift + s * 64;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = tid + T * k;
+            const int q = idx >> 3, slot = idx & 7, c8 = slot ^ (q & 7);
+            const int py = q / PW, px = q - py * PW;
+            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+            const bool valid = q < (TH + 2) * PW && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(buf + q * 128 + slot * 16);
+            const f32x4 sc0 = *reinterpret_cast<const f32x4*>(csc + c8 * 8), sc1 = *reinterpret_cast<const f32x4*>(csc + c8 * 8 + 4);
+            const f32x4 sh0 = *reinterpret_cast<const f32x4*>(csh + c8 * 8), sh1 = *reinterpret_cast<const f32x4*>(csh + c8 * 8 + 4);
+            float x[8];
+            unpack8(raw, x);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] = fmaxf(x[e] * sc0[e] + sh0[e], 0.f);
+                x[4 + e] = fmaxf(x[4 + e] * sc1[e] + sh1[e], 0.f);
+            }
+            u32x4 pk = pack8(x);
+            if (!valid) pk = u32x4{0u, 0u, 0u, 0u};
+            asm volatile("ds_write_b128 %0, %1" ::"v"(pbase + (unsigned)(q * 128 + slot * 16)), "v"(pk) : "memory");
+            if (mine && valid && py >= 1 && py <= TH && px >= 1 && px <= TW) {      // this tile's own pixels: the activation and its mask
+                const long long pix = ((long long)img * p.Hi + iy) * p.Wi + ix;
+                *reinterpret_cast<u32x4*>(p.bnin_act + pix * p.Cin + s * 64 + c8 * 8) = pk;
+                unsigned m = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) {
+                    m |= ((pk[w2] & 0x7FFFu) != 0u && !(pk[w2] & 0x8000u)) ? (1u << (2 * w2)) : 0u;
+                    m |= ((pk[w2] & 0x7FFF0000u) != 0u && !(pk[w2] & 0x80000000u)) ? (1u << (2 * w2 + 1)) : 0u;
+                }
+                p.bnin_mask[pix * (p.Cin >> 3) + s * 8 + c8] = (unsigned char)m;
+            }
+        }
+    };
 
     // ------------------------------------------------------------------ loader state
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
@@ -1301,6 +1391,7 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
             __builtin_amdgcn_s_barrier();
             if (kh == 0 && s + 1 < nsub) issue_a(s + 1);
             if (ld_k < K) issue_b();
+            if (BNIN && kh == 0) __builtin_amdgcn_s_barrier();      // (the MFMA waves have transformed this chunk's patch)
             pend += issued_in(k) - (k + 1 < PB ? 3 * BPV : issued_in(k + 1 - PB));
             if (++kh == 3) { kh = 0; ++s; }
         }
@@ -1321,6 +1412,11 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads of the buffers refilled next have completed
         __builtin_amdgcn_s_barrier();
+        if (BNIN && kh == 0) {                                 // this chunk's patch has landed: BatchNorm + ReLU in place, then everyone reads it
+            bnin_transform(s);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         const bool do_a = !LW && kh == 0 && s + 1 < nsub, do_b = !LW && ld_k < K;
         if (!INTERLEAVE) {
             if (do_a) issue_a(s + 1);
@@ -1859,18 +1955,19 @@ int launch_stream_1x1(const ConvParams& p, hipStream_t s) {
     return FRCNN_OK;
 }
 
-template <int SB, int SMODE, int LW = 0, int BNT = 64>
+template <int SB, int SMODE, int LW = 0, int BNT = 64, bool BNIN = false>
 int launch_patch_sm(const ConvParams& p, hipStream_t s, const int tiles_x, const int tiles_y, const int grid) {
-    constexpr int smem = 2 * 24 * 1024 + SB * 3 * BNT * 128;
+    constexpr int smem = 2 * 24 * 1024 + SB * 3 * BNT * 128 + (BNIN ? 2 * 512 * 4 : 0);      // BNIN: + scale / shift of up to 512 input channels
     static_assert(smem <= 163840, "LDS budget");
     constexpr int occw = LW ? 3 : 2;             // waves per SIMD of the one workgroup a CU holds
-    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv3x3_patch_kernel<SB, SMODE, occw, LW, BNT>), smem) != 0) {
+    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv3x3_patch_kernel<SB, SMODE, occw, LW, BNT, BNIN>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop(patch 3x3): cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
-    snprintf(g_last_inst, sizeof(g_last_inst), "conv3x3_patch<SB=%d,SMODE=%d%s%s> grid=%dx1 tpb=1", SB, SMODE, LW ? ",LW=4" : "", BNT == 128 ? ",BN=128" : "", grid);
+    snprintf(g_last_inst, sizeof(g_last_inst), "conv3x3_patch<SB=%d,SMODE=%d%s%s%s> grid=%dx1 tpb=1", SB, SMODE, LW ? ",LW=4" : "", BNT == 128 ? ",BN=128" : "",
+             BNIN ? ",BNIN=1" : "", grid);
     if (p.dry_run) return FRCNN_OK;
-    hipLaunchKernelGGL((conv3x3_patch_kernel<SB, SMODE, occw, LW, BNT>), dim3(grid), dim3(512 + 64 * LW), smem, s, p, tiles_x, tiles_y);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<SB, SMODE, occw, LW, BNT, BNIN>), dim3(grid), dim3(512 + 64 * LW), smem, s, p, tiles_x, tiles_y);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop(patch 3x3)");
     return FRCNN_OK;
 }
@@ -1882,6 +1979,14 @@ int launch_patch(ConvParams p, hipStream_t s, const int n_img, int sb, const int
     p.tiles_n = p.Cout / bn;
     p.items = p.tiles_m * p.tiles_n;
     const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
+    if (p.bnin_part) {                           // the input layer's BatchNorm + ReLU applied by this launch (loader-wave forms, forward only)
+        if (smode == 2 || p.Cin > 512 || !(bn == 128 || sb == 4)) {
+            frcnn_set_error("frcnn_conv2d_fprop_bnin(patch 3x3): forward convolutions with at most 512 input channels on the loader-wave forms");
+            return FRCNN_EINVAL;
+        }
+        if (bn == 128) return smode == 1 ? launch_patch_sm<2, 1, 4, 128, true>(p, s, tiles_x, tiles_y, p.items) : launch_patch_sm<2, 0, 4, 128, true>(p, s, tiles_x, tiles_y, p.items);
+        return smode == 1 ? launch_patch_sm<4, 1, 4, 64, true>(p, s, tiles_x, tiles_y, p.items) : launch_patch_sm<4, 0, 4, 64, true>(p, s, tiles_x, tiles_y, p.items);
+    }
     if (bn == 128) {                             // 128 output channels per workgroup: 2-slot weight ring (144 KB of LDS), loader waves
         if (smode == 1) return launch_patch_sm<2, 1, 4, 128>(p, s, tiles_x, tiles_y, p.items);
         if (smode == 2) return launch_patch_sm<2, 2, 4, 128>(p, s, tiles_x, tiles_y, p.items);
@@ -2407,10 +2512,18 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
 #ifdef FRCNN_SWEEP
     if (const char* e = getenv("FRCNN_WRES")) wres_on = patch && d->cin == 64 && atoi(e) != 0;
 #endif
+    bool patch_bnin = false;
     if (bn_in && !wres_on) {
-        frcnn_set_error("conv2d_fprop_bnin: only 3x3 / stride 1 / pad 1 layers with 64 input channels that run on the weights-resident kernel "
-                        "(frcnn_conv2d_bnin_supported)");
-        return FRCNN_EINVAL;
+        // ... or on the patch-resident kernel's loader-wave forms (conv3 / conv4 at the benchmark's sizes)
+        patch_bnin = patch_on && d->in_pix_stride == d->cin && d->cin <= 512 && !red && (patch_bn == 128 || patch_sb == 4);
+#ifdef FRCNN_SWEEP
+        if (const char* e = getenv("FRCNN_PATCH_LW")) { if (atoi(e) != 4 && patch_bn != 128) patch_bnin = false; }
+#endif
+        if (!patch_bnin) {
+            frcnn_set_error("conv2d_fprop_bnin: only 3x3 / stride 1 / pad 1 layers that run on the weights-resident kernel (64 input channels) or on "
+                            "the patch-resident kernel's loader-wave forms (frcnn_conv2d_bnin_supported)");
+            return FRCNN_EINVAL;
+        }
     }
     if (wres_on) {
         FRCNN_CHECK_ARG(!bn_in || d->in_pix_stride == 64, "conv2d_fprop_bnin: the input must be the dense [M][64] output of the previous convolution");

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(const bf16_t* __res
             store_fp8_pair(b2.out8 + i * 8, pack8_fp8(xr, f8_qs), v, (C & 15) == 0, ok);
             if (ok) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f8_max = fmaxf(f8_max, fabsf(xr[e]));
+                for (int e = 0; e < 8; ++e) f8_max = amax_fold(f8_max, xr[e]);
             }
         }
         if (relu_mask) {
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
             if (dz8) {
                 store_fp8_pair(dz8 + i * 8, pack8_bf8(o, f8_qs), v, (C & 15) == 0, ok[u]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f8_max = fmaxf(f8_max, fabsf(o[e]));
+                for (int e = 0; e < 8; ++e) f8_max = amax_fold(f8_max, o[e]);
             }
         }
     }

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const bf16_t* __restr
         unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), f);
         *reinterpret_cast<u32x2*>(out8 + i * 8) = E5M2 ? pack8_bf8(f, qs) : pack8_fp8(f, qs);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(f[e]));
+        for (int e = 0; e < 8; ++e) mx = amax_fold(mx, f[e]);
     }
     if (amax) atomic_amax(amax, mx);
 }

@@ -35,7 +35,7 @@ def _out_hw(h, w):
 FP8_MIN_STAGE = int(os.environ.get("FRCNN_FP8_MIN_STAGE", "2"))      # first ResNet stage whose tensors get fp8 twins (measuring aid: 3 = conv3 on)
 # The 3x3 convolution of a bottleneck block applies the block's first BatchNorm + ReLU itself where the C ABI offers it
 # (frcnn_conv2d_fprop_bnin: conv2's layers at the benchmark's sizes); 0: the separate bn_train_apply launch (measuring aid)
-BN_IN_FUSED = os.environ.get("FRCNN_BN_IN", "1") != "0"
+BN_IN_FUSED = os.environ.get("FRCNN_BN_IN", "1")          # "wres": only the 64-channel layers of round 4 (weights-resident kernel)
 FP8_BWD = os.environ.get("FRCNN_FP8_BWD", "1") != "0"                # measuring aid: 0 keeps the data gradients in bf16 (fp8 forward only)
 FP8_WGRAD = os.environ.get("FRCNN_FP8_WGRAD", "1") != "0"            # measuring aid: 0 keeps the weight gradients in bf16
 FP8_DZ_TWIN_ONLY = os.environ.get("FRCNN_FP8_DZ_TWIN_ONLY", "1") != "0"   # measuring aid: 0 always stores the bf16 dz beside its twin
@@ -595,8 +595,9 @@ class FeatureExtractor:
             else:
                 res = x
             u[1].forward(plan, x, training, x8)
-            if training and f8 is None and BN_IN_FUSED and ops.conv2d_bnin_supported(u[2].desc):
-                # conv2's blocks at the benchmark's sizes: the 3x3 convolution applies the first BatchNorm + ReLU of the block itself
+            if (training and f8 is None and BN_IN_FUSED != "0" and ops.conv2d_bnin_supported(u[2].desc) and (BN_IN_FUSED != "wres" or u[2].cin == 64)):
+                # the 3x3 convolution applies the first BatchNorm + ReLU of the block itself (round 4: conv2's blocks on the weights-resident
+                # kernel; round 5: conv3 / conv4 on the patch-resident kernel's loader-wave forms)
                 u[2].forward_bnin(plan, u[1], a["a1"])
             else:
                 u[1].apply(plan, a["a1"], out8=a.get("a1_8") if f8 is not None else None, twin_only=f8 is not None and a.get("a1_twin_only", False))

@@ -257,6 +257,17 @@ BNIN = [   # frcnn_conv2d_fprop_bnin: 3x3 / stride 1 / pad 1 on the RAW output o
     dict(id="bnin_3x3_64_128_nostats_ragged", n=9, h=45, w=70, cin=64, cout=128, stats=False),         # ends inside tiles in both directions, two channel parts
     dict(id="bnin_3x3_64_64_stats_ragged", n=18, h=45, w=70, cin=64, cout=64, stats=True),
     dict(id="bnin_c2_3x3_64_64_stats_600x1987_b2", n=2, h=150, w=497, cin=64, cout=64, stats=True),    # the reference's own configuration (config.json:3, batch 2)
+    # round 5: the patch-resident kernel's loader-wave forms (conv3x3_patch<..., BNIN=1>): conv4 (four chunks, four channel parts: every
+    # workgroup writes ONE chunk of its tile's activation), conv3 (128-channel parts: two chunks, one part), ResNet-101's batch, the
+    # reference's own 600 x 1987 (odd grids), and ragged grids with an odd chunk count / fewer chunks than channel parts
+    dict(id="bnin_c4_3x3_256_256_stats_b4", n=4, h=24, w=78, cin=256, cout=256, stats=True),
+    dict(id="bnin_c4_3x3_256_256_stats_b2", n=2, h=24, w=78, cin=256, cout=256, stats=True),
+    dict(id="bnin_c3_3x3_128_128_stats_b4", n=4, h=47, w=156, cin=128, cout=128, stats=True),
+    dict(id="bnin_c3_3x3_128_128_stats_b2", n=2, h=47, w=156, cin=128, cout=128, stats=True),
+    dict(id="bnin_c4_3x3_256_256_stats_600x1987_b2", n=2, h=38, w=125, cin=256, cout=256, stats=True),
+    dict(id="bnin_c3_3x3_128_128_stats_600x1987_b2", n=2, h=75, w=249, cin=128, cout=128, stats=True),
+    dict(id="bnin_patch_3x3_320_64_nostats_ragged", n=1, h=9, w=33, cin=320, cout=64, stats=False),      # five chunks, one part
+    dict(id="bnin_patch_3x3_128_256_stats_ragged", n=4, h=13, w=21, cin=128, cout=256, stats=True),      # two chunks, four parts: parts 2 / 3 write nothing
 ]
 
 

@@ -63,7 +63,7 @@ def _plan_instantiations(monkeypatch, depth, batch, proposals=None, precision="b
 def test_every_plan_instantiation_has_a_parity_case(monkeypatch, ops, depth, batch, proposals):
     used, launches = _plan_instantiations(monkeypatch, depth, batch, proposals)
     covered = conv_cases.covered_instantiations(ops)
-    assert len(used) >= 20 and launches >= 200
+    assert len(used) >= 20 and launches >= 150          # (200 before round 5 folded BatchNorm launches into their consumers)
     missing = sorted(k for k in used if k not in covered)
     assert not missing, "conv kernels of the R%d batch-%d train plan without an oracle-compared GPU case:\n  %s" % (depth, batch, "\n  ".join(missing))
 
@@ -74,7 +74,7 @@ def test_reference_default_plan_instantiations_have_parity_cases(monkeypatch, op
     branches of the 3x3 dispatch than 375 x 1242 takes.  (tests/test_gpu_reference_default.py runs the step itself.)"""
     used, launches = _plan_instantiations(monkeypatch, 50, 2, image_shape=(600, 1987, 3))
     covered = conv_cases.covered_instantiations(ops)
-    assert len(used) >= 20 and launches >= 190
+    assert len(used) >= 20 and launches >= 150
     missing = sorted(k for k in used if k not in covered)
     assert not missing, "conv kernels of the 600x1987 batch-2 train plan without an oracle-compared GPU case:\n  %s" % "\n  ".join(missing)
 
@@ -96,7 +96,7 @@ def test_every_fpn_plan_instantiation_has_a_parity_case(monkeypatch, ops):
     covered = conv_cases.covered_instantiations(ops)
     for batch, precision in ((8, "fp8"), (4, "bf16"), (2, "bf16")):
         used, launches = _plan_instantiations(monkeypatch, 50, batch, precision=precision, topology="fpn")
-        assert launches >= 260           # (round 4: 12 + 4 x 2 launches folded into their neighbours)
+        assert launches >= 220           # (round 4: 12 + 4 x 2 launches folded into their neighbours; round 5: BatchNorm launches into their consumers)
         missing = sorted(k for k in used if k not in covered)
         assert not missing, "conv kernels of the FPN R50 batch-%d %s train plan without an oracle-compared GPU case:\n  %s" % (
             batch, precision, "\n  ".join(missing))

@@ -453,12 +453,18 @@ def test_configs4_workload_fpn_fp8_batch8_full_size():
 
 
 # Bounds of the fp8-vs-bf16 loss difference at configs[4]'s full size, both runs on the SAME proposals and sample indices (teacher
-# forced): absolute for the mean classification losses, relative for the summed regression losses (sums of un-normalised box terms of
-# an untrained head).  PROVISIONAL values of round 4's un-injected first step (rpn_cls 0.00064, rcnn_cls 0.0128; rpn_reg 0.178 of 3.66,
-# rcnn_reg 11.3 of 56.7) x 2 until the injected run's own figures are in (see the measured line in the assertion comments below).
-FP8_LOSS_BOUND = {"rpn_cls": 0.002, "rcnn_cls": 0.03, "rpn_reg": 0.1, "rcnn_reg": 0.25}
-# ... and of the relative difference between two fp8 runs of the same second step (eager vs replayed) on the same proposals
-FP8_RERUN_BOUND = {"rpn_cls": 1e-2, "rcnn_cls": 0.1, "rpn_reg": 0.1, "rcnn_reg": 0.3}
+# forced): 2x what MI355X measures (round 5, steps 0 / 1: rpn_cls 0.00057 / 0.00091 and rcnn_cls 0.063 / 0.079 absolute -- the latter of
+# 6.26 / 5.36: an untrained 8-way head far above ln 8, where the loss is the logit margin itself and carries the fp8 error of the pooled
+# features one to one --; rpn_reg 0.190 of 3.67 / 0.039 of 3.53, rcnn_reg 1.20 of 69.2 / 1.36 of 55.1 relative).  Absolute for the mean
+# classification losses, relative for the summed regression losses.  Round 4 compared UN-injected runs: its rcnn_reg differed by 11.3 of
+# 56.7 (20 %) and needed a bound of 0.4 because the two runs pooled different RoIs; on the same RoIs the difference is 1.7-2.5 %.
+FP8_LOSS_BOUND = {"rpn_cls": 0.002, "rcnn_cls": 0.16, "rpn_reg": 0.1, "rcnn_reg": 0.05}
+# ... and of the relative difference between two fp8 runs of the same second step (eager vs replayed) on the same proposals: 3x the
+# larger of two boxes' measurements (round 5: rpn_cls 8.1e-4 / 5.8e-4, rpn_reg 4.1e-3 / 5.7e-3, rcnn_cls 3.1e-2 / 9.6e-3, rcnn_reg
+# 5.8e-3 / 6.8e-2 -- a SUM of Huber terms over the few foreground rows of an untrained head: the two runs' weights differ by 1e-4 after
+# the first update, under delayed scaling a one-ulp amax change moves every rounding boundary of a tensor).  Round 4, un-injected: rcnn_reg
+# moved by 53 % and was bounded by 2.0.
+FP8_RERUN_BOUND = {"rpn_cls": 2.5e-3, "rpn_reg": 1.7e-2, "rcnn_cls": 0.1, "rcnn_reg": 0.2}
 
 
 def test_call_training_mode_on_the_pyramid(run):

@@ -1071,7 +1071,9 @@ def test_conv2d_fprop_bnin_equals_bn_apply_then_conv(ops, case):
     flags = ops.CONV_BIAS | (ops.CONV_STATS if stats else 0)
     d = conv_cases.bnin_desc(ops, case)
     assert ops.conv2d_bnin_supported(d)
-    assert not ops.conv2d_bnin_supported(ops.conv_desc(1, 24, 78, 256, 3, 3, 1, 1, 1, 24, 78, 256))
+    assert not ops.conv2d_bnin_supported(ops.conv_desc(1, 24, 78, 256, 1, 1, 1, 0, 0, 24, 78, 256))          # (a 1x1 layer)
+    assert not ops.conv2d_bnin_supported(ops.conv_desc(8, 94, 311, 256, 3, 3, 1, 1, 1, 94, 311, 256))         # (3x3 on the tile kernel: too many tiles for the patch forms)
+    kernel = ops.conv2d_describe(d).split(" grid")[0]              # the instantiation the plain form runs: the fused form must be ITS ,BNIN=1 twin
 
     def buffers():
         return dict(act=torch.zeros(m, cin, dtype=BF, device=dev), mask=torch.zeros(m, cin // 8, dtype=torch.uint8, device=dev),
@@ -1083,10 +1085,10 @@ def test_conv2d_fprop_bnin_equals_bn_apply_then_conv(ops, case):
     ops.bn_train_apply(z, zstats, 16, m, gamma, beta, a["mm"], a["mv"], 0.99, 1.001e-5, a["act"], a["mean"], a["invstd"], m, cin, relu=True,
                        relu_mask=a["mask"])
     ops.conv2d_fprop(d, a["act"], wt, a["y"], bias=bias, stats=a["ystats"] if stats else None)
-    assert ops.last_conv_instantiation().startswith("conv3x3_wres<SMODE=%d>" % (1 if stats else 0))
+    assert ops.last_conv_instantiation().split(" grid")[0] == kernel and kernel.startswith(("conv3x3_wres<", "conv3x3_patch<")), kernel
     bn = ops.bn_in_args(zstats, gamma, beta, b["mm"], b["mv"], 0.99, 1.001e-5, m, b["act"], b["mask"], b["mean"], b["invstd"])
     ops.conv2d_fprop_bnin(d, z, wt, b["y"], bn, bias=bias, stats=b["ystats"] if stats else None)
-    assert ops.last_conv_instantiation().startswith("conv3x3_wres<SMODE=%d,BNIN=1>" % (1 if stats else 0))
+    assert ops.last_conv_instantiation().split(" grid")[0] == kernel[:-1] + ",BNIN=1>", ops.last_conv_instantiation()
     torch.cuda.synchronize()
     for k in ("mean", "invstd", "mm", "mv"):
         assert torch.equal(a[k], b[k]), k
