@@ -84,6 +84,29 @@ __device__ __forceinline__ void lds_add_f32(unsigned addr, float v) {
     asm volatile("ds_add_f32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
+// ReLU bit mask of 8 stored bf16 activations (bit e: element e > 0), as bn_train_apply_kernel derives it
+__device__ __forceinline__ unsigned relu_bits8(const u32x4 pk) {
+    unsigned m = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+        m |= ((pk[w2] & 0x7FFFu) != 0u && !(pk[w2] & 0x8000u)) ? (1u << (2 * w2)) : 0u;
+        m |= ((pk[w2] & 0x7FFF0000u) != 0u && !(pk[w2] & 0x80000000u)) ? (1u << (2 * w2 + 1)) : 0u;
+    }
+    return m;
+}
+// Eight CONSECUTIVE lanes hold the mask bytes of the eight channel vectors of one row (this lane: vector c8): the row's 8 mask bytes as two
+// dwords, valid in all eight lanes -- one 8-byte store per row instead of eight byte stores (partial-line byte writes are what the
+// BatchNorm kernels avoid the same way).  Every lane of the group must call it.
+__device__ __forceinline__ u32x2 pool_mask8(const unsigned m, const int c8) {
+    unsigned lo = c8 < 4 ? m << (8 * c8) : 0u, hi = c8 >= 4 ? m << (8 * (c8 - 4)) : 0u;
+#pragma unroll
+    for (int sh = 1; sh < 8; sh <<= 1) {
+        lo |= (unsigned)__shfl_xor((int)lo, sh);
+        hi |= (unsigned)__shfl_xor((int)hi, sh);
+    }
+    return u32x2{lo, hi};
+}
+
 constexpr unsigned kOob = 0xFFFFFFF0u;       // voffset beyond every buffer: the hardware range check returns zeros
 
 inline int num_cus() {

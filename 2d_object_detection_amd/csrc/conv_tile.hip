@@ -16,9 +16,18 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, bool KWS, bool FIX, int F8>
+// BNIN (frcnn_conv2d_fprop_bnin on a 1x1 / stride-1 layer: the third convolution of a bottleneck block): the A operand is the RAW output z of the
+// previous convolution and this kernel applies that layer's training-mode BatchNorm + ReLU itself.  Scale / shift of the Cin input channels
+// come from the f64 statistics slots (one channel per thread, bn_train_apply_kernel's additions in its order: same bits) into LDS behind
+// everything else; every landed A slice is transformed IN PLACE by all 512 threads (two 16-byte slots each) between the slice barrier and
+// one more barrier -- an element is transformed once per workgroup, not once per wave column as a fragment-register form would -- and the
+// activation + its ReLU bit mask, which the backward pass reads, leave from there: rows are dealt to the channel-part workgroups of a
+// pixel tile by (row / 8 + slice) mod parts, a wave-uniform rule, with buffer stores whose masked lanes go out of range, so every wave
+// knows how many stores it has in flight behind the next slice's DMA and the counted vmcnt waits stay exact.
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32, bool KWS, bool FIX, int F8, bool BNIN = false>
 __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(!BNIN || (LIN && S == 2 && BM == 128 && BK == 64 && SMODE != 2 && !F32 && !KWS && !FIX && !F8), "BatchNorm on the input side: 1x1 stride-1 forward layers, two-slot ring");
     // SMODE 0: plain, 1: BatchNorm statistics of the output (forward), 2: BatchNorm-backward reduce of the consumer layer
     constexpr bool STATS = SMODE == 1, RED = SMODE == 2;
     // 8 waves as a 2 x 4 grid (a 4-wave variant with four times the MFMA work per wave and a software-pipelined fragment-read
@@ -72,6 +81,7 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;                  // [S A tiles][S B tiles]
     unsigned char* stage = smem + STAGE_OFF;     // [BM][ROWB]
+    float* s_scale = reinterpret_cast<float*>(smem + BIG + 2 * BN * 4);      // BNIN: [Cin] scale, [Cin] shift
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -459,6 +469,116 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     }
     int to_issue = total_slices - (total_slices < S - 1 ? total_slices : S - 1);
     int slot = 0;
+    int bn_st = 0;                               // BNIN: stores this wave issued after its most recent DMA issue
+    // wait until the DMA issued `base + bn_st` vector-memory operations ago has landed (base: epilogue stores younger than it)
+    auto wait_dma = [&](const int base) {
+        switch (base + bn_st) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    const __amdgpu_buffer_rsrc_t rsrc_act = __builtin_amdgcn_make_buffer_rsrc(BNIN ? (void*)p.bnin_act : (void*)p.y, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_msk = __builtin_amdgcn_make_buffer_rsrc(BNIN ? (void*)p.bnin_mask : (void*)p.y, 0, p.x_bytes >> 4, 0x00020000);
+    if (BNIN) {
+        if (tid < p.Cin) {
+            const int c = tid;
+            double a[4][FRCNN_STAT_SLOTS / 4], b[4][FRCNN_STAT_SLOTS / 4];
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int k = 0; k < FRCNN_STAT_SLOTS / 4; ++k) {
+                    a[sl][k] = p.bnin_part[((long long)(sl + 4 * k) * 2) * p.Cin + c];
+                    b[sl][k] = p.bnin_part[((long long)(sl + 4 * k) * 2 + 1) * p.Cin + c];
+                }
+            double ps[4], pq[4];
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < FRCNN_STAT_SLOTS / 4; ++k) { s0 += a[sl][k]; s1 += b[sl][k]; }
+                ps[sl] = s0;
+                pq[sl] = s1;
+            }
+            const double sum = ps[0] + ps[1] + ps[2] + ps[3];
+            const double ssq_ = pq[0] + pq[1] + pq[2] + pq[3];
+            const double mean = sum * p.bnin_inv_count;
+            double var = ssq_ * p.bnin_inv_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)p.bnin_eps));
+            const float sc = p.bnin_gamma[c] * invstd;
+            const float sh = p.bnin_beta[c] - (float)mean * sc;
+            // (asm forms: a DS write hipcc emits itself waits for ALL pending LDS-DMA)
+            asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(s_scale + c)), "v"(sc) : "memory");
+            asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(s_scale + p.Cin + c)), "v"(sh) : "memory");
+            if (blockIdx.x == 0) {
+                p.bnin_mean[c] = (float)mean;
+                p.bnin_invstd[c] = invstd;
+                p.bnin_mm[c] = p.bnin_mm[c] * p.bnin_momentum + (float)mean * (1.f - p.bnin_momentum);
+                p.bnin_mv[c] = p.bnin_mv[c] * p.bnin_momentum + (float)(var * p.bnin_unbias) * (1.f - p.bnin_momentum);
+            }
+        }
+        // (workgroup 0's four stores are YOUNGER than the slices issued so far: operations beyond a wait's count only make it conservative)
+    }
+    // BNIN: BatchNorm + ReLU of the landed A slice `ks` of the tile at row m0, in place (slot position sp of row r holds channel vector
+    // sp ^ (r & 7) of the slice), and this workgroup's share of the activation / mask rows
+    auto bnin_slice = [&](const int slot_, const int ks, const int m0_) {
+        unsigned char* cA = ring + slot_ * A_BYTES;
+        const unsigned abase = lds_addr(cA);
+        const int sp = tid & 7, r0 = tid >> 3;
+        const int c8 = sp ^ (r0 & 7);
+        const float* csc = s_scale + ks * 64 + c8 * 8;
+        const float* csh = csc + p.Cin;
+        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(csc), sc1 = *reinterpret_cast<const f32x4*>(csc + 4);
+        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(csh), sh1 = *reinterpret_cast<const f32x4*>(csh + 4);
+#pragma unroll
+        for (int k = 0; k < BM / 64; ++k) {
+            const int r = r0 + 64 * k;
+#ifndef FRCNN_BNIN_NOMATH
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(cA + r * 128 + sp * 16);
+            float x[8];
+            unpack8(raw, x);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] = fmaxf(x[e] * sc0[e] + sh0[e], 0.f);
+                x[4 + e] = fmaxf(x[4 + e] * sc1[e] + sh1[e], 0.f);
+            }
+            const u32x4 pk = pack8(x);
+            asm volatile("ds_write_b128 %0, %1" ::"v"(abase + (unsigned)(r * 128 + sp * 16)), "v"(pk) : "memory");
+#else
+            const u32x4 pk = u32x4{(unsigned)r, 0u, 0u, 0u};
+#endif
+#ifndef FRCNN_BNIN_NOSTORE
+            if (((wave + 8 * k + ks) % p.tiles_n) == tn) {          // (r >> 3 == wave + 8 k: wave-uniform)
+                const bool ok = m0_ + r < p.M;
+                const unsigned row = (unsigned)(m0_ + r);
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_act, ok ? (row * (unsigned)p.Cin + (unsigned)(ks * 64 + c8 * 8)) * 2u : kOob, 0, 0);
+                bn_st += 1;
+#ifndef FRCNN_BNIN_NOMASK
+#ifndef FRCNN_BNIN_POOLMASK
+                // one byte per lane.  (Pooling the eight bytes of a row with cross-lane shuffles into one 8-byte store -- what the patch /
+                // weights-resident forms do, where no LDS-DMA is pending in the transforming waves -- measured SLOWER here: 64 -> 256 at
+                // M = 116,936 36.0 against 32.2 us, 128 -> 512 28.9 against 27.6: the shuffles are DS operations behind the ring's DMA)
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)relu_bits8(pk), rsrc_msk, ok ? row * (unsigned)(p.Cin >> 3) + (unsigned)(ks * 8 + c8) : kOob, 0, 0);
+#else
+                const u32x2 mk = pool_mask8(relu_bits8(pk), c8);
+                __builtin_amdgcn_raw_buffer_store_b64(mk, rsrc_msk, (ok && sp == 0) ? row * (unsigned)(p.Cin >> 3) + (unsigned)(ks * 8) : kOob, 0, 0);
+#endif
+                bn_st += 1;
+#endif
+            }
+#endif
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
     for (int t = 0; t < tile_count; ++t) {
         const int m0 = (tm_begin + t) * BM;
 #pragma unroll
@@ -503,12 +623,14 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
 #pragma unroll
                 for (int c = 0; c < S; ++c) {
                     FRCNN_KSTAMP(nk - left + c, 0);
-                    FRCNN_WAIT_IMM((S - 2) * LC);
+                    if (BNIN) wait_dma(0);
+                    else FRCNN_WAIT_IMM((S - 2) * LC);
                     FRCNN_KSTAMP(nk - left + c, 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's fragment reads of the slot refilled next have completed
                     __builtin_amdgcn_s_barrier();        // slice landed for everyone; everyone finished reading the slot refilled next
                     FRCNN_KSTAMP(nk - left + c, 2);
                     issue_slice((c + S - 1) % S);
+                    if (BNIN) { bn_st = 0; bnin_slice(c, nk - left + c, m0); }
                     FRCNN_KSTAMP(nk - left + c, 3);
                     mfma_slice(c);
                     FRCNN_KSTAMP(nk - left + c, 4);
@@ -517,7 +639,11 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
                 left -= S;
                 continue;
             }
-            if (after_epilogue) FRCNN_WAIT_IMM(ST_IT);                     // (MULTI: S == 2)
+            if (BNIN) {
+                if (after_epilogue) wait_dma(ST_IT);                       // (the previous tile's epilogue stores are younger than this slice's DMA)
+                else if (to_issue > 0) wait_dma(0);
+                else FRCNN_WAIT_IMM(0);
+            } else if (after_epilogue) FRCNN_WAIT_IMM(ST_IT);              // (MULTI: S == 2)
             else if (to_issue > 0) FRCNN_WAIT_IMM((S - 2) * LC);
             else FRCNN_WAIT_IMM(0);
             after_epilogue = false;
@@ -526,7 +652,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
             if (to_issue > 0) {
                 issue_slice(slot == 0 ? S - 1 : slot - 1);
                 --to_issue;
+                bn_st = 0;
             }
+            if (BNIN) bnin_slice(slot, nk - left, m0);
             mfma_slice(slot);
             slot = slot + 1 == S ? 0 : slot + 1;
             --left;
@@ -1246,16 +1374,13 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
             u32x4 pk = pack8(x);
             if (!valid) pk = u32x4{0u, 0u, 0u, 0u};
             asm volatile("ds_write_b128 %0, %1" ::"v"(pbase + (unsigned)(q * 128 + slot * 16)), "v"(pk) : "memory");
-            if (mine && valid && py >= 1 && py <= TH && px >= 1 && px <= TW) {      // this tile's own pixels: the activation and its mask
-                const long long pix = ((long long)img * p.Hi + iy) * p.Wi + ix;
-                *reinterpret_cast<u32x4*>(p.bnin_act + pix * p.Cin + s * 64 + c8 * 8) = pk;
-                unsigned m = 0;
-#pragma unroll
-                for (int w2 = 0; w2 < 4; ++w2) {
-                    m |= ((pk[w2] & 0x7FFFu) != 0u && !(pk[w2] & 0x8000u)) ? (1u << (2 * w2)) : 0u;
-                    m |= ((pk[w2] & 0x7FFF0000u) != 0u && !(pk[w2] & 0x80000000u)) ? (1u << (2 * w2 + 1)) : 0u;
+            if (mine) {                          // (workgroup-uniform) this tile's own pixels: the activation and its mask
+                const u32x2 mk = pool_mask8(relu_bits8(pk), c8);      // the row's eight mask bytes of this chunk: one 8-byte store by its first lane
+                if (valid && py >= 1 && py <= TH && px >= 1 && px <= TW) {
+                    const long long pix = ((long long)img * p.Hi + iy) * p.Wi + ix;
+                    *reinterpret_cast<u32x4*>(p.bnin_act + pix * p.Cin + s * 64 + c8 * 8) = pk;
+                    if (slot == 0) *reinterpret_cast<u32x2*>(p.bnin_mask + pix * (p.Cin >> 3) + s * 8) = mk;
                 }
-                p.bnin_mask[pix * (p.Cin >> 3) + s * 8 + c8] = (unsigned char)m;
             }
         }
     };
@@ -1749,16 +1874,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wres_kernel(const ConvParams p
                 u32x4 pk = pack8(x);
                 if (!valid) pk = u32x4{0u, 0u, 0u, 0u};
                 asm volatile("ds_write_b128 %0, %1" ::"v"(pbase + (unsigned)(q * 128 + slot * 16)), "v"(pk) : "memory");
-                if (tn == 0 && valid && py >= 1 && py <= TH && px >= 1 && px <= TW) {      // this tile's own pixels: the activation and its mask
-                    const long long pix = ((long long)img_t * p.Hi + iy) * p.Wi + ix;
-                    *reinterpret_cast<u32x4*>(p.bnin_act + pix * 64 + c8 * 8) = pk;
-                    unsigned m = 0;
-#pragma unroll
-                    for (int w2 = 0; w2 < 4; ++w2) {
-                        m |= ((pk[w2] & 0x7FFFu) != 0u && !(pk[w2] & 0x8000u)) ? (1u << (2 * w2)) : 0u;
-                        m |= ((pk[w2] & 0x7FFF0000u) != 0u && !(pk[w2] & 0x80000000u)) ? (1u << (2 * w2 + 1)) : 0u;
+                if (tn == 0) {                   // (workgroup-uniform) this tile's own pixels: the activation and its mask
+                    const u32x2 mk = pool_mask8(relu_bits8(pk), c8);      // the row's eight mask bytes: one 8-byte store by its first lane
+                    if (valid && py >= 1 && py <= TH && px >= 1 && px <= TW) {
+                        const long long pix = ((long long)img_t * p.Hi + iy) * p.Wi + ix;
+                        *reinterpret_cast<u32x4*>(p.bnin_act + pix * 64 + c8 * 8) = pk;
+                        if (slot == 0) *reinterpret_cast<u32x2*>(p.bnin_mask + pix * 8) = mk;
                     }
-                    p.bnin_mask[pix * 8 + c8] = (unsigned char)m;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2058,22 +2180,22 @@ int launch_wres(ConvParams p, hipStream_t s, const int n_img) {
 
 unsigned long long* g_stamp_buffer = nullptr;    // FRCNN_STAMPS builds: set through frcnn_debug_set_stamp_buffer (tools/conv_stamps.py)
 
-template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false, bool FIX = false, int F8 = 0>
+template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false, bool FIX = false, int F8 = 0, bool BNIN = false>
 int launch_tile(const ConvParams& p, hipStream_t s) {
     constexpr int ring = KWS ? 2 * 3 * 8 * 1024 + S * BN * BK * 2 : S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
-    constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4;
+    constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4 + (BNIN ? 2 * 512 * 4 : 0);   // BNIN: + scale / shift of <= 512 input channels
     static_assert(smem <= 163840, "LDS budget");
     static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
-    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8>), smem) != 0) {
+    if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8, BNIN>), smem) != 0) {
         frcnn_set_error("frcnn_conv2d_fprop: cannot reserve %d B of LDS", smem);
         return FRCNN_EINVAL;
     }
     const int grid_x = FIX ? ((2 * p.items + 15) / 16) * 16 : p.items;      // FIX: two halves per tile, whole pairs per XCD
-    snprintf(g_last_inst, sizeof(g_last_inst), "conv_tile<BM=%d,BN=%d,BK=%d,S=%d,LIN=%d,SMODE=%d,OCC=%d,MULTI=%d,F32=%d,KWS=%d%s%s> grid=%dx%d tpb=%d",
-             BM, BN, BK, S, (int)LIN, SMODE, OCC, (int)MULTI, (int)F32, (int)KWS, FIX ? ",FIX=1" : "", F8 == 1 ? ",F8=1" : F8 == 2 ? ",F8=2" : "", grid_x, F32 ? p.split : 1,
-             p.tiles_per_block);
+    snprintf(g_last_inst, sizeof(g_last_inst), "conv_tile<BM=%d,BN=%d,BK=%d,S=%d,LIN=%d,SMODE=%d,OCC=%d,MULTI=%d,F32=%d,KWS=%d%s%s%s> grid=%dx%d tpb=%d",
+             BM, BN, BK, S, (int)LIN, SMODE, OCC, (int)MULTI, (int)F32, (int)KWS, FIX ? ",FIX=1" : "", F8 == 1 ? ",F8=1" : F8 == 2 ? ",F8=2" : "", BNIN ? ",BNIN=1" : "",
+             grid_x, F32 ? p.split : 1, p.tiles_per_block);
     if (p.dry_run) return FRCNN_OK;              // frcnn_conv2d_describe: the dispatch decision only
-    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8>), dim3(grid_x, F32 ? p.split : 1), dim3(512), smem, s, p);
+    hipLaunchKernelGGL((conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8, BNIN>), dim3(grid_x, F32 ? p.split : 1), dim3(512), smem, s, p);
     FRCNN_CHECK_LAUNCH("frcnn_conv2d_fprop");
     return FRCNN_OK;
 }
@@ -2081,6 +2203,22 @@ int launch_tile(const ConvParams& p, hipStream_t s) {
 template <int BM, int BN, int BK, int S, int OCC, bool MULTI, bool FIX = false>
 int launch_tile_flags(const ConvParams& p, hipStream_t s) {
     const int smode = (p.flags & FRCNN_CONV_STATS) ? 1 : (p.red_part ? 2 : 0);
+    if (p.bnin_part) {
+        // the input layer's BatchNorm + ReLU applied to the landed A slices (conv_tile_kernel, BNIN): 1x1 / stride-1 forward layers on the
+        // two-slot 128-row forms
+        if constexpr (S == 2 && BM == 128 && BK == 64 && !FIX) {
+            if (!p.linear_a || smode == 2 || p.f8_x_scale || p.Cin > 512 || p.in_pix_stride != p.Cin) {
+                frcnn_set_error("conv2d_fprop_bnin(1x1): dense 1x1 / stride-1 forward layers with at most 512 input channels");
+                return FRCNN_EINVAL;
+            }
+            constexpr int O = OCC > 2 ? 2 : OCC;    // (the transform pass does not fit the 80 VGPRs of three workgroups per CU: 10 would spill)
+            if (smode == 1) return launch_tile<BM, BN, BK, S, true, 1, O, MULTI, false, false, false, 0, true>(p, s);
+            return launch_tile<BM, BN, BK, S, true, 0, O, MULTI, false, false, false, 0, true>(p, s);
+        } else {
+            frcnn_set_error("conv2d_fprop_bnin(1x1): no BatchNorm-in form of the %d x %d x %d tile with %d ring slots", BM, BN, BK, S);
+            return FRCNN_EINVAL;
+        }
+    }
     if (p.f8_x_scale) {
         // fp8 operands: forward convolutions (x e4m3; with or without statistics) and data gradients (x e5m2; plain or with the fused
         // BatchNorm-backward reduce)
@@ -2460,7 +2598,7 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     // 4.053 -> 4.105 ms.  The statistics form stays compiled (FRCNN_SWEEP builds: FRCNN_STREAM_1X1_STATS=1) for the record.
     bool use_stream = p.linear_a && p.direct_out && (d->cin == 64 || d->cin == 128) && d->in_pix_stride == d->cin && !(flags & FRCNN_CONV_STATS) &&
                   !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_RELU | FRCNN_CONV_STATS | FRCNN_CONV_WGRAD_ACCUMULATE)) && !red && !f8_x_scale &&
-                  !d->workspace && M >= 4096;
+                  !d->workspace && M >= 4096 && !bn_in;
     if (use_stream) use_stream = d->cin == 64 ? d->cout % 128 == 0 || d->cout == 64 : d->cout % 64 == 0;
 #ifdef FRCNN_SWEEP
     if (const char* e = getenv("FRCNN_STREAM_1X1_OLD")) { if (atoi(e)) use_stream = false; }
@@ -2513,7 +2651,10 @@ int conv2d_fprop_impl(const frcnn_conv_desc* d, const frcnn_bf16* x, const frcnn
     if (const char* e = getenv("FRCNN_WRES")) wres_on = patch && d->cin == 64 && atoi(e) != 0;
 #endif
     bool patch_bnin = false;
-    if (bn_in && !wres_on) {
+    // ... a 1x1 / stride-1 layer (the block's third convolution) takes the BatchNorm of its input on the tile kernel's two-slot forms
+    const bool tile_bnin = bn_in && !patch && p.linear_a && d->kh == 1 && d->in_pix_stride == d->cin && d->cin % 64 == 0 && d->cin <= 512 && !red && !f8_x_scale &&
+                           !d->workspace && !(flags & ~(FRCNN_CONV_BIAS | FRCNN_CONV_RELU | FRCNN_CONV_STATS));
+    if (bn_in && !wres_on && !tile_bnin) {
         // ... or on the patch-resident kernel's loader-wave forms (conv3 / conv4 at the benchmark's sizes)
         patch_bnin = patch_on && d->in_pix_stride == d->cin && d->cin <= 512 && !red && (patch_bn == 128 || patch_sb == 4);
 #ifdef FRCNN_SWEEP

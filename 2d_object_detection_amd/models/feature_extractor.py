@@ -35,7 +35,15 @@ def _out_hw(h, w):
 FP8_MIN_STAGE = int(os.environ.get("FRCNN_FP8_MIN_STAGE", "2"))      # first ResNet stage whose tensors get fp8 twins (measuring aid: 3 = conv3 on)
 # The 3x3 convolution of a bottleneck block applies the block's first BatchNorm + ReLU itself where the C ABI offers it
 # (frcnn_conv2d_fprop_bnin: conv2's layers at the benchmark's sizes); 0: the separate bn_train_apply launch (measuring aid)
-BN_IN_FUSED = os.environ.get("FRCNN_BN_IN", "1")          # "wres": only the 64-channel layers of round 4 (weights-resident kernel)
+# Which convolutions apply the BatchNorm + ReLU of their INPUT layer themselves (frcnn_conv2d_fprop_bnin): "0" none, "wres" round 4's 64-channel
+# 3x3 layers (weights-resident kernel), "3x3" (default) those + the 3x3 layers on the patch-resident kernel (conv3 / conv4), "1" also the 1x1
+# layer behind a block's second BatchNorm (tile kernel).  Measured on MI355X (round 5; tools/bnin_bench.py, isolated graph replays, us,
+# bn_train_apply + convolution back to back -> fused): 3x3 conv2 31.5 -> 25.5, conv3 24.8 -> 21.5, conv4 20.4 -> 20.6; 1x1 conv2 33.7 -> 32.2,
+# conv3 25.7 -> 27.6, conv4 20.0 -> 20.3 (byte mask stores; 36.0 / 28.9 / 21.5 with the mask bytes pooled by cross-lane shuffles).  In the step
+# (same-box A/B, ms): "wres" 3.885 -> "3x3" 3.858; "3x3" 3.903 / 3.909 -> "1" 3.932 / 3.903.  The in-place transform of a landed tile is VALU
+# work that EVERY channel-part workgroup of a pixel tile repeats (4 - 8 x for the 1x1 layers: 2.5 - 5 us per launch) and the ReLU bit mask
+# costs as much again (1.3 - 4 us): on the 1x1 layers that is what the 5 - 11 us BatchNorm launch cost.  DESIGN.md section 0.6.
+BN_IN_FUSED = os.environ.get("FRCNN_BN_IN", "3x3")
 FP8_BWD = os.environ.get("FRCNN_FP8_BWD", "1") != "0"                # measuring aid: 0 keeps the data gradients in bf16 (fp8 forward only)
 FP8_WGRAD = os.environ.get("FRCNN_FP8_WGRAD", "1") != "0"            # measuring aid: 0 keeps the weight gradients in bf16
 FP8_DZ_TWIN_ONLY = os.environ.get("FRCNN_FP8_DZ_TWIN_ONLY", "1") != "0"   # measuring aid: 0 always stores the bf16 dz beside its twin
@@ -595,15 +603,20 @@ class FeatureExtractor:
             else:
                 res = x
             u[1].forward(plan, x, training, x8)
-            if (training and f8 is None and BN_IN_FUSED != "0" and ops.conv2d_bnin_supported(u[2].desc) and (BN_IN_FUSED != "wres" or u[2].cin == 64)):
+            bnin = training and f8 is None and BN_IN_FUSED != "0"
+            if bnin and ops.conv2d_bnin_supported(u[2].desc) and (BN_IN_FUSED != "wres" or u[2].cin == 64):
                 # the 3x3 convolution applies the first BatchNorm + ReLU of the block itself (round 4: conv2's blocks on the weights-resident
                 # kernel; round 5: conv3 / conv4 on the patch-resident kernel's loader-wave forms)
                 u[2].forward_bnin(plan, u[1], a["a1"])
             else:
                 u[1].apply(plan, a["a1"], out8=a.get("a1_8") if f8 is not None else None, twin_only=f8 is not None and a.get("a1_twin_only", False))
                 u[2].forward(plan, a["a1"], training, a.get("a1_8") if f8 is not None else None)
-            u[2].apply(plan, a["a2"], out8=a.get("a2_8") if f8 is not None else None, twin_only=f8 is not None and a.get("a2_twin_only", False))
-            u[3].forward(plan, a["a2"], training, a.get("a2_8") if f8 is not None else None)
+            if bnin and BN_IN_FUSED not in ("wres", "3x3") and ops.conv2d_bnin_supported(u[3].desc):
+                # ... and the block's third convolution (1x1) its second BatchNorm + ReLU (round 5: the tile kernel transforms every landed A slice)
+                u[3].forward_bnin(plan, u[2], a["a2"])
+            else:
+                u[2].apply(plan, a["a2"], out8=a.get("a2_8") if f8 is not None else None, twin_only=f8 is not None and a.get("a2_twin_only", False))
+                u[3].forward(plan, a["a2"], training, a.get("a2_8") if f8 is not None else None)
             o8 = a.get("out_8") if f8 is not None else None
             if fused_shortcut:
                 u[3].apply(plan, a["out"], relu=True, dual=u[0], out8=o8)

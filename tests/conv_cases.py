@@ -268,11 +268,25 @@ BNIN = [   # frcnn_conv2d_fprop_bnin: 3x3 / stride 1 / pad 1 on the RAW output o
     dict(id="bnin_c3_3x3_128_128_stats_600x1987_b2", n=2, h=75, w=249, cin=128, cout=128, stats=True),
     dict(id="bnin_patch_3x3_320_64_nostats_ragged", n=1, h=9, w=33, cin=320, cout=64, stats=False),      # five chunks, one part
     dict(id="bnin_patch_3x3_128_256_stats_ragged", n=4, h=13, w=21, cin=128, cout=256, stats=True),      # two chunks, four parts: parts 2 / 3 write nothing
+    # round 5: 1x1 / stride-1 layers on the tile kernel (conv_tile<..., BNIN=1>: every landed A slice transformed in place) -- the third
+    # convolution of a bottleneck block at the benchmark's sizes (tile runs of 8 / 4 with one / two slices; 128 x 128 tiles with four),
+    # ResNet-101's batch (the three-workgroup form's shapes run the two-workgroup BNIN twin), the reference's 600 x 1987, tails
+    dict(id="bnin_c2_1x1_64_256_stats_b4", n=4, h=94, w=311, cin=64, cout=256, stats=True, k=1),
+    dict(id="bnin_c3_1x1_128_512_stats_b4", n=4, h=47, w=156, cin=128, cout=512, stats=True, k=1),
+    dict(id="bnin_c4_1x1_256_1024_stats_b4", n=4, h=24, w=78, cin=256, cout=1024, stats=True, k=1),
+    dict(id="bnin_c4_1x1_256_1024_stats_b2", n=2, h=24, w=78, cin=256, cout=1024, stats=True, k=1),
+    dict(id="bnin_c2_1x1_64_256_stats_600x1987_b2", n=2, h=150, w=497, cin=64, cout=256, stats=True, k=1),
+    dict(id="bnin_c3_1x1_128_512_stats_600x1987_b2", n=2, h=75, w=249, cin=128, cout=512, stats=True, k=1),
+    dict(id="bnin_c4_1x1_256_1024_stats_600x1987_b2", n=2, h=38, w=125, cin=256, cout=1024, stats=True, k=1),
+    dict(id="bnin_1x1_64_256_stats_tail", n=2, h=13, w=17, cin=64, cout=256, stats=True, k=1),           # M = 442: four tiles, the last with 58 rows
+    dict(id="bnin_1x1_192_64_nostats_tail", n=3, h=9, w=11, cin=192, cout=64, stats=False, k=1),         # three slices, one channel part
+    dict(id="bnin_1x1_128_384_relu_nostats", n=1, h=40, w=33, cin=128, cout=384, stats=False, k=1),      # six parts (not a power of two)
 ]
 
 
 def bnin_desc(ops, c):
-    return ops.conv_desc(c["n"], c["h"], c["w"], c["cin"], 3, 3, 1, 1, 1, c["h"], c["w"], c["cout"], flags=ops.CONV_BIAS | (ops.CONV_STATS if c["stats"] else 0))
+    k = c.get("k", 3)
+    return ops.conv_desc(c["n"], c["h"], c["w"], c["cin"], k, k, 1, k // 2, k // 2, c["h"], c["w"], c["cout"], flags=ops.CONV_BIAS | (ops.CONV_STATS if c["stats"] else 0))
 
 
 def covered_instantiations(ops):

@@ -1066,14 +1066,17 @@ def test_conv2d_fprop_bnin_equals_bn_apply_then_conv(ops, case):
         rows = slice(s_ * m // 16, (s_ + 1) * m // 16)
         zstats[s_, 0], zstats[s_, 1] = zf[rows].sum(0), (zf[rows] * zf[rows]).sum(0)
     gamma, beta = (torch.rand(cin, generator=g) + 0.5).to(dev), (torch.randn(cin, generator=g) * 0.2).to(dev)
-    wt = (torch.randn(cout, 3, 3, cin, generator=g) / 24.0).to(BF).to(dev)
+    kk = case.get("k", 3)
+    wt = (torch.randn(cout, kk, kk, cin, generator=g) / (8.0 * kk)).to(BF).to(dev)
     bias = torch.randn(cout, generator=g).to(dev)
     flags = ops.CONV_BIAS | (ops.CONV_STATS if stats else 0)
     d = conv_cases.bnin_desc(ops, case)
     assert ops.conv2d_bnin_supported(d)
-    assert not ops.conv2d_bnin_supported(ops.conv_desc(1, 24, 78, 256, 1, 1, 1, 0, 0, 24, 78, 256))          # (a 1x1 layer)
+    assert not ops.conv2d_bnin_supported(ops.conv_desc(1, 24, 78, 1024, 1, 1, 1, 0, 0, 24, 78, 256))         # (a 1x1 layer with 16 slices: three-slot ring)
+    assert not ops.conv2d_bnin_supported(ops.conv_desc(4, 47, 156, 256, 1, 1, 2, 0, 0, 24, 78, 512))         # (a strided 1x1 layer)
     assert not ops.conv2d_bnin_supported(ops.conv_desc(8, 94, 311, 256, 3, 3, 1, 1, 1, 94, 311, 256))         # (3x3 on the tile kernel: too many tiles for the patch forms)
-    kernel = ops.conv2d_describe(d).split(" grid")[0]              # the instantiation the plain form runs: the fused form must be ITS ,BNIN=1 twin
+    # the instantiation the plain form runs: the fused form must be ITS ,BNIN=1 twin (the three-workgroup tile form's twin holds two per CU)
+    kernel = ops.conv2d_describe(d).split(" grid")[0]
 
     def buffers():
         return dict(act=torch.zeros(m, cin, dtype=BF, device=dev), mask=torch.zeros(m, cin // 8, dtype=torch.uint8, device=dev),
@@ -1085,10 +1088,10 @@ def test_conv2d_fprop_bnin_equals_bn_apply_then_conv(ops, case):
     ops.bn_train_apply(z, zstats, 16, m, gamma, beta, a["mm"], a["mv"], 0.99, 1.001e-5, a["act"], a["mean"], a["invstd"], m, cin, relu=True,
                        relu_mask=a["mask"])
     ops.conv2d_fprop(d, a["act"], wt, a["y"], bias=bias, stats=a["ystats"] if stats else None)
-    assert ops.last_conv_instantiation().split(" grid")[0] == kernel and kernel.startswith(("conv3x3_wres<", "conv3x3_patch<")), kernel
+    assert ops.last_conv_instantiation().split(" grid")[0] == kernel and kernel.startswith(("conv3x3_wres<", "conv3x3_patch<", "conv_tile<")), kernel
     bn = ops.bn_in_args(zstats, gamma, beta, b["mm"], b["mv"], 0.99, 1.001e-5, m, b["act"], b["mask"], b["mean"], b["invstd"])
     ops.conv2d_fprop_bnin(d, z, wt, b["y"], bn, bias=bias, stats=b["ystats"] if stats else None)
-    assert ops.last_conv_instantiation().split(" grid")[0] == kernel[:-1] + ",BNIN=1>", ops.last_conv_instantiation()
+    assert ops.last_conv_instantiation().split(" grid")[0] == kernel[:-1].replace("OCC=3", "OCC=2") + ",BNIN=1>", ops.last_conv_instantiation()
     torch.cuda.synchronize()
     for k in ("mean", "invstd", "mm", "mv"):
         assert torch.equal(a[k], b[k]), k
