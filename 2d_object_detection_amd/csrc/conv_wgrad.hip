@@ -1074,6 +1074,11 @@ extern "C" const char* frcnn_conv2d_wgrad_describe_fp8(const frcnn_conv_desc* d)
     return rc == FRCNN_OK ? frcnn_last_conv_instantiation() : nullptr;
 }
 
+// A/B builds: FRCNN_DEFINES=FRCNN_WGRAD_LDS_PAD=<bytes> makes every grouped launch REQUEST at least that much LDS per workgroup (84 KB: one
+// workgroup per CU), so that the kernels of another stream find room beside them (FRCNN_WGRAD_TRAIL, models/feature_extractor.py)
+#ifndef FRCNN_WGRAD_LDS_PAD
+#define FRCNN_WGRAD_LDS_PAD 0
+#endif
 extern "C" int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* table_dev, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(table_host && table_dev, "conv2d_wgrad_grouped: null pointer");
     const WgradGroup* h = reinterpret_cast<const WgradGroup*>(table_host);
@@ -1084,8 +1089,8 @@ extern "C" int frcnn_conv2d_wgrad_grouped(const void* table_host, const void* ta
 #define FRCNN_GROUP_LAUNCH1(BM_, BN_, S_, OCC_, MODE_, IDX_, F8_)                                                                  \
     if (h[IDX_].n > 0 && h[IDX_].bm == BM_ && h[IDX_].bn == BN_ && h[IDX_].stages == S_) {                                         \
         constexpr int ring_b = S_ * 64 * (BM_ + BN_) * 2, stage_b = BM_ * (BN_ * 4 + 16);                                          \
-        constexpr int smem_b = ring_b > stage_b ? ring_b : stage_b;                                                                \
-        static_assert(smem_b * OCC_ <= 163840, "LDS budget");                                                                      \
+        constexpr int smem_b = FRCNN_WGRAD_LDS_PAD > (ring_b > stage_b ? ring_b : stage_b) ? FRCNN_WGRAD_LDS_PAD : (ring_b > stage_b ? ring_b : stage_b);  \
+        static_assert(smem_b <= 163840, "LDS budget");                                                                             \
         FRCNN_CHECK_ARG(t_dry_run || frcnn_allow_big_lds(reinterpret_cast<const void*>(&wgrad_group_kernel<BM_, BN_, S_, MODE_, OCC_, F8_>), smem_b) == 0, \
                         "conv2d_wgrad_grouped: cannot reserve %d B of LDS", smem_b);                                              \
         if (!t_dry_run) hipLaunchKernelGGL((wgrad_group_kernel<BM_, BN_, S_, MODE_, OCC_, F8_>), dim3(h[IDX_].total), dim3(512), smem_b, s, dv + IDX_);   \

@@ -95,6 +95,10 @@ class GradientSynchronizer:
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
 
+    def note_replay(self, calls):
+        """A captured data-parallel step (FasterRCNN, FRCNN_CAPTURE_COLLECTIVES) replayed `calls` all-reduces without going through reduce_bucket."""
+        self.calls += calls
+
     def wait_all(self):
         if self.active and self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.comm_stream)

@@ -39,6 +39,11 @@ RPN_DGRAD_ON_SIDE_STREAM = os.environ.get("FRCNN_RPN_DGRAD_SIDE", "1") != "0"
 # twice each): pyramid + fp8 + batch 8 (82 k regions per image: 53 + 83 us of one-workgroup-per-image kernels) 8.697 -> 8.605 ms; C4 batch 4
 # 4.087 -> 4.089 (neutral: that chain is not the critical one there).
 RPN_TARGETS_UNDER_FORWARD = os.environ.get("FRCNN_RPN_TARGETS_EARLY", "1") != "0"
+# Data-parallel steps as ONE hipGraph with the gradient-bucket all-reduces (and the synchronised-BatchNorm sync points) captured inside it
+# (Plan.capture_with_hook) instead of segment graphs with the collectives launched from the host between them.  Opt-in: RCCL's stream
+# capture has run on this pool's hardware at world 1 only (tests/test_gpu_model.py, bench.py's captured_collectives_world1 leg) -- no
+# multi-GPU node was available to any round -- and a capture that hangs at N > 1 would take a whole job down, a refused one falls back.
+CAPTURE_COLLECTIVES = os.environ.get("FRCNN_CAPTURE_COLLECTIVES", "0") not in ("", "0")
 
 
 class _Modules:
@@ -130,6 +135,7 @@ class FasterRCNN:
         self.status = torch.zeros(4, dtype=torch.int32, device=self.device)     # [0] |= 1: empty background set while sampling
         self.use_graphs = True
         self._inject_proposals = False       # train_step(..., proposals_override=...): the plan being built takes its proposals from the caller
+        self.capture_collectives = CAPTURE_COLLECTIVES      # data-parallel steps as one graph with their collectives inside (see above)
 
     # ------------------------------------------------------------------ parameters
     def init_weights(self, seed=0):
@@ -584,6 +590,18 @@ class FasterRCNN:
         if sync_fn is None and plan.captured and not collectives:
             plan.replay()                        # nothing to interleave between segments: the whole step is one graph
             return self._losses_dict(built), built["preds"]
+        if sync_fn is not None and plan.captured and self.capture_collectives:
+            # the data-parallel step as ONE graph with its collectives inside (Plan.capture_with_hook); falls back to the segment
+            # graphs below if the capture is refused
+            dp = built.get("dp")
+            owner = getattr(sync_fn, "__self__", sync_fn)
+            if dp is None or dp["owner"] is not owner:
+                dp = built["dp"] = self._capture_data_parallel(built, sync_fn, owner, (images, gt_labels, gt_boxes, proposals_override))
+            if dp["graph"] is not None:
+                dp["graph"].replay()
+                if hasattr(owner, "note_replay"):
+                    owner.note_replay(dp["calls"])
+                return self._losses_dict(built), built["preds"]
         done = 0                                 # gradient buckets handed to the data-parallel hook so far
         for i in range(nseg):
             if collectives:
@@ -596,6 +614,36 @@ class FasterRCNN:
                 sync_fn(done, len(plan.bucket_ends) + 1)     # (hook protocol: bucket index, buckets + the update segment)
                 done += 1
         return self._losses_dict(built), built["preds"]
+
+    def _capture_data_parallel(self, built, sync_fn, owner, feed):
+        """One eager data-parallel step on a scratch copy of the state (the communicator's first collective must not happen inside a
+        capture), then the capture.  Returns {"graph": CUDAGraph or None, ...}; a refused capture is remembered and reported once."""
+        plan, optimizer = built["plan"], built["optimizer"]
+        calls0 = getattr(owner, "calls", 0)
+        state = self._snapshot(optimizer)
+        try:
+            done = 0
+            for i in range(len(plan.segments)):
+                plan.sync_before(i)
+                plan.run_segment(i)
+                if done < len(plan.bucket_ends) and i == plan.bucket_ends[done]:
+                    sync_fn(done, len(plan.bucket_ends) + 1)
+                    done += 1
+            torch.cuda.synchronize()
+            calls = getattr(owner, "calls", 0) - calls0
+            self._restore(state, optimizer)
+            graph = plan.capture_with_hook(sync_fn)
+            torch.cuda.synchronize()
+            if hasattr(owner, "calls"):
+                owner.calls = calls0              # (the warm-up step and the capture pass are not training steps)
+            err = None
+        except Exception as e:                    # capture refused (backend without stream-capture support, ...): segment graphs
+            graph, calls, err = None, 0, "%s: %s" % (type(e).__name__, e)
+            import warnings
+            warnings.warn("data-parallel step could not be captured as one graph (%s): running its segment graphs" % err)
+        self._restore(state, optimizer)
+        self._feed(built, *feed)
+        return {"graph": graph, "owner": owner, "calls": calls, "error": err}
 
     def _run_with_collectives(self, plan):
         """Eager run of a plan, with the all-reduces of its sync points (synchronised BatchNorm) when there are several ranks."""

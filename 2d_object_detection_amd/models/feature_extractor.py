@@ -23,6 +23,8 @@ BF16 = torch.bfloat16
 BN_EPS = 1.001e-5          # Keras ResNet50 BatchNormalization epsilon [TF-ext]
 BN_MOMENTUM = 0.99
 GROUPED_WGRAD = os.environ.get("FRCNN_GROUPED_WGRAD", "1") != "0"      # (0: one weight-gradient launch per layer)
+# measuring aid: the grouped weight-gradient launches of conv4 / conv3 on a side stream under the next stage's backward chain (single GPU: no bucket cuts)
+WGRAD_TRAIL = os.environ.get("FRCNN_WGRAD_TRAIL", "0") != "0"
 STACKS = {50: ((64, 3, 1), (128, 4, 2), (256, 6, 2)), 101: ((64, 3, 1), (128, 4, 2), (256, 23, 2))}
 
 
@@ -656,14 +658,20 @@ class FeatureExtractor:
             if deferred:
                 group = ops.WgradGroup(deferred, self.device)
                 plan.hold(group)
-                plan.add(ops.conv2d_wgrad_grouped, group)
+                if WGRAD_TRAIL:
+                    # the stage's weight gradients on a side stream that trails the main chain (nothing before the update reads them)
+                    with plan.branch("wgrad_trail", follow=True):
+                        plan.add(ops.conv2d_wgrad_grouped, group)
+                else:
+                    plan.add(ops.conv2d_wgrad_grouped, group)
                 del deferred[:]
 
         for (n, ci, f, s, first) in reversed(self.specs):
             stage = int(n[4])
             if prev_stage is not None and stage != prev_stage:
                 flush_deferred()
-                plan.cut("bwd_conv%d" % stage)
+                if not WGRAD_TRAIL:               # (a segment's end joins its side streams: the trailing form keeps the backbone's backward pass in one segment)
+                    plan.cut("bwd_conv%d" % stage)
             prev_stage = stage
             defer = deferred if stage in grouped_stage else None
             u, a, xin = self.units[n], self.acts[n], xs[n]

@@ -181,6 +181,25 @@ class Plan:
         self._whole = g
         return graphs
 
+    def capture_with_hook(self, hook, error_mode="thread_local"):
+        """The whole step as ONE hipGraph INCLUDING what a data-parallel driver does between the segments: hook(bucket, n) is called
+        inside the capture after every bucket-completing segment (its collectives -- RCCL all-reduces on a side stream that forks
+        from / joins the capturing stream -- become nodes of the graph), and the sync points' all-reduces (synchronised BatchNorm)
+        are captured on the main stream.  A data-parallel step then is one replay: no event record / stream wait / collective launch
+        from the host between segment graphs.  error_mode "thread_local": the process group's watchdog thread may query events while
+        this thread captures."""
+        g = torch.cuda.CUDAGraph()
+        pool = self._graphs[0].pool() if self._graphs else None
+        with torch.cuda.graph(g, pool=pool, capture_error_mode=error_mode):
+            done = 0
+            for i in range(len(self.segments)):
+                self.sync_before(i)
+                self.run_segment(i)
+                if done < len(self.bucket_ends) and i == self.bucket_ends[done]:
+                    hook(done, len(self.bucket_ends) + 1)
+                    done += 1
+        return g
+
     def replay_segment(self, i):
         self._graphs[i].replay()
 

@@ -481,6 +481,11 @@ def measure(spec, args, rank, world, dev, windows, with_segmented, with_rccl_leg
                     "note": "world 1: the call path (comm stream, ready events, segment graphs) runs; a one-rank all-reduce moves no bytes over xGMI"}
         except Exception as e:                                 # (never fail the headline on the rehearsal leg)
             rccl = {"error": "%s: %s" % (type(e).__name__, e)}
+        # ... and with the data-parallel step captured as ONE graph, its all-reduces inside (FasterRCNN.capture_collectives): first in a
+        # CHILD process under a time-out (tests/_dp_capture_child.py: a small model; a stream capture RCCL refuses raises there, one that
+        # hangs is killed there), then -- only if the child succeeded -- the same leg on this model
+        if isinstance(rccl, dict) and "error" not in rccl:
+            rccl["captured"] = captured_collectives_leg(model, window, hook, D, args)
 
     out = {
         "metric": METRIC, "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -510,6 +515,38 @@ def measure(spec, args, rank, world, dev, windows, with_segmented, with_rccl_leg
     del model, opt, batches
     torch.cuda.empty_cache()
     return out
+
+
+def captured_collectives_leg(model, window, hook, D, args):
+    child = os.path.join(ROOT, "tests", "_dp_capture_child.py")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        proc = subprocess.Popen([sys.executable, child], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        try:
+            text, _ = proc.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.communicate()
+            return {"error": "probe child did not finish within 180 s: captured form not attempted in this process"}
+        ok = [ln for ln in text.splitlines() if ln.startswith("DP_CAPTURE_OK")]
+        if proc.returncode != 0 or not ok:
+            return {"error": "probe child failed (rc %d): %s" % (proc.returncode, text[-300:])}
+        probe = json.loads(ok[0][len("DP_CAPTURE_OK "):])
+        fs = D.GradientSynchronizer(model.store.g, model.store.buckets, force=True)
+        keep_hook, keep_flag = hook[0], model.capture_collectives
+        hook[0], model.capture_collectives = fs.after_segment, True
+        try:
+            leg = sorted(window()[0] / args.steps * 1e3 for _ in range(3))[1]
+            dp = model._train_plan.get("dp") or {}
+        finally:
+            hook[0], model.capture_collectives = keep_hook, keep_flag
+        return {"ms_per_step": round(leg, 4), "one_graph": dp.get("graph") is not None, "fallback_reason": dp.get("error"),
+                "all_reduces_per_step": fs.calls / (3.0 * args.steps), "probe_small_model_ms": probe,
+                "note": "the step and its bucket all-reduces replayed as ONE hipGraph (FRCNN_CAPTURE_COLLECTIVES; opt-in for N > 1)"}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def attach_roofline(out, fam, spec, ms):

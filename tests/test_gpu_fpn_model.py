@@ -444,12 +444,16 @@ def test_configs4_workload_fpn_fp8_batch8_full_size():
     # -- tools/probes/diag_configs4.py, profiles/r04_run_to_run_noise.txt: the forward pass and the heads' gradients are reproducible
     # (1e-6), the random-init backbone's backward pass amplifies the order of the RoI / BatchNorm float sums by 10^4 on its way down
     assert e_w < 3e-4, e_w
-    # (c) fp8 against bf16 on the same proposals and samples, both steps: the difference is the fp8 arithmetic
-    for s in (0, 1):
-        for k in ("rpn_cls", "rcnn_cls"):
-            assert diff[k][s] < FP8_LOSS_BOUND[k], (k, s, diff[k])
-        for k in ("rpn_reg", "rcnn_reg"):
-            assert diff[k][s] < FP8_LOSS_BOUND[k] * max(abs(h_ref[s][k]), 1e-3), (k, s, diff[k], h_ref[s][k])
+    # (c) fp8 against bf16 on the same proposals and samples.  Step 0: same weights too -- the difference IS the fp8 forward arithmetic and
+    # reproduces to five digits from box to box.  Step 1: the two models have taken DIFFERENT first updates (the fp8 backbone gradient
+    # differs from the bf16 one by 19-30 %, DESIGN 0.4, and one update at this learning rate moves rcnn_reg from 68 to 34-56): the same
+    # RoIs and samples, but two different heads -- reported, and bounded only against a gross failure
+    for k in ("rpn_cls", "rcnn_cls"):
+        assert diff[k][0] < FP8_LOSS_BOUND[k], (k, 0, diff[k])
+        assert diff[k][1] < FP8_LOSS_BOUND_STEP1[k], (k, 1, diff[k])
+    for k in ("rpn_reg", "rcnn_reg"):
+        assert diff[k][0] < FP8_LOSS_BOUND[k] * max(abs(h_ref[0][k]), 1e-3), (k, 0, diff[k], h_ref[0][k])
+        assert diff[k][1] < FP8_LOSS_BOUND_STEP1[k] * max(abs(h_ref[1][k]), 1e-3), (k, 1, diff[k], h_ref[1][k])
 
 
 # Bounds of the fp8-vs-bf16 loss difference at configs[4]'s full size, both runs on the SAME proposals and sample indices (teacher
@@ -459,6 +463,9 @@ def test_configs4_workload_fpn_fp8_batch8_full_size():
 # classification losses, relative for the summed regression losses.  Round 4 compared UN-injected runs: its rcnn_reg differed by 11.3 of
 # 56.7 (20 %) and needed a bound of 0.4 because the two runs pooled different RoIs; on the same RoIs the difference is 1.7-2.5 %.
 FP8_LOSS_BOUND = {"rpn_cls": 0.002, "rcnn_cls": 0.16, "rpn_reg": 0.1, "rcnn_reg": 0.05}
+# ... of the SECOND step (after different first updates, see the assertion): 2x the largest of three boxes' measurements (rpn_cls 0.00091,
+# rcnn_cls 0.079, rpn_reg 0.033 relative, rcnn_reg 0.025 / 0.005 / 0.25 relative)
+FP8_LOSS_BOUND_STEP1 = {"rpn_cls": 0.002, "rcnn_cls": 0.16, "rpn_reg": 0.1, "rcnn_reg": 0.5}
 # ... and of the relative difference between two fp8 runs of the same second step (eager vs replayed) on the same proposals: 3x the
 # larger of two boxes' measurements (round 5: rpn_cls 8.1e-4 / 5.8e-4, rpn_reg 4.1e-3 / 5.7e-3, rcnn_cls 3.1e-2 / 9.6e-3, rcnn_reg
 # 5.8e-3 / 6.8e-2 -- a SUM of Huber terms over the few foreground rows of an untrained head: the two runs' weights differ by 1e-4 after

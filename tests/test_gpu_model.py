@@ -407,3 +407,28 @@ def test_proposals_override_is_the_nms_output_replaced(setup, topology):
     assert m_same._train_plan is not built and m_same._train_plan["plan"].num_launches == plain["launches"]
     with pytest.raises(TypeError):
         m_same.train_step(images, gl, gb, built["optimizer"], proposals_override=other.cpu())
+
+
+def test_captured_collectives_at_world_one():
+    """FRCNN_CAPTURE_COLLECTIVES / FasterRCNN.capture_collectives: the data-parallel step as ONE hipGraph with its four bucket all-reduces
+    (RCCL, world 1: the call path, no bytes over xGMI) captured inside -- no host-side event record / stream wait / collective launch
+    between segment graphs (0.087 ms per step).  Runs in a child process under a time-out: a stream capture that
+    RCCL refuses raises (and the model falls back to the segment graphs), one that hangs must not take this session with it.  The child
+    checks losses and weights against the plain step and the segment-graph form and counts the all-reduces."""
+    import os
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_capture_child.py")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.Popen([sys.executable, child], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        out, _ = proc.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        out, _ = proc.communicate()
+        pytest.fail("the captured data-parallel step did not finish within 240 s (stuck capture?); output:\n" + out[-2000:])
+    assert proc.returncode == 0 and "DP_CAPTURE_OK" in out, out[-3000:]
+    print([ln for ln in out.splitlines() if ln.startswith("DP_CAPTURE_OK")][0])
