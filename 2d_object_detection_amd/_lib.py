@@ -48,7 +48,7 @@ class SgdFused(Structure):
                 ("arrive", c_void_p)]
 
 
-ABI_VERSION = 6          # FRCNN_ABI_VERSION of include/frcnn_hip.h this table was written against (load() refuses any other library)
+ABI_VERSION = 7          # FRCNN_ABI_VERSION of include/frcnn_hip.h this table was written against (load() refuses any other library)
 
 CONV_BIAS, CONV_RELU, CONV_OUT_F32, CONV_ADD_RES, CONV_STATS, CONV_SPLITK_ATOMIC, CONV_WGRAD_ACCUMULATE = 1, 2, 4, 8, 16, 32, 64
 CONV_WGRAD_STEM_UNPACK = 128

@@ -1033,8 +1033,10 @@ __global__ void sgd_fused_kernel(float* __restrict__ w, const float* __restrict_
     }
     // every wave of every workgroup has read *step (it used the rate) before its workgroup arrives here: the last arriver may move it.
     // (No fence: nothing but the counter itself is handed over, and a fence would hold the workgroup until its stores have landed.)
+    // (arrive == NULL: a launch over PART of the buffer -- a gradient bucket updated early, under the rest of the backward pass; the launch
+    // over the last part carries the counter)
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (f.arrive && threadIdx.x == 0) {
         if (atomicAdd(f.arrive, 1u) == gridDim.x - 1) {
             *f.arrive = 0u;
             *step = st + 1;
@@ -1410,7 +1412,7 @@ extern "C" int frcnn_sgd_momentum(float* w, const float* g, float* v, frcnn_bf16
 extern "C" int frcnn_sgd_momentum_fused(float* w, const float* g, float* v, frcnn_bf16* w_bf16, int64_t n, float momentum, float grad_scale,
                                         int64_t* step, const int64_t* boundaries, const float* values, int nb, const frcnn_sgd_fused* f,
                                         frcnn_stream_t stream) {
-    FRCNN_CHECK_ARG(w && g && v && step && values && (nb == 0 || boundaries) && f && f->arrive, "sgd_momentum_fused: null pointer");
+    FRCNN_CHECK_ARG(w && g && v && step && values && (nb == 0 || boundaries) && f, "sgd_momentum_fused: null pointer");
     FRCNN_CHECK_ARG(f->decay_end >= 0 && f->decay_end <= n, "sgd_momentum_fused: decay_end outside [0, n]");
     FRCNN_CHECK_ARG(f->stem_begin < 0 || (f->stem_packed && f->stem_cout > 0 && f->stem_begin + (int64_t)f->stem_cout * 147 <= n),
                     "sgd_momentum_fused: stem range outside the buffer or no packed destination");

@@ -44,6 +44,13 @@ RPN_TARGETS_UNDER_FORWARD = os.environ.get("FRCNN_RPN_TARGETS_EARLY", "1") != "0
 # capture has run on this pool's hardware at world 1 only (tests/test_gpu_model.py, bench.py's captured_collectives_world1 leg) -- no
 # multi-GPU node was available to any round -- and a capture that hangs at N > 1 would take a whole job down, a refused one falls back.
 CAPTURE_COLLECTIVES = os.environ.get("FRCNN_CAPTURE_COLLECTIVES", "0") not in ("", "0")
+# Opt-in (FRCNN_SGD_EARLY=1, single GPU): a gradient bucket (heads + RPN, conv4, conv3) is updated as soon as it is final, on a side stream
+# under the rest of the backward pass (SGD.apply_bucket_plan: the fused kernel over that part of the flat buffers); the plan's last launch
+# updates conv2 + stem, re-packs the stem and moves the step counter.  Same arithmetic element for element (tests), and MEASURED SLOWER:
+# same-box A/B 3.95 -> 4.09 / 4.11 ms (gpurun_out/r5_ab4.txt).  The trace says why: every fork of the replayed hipGraph moves the main
+# chain to another hardware queue and leaves the chip idle for 10 - 17 us (three forks + the join), and the update kernel -- a streaming
+# kernel on all CUs -- doubles the BatchNorm kernel it runs beside (24 -> 45 us); 64 us of update at the end of the step cost less.
+SGD_EARLY = os.environ.get("FRCNN_SGD_EARLY", "0") != "0"
 
 
 class _Modules:
@@ -331,10 +338,13 @@ class FasterRCNN:
                 plan.join("rpn_side")
                 mods.rpn.backward_data_plan(plan, g_feat, consumer=mods.fe.last_unit())
             plan.join("detections")
+            early = self._early_update_hook(plan, optimizer)
+            if early:
+                early("heads")
             plan.cut("bwd_conv4")
-            mods.fe.backward_plan(plan, g_feat, g_feat_reduced=True)
+            mods.fe.backward_plan(plan, g_feat, g_feat_reduced=True, on_stage_done=(lambda stage: early("conv%d" % stage)) if early else None)
             plan.cut("update")
-            optimizer.apply_plan(plan, stem=mods.fe.stem)     # SGD + the stem's packed taps + the step counter: one launch
+            self._final_update(plan, optimizer, mods.fe.stem, early)     # SGD (of what is left) + the stem's packed taps + the step counter: one launch
             if mods.fe.f8 is not None:
                 # fp8 mode: next step's e4m3 weights from the updated masters (one launch), next step's activation scales from this
                 # step's amax row
@@ -455,10 +465,14 @@ class FasterRCNN:
             plan.hold(red4)
             neck.backward_plan(plan, stage_maps, targets, red4=red4)
             plan.join("detections")
+            early = self._early_update_hook(plan, optimizer)
+            if early:
+                early("heads")
             plan.cut("bwd_conv4")
-            fe.backward_plan(plan, g_feat, g_feat_reduced=True, injected=(first_of[4], first_of[3]))
+            fe.backward_plan(plan, g_feat, g_feat_reduced=True, injected=(first_of[4], first_of[3]),
+                             on_stage_done=(lambda stage: early("conv%d" % stage)) if early else None)
             plan.cut("update")
-            optimizer.apply_plan(plan, stem=fe.stem)          # SGD + the stem's packed taps + the step counter: one launch
+            self._final_update(plan, optimizer, fe.stem, early)          # SGD (of what is left) + the stem's packed taps + the step counter: one launch
             if fe.f8 is not None:
                 fe.quantize_weights_plan(plan, extra=neck.quant_entries()[0] + rpn.quant_entries()[0])
                 fe.f8.plan_update(plan)
@@ -467,6 +481,32 @@ class FasterRCNN:
         aux = {"rpn_out": rpn_out, "rcnn_out": rcnn_out, "nms_rpn": nms_rpn, "nms_rcnn": nms_rcnn, "targets": t, "feature_maps": fe.feature_maps,
                "pyramid": pyramid, "stage_maps": stage_maps, "roi_levels": rcnn.levels}
         return {"plan": plan, "io": io, "losses": losses, "preds": preds, "aux": aux, "batch": batch}
+
+    def _early_update_hook(self, plan, optimizer):
+        """(SGD_EARLY) callable(bucket name) that appends the early update of that gradient bucket on the trailing side stream, or None."""
+        if not (SGD_EARLY and self.world_size == 1 and optimizer.early_ok()):
+            return None
+        buckets = {name: (b, e) for name, b, e in self.store.buckets}
+        last = self.store.buckets[-1][0]
+        done = []
+
+        def early(name):
+            if name in buckets and name != last and name not in done:
+                b, e = buckets[name]
+                assert b == (done and buckets[done[-1]][1] or 0), "gradient buckets become final in registration order"
+                with plan.branch("sgd_early", follow=True):
+                    optimizer.apply_bucket_plan(plan, b, e)
+                done.append(name)
+        early.done = done
+        early.buckets = buckets
+        return early
+
+    def _final_update(self, plan, optimizer, stem, early):
+        if early and early.done:
+            plan.join("sgd_early")               # (the early launches have read the step counter: the last launch may move it)
+            optimizer.apply_plan(plan, stem=stem, first=early.buckets[early.done[-1]][1])
+        else:
+            optimizer.apply_plan(plan, stem=stem)
 
     def _inject_proposals_plan(self, plan, io, training, rois, regions_abs, batch, P, W, H):
         """Test hook (train_step(..., proposals_override=...)): two launches behind the proposal NMS overwrite its kept boxes -- `rois`

@@ -631,7 +631,7 @@ class FeatureExtractor:
         """The conv unit whose BatchNorm+ReLU produces feature_maps (consumer of the feature-map gradient)."""
         return self.units[self.specs[-1][0]][3]
 
-    def backward_plan(self, plan, g_feat, g_feat_reduced=False, injected=()):
+    def backward_plan(self, plan, g_feat, g_feat_reduced=False, injected=(), on_stage_done=None):
         """g_feat: bf16 gradient w.r.t. feature_maps [B*gh*gw, C].  Cuts the plan after each stage.
         g_feat_reduced: the kernel that wrote g_feat already ran the BN-backward reduce of last_unit().
         injected: names of stride-2 first blocks whose input-gradient buffer acts[name]["gin"] ALREADY holds a gradient w.r.t. the
@@ -670,6 +670,8 @@ class FeatureExtractor:
             stage = int(n[4])
             if prev_stage is not None and stage != prev_stage:
                 flush_deferred()
+                if on_stage_done is not None:     # every gradient of stage `prev_stage` is final (its bucket of the flat buffer)
+                    on_stage_done(prev_stage)
                 if not WGRAD_TRAIL:               # (a segment's end joins its side streams: the trailing form keeps the backbone's backward pass in one segment)
                     plan.cut("bwd_conv%d" % stage)
             prev_stage = stage

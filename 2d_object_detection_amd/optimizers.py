@@ -44,12 +44,44 @@ class SGD:
         self.values = torch.tensor(self.schedule.values, dtype=torch.float32, device=dev)
         self.nb = nb
 
-    def apply_plan(self, plan, grad_scale=1.0, stem=None):
-        """The update of a training plan: SGD over the flat buffers, the stem's packed bf16 taps (stem: the backbone's stem unit, or
-        None), the step counter + 1 -- ONE launch when the store's decay ranges are [regularised | rest] (they are: the regularised
-        kernels are registered first), else one launch per range and the two small ones."""
+    def early_ok(self):
+        """Can finished gradient buckets be updated one by one (apply_bucket_plan)?  The store's decay ranges must be [regularised | rest]."""
+        ranges = self.store.decay_ranges()
+        return len(ranges) == 2 and ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][2] == 0.0
+
+    def apply_bucket_plan(self, plan, begin, end, grad_scale=1.0):
+        """The update of ONE finished gradient bucket [begin, end) of the flat buffers, ahead of the plan's last launch (apply_plan with
+        the same `first`): the fused kernel over that part, without the stem re-pack and without touching the step counter (the rate is
+        read from it: every launch of a step sees the same value, the last one moves it).  Element for element the arithmetic of the
+        one-launch form."""
         st = self.store
         ranges = st.decay_ranges()
+        decay_end = min(max(ranges[0][1] - begin, 0), end - begin)
+        fused = ops.sgd_fused_args(decay_end, ranges[0][2], None)
+        plan.hold(fused)
+        plan.add(ops.sgd_momentum_fused, st.w[begin:end], st.g[begin:end], self.velocity[begin:end], st.wb[begin:end], end - begin, self.momentum,
+                 grad_scale, self.iterations, self.boundaries, self.values, self.nb, fused)
+
+    def apply_plan(self, plan, grad_scale=1.0, stem=None, first=0):
+        """The update of a training plan: SGD over the flat buffers, the stem's packed bf16 taps (stem: the backbone's stem unit, or
+        None), the step counter + 1 -- ONE launch when the store's decay ranges are [regularised | rest] (they are: the regularised
+        kernels are registered first), else one launch per range and the two small ones.  first > 0: the elements below it were
+        updated by earlier apply_bucket_plan launches of this plan."""
+        st = self.store
+        ranges = st.decay_ranges()
+        if first > 0:
+            assert self.early_ok() and (stem is None or st.offset(stem.name + "_conv/kernel") >= first)
+            n = ranges[1][1] - first
+            self._arrive = torch.zeros(4, dtype=torch.int32, device=st.device)
+            plan.zero(self._arrive)
+            decay_end = min(max(ranges[0][1] - first, 0), n)
+            if stem is not None:
+                fused = ops.sgd_fused_args(decay_end, ranges[0][2], self._arrive, st.offset(stem.name + "_conv/kernel") - first, stem.cout, stem.w_packed)
+            else:
+                fused = ops.sgd_fused_args(decay_end, ranges[0][2], self._arrive)
+            plan.add(ops.sgd_momentum_fused, st.w[first:], st.g[first:], self.velocity[first:], st.wb[first:], n, self.momentum, grad_scale,
+                     self.iterations, self.boundaries, self.values, self.nb, fused)
+            return
         if len(ranges) == 2 and ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][2] == 0.0:
             n = ranges[1][1]
             self._arrive = torch.zeros(4, dtype=torch.int32, device=st.device)      # [0]: arrival counter of the fused launch

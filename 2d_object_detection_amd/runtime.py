@@ -15,6 +15,9 @@ import torch
 
 _NOBRANCH = set(filter(None, os.environ.get("FRCNN_NOBRANCH", "").split(",")))   # measuring aid (tools/ab_plan.sh): these branches stay on the main stream
 _SERIAL = bool(os.environ.get("FRCNN_SERIAL_PLAN"))      # debugging aid: run branch launches on the main stream
+# TIMING-ONLY what-if aid (tools/ab_lib.sh): launches of these ops (function names, comma separated) are dropped from every plan -- the results
+# are garbage; the step time says what the family costs ON the critical path, i.e. the most any fusion / overlap of it could save
+_SKIP_OPS = set(filter(None, os.environ.get("FRCNN_SKIP_OPS", "").split(",")))
 
 
 class _Branch:
@@ -52,6 +55,8 @@ class Plan:
 
     # -- construction
     def add(self, fn, *args, **kwargs):
+        if _SKIP_OPS and getattr(fn, "__name__", "") in _SKIP_OPS:
+            return
         br = None if _SERIAL else self._branch
         if br is not None and br[0] in _NOBRANCH:
             br = None
@@ -115,15 +120,20 @@ class Plan:
         ev.record(side.pop(name))
         main.wait_event(ev)
 
-    def run_segment(self, i):
+    def run_segment(self, i, carry=None):
+        """carry (Plan.run): the side streams still open from earlier segments; they are NOT joined at this segment's end -- a branch
+        opened with follow=True may trail the main chain across cuts (the early optimizer updates of finished gradient buckets) until
+        a join entry or the plan's end.  Stand-alone (segment graphs of a data-parallel step): every branch is joined at the end."""
         main = None                                # (no CUDA call for plans without branches: host-logic tests run on CPU)
         if i == 0:
             self._zero_prologue()
-        side = {}
+        side = {} if carry is None else carry
         prev_branch = None
         for fn, args, kwargs, br in self.segments[i]:
             if fn is None:
                 if args[0] in side:
+                    if main is None:
+                        main = torch.cuda.current_stream()
                     self._join(main, side, args[0])
             elif br is None:
                 fn(*args, **kwargs)
@@ -142,12 +152,18 @@ class Plan:
                 with torch.cuda.stream(side[name]):
                     fn(*args, **kwargs)
             prev_branch = br if fn is not None else prev_branch
-        for name in list(side):
-            self._join(main, side, name)
+        if carry is None:
+            for name in list(side):
+                self._join(main, side, name)
 
     def run(self):
+        side = {}
         for i in range(len(self.segments)):
-            self.run_segment(i)
+            self.run_segment(i, carry=side)
+        if side:
+            main = torch.cuda.current_stream()
+            for name in list(side):
+                self._join(main, side, name)
 
     def sync_before(self, i):
         """All-reduce (SUM over the default process group) the partial sums segment i waits for (sync_point)."""

@@ -34,10 +34,11 @@ typedef uint8_t frcnn_fp8;     /* OCP e4m3fn (gfx950's fp8: 4 exponent bits, bia
 
 /* Version of this header's structs and signatures.  Bumped whenever a struct grows or a signature changes (2: frcnn_conv_desc
  * gained workspace / workspace_bytes, frcnn_bn_bwd_apply_fused gained count / param_grad_scale; 3: the fp8 entry points; 5: frcnn_fp8_update_scales gained limit / status,
- * frcnn_losses_head_grad gained bias_grad, FRCNN_CONV_WGRAD_ACCUMULATE / _STEM_UNPACK, the fused launches of round 4; 6: frcnn_conv2d_fprop_bnin).  A
+ * frcnn_losses_head_grad gained bias_grad, FRCNN_CONV_WGRAD_ACCUMULATE / _STEM_UNPACK, the fused launches of round 4; 6: frcnn_conv2d_fprop_bnin; 7: frcnn_conv2d_fprop_bnin on the
+ * patch-resident 3x3 and 1x1 tile forms, frcnn_sgd_fused.arrive may be NULL).  A
  * binding must compare frcnn_abi_version() with the FRCNN_ABI_VERSION it was written against and refuse any other library:
  * an older build would read the descriptor past the caller's struct. */
-#define FRCNN_ABI_VERSION 6
+#define FRCNN_ABI_VERSION 7
 int frcnn_abi_version(void);
 const char* frcnn_last_error(void);
 /* sha1 (12 hex digits) over the kernel sources and this header the library was built from, or "unknown" (csrc/build.py passes it):
@@ -390,7 +391,7 @@ typedef struct frcnn_sgd_fused {
     int64_t stem_begin;           /* -1: no stem re-pack */
     int stem_cout;
     frcnn_bf16* stem_packed;
-    uint32_t* arrive;
+    uint32_t* arrive;             /* NULL (ABI 7): the launch covers PART of the parameters and leaves the step counter alone */
 } frcnn_sgd_fused;
 int frcnn_sgd_momentum_fused(float* w, const float* g, float* v, frcnn_bf16* w_bf16, int64_t n, float momentum, float grad_scale,
                              int64_t* step, const int64_t* boundaries, const float* values, int nb, const frcnn_sgd_fused* f,

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_bound():
     for sym in declared:
         assert hasattr(handle, sym), "header declares %s but the library does not export it" % sym
     assert sorted(lib_mod.EXPORTED_SYMBOLS) == declared, "ctypes table and header differ"
-    assert handle.frcnn_abi_version() == lib_mod.ABI_VERSION == 6
+    assert handle.frcnn_abi_version() == lib_mod.ABI_VERSION == 7
 
 
 def test_argument_validation_without_gpu():

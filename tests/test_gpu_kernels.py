@@ -945,6 +945,39 @@ def test_sgd_fused_equals_separate_launches(ops):
         assert int(step_b) == step_val + 2 and int(arrive[0]) == 0
 
 
+def test_sgd_bucket_launches_equal_the_one_launch_update(ops):
+    """SGD.apply_bucket_plan + apply_plan(first=...) (round 5: a finished gradient bucket is updated under the rest of the backward pass):
+    frcnn_sgd_momentum_fused over PARTS of the flat buffers -- arrive = NULL: no counter update -- followed by the launch over the last
+    part (stem re-pack, step counter) == the one launch over everything, bit for bit; the partial launches leave the step counter alone."""
+    g = torch.Generator().manual_seed(32)
+    dev = "cuda"
+    n, decay_end, stem_begin, cout = 300_032, 70_016, 280_000, 64
+    cuts = [0, 69_952, 70_400, 200_000, 270_016, n]                # (the decay boundary lies INSIDE the second part; the stem in the last)
+    w, gr, v = torch.randn(n, generator=g), torch.randn(n, generator=g), torch.randn(n, generator=g)
+    bounds = torch.tensor([40000, 80000, 0], dtype=torch.int64, device=dev)
+    values = torch.tensor([1e-3, 1e-4, 1e-5], device=dev)
+    gd = gr.to(dev)
+    wa, va, wb_a = w.to(dev), v.to(dev), torch.zeros(n, dtype=BF, device=dev)
+    wbb, vb, wb_b = w.to(dev), v.to(dev), torch.zeros(n, dtype=BF, device=dev)
+    step_a = torch.tensor([40001], dtype=torch.int64, device=dev)
+    step_b = step_a.clone()
+    pk_a, pk_b = torch.zeros(cout, 7, 8, 4, dtype=BF, device=dev), torch.zeros(cout, 7, 8, 4, dtype=BF, device=dev)
+    arrive_a, arrive_b = torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
+    ops.sgd_momentum_fused(wa, gd, va, wb_a, n, 0.9, 1.0, step_a, bounds, values, 2, ops.sgd_fused_args(decay_end, 0.0005, arrive_a, stem_begin, cout, pk_a))
+    for b, e in zip(cuts[:-2], cuts[1:-1]):
+        part = ops.sgd_fused_args(min(max(decay_end - b, 0), e - b), 0.0005, None)
+        ops.sgd_momentum_fused(wbb[b:e], gd[b:e], vb[b:e], wb_b[b:e], e - b, 0.9, 1.0, step_b, bounds, values, 2, part)
+        torch.cuda.synchronize()
+        assert int(step_b) == 40001, "a partial launch moved the step counter"
+    b = cuts[-2]
+    last = ops.sgd_fused_args(0, 0.0005, arrive_b, stem_begin - b, cout, pk_b)
+    ops.sgd_momentum_fused(wbb[b:], gd[b:], vb[b:], wb_b[b:], n - b, 0.9, 1.0, step_b, bounds, values, 2, last)
+    torch.cuda.synchronize()
+    assert torch.equal(wa, wbb) and torch.equal(va, vb) and torch.equal(wb_a.view(torch.int16), wb_b.view(torch.int16))
+    assert torch.equal(pk_a.view(torch.int16), pk_b.view(torch.int16)) and float(pk_a.float().abs().sum()) > 0
+    assert int(step_a) == int(step_b) == 40002 and int(arrive_b[0]) == 0
+
+
 @pytest.mark.parametrize("m,c", [(7488, 128), (200, 64), (29952, 256)])
 def test_cast_and_relu_colsum_fused_equal_two_launches(ops, m, c):
     """frcnn_cast_colsum == frcnn_cast_f32_bf16 + frcnn_colsum_bf16 and frcnn_relu_bwd_colsum == frcnn_relu_bwd + frcnn_colsum_bf16: the

@@ -184,6 +184,51 @@ def test_gradient_buckets_coincide_with_plan_segments(monkeypatch):
         assert first_update is not None and first_update > plan.bucket_ends[-1]
 
 
+def test_early_bucket_updates_follow_every_write_of_their_bucket(monkeypatch):
+    """Single GPU, FRCNN_SGD_EARLY=1 (opt-in): the update launches of a train plan tile the flat parameter buffer exactly once, in bucket order; the
+    early launch of bucket j comes after the LAST launch that writes a gradient of bucket j (plan order = enqueue order: the trailing side
+    stream waits for the main stream's position) and never touches the step counter; the last launch carries stem re-pack and counter.
+    With two ranks there is one launch, in the update segment (a bucket's update must follow its all-reduce)."""
+    import copy
+    ops = importlib.import_module("2d_object_detection_amd.ops")
+    monkeypatch.setattr(ops, "anchors_generate", lambda out, *a, **k: out.zero_())
+    monkeypatch.setattr(ops, "clip_to_window", lambda boxes, out, w: out.copy_(boxes))
+    M = importlib.import_module("2d_object_detection_amd.models.faster_rcnn")
+    cfg = copy.deepcopy(CFG.default_config())
+    cfg["image_shape"] = [128, 192, 3]
+    monkeypatch.setattr(M, "SGD_EARLY", True)         # (opt-in: measured slower on MI355X, models/faster_rcnn.py)
+    for topology in ("c4", "fpn"):
+        for world in (1, 2):
+            model = M.FasterRCNN(cfg, device="cpu", world_size=world, topology=topology)
+            opt = OPT.SGD(learning_rate=1e-3, momentum=0.9)
+            opt.bind(model.store)
+            plan = model._build(model._train, 2, True, opt)["plan"]
+            st = model.store
+            order, updates, last_write = 0, [], {}
+            for si, seg in enumerate(plan.segments):
+                for fn, args, kwargs, br in seg:
+                    if fn is None:
+                        continue
+                    order += 1
+                    if fn is ops.sgd_momentum_fused:
+                        begin = (args[0].data_ptr() - st.w.data_ptr()) // 4
+                        updates.append((order, begin, begin + int(args[4]), args[11], br))
+                        continue
+                    for off in _grad_writes(ops, st, fn, args, kwargs):
+                        j = next(i for i, (_n, b, e) in enumerate(st.buckets) if b <= off < e)
+                        last_write[j] = order
+            if world == 2:
+                assert len(updates) == 1 and (updates[0][1], updates[0][2]) == (0, st.size) and updates[0][4] is None
+                continue
+            assert len(updates) == len(st.buckets), updates
+            for j, ((o, b, e, fused, br), (name, bb, be)) in enumerate(zip(updates, st.buckets)):
+                assert (b, e) == (bb, be), (name, b, e)
+                assert o > last_write[j], "bucket %s is updated at launch %d, but launch %d still writes its gradient" % (name, o, last_write[j])
+                is_last = j == len(st.buckets) - 1
+                assert bool(fused.arrive) == is_last and (fused.stem_begin >= 0) == is_last
+                assert (br is not None and br[0] == "sgd_early" and br[1]) == (not is_last)
+
+
 def test_bench_self_launches_its_ranks(monkeypatch, capsys):
     """`python bench.py --gpus N` outside torchrun (the way the driver runs N = 1) must not die on WORLD_SIZE != N: the parent starts
     `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD before any GPU call, relays rank 0's JSON line and

@@ -14,5 +14,6 @@ for v in $MODES; do
   STATS=$(find $OUT/trace -name '*kernel_stats.csv' | head -1)
   python3 profiles/summarize.py $STATS 30 90 150 > gpurun_out/${TAG}_${i}_summary.txt
   echo "== $v"; head -3 gpurun_out/${TAG}_${i}_summary.txt
+  cp $(find $OUT/trace -name '*kernel_trace.csv' | head -1) gpurun_out/${TAG}_${i}_kernel_trace.csv
   rm -rf $OUT/trace
 done
