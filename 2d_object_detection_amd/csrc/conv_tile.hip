@@ -2344,6 +2344,10 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
         while (tpb > 1 && ((tiles_m128 + tpb - 1) / tpb) * tn64 < min_groups) tpb >>= 1;
         if (tpb > 1) { bn = 64; stages = 2; }
     }
+    // Long K on a small grid (the 1024 -> 256 layers of conv4 at M = 3,744: ResNet-101 at batch 2, BASELINE configs[3]): 128-row tiles give
+    // 120 workgroups on 256 CUs; 64-row tiles put a workgroup on (almost) every CU.  tools/tile_sweep.py --batch=2 (round 5, us): 1x1
+    // 1024 -> 256 10.1 -> 8.7; no gain on the short-K layers of that grid (256 -> 1024: 8.4 either way) or with more tiles than 0.6 x CUs.
+    if (bk == 64 && tpb == 1 && bn == 64 && stages == 3 && p.taps == 1 && !p.f8_x_scale && p.Ktot / 64 < 64 && 5 * tiles_m128 * ((d->cout + 63) / 64) <= 3 * num_cus()) bm = 64;   // (64+ slices: the split-K pair form below)
 #ifdef FRCNN_WIDE_N
     // 256 output channels per tile for the short-K 1x1 layers that write 4x the channels they read (64 -> 256, 128 -> 512,
     // 256 -> 1024 and the data gradients of their mirror images): a CU takes in ~37 GB/s through its load path whatever the
@@ -2443,6 +2447,7 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
 #endif
     FRCNN_TILE(128, 64, 64, 2, 3)          // (48 KB of LDS, <= 80 VGPRs: three workgroups per CU)
     FRCNN_TILE(128, 64, 64, 3, 2)
+    FRCNN_TILE(64, 64, 64, 3, 2)           // (long K on a small grid, see above)
     FRCNN_TILE(128, 64, 32, 2, 2)
 #ifdef FRCNN_SWEEP
     FRCNN_RUN(128, 128, 64, 1)
@@ -2455,7 +2460,6 @@ int conv_tile_dispatch(ConvParams p, const frcnn_conv_desc* d, hipStream_t s) {
     FRCNN_TILE(64, 64, 128, 2, 2)
     FRCNN_TILE(128, 128, 64, 3, 1)
     FRCNN_TILE(64, 128, 64, 3, 2)
-    FRCNN_TILE(64, 64, 64, 3, 2)
     FRCNN_TILE(128, 64, 64, 4, 1)
     FRCNN_TILE(128, 64, 64, 6, 1)
     FRCNN_TILE(128, 128, 64, 4, 1)

@@ -198,31 +198,7 @@ def profile_kernels(model, built, steps=3):
                  "roi_bwd_nonzero_fraction_in_step": round(nz_frac, 4)}
     model._restore(state, built["optimizer"])
     if os.environ.get("FRCNN_LAYER_TABLE"):
-        # per-launch table (median over steps) for kernel work: shape, us, TFLOP/s, GB/s of compulsory traffic, kernel
-        n = len(records)
-        with open(os.environ["FRCNN_LAYER_TABLE"], "w") as fh:
-            for j, (fn, args, kwargs, name, fl, by, nk) in enumerate(records):
-                if name not in (FAM_CONV, FAM_CONV_F8, FAM_WGRAD):
-                    continue
-                per = sorted(events[it * n + j][3].elapsed_time(events[it * n + j][4]) * 1e3 for it in range(steps))
-                us = max(per[len(per) // 2] - pair_overhead_s * 1e6, 0.1)
-                d = args[0] if fn is not ops.conv2d_wgrad_grouped else args[0].items[0][0]
-                m = d.n * d.ho * d.wo
-                byts = 2.0 * (m * d.cin + m * d.cout + d.cout * d.kh * d.kw * d.cin)
-                pk = 5.0e15 if name == FAM_CONV_F8 else 2.5e15
-                if name == FAM_CONV_F8:
-                    byts = 1.0 * (m * d.cin + d.cout * d.kh * d.kw * d.cin) + 2.0 * m * d.cout
-                roof = max(fl / pk, byts / 8e12) * 1e6
-                inst = ""
-                if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce or fn is ops.conv2d_fprop_bnin:
-                    inst = ops.conv2d_describe(d, fn is ops.conv2d_dgrad_bnreduce) + (" +bnin" if fn is ops.conv2d_fprop_bnin else "")
-                if fn is ops.conv2d_fprop_fp8:
-                    inst = ops.conv2d_describe_fp8(d)
-                if fn is ops.conv2d_dgrad_fp8:
-                    inst = ops.conv2d_describe_dgrad_fp8(d, kwargs.get("red") is not None)
-                fh.write("%-12s M=%7d cin=%5d cout=%5d k=%dx%d s=%d  %8.1f us %7.1f TF/s %7.0f GB/s(min traffic)  roof %6.1f us (%s) frac %.2f  %s\n" % (
-                    "wgrad" if name == FAM_WGRAD else "fp8" if name == FAM_CONV_F8 else "fprop/dgrad", m, d.cin, d.cout, d.kh, d.kw, d.stride, us, fl / us / 1e6, byts / us / 1e3, roof,
-                    "mfma" if fl / pk > byts / 8e12 else "hbm", roof / us, inst))
+        write_layer_table(os.environ["FRCNN_LAYER_TABLE"], ops, records, events, steps, pair_overhead_s)
     fam = {}
     for name, fl, by, e0, e1, nk in events:
         f = fam.setdefault(name, {"launches": 0, "plan_calls": 0, "seconds": 0.0, "flops": 0.0, "bytes": 0.0})
@@ -239,6 +215,78 @@ def profile_kernels(model, built, steps=3):
         if k.startswith("RoI crop+pool backward"):
             f.update(dense)
     return fam
+
+
+def launch_bytes(ops, fn, args, kwargs):
+    """(operand bytes of the bare convolution, ALL bytes the launch must move) of one conv / weight-gradient plan call: the second adds what
+    the fused epilogue or prologue reads and writes -- the residual (+ its mask), the consumer BatchNorm's z and mask of a fused
+    backward reduce, the activation and mask an absorbed forward BatchNorm writes -- which round 4's table left out."""
+    if fn is ops.conv2d_wgrad_grouped:
+        base = full = 0.0
+        for it in args[0].items:
+            d = it[0]
+            m, es = d.n * d.ho * d.wo, (1.0 if len(it) > 4 else 2.0)
+            b_ = es * (d.n * d.hi * d.wi * d.cin + m * d.cout) + 4.0 * d.cout * d.kh * d.kw * d.cin
+            base += b_
+            full += b_
+        return base, full
+    d = args[0]
+    m = d.n * d.ho * d.wo
+    m_in = d.n * d.hi * d.wi
+    if fn in (ops.conv2d_wgrad, ops.conv2d_wgrad_fp8):
+        es = 1.0 if fn is ops.conv2d_wgrad_fp8 else 2.0
+        b_ = es * (m_in * min(d.cin, d.in_pix_stride) + m * d.cout) + 4.0 * d.cout * d.kh * d.kw * d.cin
+        return b_, b_
+    es_in = 1.0 if fn in (ops.conv2d_fprop_fp8, ops.conv2d_dgrad_fp8) else 2.0
+    m_out = d.n * d.out_h * d.out_w if getattr(d, "out_scatter", 1) > 1 else m
+    out_es = 4.0 if (d.flags & (ops.CONV_OUT_F32 | ops.CONV_SPLITK_ATOMIC)) else 2.0
+    base = es_in * (min(m_in, m * d.kh * d.kw) * min(d.cin, d.in_pix_stride) + d.cout * d.kh * d.kw * d.cin) + out_es * m * d.cout
+    full = base
+    if kwargs.get("res") is not None:
+        full += 2.0 * m * d.cout + (m * d.cout / 8.0 if kwargs.get("res_mask") is not None else 0.0)
+    red = kwargs.get("red") if fn is not ops.conv2d_dgrad_bnreduce else args[4]
+    if red is not None:
+        full += 2.0 * m_out * d.cout + m_out * d.cout / 8.0       # the consumer layer's z rows and ReLU mask bytes
+    if fn is ops.conv2d_fprop_bnin:
+        full += 2.0 * m_in * d.cin + m_in * d.cin / 8.0           # the absorbed BatchNorm's activation and mask stores
+    return base, full
+
+
+def write_layer_table(path, ops, records, events, steps, pair_overhead_s):
+    """Per-launch table (median over the profiled steps) of the MFMA families: shape, us, TFLOP/s, roofline time max(FLOP / MFMA peak,
+    bytes / HBM) with the launch's FULL byte count (launch_bytes) priced at the 8.0 TB/s spec and at the 6.3 TB/s the guide calls
+    achievable, and the kernel that ran.  Last lines: sum of rooflines / sum of measured times."""
+    n = len(records)
+    tot = {"us": 0.0, "roof8": 0.0, "roof63": 0.0, "roof_min": 0.0}
+    with open(path, "w") as fh:
+        for j, (fn, args, kwargs, name, fl, by, nk) in enumerate(records):
+            if name not in (FAM_CONV, FAM_CONV_F8, FAM_WGRAD):
+                continue
+            per = sorted(events[it * n + j][3].elapsed_time(events[it * n + j][4]) * 1e3 for it in range(steps))
+            us = max(per[len(per) // 2] - pair_overhead_s * 1e6, 0.1)
+            d = args[0] if fn is not ops.conv2d_wgrad_grouped else args[0].items[0][0]
+            m = d.n * d.ho * d.wo
+            base, full = launch_bytes(ops, fn, args, kwargs)
+            pk = 5.0e15 if name == FAM_CONV_F8 else 2.5e15
+            roof8, roof63, roof_min = max(fl / pk, full / 8e12) * 1e6, max(fl / pk, full / 6.3e12) * 1e6, max(fl / pk, base / 8e12) * 1e6
+            for k_, v_ in (("us", us), ("roof8", roof8), ("roof63", roof63), ("roof_min", roof_min)):
+                tot[k_] += v_
+            inst = ""
+            if fn is ops.conv2d_fprop or fn is ops.conv2d_dgrad_bnreduce or fn is ops.conv2d_fprop_bnin:
+                inst = ops.conv2d_describe(d, fn is ops.conv2d_dgrad_bnreduce) + (" +bnin" if fn is ops.conv2d_fprop_bnin else "")
+            if fn is ops.conv2d_fprop_fp8:
+                inst = ops.conv2d_describe_fp8(d)
+            if fn is ops.conv2d_dgrad_fp8:
+                inst = ops.conv2d_describe_dgrad_fp8(d, kwargs.get("red") is not None)
+            if fn is ops.conv2d_wgrad_grouped:
+                inst = "%d layers" % len(args[0].items)
+            fh.write("%-12s M=%7d cin=%5d cout=%5d k=%dx%d s=%d  %8.1f us %7.1f TF/s  bytes %7.1f MB (conv operands %7.1f)  roof %6.1f us @8.0 / %6.1f @6.3 TB/s (%s)  "
+                     "frac %.2f / %.2f  %s\n" % (
+                         "wgrad" if name == FAM_WGRAD else "fp8" if name == FAM_CONV_F8 else "fprop/dgrad", m, d.cin, d.cout, d.kh, d.kw, d.stride, us,
+                         fl / us / 1e6, full / 1e6, base / 1e6, roof8, roof63, "mfma" if fl / pk > full / 6.3e12 else "hbm", roof8 / us, roof63 / us, inst))
+        fh.write("SUM measured %.1f us; sum of rooflines: %.1f us at 8.0 TB/s (ratio %.3f), %.1f us at 6.3 TB/s (ratio %.3f); with the bare conv operands "
+                 "only (round 4's column) %.1f us (ratio %.3f)\n" % (tot["us"], tot["roof8"], tot["roof8"] / tot["us"], tot["roof63"], tot["roof63"] / tot["us"],
+                                                                      tot["roof_min"], tot["roof_min"] / tot["us"]))
 
 
 def usable_cores():

@@ -54,6 +54,11 @@ FPROP = [
     dict(id="small_run_512", n=4, h=64, w=64, cin=64, cout=512, k=1, s=1, p=0, bias=True, relu=False, stats=True),
     dict(id="small_3x3_128_stats", n=1, h=9, w=11, cin=128, cout=128, k=3, s=1, p=1, bias=True, relu=False, stats=True),
     dict(id="c4_3x3_256_256_b2", n=2, h=24, w=78, cin=256, cout=256, k=3, s=1, p=1, bias=True, relu=False, stats=True),
+    # 64-row tiles (round 5): long K on a grid that 128-row tiles would leave half empty -- conv4's 1024 -> 256 and stride-2 512 -> 256 at
+    # M = 3,744 (ResNet-101, batch 2: BASELINE configs[3]), and a 58-row tail
+    dict(id="c4_1x1_1024_256_stats_b2_bm64", n=2, h=24, w=78, cin=1024, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True),
+    dict(id="c4_s2_512_256_stats_b2_bm64", n=2, h=47, w=156, cin=512, cout=256, k=1, s=2, p=0, bias=True, relu=False, stats=True),
+    dict(id="bm64_1x1_512_128_relu_tail", n=1, h=13, w=34, cin=512, cout=128, k=1, s=1, p=0, bias=True, relu=True, stats=False),
     # split-K fix-up form (ws: the descriptor carries a workspace): fewer tiles than CUs, >= 64 K slices
     dict(id="rpn_like_3x3_1024_256_relu_fix_w15", n=4, h=24, w=15, cin=1024, cout=256, k=3, s=1, p=1, bias=True, relu=True, stats=False, ws=True),   # (rows narrower than a 16-pixel patch tile: the tile kernel's pair form)
     dict(id="k4096_1x1_stats_fix", n=1, h=24, w=78, cin=4096, cout=256, k=1, s=1, p=0, bias=True, relu=False, stats=True, ws=True),
@@ -132,6 +137,7 @@ DGRAD = [
     dict(id="c2_dg_256_64_red", n=4, h=94, w=311, cin=256, cout=64, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1),
     dict(id="c2_dg_64_64_plain", n=4, h=94, w=311, cin=64, cout=64, k=1, res=False, res_mask=False, red=False, mask=False, scatter=1),
     dict(id="c4_dg_1024_256_red", n=4, h=24, w=78, cin=1024, cout=256, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1),
+    dict(id="c4_dg_1024_256_red_b2_bm64", n=2, h=24, w=78, cin=1024, cout=256, k=1, res=False, res_mask=False, red=True, mask=True, scatter=1),   # 64-row tiles (ResNet-101, batch 2)
     dict(id="c4_dg_3x3_256_256_red", n=4, h=24, w=78, cin=256, cout=256, k=3, res=False, res_mask=False, red=True, mask=True, scatter=1),
     dict(id="rpn_heads_dg_128_256", n=4, h=24, w=78, cin=128, cout=256, k=1, res=False, res_mask=False, red=False, mask=False, scatter=1),
     dict(id="rpn_heads_dg_128_256_b8", n=8, h=24, w=78, cin=128, cout=256, k=1, res=False, res_mask=False, red=False, mask=False, scatter=1),   # 128 x 128 tiles
