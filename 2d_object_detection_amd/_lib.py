@@ -96,6 +96,7 @@ _SIGNATURES = {
     "frcnn_bn_apply": (c_int, [P, P, P, P, c_int, P, c_int64, c_int, P]),
     "frcnn_bn_train_apply": (c_int, [P, P, c_int, c_int64, P, P, P, P, c_float, c_float, P, c_int, P, P, P, P, c_int64, c_int, POINTER(Fp8Out), P]),
     "frcnn_bn_bwd_apply_fused": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int64, c_float, POINTER(Fp8Out), P]),
+    "frcnn_bn_bwd_apply_fused_red2": (c_int, [P, P, P, P, P, P, P, c_int, P, P, P, c_int64, c_int, c_int64, c_float, POINTER(Fp8Out), POINTER(BnReduce), P]),
     "frcnn_bn_bwd_blocks": (c_int, [c_int64]),
     "frcnn_bn_bwd_reduce": (c_int, [P, P, P, P, P, P, P, c_int64, c_int, P]),
     "frcnn_bn_bwd_finalize": (c_int, [P, c_int, c_int, c_int64, P, P, P, P, P]),

@@ -94,7 +94,12 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int ES = F8 ? 1 : 2;                             // bytes per operand element
     constexpr int NW = 8, T = 512, BKP = F8 ? 128 : 64, KK = 2;
-    constexpr int WM = 2, WN = 4;
+#ifndef FRCNN_WGRAD_WM
+#define FRCNN_WGRAD_WM 2
+#endif
+    // wave grid: WM x WN = 8 waves.  (A/B builds: FRCNN_DEFINES=FRCNN_WGRAD_WM=4 gives 128 x 64 tiles 32 x 32 wave tiles -- 8 instead of 10
+    // transposing reads per 4 MFMAs.)
+    constexpr int WM = (BM == 128 && BN == 64) ? FRCNN_WGRAD_WM : 2, WN = 8 / WM;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = (WTM + 15) / 16, NI = (WTN + 15) / 16;
     constexpr bool N_SPLIT = WTN >= 16;                       // BN = 32: only waves with wn < 2 own columns

@@ -567,7 +567,15 @@ __global__ __launch_bounds__(256) void bn_train_apply_pool_kernel(const bf16_t* 
 
 // fused BN backward finalize + apply: c1 = sum(g)/m, c2 = sum(g*xhat)/m of the workgroup's 64 channels from the reduce
 // kernel's slot partials; the row-chunk-0 workgroups publish dgamma / dbeta.
-template <int MASK, int LEGACY = 0>          // LEGACY 1: round-1 placement and cached loads (FRCNN_SWEEP A/B runs only)
+// RED2 (frcnn_bn_bwd_apply_fused_red2): the same launch ALSO runs the backward reduce of a SECOND BatchNorm that receives the same masked
+// gradient -- the shortcut branch of a stage's first block (conv<N>_block1_0_bn) next to the block-final BatchNorm (..._3_bn): sum g*m and
+// sum g*m*xhat2 with xhat2 from the second layer's z / mean / invstd, per thread over the rows it streams anyway (the rows, their order
+// and the workgroup's reduction tree are bn_bwd_reduce_kernel's: the slot partials are the same numbers), one more 16-byte load per row
+// vector instead of a launch that re-reads g, z2 and the mask.
+struct BnRed2 {
+    const bf16_t* z; const float* mean; const float* invstd; float* part;
+};
+template <int MASK, int LEGACY = 0, bool RED2 = false>          // LEGACY 1: round-1 placement and cached loads (FRCNN_SWEEP A/B runs only)
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* __restrict__ gout, const void* __restrict__ act,
                                                                  const bf16_t* __restrict__ z, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -575,8 +583,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                  bf16_t* __restrict__ dz, bf16_t* __restrict__ gpre, int64_t M, int C,
                                                                  int rows_per_block, int strips, int chunks, uint8_t* __restrict__ dz8,
-                                                                 const float* __restrict__ dz8_qscale, float* __restrict__ dz8_amax) {
+                                                                 const float* __restrict__ dz8_qscale, float* __restrict__ dz8_amax, const BnRed2 r2) {
     __shared__ double red[2][4][64];
+    __shared__ float red2[RED2 ? 32 : 1][8][17];  // RED2: [row lane][vector][16 sums + pad], as bn_bwd_reduce_kernel
     __shared__ float s_par[4][64];                // gamma*invstd, mean, invstd (xhat), c1, c2 folded: a, mu, is, k1, k2
     __shared__ float s_c2[64];
     int strip, chunk;
@@ -611,12 +620,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
     }
     const int v = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int C8 = C / 8, cv = c0 / 8 + v;
-    if (cv >= C8) return;
+    if (cv >= C8) return;                        // (RED2: the host requires C % 64 == 0 -- nobody leaves before the reduction's barriers)
     float ga[8], mu[8], is[8], k1[8], k2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         ga[e] = s_par[0][v * 8 + e]; mu[e] = s_par[1][v * 8 + e]; is[e] = s_par[2][v * 8 + e];
         k1[e] = s_par[3][v * 8 + e]; k2[e] = s_c2[v * 8 + e];
+    }
+    float mu2[RED2 ? 8 : 1], is2[RED2 ? 8 : 1], sg2[RED2 ? 8 : 1], sgx2[RED2 ? 8 : 1];
+    if (RED2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mu2[e] = r2.mean[cv * 8 + e]; is2[e] = r2.invstd[cv * 8 + e]; sg2[e] = sgx2[e] = 0.f; }
     }
     const int64_t row_begin = (int64_t)chunk * rows_per_block;
     const int64_t row_end = min(M, row_begin + (int64_t)rows_per_block);
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
     // error-feedback chain does not depend on U.
     constexpr int U = LEGACY == 1 ? 1 : FRCNN_BN_U;
     for (int64_t rb = row_begin; rb < row_end; rb += 32 * U) {
-        u32x4 graw[U], zraw[U], araw[U];
+        u32x4 graw[U], zraw[U], araw[U], z2raw[RED2 ? U : 1];
         unsigned mraw[U];
         bool ok[U];
 #pragma unroll
@@ -653,6 +667,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
                 zraw[u] = LEGACY == 1 ? *reinterpret_cast<const u32x4*>(z + i * 8) : load_stream(z + i * 8);    //  gradient and of z: streamed)
                 if (MASK == 1) araw[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(act) + i * 8);
                 if (MASK == 2) mraw[u] = reinterpret_cast<const uint8_t*>(act)[i];
+                if (RED2) z2raw[u] = *reinterpret_cast<const u32x4*>(r2.z + i * 8);
             }
         }
 #pragma unroll
@@ -670,6 +685,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
                 const unsigned m = mraw[u];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = ((m >> e) & 1u) ? g[e] : 0.f;
+            }
+            if (RED2 && ok[u]) {                 // (g is the masked gradient here: bn_bwd_reduce_kernel's terms)
+                float z2[8];
+                unpack8(z2raw[u], z2);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sg2[e] += g[e];
+                    sgx2[e] += g[e] * ((z2[e] - mu2[e]) * is2[e]);
+                }
             }
             if (ok[u]) {
 #pragma unroll
@@ -693,6 +717,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const bf16_t* _
         }
     }
     if (dz8 && dz8_amax) atomic_amax(dz8_amax, f8_max);
+    if (RED2) {                                  // workgroup reduction + slot atomics of bn_bwd_reduce_kernel
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red2[rl][v][e] = sg2[e]; red2[rl][v][8 + e] = sgx2[e]; }
+        __syncthreads();
+        for (int s = 16; s > 0; s >>= 1) {
+            if (rl < s) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red2[rl][v][e] += red2[rl + s][v][e];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < 128) {
+            const int stat = threadIdx.x >> 6, cl = threadIdx.x & 63;
+            const int slot = (chunk * strips + strip) & (FRCNN_STAT_SLOTS - 1);
+            atomicAdd(r2.part + ((int64_t)slot * 2 + stat) * C + c0 + cl, red2[0][cl >> 3][stat * 8 + (cl & 7)]);
+        }
+    }
 }
 
 template <bool MASK>
@@ -1210,13 +1251,19 @@ extern "C" int frcnn_bn_train_apply(const frcnn_bf16* z, const double* stats_par
     return FRCNN_OK;
 }
 
-extern "C" int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z,
-                                        const float* mean, const float* invstd, const float* gamma, const float* partial, int slots,
-                                        float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, int64_t count,
-                                        float param_grad_scale, const frcnn_fp8_out* f8, frcnn_stream_t stream) {
+static int bn_bwd_apply_fused_impl(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z,
+                                   const float* mean, const float* invstd, const float* gamma, const float* partial, int slots,
+                                   float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, int64_t count,
+                                   float param_grad_scale, const frcnn_fp8_out* f8, const frcnn_bn_reduce* red2, frcnn_stream_t stream) {
     FRCNN_CHECK_ARG(gout && z && mean && invstd && gamma && partial && dgamma && dbeta && (dz || f8) && m > 0 && slots > 0 && c % 8 == 0 &&
                         !(act && relu_mask),
                     "bn_bwd_apply_fused: bad arguments (dz may be NULL only with an fp8 twin)");
+    BnRed2 r2 = {nullptr, nullptr, nullptr, nullptr};
+    if (red2) {
+        FRCNN_CHECK_ARG(red2->z && red2->mean && red2->invstd && red2->partial && c % 64 == 0 && relu_mask,
+                        "bn_bwd_apply_fused_red2: second reduce needs z / mean / invstd / partial, a ReLU bit mask and c %% 64 == 0");
+        r2.z = CBF(red2->z); r2.mean = red2->mean; r2.invstd = red2->invstd; r2.part = red2->partial;
+    }
     FRCNN_CHECK_ARG(!f8 || (f8->out8 && f8->qscale), "bn_bwd_apply_fused: fp8 output without buffer / scale");
     const int rows = strip_rows_per_block(m, c);
     const int strips = (c + 63) / 64, chunks = (int)((m + rows - 1) / rows);
@@ -1225,7 +1272,14 @@ extern "C" int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16
 #define FRCNN_LAUNCH(MODE, PTR, LEG)                                                                                                      \
     hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<MODE, LEG>), grid, dim3(256), 0, S_(stream), CBF(gout), (const void*)(PTR), CBF(z), mean, \
                        invstd, gamma, partial, slots, inv_m, param_grad_scale, dgamma, dbeta, BF(dz), BF(gpre), m, c, rows, strips, chunks,   \
-                       f8 ? f8->out8 : (uint8_t*)nullptr, f8 ? f8->qscale : (const float*)nullptr, f8 ? f8->amax : (float*)nullptr)
+                       f8 ? f8->out8 : (uint8_t*)nullptr, f8 ? f8->qscale : (const float*)nullptr, f8 ? f8->amax : (float*)nullptr, r2)
+    if (red2) {
+        hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<2, 0, true>), grid, dim3(256), 0, S_(stream), CBF(gout), (const void*)relu_mask, CBF(z), mean,
+                           invstd, gamma, partial, slots, inv_m, param_grad_scale, dgamma, dbeta, BF(dz), BF(gpre), m, c, rows, strips, chunks,
+                           f8 ? f8->out8 : (uint8_t*)nullptr, f8 ? f8->qscale : (const float*)nullptr, f8 ? f8->amax : (float*)nullptr, r2);
+        FRCNN_CHECK_LAUNCH("bn_bwd_apply_fused_red2");
+        return FRCNN_OK;
+    }
 #ifdef FRCNN_SWEEP
     const char* ev = getenv("FRCNN_BN_VAR");
     if (ev && atoi(ev) == 4) {
@@ -1240,6 +1294,23 @@ extern "C" int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16
 #undef FRCNN_LAUNCH
     FRCNN_CHECK_LAUNCH("bn_bwd_apply_fused");
     return FRCNN_OK;
+}
+
+extern "C" int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, const uint8_t* relu_mask, const frcnn_bf16* z,
+                                        const float* mean, const float* invstd, const float* gamma, const float* partial, int slots,
+                                        float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, int64_t count,
+                                        float param_grad_scale, const frcnn_fp8_out* f8, frcnn_stream_t stream) {
+    return bn_bwd_apply_fused_impl(gout, act, relu_mask, z, mean, invstd, gamma, partial, slots, dgamma, dbeta, dz, gpre, m, c, count, param_grad_scale, f8,
+                                   nullptr, stream);
+}
+
+extern "C" int frcnn_bn_bwd_apply_fused_red2(const frcnn_bf16* gout, const uint8_t* relu_mask, const frcnn_bf16* z, const float* mean,
+                                             const float* invstd, const float* gamma, const float* partial, int slots, float* dgamma,
+                                             float* dbeta, frcnn_bf16* dz, int64_t m, int c, int64_t count, float param_grad_scale,
+                                             const frcnn_fp8_out* f8, const frcnn_bn_reduce* red2, frcnn_stream_t stream) {
+    FRCNN_CHECK_ARG(red2, "bn_bwd_apply_fused_red2: null frcnn_bn_reduce");
+    return bn_bwd_apply_fused_impl(gout, nullptr, relu_mask, z, mean, invstd, gamma, partial, slots, dgamma, dbeta, dz, nullptr, m, c, count,
+                                   param_grad_scale, f8, red2, stream);
 }
 
 extern "C" int frcnn_bn_bwd_blocks(int64_t m) { (void)m; return FRCNN_STAT_SLOTS; }

@@ -25,6 +25,8 @@ BN_MOMENTUM = 0.99
 GROUPED_WGRAD = os.environ.get("FRCNN_GROUPED_WGRAD", "1") != "0"      # (0: one weight-gradient launch per layer)
 # measuring aid: the grouped weight-gradient launches of conv4 / conv3 on a side stream under the next stage's backward chain (single GPU: no bucket cuts)
 WGRAD_TRAIL = os.environ.get("FRCNN_WGRAD_TRAIL", "0") != "0"
+# the backward reduce of a first block's shortcut BatchNorm inside the block-final BatchNorm's backward-apply launch (0: its own launch)
+BN_RED2 = os.environ.get("FRCNN_BN_RED2", "1") != "0"
 STACKS = {50: ((64, 3, 1), (128, 4, 2), (256, 6, 2)), 101: ((64, 3, 1), (128, 4, 2), (256, 23, 2))}
 
 
@@ -271,10 +273,12 @@ class _ConvBN:
             self._red = (relu, ops.bn_reduce_args(self.z, self.relu_mask if relu else None, self.mean, self.invstd, self.bwd_partial))
         return self._red[1]
 
-    def backward_bn(self, plan, gout, act, gpre=None, reduced=False, mask=None):
+    def backward_bn(self, plan, gout, act, gpre=None, reduced=False, mask=None, also_reduce=None):
         """reduced: the kernel that produced gout already accumulated this layer's backward sums (conv2d_dgrad_bnreduce).
         mask: ReLU bit mask to apply to gout instead of this layer's own (the shortcut BN of a block receives the block-output
-        gradient masked by the block's final ReLU)."""
+        gradient masked by the block's final ReLU).
+        also_reduce: a second conv unit whose BatchNorm receives the SAME masked gradient (the shortcut unit of a stage's first block):
+        this launch accumulates its backward sums too (ops.bn_bwd_apply_fused_red2); its own backward_bn then runs with reduced=True."""
         st = self.store
         if mask is None:
             mask = self.relu_mask if act is not None else None   # (act only says whether the layer ends in a ReLU)
@@ -284,6 +288,14 @@ class _ConvBN:
             plan.sync_point(self.name + "_bn_bwd", [self.bwd_partial])
         # fp8 mode: where both consumers of dz (data gradient, weight gradient) read its e5m2 twin, the bf16 tensor is not stored
         dz = None if (getattr(self, "dz_twin_only", False) and self.dz8 is not None) else self.dz
+        if also_reduce is not None:
+            assert mask is not None and gpre is None and self.cout % 64 == 0 and also_reduce.cout == self.cout and also_reduce.m == self.m
+            red2 = also_reduce.reduce_args(relu=False)
+            plan.hold(red2)
+            plan.add(ops.bn_bwd_apply_fused_red2, gout, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"), self.bwd_partial,
+                     self.bwd_blocks, st.grad(self.name + "_bn/gamma"), st.grad(self.name + "_bn/beta"), dz, self.m, self.cout, mask, red2,
+                     count=self.m * self.sync_world, param_grad_scale=1.0 / self.sync_world, f8=self.dz8.out if self.dz8 is not None else None)
+            return
         plan.add(ops.bn_bwd_apply_fused, gout, None, self.z, self.mean, self.invstd, st.weight(self.name + "_bn/gamma"),
                  self.bwd_partial, self.bwd_blocks, st.grad(self.name + "_bn/gamma"), st.grad(self.name + "_bn/beta"), dz, gpre,
                  self.m, self.cout, relu_mask=mask, count=self.m * self.sync_world, param_grad_scale=1.0 / self.sync_world,
@@ -681,7 +693,9 @@ class FeatureExtractor:
             # the block-output gradient after the final ReLU (g * mask) is never materialised: its two consumers -- the
             # shortcut branch and the residual add of the block-input gradient -- read gout and the block's ReLU bit mask
             gblock, mblock = gout, u[3].relu_mask
-            u[3].backward_bn(plan, gout, a["out"], reduced=gout_reduced)
+            # (first block of a stage: the shortcut BatchNorm's backward sums -- same gradient, same mask -- in the same launch)
+            red2 = first and BN_RED2 and u[3].cout % 64 == 0
+            u[3].backward_bn(plan, gout, a["out"], reduced=gout_reduced, also_reduce=u[0] if red2 else None)
             u[3].backward_weights(plan, a["a2"], defer, a.get("a2_8"))
             u[3].backward_data(plan, a["g2"], consumer=u[2])
             u[2].backward_bn(plan, a["g2"], a["a2"], reduced=True)
@@ -691,7 +705,7 @@ class FeatureExtractor:
             u[1].backward_weights(plan, xin, defer, xs8[n])
             prev = prev_of[n]                     # block whose output this block's input gradient is (None: max-pool output)
             if first:
-                u[0].backward_bn(plan, gblock, None, mask=mblock)
+                u[0].backward_bn(plan, gblock, None, mask=mblock, reduced=red2)
                 u[0].backward_weights(plan, xin, defer, xs8[n])
                 if s != 1 and n in injected:
                     u[1].backward_data(plan, a["gin"], res=a["gin"])      # add to the gradient the other consumer left there

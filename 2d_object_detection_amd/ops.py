@@ -351,6 +351,13 @@ def bn_bwd_apply_fused(gout, act, z, mean, invstd, gamma, partial, slots, dgamma
          _p(dgamma), _p(dbeta), _p(dz), _p(gpre), m, c, count, float(param_grad_scale), byref(f8) if f8 is not None else None, _stream())
 
 
+def bn_bwd_apply_fused_red2(gout, z, mean, invstd, gamma, partial, slots, dgamma, dbeta, dz, m, c, relu_mask, red2, count=0, param_grad_scale=1.0, f8=None):
+    """bn_bwd_apply_fused (ReLU bit mask form) + the backward reduce of a second BatchNorm fed by the same masked gradient (red2 = bn_reduce_args
+    of that layer: the shortcut BatchNorm of a stage's first block)."""
+    call("frcnn_bn_bwd_apply_fused_red2", _p(gout), _p(relu_mask), _p(z), _p(mean), _p(invstd), _p(gamma), _p(partial), slots, _p(dgamma), _p(dbeta),
+         _p(dz), m, c, count, float(param_grad_scale), byref(f8) if f8 is not None else None, byref(red2), _stream())
+
+
 def bn_bwd_blocks(m):
     return _lib.load().frcnn_bn_bwd_blocks(m)
 

@@ -322,6 +322,15 @@ int frcnn_bn_bwd_apply_fused(const frcnn_bf16* gout, const frcnn_bf16* act, cons
                              float* dgamma, float* dbeta, frcnn_bf16* dz, frcnn_bf16* gpre, int64_t m, int c, int64_t count,
                              float param_grad_scale, const struct frcnn_fp8_out* f8 /* NULL, or the e5m2 twin of dz; with a twin dz may be
                              NULL: the bf16 tensor is then not stored (every consumer reads the twin) */, frcnn_stream_t stream);
+/* frcnn_bn_bwd_apply_fused (ReLU bit mask form, no gpre) that ALSO runs the backward reduce of a second BatchNorm receiving the same
+ * masked gradient (red2: its z / mean / invstd / partial; red2->relu_mask is ignored -- the mask is this launch's): the shortcut
+ * BatchNorm of a stage's first block beside the block-final one (Keras conv<N>_block1_0_bn / _3_bn,
+ * models/feature_extractor.py:8).  == frcnn_bn_bwd_apply_fused + frcnn_bn_bwd_reduce(gout, relu_mask, red2...), the slot partials up to
+ * the order of their float atomics.  c % 64 == 0.  (ABI 7) */
+int frcnn_bn_bwd_apply_fused_red2(const frcnn_bf16* gout, const uint8_t* relu_mask, const frcnn_bf16* z, const float* mean,
+                                  const float* invstd, const float* gamma, const float* partial, int slots, float* dgamma, float* dbeta,
+                                  frcnn_bf16* dz, int64_t m, int c, int64_t count, float param_grad_scale,
+                                  const struct frcnn_fp8_out* f8, const struct frcnn_bn_reduce* red2, frcnn_stream_t stream);
 /* g_out = g * (act > 0): ReLU backward without BN (RPN intermediate layer) */
 int frcnn_relu_bwd(const frcnn_bf16* g, const frcnn_bf16* act, frcnn_bf16* out, int64_t n, frcnn_stream_t stream);
 /* per-channel column sum of a bf16 [m,c] matrix ADDED (float atomics) to fp32 out[c] (bias gradients;

@@ -118,6 +118,42 @@ def test_bn_forward_backward(ops):
     assert torch.equal(pa, pb) and all(torch.equal(x, y) for x, y in zip(res_a, res_b)), "bit mask == activation mask"
 
 
+@pytest.mark.parametrize("m,c", [(7488, 1024), (29328, 512), (5000, 256), (203, 64)])
+def test_bn_bwd_apply_red2_equals_apply_plus_reduce(ops, m, c):
+    """frcnn_bn_bwd_apply_fused_red2 == frcnn_bn_bwd_apply_fused (ReLU bit mask form) + frcnn_bn_bwd_reduce of a second BatchNorm on the same
+    masked gradient (the shortcut BatchNorm of a stage's first block: conv<N>_block1_0_bn beside _3_bn): dz, dgamma, dbeta bit for bit; the
+    second layer's slot partials up to the order of their float atomics (the workgroups and their reduction trees are the same: with one
+    row chunk per strip -- the small case -- bit for bit).  Shapes: conv4 / conv3 at the benchmark's batch, ragged row counts."""
+    g = torch.Generator().manual_seed(m + c)
+    dev = "cuda"
+    nb = ops.bn_bwd_blocks(m)
+    gout, z, z2 = (torch.randn(m, c, generator=g).to(BF).to(dev) for _ in range(3))
+    rmask = torch.randint(0, 256, (m, c // 8), generator=g, dtype=torch.uint8).to(dev)
+    mean, mean2 = torch.randn(c, generator=g).to(dev) * 0.1, torch.randn(c, generator=g).to(dev) * 0.1
+    invstd, invstd2 = (torch.rand(c, generator=g) + 0.5).to(dev), (torch.rand(c, generator=g) + 0.5).to(dev)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
+    part = torch.zeros(nb, 2, c, device=dev)
+    ops.bn_bwd_reduce(gout, None, z, mean, invstd, part, m, c, relu_mask=rmask)
+
+    def outs():
+        return dict(dg=torch.empty(c, device=dev), db=torch.empty(c, device=dev), dz=torch.empty(m, c, dtype=BF, device=dev),
+                    p2=torch.full((nb, 2, c), 0.25, device=dev))
+    a, b = outs(), outs()
+    ops.bn_bwd_apply_fused(gout, None, z, mean, invstd, gamma, part, nb, a["dg"], a["db"], a["dz"], None, m, c, relu_mask=rmask)
+    ops.bn_bwd_reduce(gout, None, z2, mean2, invstd2, a["p2"], m, c, relu_mask=rmask)
+    red2 = ops.bn_reduce_args(z2, None, mean2, invstd2, b["p2"])
+    ops.bn_bwd_apply_fused_red2(gout, z, mean, invstd, gamma, part, nb, b["dg"], b["db"], b["dz"], m, c, rmask, red2)
+    torch.cuda.synchronize()
+    assert torch.equal(a["dz"].view(torch.int16), b["dz"].view(torch.int16)) and torch.equal(a["dg"], b["dg"]) and torch.equal(a["db"], b["db"])
+    sa, sb = a["p2"].double().sum(0), b["p2"].double().sum(0)
+    assert float(sa.abs().max()) > 1.0 and float(((sa - sb).abs() / (sa.abs() + 1.0)).max()) < 1e-4, "second layer's backward sums"      # (fp32 slot atomics: a few ulp of sums of magnitude 10 - 300)
+    if m <= 300:
+        assert torch.equal(a["p2"], b["p2"])
+    with pytest.raises(RuntimeError):
+        ops.bn_bwd_apply_fused_red2(gout[:, :72].contiguous(), z[:, :72].contiguous(), mean[:72], invstd[:72], gamma[:72], part[:, :, :72].contiguous(), nb,
+                                    b["dg"][:72], b["db"][:72], b["dz"][:, :72].contiguous(), m, 72, rmask[:, :9].contiguous(), red2)       # c % 64 != 0
+
+
 def test_bn_wide_channels_and_eval(ops):
     g = torch.Generator().manual_seed(1)
     m, c = 300, 1024
