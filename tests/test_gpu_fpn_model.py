@@ -279,7 +279,7 @@ def test_backbone_gradient_injection_is_additive():
         return fe, inj
 
     ops_mod = importlib.import_module("2d_object_detection_amd.ops")
-    (fa, _), (fb, inj) = run_once(False), run_once(True)
+    (fa, _), (fa2, _), (fb, inj) = run_once(False), run_once(False), run_once(True)
     for n in ("conv4_block1", "conv3_block1"):
         d = fb.acts[n]["gin"].float() - fa.acts[n]["gin"].float()
         if n == "conv4_block1":        # nothing upstream of conv4_block1 differs between the runs: d is the injected tensor up to the bf16
@@ -302,8 +302,13 @@ def test_backbone_gradient_injection_is_additive():
     # float atomics, a different arrival order flips last bits of the top layer's dz (1e-6 of its norm), and every layer below amplifies
     # that about tenfold at this geometry (192 pixels per BatchNorm, random initialisation): tools/probes/diag_fe_repeat.py measures
     # 2e-6 at conv4_block6_3, 4e-4 at conv4_block6_1, 7e-3 at conv4_block2_1, 1e-2 at the stem between identical runs.
-    assert _rel(fa.store.grad("conv4_block6_3_conv/kernel"), fb.store.grad("conv4_block6_3_conv/kernel")) < 1e-4, "downstream gradients must not"
-    assert _rel(fa.store.grad("conv4_block2_1_conv/kernel"), fb.store.grad("conv4_block2_1_conv/kernel")) < 5e-2, "downstream gradients must not"
+    # not a fixed 5e-2 (a real non-additivity below it would pass) -- the bound is the noise of THIS box, measured here: the same
+    # un-injected plan run twice (fa, fa2), times three, plus a floor for a box that happens to repeat itself bit for bit
+    for name in ("conv4_block6_3_conv/kernel", "conv4_block2_1_conv/kernel"):
+        noise = _rel(fa2.store.grad(name), fa.store.grad(name))
+        moved = _rel(fb.store.grad(name), fa.store.grad(name))
+        print("%s: run-to-run %.3g, injected vs plain %.3g" % (name, noise, moved))
+        assert moved <= 3.0 * noise + 2e-5, "downstream gradients must not change: %s moved by %g where two identical runs differ by %g" % (name, moved, noise)
 
 
 def _full_size_discrete_checks(model, cfg, gl, gb, losses, step, seed):
