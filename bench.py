@@ -117,7 +117,7 @@ def classify(ops, fn, args, kwargs):
     if fn is ops.conv2d_wgrad_grouped:
         return FAM_WGRAD, sum(conv_flops(it[0], *_true_dims(it[0])) for it in args[0].items), 0.0
     name = getattr(fn, "__name__", str(fn))
-    if name in ("bn_train_apply", "bn_apply", "bn_bwd_apply_fused", "bn_bwd_reduce", "bn_train_apply_maxpool", "bn_train_apply_dual"):
+    if name in ("bn_train_apply", "bn_apply", "bn_bwd_apply_fused", "bn_bwd_apply_fused_red2", "bn_bwd_reduce", "bn_train_apply_maxpool", "bn_train_apply_dual"):
         return "batchnorm apply / reduce (bn_*_kernel)", 0.0, _tensor_bytes(args, kwargs)
     if name in ("roi_crop_pool_fwd", "roi_crop_pool_fwd_level"):
         return "RoI crop+pool forward (roi_fwd_kernel)", 0.0, _tensor_bytes(args, kwargs)
