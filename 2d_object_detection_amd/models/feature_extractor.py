@@ -46,7 +46,7 @@ FP8_MIN_STAGE = int(os.environ.get("FRCNN_FP8_MIN_STAGE", "2"))      # first Res
 # conv3 25.7 -> 27.6, conv4 20.0 -> 20.3 (byte mask stores; 36.0 / 28.9 / 21.5 with the mask bytes pooled by cross-lane shuffles).  In the step
 # (same-box A/B, ms): "wres" 3.885 -> "3x3" 3.858; "3x3" 3.903 / 3.909 -> "1" 3.932 / 3.903.  The in-place transform of a landed tile is VALU
 # work that EVERY channel-part workgroup of a pixel tile repeats (4 - 8 x for the 1x1 layers: 2.5 - 5 us per launch) and the ReLU bit mask
-# costs as much again (1.3 - 4 us): on the 1x1 layers that is what the 5 - 11 us BatchNorm launch cost.  DESIGN.md section 0.6.
+# costs as much again (1.3 - 4 us): on the 1x1 layers that is what the 5 - 11 us BatchNorm launch cost.  DESIGN.md section 0.2.
 BN_IN_FUSED = os.environ.get("FRCNN_BN_IN", "3x3")
 FP8_BWD = os.environ.get("FRCNN_FP8_BWD", "1") != "0"                # measuring aid: 0 keeps the data gradients in bf16 (fp8 forward only)
 FP8_WGRAD = os.environ.get("FRCNN_FP8_WGRAD", "1") != "0"            # measuring aid: 0 keeps the weight gradients in bf16
