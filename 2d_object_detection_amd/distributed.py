@@ -68,16 +68,26 @@ class GradientSynchronizer:
     `grad` is the flat fp32 gradient tensor, `buckets` a list of (name, begin, end) in the order the
     buckets become final.  Use `after_segment` as the `sync_fn` of FasterRCNN.train_step."""
 
-    def __init__(self, grad, buckets, group=None, force=None):
-        """force (default: FRCNN_FORCE_COLLECTIVES): issue the all-reduces at world 1 as well (needs an initialised group)."""
+    def __init__(self, grad, buckets, group=None, force=None, compress=None):
+        """force (default: FRCNN_FORCE_COLLECTIVES): issue the all-reduces at world 1 as well (needs an initialised group).
+        compress (default: FRCNN_GRAD_COMPRESS; None / "bf16"): "bf16" sends every bucket as bfloat16 -- cast on the comm stream, SUM
+        all-reduce of half the bytes (28.3 MB instead of 56.6 MB per step for ResNet-50), the sum written back
+        into the fp32 gradient.  Every rank's contribution is rounded to 8 significand bits before the sum, and so is every partial
+        sum of the reduction: on two ranks an element of the reduced gradient is within 2^-8 (sum_r |g_r| + |sum_r g_r|) of the fp32
+        all-reduce (tests/test_distributed_gloo.py checks exactly that; a ring over W ranks adds one rounding per hop); the momentum
+        buffer and the weights stay fp32.  Off by default: the reference sums fp32 gradients."""
         self.grad = grad
         self.buckets = list(buckets)
+        compress = os.environ.get("FRCNN_GRAD_COMPRESS", "") if compress is None else compress
+        assert compress in ("", "none", "bf16", None), compress
+        self.compress = "bf16" if compress == "bf16" else None
+        self._half = torch.empty(max(e - b for _, b, e in self.buckets), dtype=torch.bfloat16, device=grad.device) if self.compress else None
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (bool(force_collectives() if force is None else force) and dist.is_initialized())
         self.on_gpu = grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if (self.on_gpu and self.active) else None
-        self.bytes_per_step = sum(e - b for _, b, e in self.buckets) * grad.element_size()
+        self.bytes_per_step = sum(e - b for _, b, e in self.buckets) * (2 if self.compress else grad.element_size())
         self.calls = 0                               # all-reduces issued so far
 
     def reduce_bucket(self, i):
@@ -91,7 +101,17 @@ class GradientSynchronizer:
             ready.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ready)
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce(view)
+        else:
+            self._all_reduce(view)
+
+    def _all_reduce(self, view):
+        if self.compress:
+            # (the buckets are reduced one after the other on the comm stream: one staging buffer serves them all)
+            half = self._half[:view.numel()]
+            half.copy_(view)
+            dist.all_reduce(half, op=dist.ReduceOp.SUM, group=self.group)
+            view.copy_(half)
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
 

@@ -542,7 +542,7 @@ def measure(spec, args, rank, world, dev, windows, with_segmented, with_rccl_leg
         "config": {"workload": workload_text(spec, world),
                    "global_batch": world * B, "image_shape": cfg["image_shape"], "parallelism": "dp%d" % world,
                    "hip_graphs": model.use_graphs, "kernel_launches_per_step": model._train_plan["plan"].num_launches,
-                   "resident_batches": NB,
+                   "resident_batches": NB, "grad_compress": getattr(sync, "compress", None),
                    "segmented_ms_per_step": None if segmented_ms is None else round(segmented_ms, 4),
                    "forced_collectives_world1": rccl,
                    "segments": len(model._train_plan["plan"].segments)},

@@ -36,6 +36,24 @@ def _worker(rank, world, port, tmp):
             done.append(torch.equal(g[b2:e2], torch.arange(b2, e2, dtype=torch.float32) * (rank + 1)))   # not yet reduced
     assert all(done), done
 
+    # 1b. bf16 gradient buckets (compress="bf16"): half the bytes on the wire.  Rounding bound against the fp32 all-reduce, per element:
+    #     every rank's contribution is rounded to bf16 (relative error <= 2^-8: eight significand bits) and so is every partial sum of the
+    #     reduction: |error| <= 2^-8 (sum_r |g_r| + |sum_r g_r|) for two ranks; exact for values whose sums bf16 represents
+    gen_c = torch.Generator().manual_seed(11)
+    parts = [torch.randn(100, generator=gen_c) * 10 ** torch.randint(-3, 3, (100,), generator=gen_c).float() for _ in range(world)]
+    gc = parts[rank].clone()
+    sc = D.GradientSynchronizer(gc, buckets, compress="bf16")
+    assert sc.bytes_per_step == 200 and sync.bytes_per_step == 400
+    for seg in range(4):
+        sc.after_segment(seg, 5)
+    exact = sum(parts)
+    bound = 2.0 ** -8 * (torch.stack([x.abs() for x in parts]).sum(0) + exact.abs()) + 1e-30
+    assert bool(((gc - exact).abs() <= bound).all()), float(((gc - exact).abs() / bound).max())
+    assert float((gc - exact).abs().max()) > 0, "bf16 buckets rounded nothing: was the compressed path taken?"
+    gi = (torch.arange(100, dtype=torch.float32) % 64) * (rank + 1)            # integers below 2^8: bf16 holds them and their sums exactly
+    D.GradientSynchronizer(gi, buckets, compress="bf16").after_segment(0, 2)
+    assert torch.equal(gi[:40], (torch.arange(40, dtype=torch.float32) % 64) * 3)
+
     # 2. loss-scaling rule: sum over ranks of (cls/world + reg) gradients == single-process gradient of the global batch
     from oracle import faster_rcnn as O
     cfg = O.default_config((64, 96, 3))
