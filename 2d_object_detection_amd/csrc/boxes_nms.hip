@@ -186,12 +186,37 @@ __device__ __forceinline__ f32x4 nms_norm(const f32x4 a) {
     return f32x4{fminf(a[0], a[2]), fminf(a[1], a[3]), fmaxf(a[0], a[2]), fmaxf(a[1], a[3])};
 }
 __device__ __forceinline__ float nms_area(const f32x4 n) { return (n[2] - n[0]) * (n[3] - n[1]); }
-__device__ __forceinline__ bool nms_over(const f32x4 a, const float area_a, const f32x4 b, const float area_b, const float thr) {
-    const float iy0 = fmaxf(a[0], b[0]), ix0 = fmaxf(a[1], b[1]);
-    const float iy1 = fminf(a[2], b[2]), ix1 = fminf(a[3], b[3]);
-    const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
-    if (!(inter > 0.0f) || area_a <= 0.0f || area_b <= 0.0f) return false;     // thr >= 0: a zero IoU never suppresses
-    return inter / (area_a + area_b - inter) > thr;
+// v_max_f32 / v_min_f32 as written (fmaxf / fminf put a canonicalising v_max x, x in front of every operand that comes from memory:
+// 8 of this test's ~45 instructions; for non-NaN operands the results are the same bits)
+__device__ __forceinline__ float vmax(const float a, const float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin(const float a, const float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+struct IouThr {                 // thr, fl(thr (1 + 4e-6)), fl(thr (1 - 4e-6))
+    float thr, hi, lo;
+};
+__device__ __forceinline__ IouThr iou_thr_of(const float thr) { return IouThr{thr, thr * (1.0f + 4e-6f), thr * (1.0f - 4e-6f)}; }
+
+__device__ __forceinline__ bool nms_over(const f32x4 a, const float area_a, const f32x4 b, const float area_b, const IouThr th) {
+    const float iy0 = vmax(a[0], b[0]), ix0 = vmax(a[1], b[1]);
+    const float iy1 = vmin(a[2], b[2]), ix1 = vmin(a[3], b[3]);
+    const float inter = vmax(iy1 - iy0, 0.0f) * vmax(ix1 - ix0, 0.0f);
+    const bool live = inter > 0.0f && area_a > 0.0f && area_b > 0.0f;           // thr >= 0: a zero IoU never suppresses
+    // The quotient is only needed where it could round to either side of thr.  With u = area_a + area_b - inter (the divisor's own
+    // value): inter > fl(u thr (1 + 4e-6)) implies inter / u > thr (1 + 3.8e-6) (two roundings of 2^-24 each against the 4e-6), whose
+    // correctly rounded value is still above thr; inter < fl(u thr (1 - 4e-6)) likewise stays below -- provided the products are
+    // normal numbers (`sure`).  Only the sliver between (or a NaN / tiny product) takes the IEEE division -- behind a wave-uniform
+    // branch, so a wave without such a lane never issues it (the division was a third of this function's VALU work, and the two
+    // callers are VALU-bound on ONE CU).  Same truth value as the division for every non-NaN input
+    // (tests/test_host_logic.py::test_nms_threshold_predicate_equals_the_division restates the arithmetic).
+    const float u = area_a + area_b - inter;
+    const float hi = u * th.hi, lo = u * th.lo;
+    const bool sure = lo > 1e-30f;
+    bool over = live && sure && inter > hi;
+    const bool sliver = live && !over && !(sure && inter < lo);
+    if (__builtin_amdgcn_ballot_w64(sliver) != 0ull) {
+        if (sliver) over = inter / u > th.thr;
+    }
+    return over;
 }
 
 // order-preserving float -> uint (handles negatives too)
@@ -236,6 +261,34 @@ __device__ void bitonic_desc(unsigned long long* keys, int n_pad) {
     __syncthreads();
 }
 
+// The same network for n_pad <= NMS_T keys with ONE KEY PER THREAD, held in a register: a stage with pair distance j < 64 is a lane
+// exchange (two ds_bpermute, no LDS store / wait / reload between dependent stages -- the in-memory form above spends ~500 cycles on
+// each of its 45-55 dependent stages), only the stages with j >= 64 (6 of 45 for 512 keys, 10 of 55 for 1024) go through keys[].
+// Thread t's key ends in keys[t]: descending.
+__device__ void bitonic_desc_reg(unsigned long long* keys, const int n_pad) {
+    const int t = threadIdx.x;
+    unsigned long long key = t < n_pad ? keys[t] : 0ull;
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            unsigned long long other;
+            if (j >= 64) {                                    // (uniform)
+                __syncthreads();                              // the previous cross-wave stage's readers are done
+                if (t < n_pad) keys[t] = key;
+                __syncthreads();
+                other = t < n_pad ? keys[t ^ j] : 0ull;
+            } else {
+                other = __shfl_xor(key, j);
+            }
+            const bool take_max = ((t & j) == 0) == ((t & k) == 0);      // lower index of the pair in a descending block, or upper in an ascending one
+            const bool gt = key > other;
+            key = (take_max == gt) ? key : other;
+        }
+    }
+    __syncthreads();
+    if (t < n_pad) keys[t] = key;
+    __syncthreads();
+}
+
 struct NmsParams {
     const float* boxes; const float* scores;
     int N, q, C, score_stride, score_offset, max_per_class, lds_keys;
@@ -250,7 +303,7 @@ struct NmsParams {
 
 // LDS of nms_class_kernel; *lds_keys: the 32-bit score keys of the N candidates are staged in LDS (else re-read from global)
 static size_t nms_class_lds(int n, int max_per_class, bool* lds_keys) {
-    const size_t fixed = (size_t)max_per_class * 20 + NMS_CH * (16 + 32 + 4 + 4 + 4) + 64 + (size_t)NMS_HC * 256 * 4 + (size_t)NMS_RK * 8 + 16;
+    const size_t fixed = (size_t)max_per_class * 20 + NMS_CH * (16 + 32 + 4 + 4 + 4) + 64 + 16 + (size_t)NMS_HC * 256 * 4 + (size_t)NMS_RK * 8 + 16;
     *lds_keys = fixed + (size_t)n * 4 <= 150 * 1024;
     return fixed + (*lds_keys ? (size_t)n * 4 : 0);
 }
@@ -266,26 +319,56 @@ static size_t nms_class_lds(int n, int max_per_class, bool* lds_keys) {
 //      sequential part costs one step per KEPT box, not per candidate.
 // The order of visits is exactly the descending composite-key order (every key of a round is larger than every key of the
 // next; inside a round the sort is total): bit-identical results to a full sort.  No host sync, no library sort.
+#ifdef FRCNN_NMS_STAMPS
+// kernel-development build (tools/nms_stamps.py): thread 0 of the first workgroups accumulates the constant-rate clock (100 MHz)
+// over the kernel's phases -- 0 key staging, 1 radix select, 2 compaction, 3 sort, 4 chunk load + kept-list test, 5 survivor
+// compaction + suppression rows, 6 walk, 7 tail; 8 rounds, 9 chunks, 10 kept, 11-13 parts of 5, 14 select passes, 15 the histogram sweeps of 1 -- into a device symbol read by frcnn_debug_nms_stamps
+__device__ unsigned long long g_nms_stamps[2][8][16];
+#define NMS_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_prev; st_prev = now_; } } while (0)
+#define NMS_COUNT(i) do { if (threadIdx.x == 0) st_acc[i] += 1ull; } while (0)
+#else
+#define NMS_STAMP(i) do { } while (0)
+#define NMS_COUNT(i) do { } while (0)
+#endif
+
 template <bool LDSK>
 __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef FRCNN_NMS_STAMPS
+    unsigned long long st_acc[16] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
+    // (every pointer is smem + a byte offset: an alignment step on the POINTER's integer value -- the form up to round 5 -- made the
+    // compiler lose the LDS address space, and the select histogram, the round's keys and the staged score keys were reached with
+    // flat_load / flat_store / flat_atomic instructions: the bitonic network's 45-55 dependent stages each paid a flat round trip)
+    const size_t o_chunk_box = (size_t)p.max_per_class * 16;
+    const size_t o_sup = o_chunk_box + NMS_CH * 16;
+    const size_t o_kept_area = o_sup + NMS_CH * 32;
+    const size_t o_chunk_area = o_kept_area + (size_t)p.max_per_class * 4;
+    const size_t o_dead = o_chunk_area + NMS_CH * 4;
+    const size_t o_rows = o_dead + NMS_CH * 4;
+    const size_t o_misc = o_rows + NMS_CH * 4;
+    const size_t o_hist = (o_misc + 64 + 15) & ~(size_t)15;
+    const size_t o_rkeys = o_hist + (size_t)NMS_HC * 256 * 4;
+    const size_t o_skeys = o_rkeys + (size_t)NMS_RK * 8;
     f32x4* kept_box = reinterpret_cast<f32x4*>(smem);                                       // [max_per_class] corner-normalised
-    f32x4* chunk_box = kept_box + p.max_per_class;                                          // [NMS_CH] corner-normalised
-    unsigned long long* sup_of = reinterpret_cast<unsigned long long*>(chunk_box + NMS_CH); // [NMS_CH][4] later candidates suppressed by row
-    float* kept_area = reinterpret_cast<float*>(sup_of + NMS_CH * 4);                       // [max_per_class]
-    float* chunk_area = kept_area + p.max_per_class;                                        // [NMS_CH]
-    int* dead = reinterpret_cast<int*>(chunk_area + NMS_CH);                                // [NMS_CH] invalid or suppressed by the kept list
-    int* rows = dead + NMS_CH;                                                              // [NMS_CH] compacted list of surviving rows
-    int* misc = rows + NMS_CH;                                                              // [16] scalars shared through LDS
-    int* hist = misc + 16;                                                                  // [256][NMS_HC]
-    unsigned long long* rkeys = reinterpret_cast<unsigned long long*>((reinterpret_cast<size_t>(hist + NMS_HC * 256) + 7) & ~(size_t)7);   // [NMS_RK]
-    unsigned int* skeys = reinterpret_cast<unsigned int*>(rkeys + NMS_RK);                  // [N] (LDSK)
+    f32x4* chunk_box = reinterpret_cast<f32x4*>(smem + o_chunk_box);                        // [NMS_CH] corner-normalised
+    unsigned long long* sup_of = reinterpret_cast<unsigned long long*>(smem + o_sup);       // [NMS_CH][4] later candidates suppressed by row
+    float* kept_area = reinterpret_cast<float*>(smem + o_kept_area);                        // [max_per_class]
+    float* chunk_area = reinterpret_cast<float*>(smem + o_chunk_area);                      // [NMS_CH]
+    int* dead = reinterpret_cast<int*>(smem + o_dead);                                      // [NMS_CH] invalid or suppressed by the kept list
+    int* rows = reinterpret_cast<int*>(smem + o_rows);                                      // [NMS_CH] compacted list of surviving rows
+    int* misc = reinterpret_cast<int*>(smem + o_misc);                                      // [16] scalars shared through LDS
+    int* hist = reinterpret_cast<int*>(smem + o_hist);                                      // [NMS_HC][256], 16-byte aligned
+    unsigned long long* rkeys = reinterpret_cast<unsigned long long*>(smem + o_rkeys);      // [NMS_RK]
+    unsigned int* skeys = reinterpret_cast<unsigned int*>(smem + o_skeys);                  // [N] (LDSK)
 
     const int b = blockIdx.x / p.C, c = blockIdx.x % p.C;
     const int bc = (p.q == 1) ? 0 : c;
     const float* boxes = p.boxes + (int64_t)b * p.N * p.q * 4;
     const float* scores = p.scores + (int64_t)b * p.N * p.score_stride + p.score_offset + c;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const IouThr thr = iou_thr_of(p.iou_thr);
 
     auto score_key = [&](const int i) -> unsigned int {       // 0: not a candidate (score <= threshold)
         if (LDSK) return skeys[i];
@@ -311,14 +394,23 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
         if (lane == 0 && valid) atomicAdd(&misc[2], valid);
     }
     __syncthreads();
+    NMS_STAMP(0);
     int remaining = misc[2];
     unsigned long long prev = ~0ull;                          // candidates with a composite key below prev are still unvisited
     int kept = 0;
+    bool first_round = true;
     while (remaining > 0 && kept < p.max_per_class) {
-        const int K = remaining < NMS_RK ? remaining : NMS_RK;
+        NMS_COUNT(8);
+        // a round takes the next K_goal best candidates -- or, as soon as a digit boundary leaves at least half of that above it, the ones
+        // above that boundary: the rounds only have to partition the keys into descending ranges, not into equal ones, and every pass of
+        // the select that is not run saves a sweep over all N candidates.  The first round aims at 512: a list that suppresses little
+        // (max_per_class = 300 of an untrained RPN's 8768) ends inside it, one that suppresses much pays one short round more.
+        const int K_goal = first_round ? NMS_RK / 2 : NMS_RK;
+        first_round = false;
+        int K = remaining < K_goal ? remaining : K_goal;
         unsigned long long T = 1ull;                          // this round takes the keys in [T, prev)
-        if (remaining > NMS_RK) {
-            // ---- radix select: T = the K-th largest unvisited composite key
+        if (remaining > K_goal) {
+            // ---- radix select: T = the K-th largest unvisited composite key (or an earlier digit boundary, see above)
             unsigned long long prefix = 0ull;
             int want = K;
             bool found = false;
@@ -326,6 +418,8 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                 const int shift = 56 - 8 * pass;
                 for (int t = threadIdx.x; t < NMS_HC * 256; t += NMS_T) hist[t] = 0;
                 __syncthreads();
+                NMS_COUNT(14);
+                NMS_STAMP(1);
                 for (int i0 = 0; i0 < p.N; i0 += NMS_T) {         // (all lanes stay in the loop: ballots below)
                     const int i = i0 + threadIdx.x;
                     const unsigned int sk = i < p.N ? score_key(i) : 0u;
@@ -335,19 +429,43 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                     // one histogram per wave (NMS_HC = 16 copies = 16 waves): no atomic ever meets another wave's; equal digits
                     // inside a wave instruction (scores cluster: an untrained RPN puts every objectness near 0.5) are
                     // serialised by the LDS unit itself, a few cycles each
-                    if (in) atomicAdd(&hist[dg * NMS_HC + wave], 1);
+#ifndef FRCNN_NMS_NOPEEL
+                    // ... unless most of the wave shares a digit (the exponent byte of scores that all lie in [0.5, 1): a 64-way same-
+                    // address atomic occupies the LDS unit for 64+ cycles, and there are N / 64 of them per pass): up to two groups of
+                    // 16+ equal digits are counted by one lane each
+                    unsigned long long todo = __ballot(in);
+                    bool mine = in;
+#pragma unroll
+                    for (int peel = 0; peel < 2; ++peel) {
+                        if (todo == 0ull) break;
+                        const int leader = __builtin_ctzll(todo);
+                        const int d0 = __builtin_amdgcn_readlane(dg, leader);
+                        const unsigned long long same = __ballot(mine && dg == d0);
+                        if (__popcll(same) < 16) break;
+                        if (lane == leader) atomicAdd(&hist[wave * 256 + d0], __popcll(same));
+                        mine = mine && dg != d0;
+                        todo &= ~same;
+                    }
+                    if (mine) atomicAdd(&hist[wave * 256 + dg], 1);
+#else
+                    if (in) atomicAdd(&hist[wave * 256 + dg], 1);
+#endif
                 }
                 __syncthreads();
+                NMS_STAMP(15);
                 if (threadIdx.x < 64) {                       // the digit d with  #(digits above d) < want <= #(digits >= d)
-                    int cnt[4], mine = 0;
+                    // (copy-major layout hist[wave][256]: a wave's atomics spread over the banks by digit, and a lane's four digits of
+                    // one copy are one 16-byte read, consecutive over the lanes -- the digit-major layout put a wave's atomics on two
+                    // banks and this loop's 64 reads on one)
+                    int cnt[4] = {0, 0, 0, 0}, mine = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int sum = 0;
+                    for (int h = 0; h < NMS_HC; ++h) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(&hist[h * 256 + lane * 4]);
 #pragma unroll
-                        for (int h = 0; h < NMS_HC; ++h) sum += hist[(lane * 4 + e) * NMS_HC + h];
-                        cnt[e] = sum;
-                        mine += sum;
+                        for (int e = 0; e < 4; ++e) cnt[e] += (int)v[e];
                     }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mine += cnt[e];
                     int incl = mine;                          // inclusive suffix sum over the lanes (Hillis-Steele, doubling)
 #pragma unroll
                     for (int sh = 1; sh < 64; sh <<= 1) {
@@ -366,15 +484,21 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                     }
                 }
                 __syncthreads();
+                const unsigned long long above = ((prefix << 8) + (unsigned long long)misc[3] + 1ull) << shift;   // first key above this digit
                 prefix = (prefix << 8) | (unsigned long long)misc[3];
                 want -= misc[4];
                 if (want == misc[5] || pass == 7) {           // the boundary does not split this digit: every key with this prefix is taken
                     T = prefix << shift;
                     found = true;
+                } else if (K - want >= K_goal / 2) {          // enough candidates lie above the digit the boundary falls into: take those
+                    T = above;                                // (K - want > 0: some digit above misc[3] is occupied, so `above` did not wrap)
+                    K -= want;
+                    found = true;
                 }
                 __syncthreads();
             }
         }
+        NMS_STAMP(1);
         // ---- compact the round's keys, pad, sort
         if (threadIdx.x == 0) misc[6] = 0;
         const int n_sort = K <= NMS_CH ? NMS_CH : K <= 512 ? 512 : NMS_RK;
@@ -396,9 +520,12 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
             }
         }
         __syncthreads();
-        bitonic_desc(rkeys, n_sort);
+        NMS_STAMP(2);
+        bitonic_desc_reg(rkeys, n_sort);
+        NMS_STAMP(3);
 
         for (int base = 0; base < n_sort; base += NMS_CH) {
+            NMS_COUNT(9);
             // ---- 1. load the chunk
             if (threadIdx.x < NMS_CH) {
                 const unsigned long long k = rkeys[base + threadIdx.x];
@@ -423,7 +550,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int j = j0 + 4 * u;
-                        if (j < kept && nms_over(cb, ca, kept_box[j], kept_area[j], p.iou_thr)) hit = 1;
+                        if (j < kept && nms_over(cb, ca, kept_box[j], kept_area[j], thr)) hit = 1;
                     }
                 }
                 hit |= __shfl_xor(hit, 1);
@@ -431,6 +558,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                 if (sub == 0 && hit) dead[cand] = 1;
             }
             __syncthreads();
+            NMS_STAMP(4);
             // ---- 3. compact the survivors (wave 0), then build their rows of the suppression matrix
             if (threadIdx.x < 64) {
                 int n_alive = 0;
@@ -444,6 +572,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                 if (lane == 0) misc[1] = n_alive;
             }
             __syncthreads();
+            NMS_STAMP(11);
             const int n_alive = misc[1];
             {
                 // a lane's four column candidates (j = 64 w + lane) stay in registers for all the rows of its wave; a row costs
@@ -458,20 +587,24 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                     ca[w] = chunk_area[w * 64 + lane];
                     cdead[w] = dead[w * 64 + lane] != 0;
                 }
+                NMS_STAMP(12);
                 for (int ri = wave; ri < n_alive; ri += NMS_T / 64) {
                     const int i = rows[ri];
                     const f32x4 rb = chunk_box[i];
                     const float ra = chunk_area[i];
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
+                        if (w < (i >> 6)) continue;           // (wave-uniform) every column of this word precedes row i: never read
                         const int j = w * 64 + lane;
-                        const bool sgt = j > i && !cdead[w] && nms_over(cb[w], ca[w], rb, ra, p.iou_thr);
+                        const bool sgt = j > i && !cdead[w] && nms_over(cb[w], ca[w], rb, ra, thr);
                         const unsigned long long m = __ballot(sgt);
                         if (lane == 0) sup_of[i * 4 + w] = m;
                     }
                 }
+                NMS_STAMP(13);
             }
             __syncthreads();
+            NMS_STAMP(5);
             // ---- 4. walk the survivors in score order (wave 0): one step per kept box
             if (threadIdx.x < 64) {
                 unsigned long long alive[4], kmask[4];
@@ -547,6 +680,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                 if (lane == 0) misc[0] = k_now;
             }
             __syncthreads();
+            NMS_STAMP(6);
             kept = misc[0];
             if (kept >= p.max_per_class) break;
         }
@@ -584,7 +718,17 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
         }
         if (threadIdx.x == 0) p.out_valid[b] = nv;
     }
+#ifdef FRCNN_NMS_STAMPS
+    __syncthreads();
+    NMS_STAMP(7);
+    if (threadIdx.x == 0 && blockIdx.x < 8) {
+        st_acc[10] = (unsigned long long)kept;
+        for (int i = 0; i < 16; ++i) g_nms_stamps[p.C == 1 ? 0 : 1][blockIdx.x][i] = st_acc[i];
+    }
+#endif
 }
+#undef NMS_STAMP
+#undef NMS_COUNT
 
 struct MergeParams {
     const float* boxes; const unsigned long long* kept_keys; const int* kept_idx;
@@ -802,3 +946,9 @@ extern "C" int frcnn_nms_combined_abs(const float* boxes, const float* scores, i
     return nms_combined_impl(boxes, scores, b, n, q, c, score_stride, score_offset, max_per_class, max_total, iou_thr, score_thr, out_boxes,
                              out_scores, out_classes, out_valid, workspace, workspace_bytes, out_boxes_abs, scale_x, scale_y, stream);
 }
+
+#ifdef FRCNN_NMS_STAMPS
+extern "C" __attribute__((visibility("default"))) int frcnn_debug_nms_stamps(unsigned long long* host) {          // [2][8][16]; development builds only (not in the header)
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_nms_stamps), sizeof(unsigned long long) * 2 * 8 * 16);
+}
+#endif

@@ -6,6 +6,7 @@ split-K implicit GEMM over the pooled rows with the (8 + 28) output filters conc
 zero-padded to 64.  Only the sampled RoI rows take part in the backward pass.
 """
 import math
+import os
 
 import torch
 
@@ -106,7 +107,7 @@ class FastRCNNDetector:
         self.regions_abs = torch.empty(batch, num_rois, 4, device=dev)
         # K split of the Dense-head GEMM ([B*P] x 50176 x 64): every split adds one fp32 tile of float atomics (memory side,
         # 1.3 TB/s); measured over 4..98 splits (tools/head_gemm_bench.py): 12-24 are fastest (29-30 us against 36 at 64)
-        split = max(1, min(16, self.flat // 64 // 8))
+        split = max(1, min(int(os.environ.get("FRCNN_HEAD_SPLIT", "16")), self.flat // 64 // 8))
         self.d_fwd = ops.conv_desc(1, 1, r, self.flat, 1, 1, 1, 0, 0, 1, r, HEAD_LD, flags=ops.CONV_SPLITK_ATOMIC, split_k=split)
         self.w_t = torch.zeros(self.flat, 1, 1, HEAD_LD, dtype=BF16, device=dev)
         if training:

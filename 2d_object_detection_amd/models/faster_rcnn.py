@@ -51,6 +51,10 @@ CAPTURE_COLLECTIVES = os.environ.get("FRCNN_CAPTURE_COLLECTIVES", "0") not in ("
 # chain to another hardware queue and leaves the chip idle for 10 - 17 us (three forks + the join), and the update kernel -- a streaming
 # kernel on all CUs -- doubles the BatchNorm kernel it runs beside (24 -> 45 us); 64 us of update at the end of the step cost less.
 SGD_EARLY = os.environ.get("FRCNN_SGD_EARLY", "0") != "0"
+# The accumulation targets only the backward pass touches (flat gradient 57 MB, the stride-2 scatter targets 90 MB) are zeroed on the
+# side stream that runs under the forward pass (Plan.late_zero_fill) instead of by the fill in front of the stem; FRCNN_LATE_ZERO=0: one
+# fill in front, as up to round 5's first bench.
+LATE_ZERO_FILL = os.environ.get("FRCNN_LATE_ZERO", "1") != "0"
 
 
 class _Modules:
@@ -216,12 +220,14 @@ class FasterRCNN:
 
         rpn_targets_early = False
         if training:
-            plan.zero(self.store.g)
+            plan.zero(self.store.g, late=True)
             # derived weights for the backward pass: all tap-flipped transposes (backbone, RPN, heads) in ONE launch, on a
             # side stream under the forward pass (first needed by the head backward passes)
             table, total = ops.make_transpose_flip_table(mods.fe.flip_entries() + mods.rpn.flip_entries() + mods.rcnn.flip_entries(), dev)
             plan.hold(table)
             with plan.branch("weight_flips"):
+                if LATE_ZERO_FILL:                   # the backward pass's accumulation targets: zeroed here, not in front of the stem
+                    plan.late_zero_fill()
                 plan.add(ops.weights_transpose_flip_batched, table, total)
                 if mods.fe.f8 is not None:           # fp8 mode: e4m3 twins of the transposes, for the fp8 data gradients
                     mods.fe.quantize_bwd_weights_plan(plan, extra=mods.rpn.quant_entries_bwd())
@@ -392,10 +398,12 @@ class FasterRCNN:
         plan.hold(t)
         cls_scale = 1.0 / self.world_size
         if training:
-            plan.zero(self.store.g)
+            plan.zero(self.store.g, late=True)
             table, total = ops.make_transpose_flip_table(fe.flip_entries() + neck.flip_entries() + rpn.flip_entries() + rcnn.flip_entries(), dev)
             plan.hold(table)
             with plan.branch("weight_flips"):        # (first needed by the backward pass: a side stream under the forward pass)
+                if LATE_ZERO_FILL:
+                    plan.late_zero_fill()
                 plan.add(ops.weights_transpose_flip_batched, table, total)
                 if fe.f8 is not None:                # precision "fp8": the backbone + the pyramid's 3x3 convolutions
                     fe.quantize_bwd_weights_plan(plan, extra=neck.quant_entries()[1] + rpn.quant_entries()[1])

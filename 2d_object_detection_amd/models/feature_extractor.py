@@ -711,7 +711,7 @@ class FeatureExtractor:
                     u[1].backward_data(plan, a["gin"], res=a["gin"])      # add to the gradient the other consumer left there
                 else:
                     if s != 1:
-                        plan.zero(a["gin"])         # (scatter target of the stride-2 data gradients)
+                        plan.zero(a["gin"], late=True)         # (scatter target of the stride-2 data gradients)
                     u[1].backward_data(plan, a["gin"])
                 if s != 1 and n in injected:
                     # the pixels the stride-2 scatter does not touch hold the other consumer's gradient, not zeros: the fused

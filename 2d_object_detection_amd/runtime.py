@@ -50,6 +50,7 @@ class Plan:
         self._branch = None
         self._streams = {}
         self._zeros, self._zero_built, self._zero_table = [], False, None
+        self._zeros_late, self._late_placed, self._late_table = [], False, None
         self.bucket_ends = []     # indices of the segments whose end completes the next gradient bucket (in bucket order)
         self.pre_sync = {}        # segment index -> tensors that must be SUM all-reduced over the ranks before it runs
 
@@ -90,21 +91,42 @@ class Plan:
         self.cut(name, bucket=False)
         self.pre_sync.setdefault(len(self.segments) - 1, []).extend(tensors)
 
-    def zero(self, tensor):
+    def zero(self, tensor, late=False):
         """`tensor` must be all zeros when the plan starts (an accumulation target: atomics, scatter, split-K).  All such
         buffers of a plan are zeroed by ONE fill launch at the head of its first segment (frcnn_fill_zero_multi); none of them
-        carries state from one run of the plan to the next."""
+        carries state from one run of the plan to the next.  late=True: the buffer is first touched after the point where the
+        branch holding the plan's late_zero_fill() entry is joined (the flat gradient, the scatter targets of the backward pass:
+        150 MB of the 160 a train step zeroes) -- its fill is that entry's launch, beside the forward pass instead of in front of
+        it; a plan without such an entry zeroes it with the others."""
         assert not self._zero_built, "plan already ran: its zero table is frozen"
-        self._zeros.append(tensor)
+        (self._zeros_late if late else self._zeros).append(tensor)
 
-    def _zero_prologue(self):
-        if not self._zeros:
+    def late_zero_fill(self):
+        """Place the fill of the late=True buffers here (inside a side branch of the first segment: everything that accumulates into
+        them must come after that branch's join)."""
+        assert not self._late_placed and len(self.segments) == 1, "one late fill, in the plan's first segment"
+        self._late_placed = True
+        self.add(self._late_fill)
+
+    def _late_fill(self):
+        if not self._zeros_late:
             return
         from . import ops
+        if self._late_table is None:
+            self._late_table = ops.make_zero_table(self._zeros_late, self._zeros_late[0].device)
+        ops.fill_zero_multi(*self._late_table)
+
+    def _zero_prologue(self):
         if not self._zero_built:
-            self._zero_table = ops.make_zero_table(self._zeros, self._zeros[0].device)
+            if not self._late_placed:
+                self._zeros, self._zeros_late = self._zeros + self._zeros_late, []
             self._zero_built = True
-        ops.fill_zero_multi(*self._zero_table)
+            if self._zeros:
+                from . import ops
+                self._zero_table = ops.make_zero_table(self._zeros, self._zeros[0].device)
+        if self._zero_table is not None:
+            from . import ops
+            ops.fill_zero_multi(*self._zero_table)
 
     def hold(self, *tensors):
         self.keep.extend(tensors)
@@ -112,7 +134,7 @@ class Plan:
 
     @property
     def num_launches(self):
-        return sum(1 for s in self.segments for e in s if e[0] is not None) + (1 if self._zeros else 0)
+        return sum(1 for s in self.segments for e in s if e[0] is not None) + (1 if self._zeros or (self._zeros_late and not self._late_placed) else 0)
 
     # -- execution
     def _join(self, main, side, name):

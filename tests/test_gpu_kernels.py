@@ -406,6 +406,40 @@ def test_nms_combined_bit_exact(ops, B, N, q, C, mpc, mt, thr):
     assert torch.equal(ob.cpu(), exp[0]), "boxes"
 
 
+@pytest.mark.parametrize("N,levels,thr,mpc", [
+    (8768, 16, 0.5, 300),        # many equal scores: the radix select of a round runs deep into the index bytes; IoUs of exactly 1/2
+    (8768, 4096, 1.0 / 3.0, 300),
+    (3000, 3, 0.5, 1000),        # almost all scores equal, more kept than one round holds
+    (22464, 64, 0.25, 300),      # score keys re-read from global memory (no LDS staging)
+])
+def test_nms_equal_scores_and_ious_on_the_threshold(ops, N, levels, thr, mpc):
+    """Boxes on a coarse grid (corners k/32, a few sizes): many pairs have an IoU that is EXACTLY a small rational -- 1/2, 1/3, 1/4 --
+    i.e. exactly on the threshold or one rounding away from it (the kernel decides inter / union > thr without the division unless the
+    quotient could round to either side; this is the case where it must divide), and scores quantised to a few levels (ties are
+    resolved by index, as in the oracle: the rounds of the kernel's select then split inside a run of equal scores)."""
+    g = torch.Generator().manual_seed(N + levels)
+    B = 2
+    y0 = torch.randint(0, 24, (B, N, 1, 1), generator=g).float()
+    x0 = torch.randint(0, 24, (B, N, 1, 1), generator=g).float()
+    h = torch.randint(1, 5, (B, N, 1, 1), generator=g).float()
+    w = torch.randint(1, 5, (B, N, 1, 1), generator=g).float()
+    boxes = torch.cat([y0, x0, y0 + h, x0 + w], -1) / 32.0
+    scores = (torch.randint(0, levels, (B, N, 1), generator=g).float() + 1) / (levels + 1)
+    scores[:, ::29, :] = 0.0
+    exp = onms.combined_nms(boxes, scores, mpc, mpc, thr, 0.0)
+    dev = "cuda"
+    ob = torch.full((B, mpc, 4), -1.0, device=dev)
+    os_ = torch.full((B, mpc), -1.0, device=dev)
+    oc = torch.full((B, mpc), -1, dtype=torch.int32, device=dev)
+    ov = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    ws = torch.empty(ops.nms_workspace_bytes(B, N, 1, mpc, mpc), dtype=torch.uint8, device=dev)
+    ops.nms_combined(boxes.to(dev), scores.to(dev), B, N, 1, 1, 1, 0, mpc, mpc, thr, 0.0, ob, os_, oc, ov, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(ov.cpu(), exp[3]), "num_valid_detections"
+    assert torch.equal(os_.cpu(), exp[1]), "scores"
+    assert torch.equal(ob.cpu(), exp[0]), "boxes"
+
+
 def test_nms_with_background_column_and_threshold(ops):
     """scores given WITH the background column (stride C+1, offset 1), threshold > 0."""
     g = torch.Generator().manual_seed(9)

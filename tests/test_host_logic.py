@@ -289,3 +289,30 @@ def test_forced_collectives_issue_all_reduces_at_world_one(monkeypatch):
             dist.destroy_process_group()
     monkeypatch.setenv("FRCNN_FORCE_COLLECTIVES", "0")
     assert not DIST.GradientSynchronizer(torch.zeros(4), [("a", 0, 4)]).active
+
+
+def test_nms_threshold_predicate_equals_the_division():
+    import numpy as np
+    """csrc/boxes_nms.hip::nms_over decides inter / u > thr without the division: above fl(u * fl(thr (1 + 4e-6))) -> True, below
+    fl(u * fl(thr (1 - 4e-6))) -> False (both only while the products are normal numbers), the sliver between -> the IEEE division.
+    The same fp32 arithmetic in numpy, on quotients packed densely around the threshold (every float within +-64 ulps of thr * u for
+    many u) and on random pairs: wherever the kernel skips the division its answer is the division's."""
+    rng = np.random.default_rng(0)
+    f = np.float32
+    for thr in (f(0.7), f(0.5), f(0.6), f(1.0 / 3.0), f(0.05), f(0.95)):
+        th_hi, th_lo = f(thr * f(1.0 + 4e-6)), f(thr * f(1.0 - 4e-6))
+        u = np.concatenate([rng.uniform(1e-6, 2.0, 4000), 10.0 ** rng.uniform(-36, -28, 500)]).astype(np.float32)
+        centre = (thr * u).astype(np.float32)
+        steps = np.arange(-64, 65, dtype=np.int32)
+        near = (centre.view(np.int32)[:, None] + steps[None, :]).view(np.float32)            # +-64 ulps around fl(thr * u)
+        inter = np.concatenate([near.ravel(), (np.repeat(u, 8) * rng.uniform(0, 1, u.size * 8)).astype(np.float32)])
+        uu = np.concatenate([np.repeat(u, steps.size), np.repeat(u, 8)])
+        hi = (uu * th_hi).astype(np.float32)
+        lo = (uu * th_lo).astype(np.float32)
+        sure = lo > f(1e-30)
+        with np.errstate(all="ignore"):
+            exact = (inter / uu).astype(np.float32) > thr
+        fast_true = sure & (inter > hi)
+        fast_false = sure & ~fast_true & (inter < lo)
+        assert np.all(exact[fast_true]) and not np.any(exact[fast_false])
+        assert fast_true.sum() + fast_false.sum() > 0.8 * inter.size - near.size      # (the division is the exception, not the rule)

@@ -14,7 +14,25 @@ g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randn(m, k, device="cuda", generator=g).to(BF)
 w = (torch.randn(n, k, device="cuda", generator=g) / k ** 0.5).to(BF)
 y = torch.zeros(m, n, device="cuda")
+# "cold" (argv[1]): a 1 GiB fill between the launches pushes x out of the 256 MB memory-side cache, as the step's own traffic does between
+# the RoI kernel that writes x and this GEMM (in the step's trace the GEMM takes 60-68 us, not the 30 of back-to-back launches)
+cold = len(sys.argv) > 1 and sys.argv[1] == "cold"
+flush = torch.empty(1 << 28, device="cuda") if cold else None
 for split in (4, 8, 12, 16, 24, 32, 48, 64, 98):
+    if cold:
+        d = ops.conv_desc(1, 1, m, k, 1, 1, 1, 0, 0, 1, m, n, flags=ops.CONV_SPLITK_ATOMIC, split_k=split)
+        ops.conv2d_fprop(d, x, w, y)
+        tot = 0.0
+        for _ in range(10):
+            flush.fill_(1.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.conv2d_fprop(d, x, w, y)
+            e1.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1) * 1e3
+        print("cold split %3d: %6.1f us (event pair around one launch)" % (split, tot / 10), flush=True)
+        continue
     d = ops.conv_desc(1, 1, m, k, 1, 1, 1, 0, 0, 1, m, n, flags=ops.CONV_SPLITK_ATOMIC, split_k=split)
     for _ in range(3):
         ops.conv2d_fprop(d, x, w, y)
