@@ -299,11 +299,18 @@ struct NmsParams {
     // (no nms_merge_kernel launch); null otherwise
     float* out_boxes; float* out_scores; int* out_classes; int* out_valid; int max_total;
     float* out_abs; float sx, sy;    // optional: the final boxes once more, scaled by [sx, sy, sx, sy] (frcnn_nms_combined_abs)
+    // team mode (nms_class_kernel<., true>): `team` workgroups per (image, class); the first round's suppression matrix is built by all
+    // of them (rows split), exchanged through team_mat [B*C][NMS_TEAM_N][NMS_TEAM_N / 64] and the arrival words team_sync [B*C][16]
+    int team; unsigned long long* team_mat; unsigned int* team_sync;
 };
 
+constexpr int NMS_TEAM = 8;                  // workgroups per (image, class) in team mode
+constexpr int NMS_TEAM_N = 512;              // candidates of the team round (NMS_RK / 2: the first round's goal)
+
 // LDS of nms_class_kernel; *lds_keys: the 32-bit score keys of the N candidates are staged in LDS (else re-read from global)
-static size_t nms_class_lds(int n, int max_per_class, bool* lds_keys) {
-    const size_t fixed = (size_t)max_per_class * 20 + NMS_CH * (16 + 32 + 4 + 4 + 4) + 64 + 16 + (size_t)NMS_HC * 256 * 4 + (size_t)NMS_RK * 8 + 16;
+static size_t nms_class_lds(int n, int max_per_class, bool team, bool* lds_keys) {
+    const size_t cap = team ? NMS_TEAM_N : NMS_CH;            // candidates whose boxes / matrix rows are resident at once
+    const size_t fixed = (size_t)max_per_class * 28 + cap * (16 + 4 + 4 + 4) + cap * (cap / 64) * 8 + 64 + 16 + (size_t)NMS_HC * 256 * 4 + (size_t)NMS_RK * 8 + 16;
     *lds_keys = fixed + (size_t)n * 4 <= 150 * 1024;
     return fixed + (*lds_keys ? (size_t)n * 4 : 0);
 }
@@ -331,7 +338,14 @@ __device__ unsigned long long g_nms_stamps[2][8][16];
 #define NMS_COUNT(i) do { } while (0)
 #endif
 
-template <bool LDSK>
+// TEAM (proposal NMS: few (image, class) lists, each long): NMS_TEAM workgroups per list.  Each of them stages the keys and runs the FIRST
+// round's select / compaction / sort itself (identical results, no exchange, on CUs that would idle otherwise); then the round's whole
+// suppression matrix -- up to 512 x 512 pair tests, the VALU-bound bulk of the one-workgroup form (kept-list test + per-chunk matrices:
+// 40 of its 67 us at 8768 -> 300) -- is built once, rows split over the team, and handed to workgroup 0 of the team through global
+// memory (release: __threadfence + arrival counter; acquire: the counter, then __threadfence).  Workgroup 0 walks the round in score
+// order from that matrix and, if the list does not end inside the round, continues alone with the rounds of the one-workgroup form.
+// Same visits in the same order: same results.  The helpers wait for nothing, so the counter is always reached.
+template <bool LDSK, bool TEAM>
 __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef FRCNN_NMS_STAMPS
@@ -341,17 +355,20 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     // (every pointer is smem + a byte offset: an alignment step on the POINTER's integer value -- the form up to round 5 -- made the
     // compiler lose the LDS address space, and the select histogram, the round's keys and the staged score keys were reached with
     // flat_load / flat_store / flat_atomic instructions: the bitonic network's 45-55 dependent stages each paid a flat round trip)
-    const size_t o_chunk_box = (size_t)p.max_per_class * 16;
-    const size_t o_sup = o_chunk_box + NMS_CH * 16;
-    const size_t o_kept_area = o_sup + NMS_CH * 32;
+    constexpr size_t CAP = TEAM ? NMS_TEAM_N : NMS_CH;        // (the chunk loop uses the first NMS_CH entries of these arrays)
+    const size_t o_kept_key = (size_t)p.max_per_class * 16;
+    const size_t o_chunk_box = o_kept_key + (size_t)p.max_per_class * 8;
+    const size_t o_sup = o_chunk_box + CAP * 16;
+    const size_t o_kept_area = o_sup + CAP * (CAP / 64) * 8;
     const size_t o_chunk_area = o_kept_area + (size_t)p.max_per_class * 4;
-    const size_t o_dead = o_chunk_area + NMS_CH * 4;
-    const size_t o_rows = o_dead + NMS_CH * 4;
-    const size_t o_misc = o_rows + NMS_CH * 4;
+    const size_t o_dead = o_chunk_area + CAP * 4;
+    const size_t o_rows = o_dead + CAP * 4;
+    const size_t o_misc = o_rows + CAP * 4;
     const size_t o_hist = (o_misc + 64 + 15) & ~(size_t)15;
     const size_t o_rkeys = o_hist + (size_t)NMS_HC * 256 * 4;
     const size_t o_skeys = o_rkeys + (size_t)NMS_RK * 8;
     f32x4* kept_box = reinterpret_cast<f32x4*>(smem);                                       // [max_per_class] corner-normalised
+    unsigned long long* kept_key = reinterpret_cast<unsigned long long*>(smem + o_kept_key);   // [max_per_class] composite keys of the kept
     f32x4* chunk_box = reinterpret_cast<f32x4*>(smem + o_chunk_box);                        // [NMS_CH] corner-normalised
     unsigned long long* sup_of = reinterpret_cast<unsigned long long*>(smem + o_sup);       // [NMS_CH][4] later candidates suppressed by row
     float* kept_area = reinterpret_cast<float*>(smem + o_kept_area);                        // [max_per_class]
@@ -363,7 +380,9 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     unsigned long long* rkeys = reinterpret_cast<unsigned long long*>(smem + o_rkeys);      // [NMS_RK]
     unsigned int* skeys = reinterpret_cast<unsigned int*>(smem + o_skeys);                  // [N] (LDSK)
 
-    const int b = blockIdx.x / p.C, c = blockIdx.x % p.C;
+    const int unit = TEAM ? (int)blockIdx.x / NMS_TEAM : (int)blockIdx.x;        // the (image, class) list
+    const int team_rank = TEAM ? (int)blockIdx.x % NMS_TEAM : 0;
+    const int b = unit / p.C, c = unit % p.C;
     const int bc = (p.q == 1) ? 0 : c;
     const float* boxes = p.boxes + (int64_t)b * p.N * p.q * 4;
     const float* scores = p.scores + (int64_t)b * p.N * p.score_stride + p.score_offset + c;
@@ -379,6 +398,8 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
         return ((unsigned long long)sk << 32) | (unsigned int)(~(unsigned int)i);
     };
 
+    unsigned int gen0 = 0u;                                   // team mode: this launch's number (see the hand-off below)
+    if (TEAM) gen0 = __hip_atomic_load(p.team_sync + (size_t)unit * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < 16) misc[threadIdx.x] = 0;
     __syncthreads();
     {
@@ -406,6 +427,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
         // the select that is not run saves a sweep over all N candidates.  The first round aims at 512: a list that suppresses little
         // (max_per_class = 300 of an untrained RPN's 8768) ends inside it, one that suppresses much pays one short round more.
         const int K_goal = first_round ? NMS_RK / 2 : NMS_RK;
+        const bool team_round = TEAM && first_round;
         first_round = false;
         int K = remaining < K_goal ? remaining : K_goal;
         unsigned long long T = 1ull;                          // this round takes the keys in [T, prev)
@@ -523,6 +545,169 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
         NMS_STAMP(2);
         bitonic_desc_reg(rkeys, n_sort);
         NMS_STAMP(3);
+
+        if (TEAM && team_round) {
+            // ================= the team round: n_sort <= NMS_TEAM_N candidates, kept == 0
+            constexpr int NBM = NMS_TEAM_N / 64;                  // matrix words per row (capacity)
+            const int NB = n_sort >> 6;                           // ... in use
+            for (int t = threadIdx.x; t < n_sort; t += NMS_T) {
+                const unsigned long long k = rkeys[t];
+                f32x4 bx = {0.f, 0.f, 0.f, 0.f};
+                if (k != 0ull) {
+                    const unsigned int idx = ~(unsigned int)(k & 0xFFFFFFFFull);
+                    bx = nms_norm(*reinterpret_cast<const f32x4*>(boxes + ((int64_t)idx * p.q + bc) * 4));
+                }
+                chunk_box[t] = bx;
+                chunk_area[t] = nms_area(bx);
+                dead[t] = (k == 0ull) ? 1 : 0;
+            }
+            __syncthreads();
+            NMS_STAMP(4);
+            unsigned long long* mat = p.team_mat + (size_t)unit * NMS_TEAM_N * NBM;
+            {
+                // this workgroup's rows: i = team_rank * rpw + (wave, wave + 16, ...); a lane's column candidates (j = 64 w + lane) in
+                // registers; lane w of the row's wave ends with word w and the row leaves as one 64-byte store
+                const int rpw = n_sort / NMS_TEAM;
+#pragma unroll 1
+                for (int h = 0; h * 4 < NB; ++h) {                // four column words at a time (all eight in registers: spills)
+                    f32x4 cb[4];
+                    float ca[4];
+                    bool cdead[4];
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4) {
+                        const int j = (h * 4 + w4) * 64 + lane;   // (NB is 4 or 8: a started group of four is complete)
+                        cb[w4] = chunk_box[j];
+                        ca[w4] = chunk_area[j];
+                        cdead[w4] = dead[j] != 0;
+                    }
+                    for (int ri = wave; ri < rpw; ri += NMS_T / 64) {
+                        const int i = team_rank * rpw + ri;       // (wave-uniform)
+                        const f32x4 rb = chunk_box[i];
+                        const float ra = chunk_area[i];
+                        const bool rdead = dead[i] != 0;
+                        unsigned long long mine = 0ull;
+#pragma unroll
+                        for (int w4 = 0; w4 < 4; ++w4) {
+                            const int w = h * 4 + w4;
+                            if (w < (i >> 6)) continue;           // (uniform) every column of this word precedes the row
+                            const int j = w * 64 + lane;
+                            const bool sgt = !rdead && j > i && !cdead[w4] && nms_over(cb[w4], ca[w4], rb, ra, thr);
+                            const unsigned long long m = __ballot(sgt);
+                            if (lane == w) mine = m;
+                        }
+                        if ((lane >> 2) == h) __hip_atomic_store(mat + (size_t)i * NBM + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            // hand-off as in conv_tile.hip's split-K fix-up (the form MI355X_MICROARCH.md lists as measured-valid on gfx950): payload by
+            // agent-scope relaxed atomic stores (write-through), drained by every wave's vmcnt(0); a workgroup barrier; ONE lane's
+            // agent-scope counter add.  The reader loads the payload with agent-scope relaxed atomic loads behind its own barrier.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // Arrival words that need no zeroing (a memset in front of the kernel is a 5 us launch of its own): word 0 of the list's 16 is
+            // its launch count `gen`, read by every workgroup of the team at the start of the kernel and advanced by workgroup 0 once
+            // all helpers have arrived (so after all of them have read it); helper g arrives by storing gen + 1 into word g.  Words
+            // left by earlier launches hold values <= gen; a buffer that was never used works whatever it holds, unless a word
+            // happens to equal its neighbour's garbage + 1 (2^-32 per word, on the first launch only -- frcnn_nms_workspace_bytes asks
+            // callers to zero the buffer once for that reason).
+            unsigned int* sync = p.team_sync + (size_t)unit * 16;
+            if (team_rank != 0) {
+                if (threadIdx.x == 0) __hip_atomic_store(sync + team_rank, gen0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;                                           // the helpers are done
+            }
+            NMS_STAMP(5);
+            if (threadIdx.x < NMS_TEAM && threadIdx.x > 0) {
+                long spins = 0;
+                while (__hip_atomic_load(sync + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen0 + 1u) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1l << 24)) __builtin_trap();   // (seconds: a helper that never ran -- abort loudly rather than hang)
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(sync, gen0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            NMS_STAMP(11);
+            for (int t = threadIdx.x; t < n_sort * NBM; t += NMS_T) sup_of[t] = __hip_atomic_load(mat + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            NMS_STAMP(12);
+            // ---- walk the round in score order (wave 0): the chunk loop's walk over NB row blocks instead of 4; the matrix words of
+            // ONE row block at a time in registers (all 36 word pairs at once spilled to scratch: every phase of the kernel got slower)
+            if (threadIdx.x < 64) {
+                unsigned long long alive[NBM], kmask[NBM];
+#pragma unroll
+                for (int r = 0; r < NBM; ++r) {
+                    alive[r] = __ballot(r < NB && dead[(r < NB ? r : 0) * 64 + lane] == 0);
+                    kmask[r] = 0ull;
+                }
+                int k_now = 0;
+#pragma unroll
+                for (int r = 0; r < NBM; ++r) {
+                    if (r >= NB || alive[r] == 0ull || k_now >= p.max_per_class) continue;      // (uniform)
+                    unsigned int slo[NBM], shi[NBM];              // row r*64+lane, words w >= r
+                    int wmask = 0;                                // which of them are non-zero: a step reads only those from the row's lane
+#pragma unroll
+                    for (int w = r; w < NBM; ++w) {
+                        const unsigned long long v = (w < NB && ((alive[r] >> lane) & 1ull)) ? sup_of[(size_t)(r * 64 + lane) * NBM + w] : 0ull;
+                        slo[w] = (unsigned int)v;
+                        shi[w] = (unsigned int)(v >> 32);
+                        wmask |= v != 0ull ? (1 << w) : 0;
+                    }
+                    const unsigned long long nz = __ballot(wmask != 0);
+                    while (alive[r] != 0ull && k_now < p.max_per_class) {
+                        const unsigned long long az = alive[r] & nz;
+                        const int pos = az != 0ull ? __builtin_ctzll(az) : 64;
+                        unsigned long long run = pos < 64 ? (alive[r] & ((1ull << pos) - 1ull)) : alive[r];
+                        int cnt = __popcll(run);
+                        if (k_now + cnt > p.max_per_class) {             // the cap falls inside the run: its first (cap - kept) members
+                            unsigned long long t = run, sel = 0ull;
+                            for (int need = p.max_per_class - k_now; need > 0; --need) {
+                                sel |= t & (~t + 1ull);
+                                t &= t - 1ull;
+                            }
+                            run = sel;
+                            cnt = __popcll(run);
+                        }
+                        kmask[r] |= run;
+                        k_now += cnt;
+                        alive[r] &= ~run;
+                        if (pos == 64 || k_now >= p.max_per_class) continue;
+                        kmask[r] |= 1ull << pos;
+                        ++k_now;
+                        alive[r] &= ~(1ull << pos);
+                        const int wm = __builtin_amdgcn_readlane(wmask, pos);
+#pragma unroll
+                        for (int w = r; w < NBM; ++w) {
+                            if (!((wm >> w) & 1)) continue;       // (uniform)
+                            const unsigned long long sp = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)shi[w], pos) << 32) |
+                                                          (unsigned int)__builtin_amdgcn_readlane((int)slo[w], pos);
+                            alive[w] &= ~sp;
+                        }
+                    }
+                }
+                int before = 0;
+#pragma unroll
+                for (int r = 0; r < NBM; ++r) {
+                    if ((kmask[r] >> lane) & 1ull) {
+                        const int slot = before + __popcll(kmask[r] & ((1ull << lane) - 1ull));
+                        kept_box[slot] = chunk_box[r * 64 + lane];
+                        kept_area[slot] = chunk_area[r * 64 + lane];
+                        const unsigned long long k = rkeys[r * 64 + lane];
+                        kept_key[slot] = k;
+                        const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + slot;
+                        p.kept_keys[o] = (k & 0xFFFFFFFF00000000ull) | (unsigned int)(~(unsigned int)(c * p.max_per_class + slot));
+                        p.kept_idx[o] = (int)(~(unsigned int)(k & 0xFFFFFFFFull));
+                    }
+                    before += __popcll(kmask[r]);
+                }
+                if (lane == 0) misc[0] = k_now;
+            }
+            __syncthreads();
+            NMS_STAMP(6);
+            kept = misc[0];
+            prev = T;
+            remaining -= K;
+            __syncthreads();
+            continue;
+        }
 
         for (int base = 0; base < n_sort; base += NMS_CH) {
             NMS_COUNT(9);
@@ -671,6 +856,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                         kept_box[slot] = chunk_box[r * 64 + lane];
                         kept_area[slot] = chunk_area[r * 64 + lane];
                         const unsigned long long k = rkeys[base + r * 64 + lane];
+                        kept_key[slot] = k;
                         const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + slot;
                         p.kept_keys[o] = (k & 0xFFFFFFFF00000000ull) | (unsigned int)(~(unsigned int)(c * p.max_per_class + slot));
                         p.kept_idx[o] = (int)(~(unsigned int)(k & 0xFFFFFFFFull));
@@ -688,6 +874,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
         remaining -= K;
         __syncthreads();
     }
+    if (TEAM && team_rank != 0) return;                      // (a list without candidates: no round was run)
     // zero the unused kept slots of this (image, class)
     for (int s = kept + threadIdx.x; s < p.max_per_class; s += blockDim.x) {
         const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + s;
@@ -696,20 +883,19 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     }
     if (p.out_boxes) {
         // single class: slots are already in the merged order (descending score, earlier slot first among equals); what
-        // nms_merge_kernel would emit, from this workgroup's own kept list (written by wave 0 above: fence + barrier)
-        __threadfence_block();
+        // nms_merge_kernel would emit, from this workgroup's own kept list (written by wave 0 above, in LDS: barrier)
         __syncthreads();
         const int nv = kept < p.max_total ? kept : p.max_total;
         for (int t = threadIdx.x; t < p.max_total; t += blockDim.x) {
             f32x4 bx = {0.f, 0.f, 0.f, 0.f};
             float s = 0.f;
-            if (t < nv) {
-                const int64_t o = (int64_t)b * p.max_per_class + t;
-                const int idx = p.kept_idx[o];
+            if (t < nv) {                                     // (from the LDS copy of the kept keys: no global store -> load round trip)
+                const unsigned long long k = kept_key[t];
+                const int idx = (int)(~(unsigned int)(k & 0xFFFFFFFFull));
                 bx = *reinterpret_cast<const f32x4*>(boxes + ((int64_t)idx * p.q + bc) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bx[e] = fminf(fmaxf(bx[e], 0.0f), 1.0f);
-                s = key_float((unsigned int)(p.kept_keys[o] >> 32));
+                s = key_float((unsigned int)(k >> 32));
             }
             *reinterpret_cast<f32x4*>(p.out_boxes + ((int64_t)b * p.max_total + t) * 4) = bx;
             if (p.out_abs) *reinterpret_cast<f32x4*>(p.out_abs + ((int64_t)b * p.max_total + t) * 4) = f32x4{bx[0] * p.sx, bx[1] * p.sy, bx[2] * p.sx, bx[3] * p.sy};
@@ -721,9 +907,9 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
 #ifdef FRCNN_NMS_STAMPS
     __syncthreads();
     NMS_STAMP(7);
-    if (threadIdx.x == 0 && blockIdx.x < 8) {
+    if (threadIdx.x == 0 && unit < 8) {
         st_acc[10] = (unsigned long long)kept;
-        for (int i = 0; i < 16; ++i) g_nms_stamps[p.C == 1 ? 0 : 1][blockIdx.x][i] = st_acc[i];
+        for (int i = 0; i < 16; ++i) g_nms_stamps[p.C == 1 ? 0 : 1][unit][i] = st_acc[i];
     }
 #endif
 }
@@ -878,10 +1064,17 @@ extern "C" int frcnn_decode_boxes(const float* regions, int regions_per_image, c
     return FRCNN_OK;
 }
 
+// team mode (see nms_class_kernel): single-class lists longer than the team round, few enough for every team to have its own CUs
+static bool nms_team_mode(int b, int n, int c) { return c == 1 && n > NMS_TEAM_N && b * NMS_TEAM <= 128; }
+static size_t nms_kept_bytes(int b, int c, int max_per_class) {
+    return ((size_t)b * c * max_per_class * (sizeof(unsigned long long) + sizeof(int)) + 255) & ~(size_t)255;
+}
+
 extern "C" size_t frcnn_nms_workspace_bytes(int b, int n, int c, int max_per_class, int max_total) {
-    (void)max_total; (void)n;
-    const size_t bytes = (size_t)b * c * max_per_class * (sizeof(unsigned long long) + sizeof(int));
-    return (bytes + 255) & ~(size_t)255;
+    (void)max_total;
+    size_t bytes = nms_kept_bytes(b, c, max_per_class);
+    if (nms_team_mode(b, n, c)) bytes += (size_t)b * 64 + (size_t)b * NMS_TEAM_N * (NMS_TEAM_N / 64) * sizeof(unsigned long long);    // arrival words + matrices
+    return bytes;
 }
 
 static int nms_combined_impl(const float* boxes, const float* scores, int b, int n, int q, int c, int score_stride, int score_offset,
@@ -907,16 +1100,30 @@ static int nms_combined_impl(const float* boxes, const float* scores, int b, int
     p.out_boxes = fused_merge ? out_boxes : nullptr; p.out_scores = out_scores; p.out_classes = out_classes; p.out_valid = out_valid;
     p.max_total = max_total;
     p.out_abs = out_abs; p.sx = sx; p.sy = sy;
-    bool lds_keys;
-    const size_t smem = nms_class_lds(n, max_per_class, &lds_keys);
-    p.lds_keys = lds_keys ? 1 : 0;
-    if (lds_keys) {
-        FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(nms_class_kernel<true>), smem) == 0, "nms_combined: cannot reserve %zu B of LDS", smem);
-        hipLaunchKernelGGL(nms_class_kernel<true>, dim3(b * c), dim3(NMS_T), smem, S_(stream), p);
-    } else {
-        FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(nms_class_kernel<false>), smem) == 0, "nms_combined: cannot reserve %zu B of LDS", smem);
-        hipLaunchKernelGGL(nms_class_kernel<false>, dim3(b * c), dim3(NMS_T), smem, S_(stream), p);
+    const bool team = nms_team_mode(b, n, c) && !getenv("FRCNN_NMS_NO_TEAM");
+    p.team = team ? NMS_TEAM : 1;
+    p.team_sync = nullptr; p.team_mat = nullptr;
+    if (team) {
+        p.team_sync = reinterpret_cast<unsigned int*>(ws + nms_kept_bytes(b, c, max_per_class));
+        p.team_mat = reinterpret_cast<unsigned long long*>(ws + nms_kept_bytes(b, c, max_per_class) + (size_t)b * 64);
     }
+    bool lds_keys;
+    const size_t smem = nms_class_lds(n, max_per_class, team, &lds_keys);
+    p.lds_keys = lds_keys ? 1 : 0;
+#define FRCNN_NMS_LAUNCH(LDSK, TEAM, GRID)                                                                                                  \
+    do {                                                                                                                                  \
+        FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(nms_class_kernel<LDSK, TEAM>), smem) == 0,                      \
+                        "nms_combined: cannot reserve %zu B of LDS", smem);                                                               \
+        hipLaunchKernelGGL((nms_class_kernel<LDSK, TEAM>), dim3(GRID), dim3(NMS_T), smem, S_(stream), p);                                  \
+    } while (0)
+    if (team) {
+        if (lds_keys) FRCNN_NMS_LAUNCH(true, true, b * c * NMS_TEAM);
+        else FRCNN_NMS_LAUNCH(false, true, b * c * NMS_TEAM);
+    } else {
+        if (lds_keys) FRCNN_NMS_LAUNCH(true, false, b * c);
+        else FRCNN_NMS_LAUNCH(false, false, b * c);
+    }
+#undef FRCNN_NMS_LAUNCH
     FRCNN_CHECK_LAUNCH("nms_combined(class)");
     if (fused_merge) return FRCNN_OK;
 

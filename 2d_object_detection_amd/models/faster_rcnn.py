@@ -55,6 +55,10 @@ SGD_EARLY = os.environ.get("FRCNN_SGD_EARLY", "0") != "0"
 # side stream that runs under the forward pass (Plan.late_zero_fill) instead of by the fill in front of the stem; FRCNN_LATE_ZERO=0: one
 # fill in front, as up to round 5's first bench.
 LATE_ZERO_FILL = os.environ.get("FRCNN_LATE_ZERO", "1") != "0"
+# At the head chain's two forks (Fast-RCNN targets after the proposal NMS, detection NMS after the head's post-processing) the MAIN
+# stream's next launches are enqueued / captured before the side block (Plan.mark keeps the fork point): same graph edges, another order
+# of node creation.
+MAIN_FIRST_AT_FORKS = os.environ.get("FRCNN_MAIN_FIRST", "0") != "0"
 
 
 class _Modules:
@@ -325,15 +329,27 @@ class FasterRCNN:
         # enqueued node by node with cross-queue waits, a linear one in one piece: of the seven branches tried in round 2
         # (tools/ab_plan.sh, one box) this one, the RPN side chain and the detection NMS pay; targets of the RPN at the head
         # of the step (+0.25 ms), a late zero fill (+0.12 ms), the step counter and the head's parameter gradients do not.
-        with plan.branch("rcnn_targets"):
-            rcnn_targets(mods.rcnn.regions_abs)
+        if MAIN_FIRST_AT_FORKS:
+            plan.mark("rcnn_targets")
+        else:
+            with plan.branch("rcnn_targets"):
+                rcnn_targets(mods.rcnn.regions_abs)
         # (the head-post launch also decodes the detections' boxes: the first step of their NMS)
         rcnn_out = mods.rcnn.forward_plan(plan, feat, rois, regions_done=True, decoded=det_nms.decoded)
+        if MAIN_FIRST_AT_FORKS:
+            with plan.branch("rcnn_targets"):
+                rcnn_targets(mods.rcnn.regions_abs)
         plan.join("rcnn_targets")
-        if training:
+        if training and MAIN_FIRST_AT_FORKS:
+            plan.mark("detections")
+            rcnn_losses()
             with plan.branch("detections"):
                 nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **det_cfg, buffers=det_nms, decoded_done=mods.rcnn.decoded_done)
-        rcnn_losses()
+        else:
+            if training:
+                with plan.branch("detections"):
+                    nms_rcnn = postprocess_plan(plan, self._image_shape, **rcnn_out, **det_cfg, buffers=det_nms, decoded_done=mods.rcnn.decoded_done)
+            rcnn_losses()
 
         if training:
             if RPN_DGRAD_ON_SIDE_STREAM:

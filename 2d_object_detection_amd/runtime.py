@@ -34,6 +34,9 @@ class _Branch:
         return False
 
 
+_MARK = "mark"            # second element of a Plan.mark entry's args
+
+
 class Plan:
     """Ordered launches, cut into segments.  Launches added inside `with plan.branch(name):` run on a side stream that
     forks from the main stream at the branch's first launch and is joined back by `plan.join(name)` (or at the end of
@@ -71,6 +74,13 @@ class Plan:
 
     def join(self, name):
         self.segments[-1].append((None, (name,), {}, None))
+
+    def mark(self, name):
+        """The fork point of branch `name`, ahead of its block: the branch's first launch waits for the main stream as of HERE, but the
+        block itself may be added (and so enqueued / captured) after the main-stream launches that follow the mark.  Same
+        dependencies as a block placed at the mark; a different order of node creation under graph capture (which of a fork's two
+        successors the runtime keeps on the predecessor's hardware queue depends on it)."""
+        self.segments[-1].append((None, (name, _MARK), {}, None))      # (fn None, like a join: entry walkers skip it)
 
     def cut(self, name, bucket=True):
         """Start a new segment.  bucket=True: the segment that ends here completes the next gradient bucket (the data-parallel
@@ -151,7 +161,15 @@ class Plan:
             self._zero_prologue()
         side = {} if carry is None else carry
         prev_branch = None
+        marks = {}
         for fn, args, kwargs, br in self.segments[i]:
+            if fn is None and len(args) == 2:
+                if not _SERIAL:
+                    if main is None:
+                        main = torch.cuda.current_stream()
+                    marks[args[0]] = torch.cuda.Event()
+                    marks[args[0]].record(main)
+                continue
             if fn is None:
                 if args[0] in side:
                     if main is None:
@@ -167,8 +185,10 @@ class Plan:
                 if name not in side or (follow and first_of_block):
                     if name not in self._streams:
                         self._streams[name] = torch.cuda.Stream()
-                    ev = torch.cuda.Event()
-                    ev.record(main)
+                    ev = marks.pop(name, None)
+                    if ev is None:
+                        ev = torch.cuda.Event()
+                        ev.record(main)
                     self._streams[name].wait_event(ev)
                     side[name] = self._streams[name]
                 with torch.cuda.stream(side[name]):

@@ -18,7 +18,7 @@ class NmsBuffers:
         self.classes = torch.zeros(b, t, dtype=torch.int32, device=device)
         self.valid = torch.zeros(b, dtype=torch.int32, device=device)
         self.decoded = torch.empty(b, n, c, 4, device=device)
-        self.workspace = torch.empty(ops.nms_workspace_bytes(b, n, c, int(max_output_size_per_class), t), dtype=torch.uint8,
+        self.workspace = torch.zeros(ops.nms_workspace_bytes(b, n, c, int(max_output_size_per_class), t), dtype=torch.uint8,
                                      device=device)
 
 

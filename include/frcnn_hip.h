@@ -437,7 +437,11 @@ int frcnn_encode_boxes(const float* boxes, const float* regions, int regions_per
 int frcnn_boxes_divide(const float* in, float* out, int64_t n, float w, float h, frcnn_stream_t stream);
 /* tf.image.combined_non_max_suppression as called at utils/post_processing.py:53-55.
  * boxes [B,N,q,4] (q = 1 or C), scores [B,N,*] with row stride score_stride, class c at column
- * score_offset + c.  Outputs [B,T,4], [B,T], int32 [B,T], int32 [B]. */
+ * score_offset + c.  Outputs [B,T,4], [B,T], int32 [B,T], int32 [B].
+ * Workspace: frcnn_nms_workspace_bytes() bytes, reusable from call to call; zero it once after allocating it.  (Single-class
+ * lists of more than 512 candidates run with eight workgroups per image that hand a suppression matrix over through the
+ * workspace; their arrival words count launches and need no per-call reset, but a never-used buffer should not hold
+ * arbitrary bytes.  Two calls that share a workspace must not overlap in time.) */
 size_t frcnn_nms_workspace_bytes(int b, int n, int c, int max_per_class, int max_total);
 int frcnn_nms_combined(const float* boxes, const float* scores, int b, int n, int q, int c, int score_stride,
                        int score_offset, int max_per_class, int max_total, float iou_thr, float score_thr,

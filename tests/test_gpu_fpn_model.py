@@ -472,11 +472,12 @@ FP8_LOSS_BOUND = {"rpn_cls": 0.002, "rcnn_cls": 0.16, "rpn_reg": 0.1, "rcnn_reg"
 # rcnn_cls 0.079, rpn_reg 0.033 relative, rcnn_reg 0.025 / 0.005 / 0.25 relative)
 FP8_LOSS_BOUND_STEP1 = {"rpn_cls": 0.002, "rcnn_cls": 0.16, "rpn_reg": 0.1, "rcnn_reg": 0.5}
 # ... and of the relative difference between two fp8 runs of the same second step (eager vs replayed) on the same proposals: 3x the
-# larger of two boxes' measurements (round 5: rpn_cls 8.1e-4 / 5.8e-4, rpn_reg 4.1e-3 / 5.7e-3, rcnn_cls 3.1e-2 / 9.6e-3, rcnn_reg
-# 5.8e-3 / 6.8e-2 -- a SUM of Huber terms over the few foreground rows of an untrained head: the two runs' weights differ by 1e-4 after
+# largest of three boxes' measurements (round 5: rpn_cls 8.1e-4 / 5.8e-4 / 3.2e-4, rpn_reg 4.1e-3 / 5.7e-3 / 1.8e-2 -- the third box
+# is why this is not "3x the larger of two" any more --, rcnn_cls 3.1e-2 / 9.6e-3 / 3.6e-2, rcnn_reg
+# 5.8e-3 / 6.8e-2 / 1.9e-2 -- a SUM of Huber terms over the few foreground rows of an untrained head: the two runs' weights differ by 1e-4 after
 # the first update, under delayed scaling a one-ulp amax change moves every rounding boundary of a tensor).  Round 4, un-injected: rcnn_reg
 # moved by 53 % and was bounded by 2.0.
-FP8_RERUN_BOUND = {"rpn_cls": 2.5e-3, "rpn_reg": 1.7e-2, "rcnn_cls": 0.1, "rcnn_reg": 0.2}
+FP8_RERUN_BOUND = {"rpn_cls": 2.5e-3, "rpn_reg": 5.4e-2, "rcnn_cls": 0.11, "rcnn_reg": 0.2}
 
 
 def test_call_training_mode_on_the_pyramid(run):

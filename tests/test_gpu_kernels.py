@@ -397,7 +397,7 @@ def test_nms_combined_bit_exact(ops, B, N, q, C, mpc, mt, thr):
     os_ = torch.full((B, mt), -1.0, device=dev)
     oc = torch.full((B, mt), -1, dtype=torch.int32, device=dev)
     ov = torch.full((B,), -1, dtype=torch.int32, device=dev)
-    ws = torch.empty(ops.nms_workspace_bytes(B, N, C, mpc, mt), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(ops.nms_workspace_bytes(B, N, C, mpc, mt), dtype=torch.uint8, device=dev)
     ops.nms_combined(boxes.to(dev), scores.to(dev), B, N, q, C, C, 0, mpc, mt, thr, 0.0, ob, os_, oc, ov, ws)
     torch.cuda.synchronize()
     assert torch.equal(ov.cpu(), exp[3]), "num_valid_detections"
@@ -432,7 +432,7 @@ def test_nms_equal_scores_and_ious_on_the_threshold(ops, N, levels, thr, mpc):
     os_ = torch.full((B, mpc), -1.0, device=dev)
     oc = torch.full((B, mpc), -1, dtype=torch.int32, device=dev)
     ov = torch.full((B,), -1, dtype=torch.int32, device=dev)
-    ws = torch.empty(ops.nms_workspace_bytes(B, N, 1, mpc, mpc), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(ops.nms_workspace_bytes(B, N, 1, mpc, mpc), dtype=torch.uint8, device=dev)
     ops.nms_combined(boxes.to(dev), scores.to(dev), B, N, 1, 1, 1, 0, mpc, mpc, thr, 0.0, ob, os_, oc, ov, ws)
     torch.cuda.synchronize()
     assert torch.equal(ov.cpu(), exp[3]), "num_valid_detections"
@@ -450,7 +450,7 @@ def test_nms_with_background_column_and_threshold(ops):
     dev = "cuda"
     ob, os_ = torch.empty(B, 50, 4, device=dev), torch.empty(B, 50, device=dev)
     oc, ov = torch.empty(B, 50, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev)
-    ws = torch.empty(ops.nms_workspace_bytes(B, N, C, 30, 50), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(ops.nms_workspace_bytes(B, N, C, 30, 50), dtype=torch.uint8, device=dev)
     ops.nms_combined(boxes.to(dev), full.to(dev), B, N, C, C, C + 1, 1, 30, 50, 0.5, 0.4, ob, os_, oc, ov, ws)
     torch.cuda.synchronize()
     for got, e, name in ((ov, exp[3], "valid"), (os_, exp[1], "scores"), (oc, exp[2], "classes"), (ob, exp[0], "boxes")):
@@ -1090,7 +1090,7 @@ def test_nms_combined_abs_equals_nms_then_scale(ops, B, N, q, C, mpc, mt):
         ob, os_ = torch.full((B, mt, 4), -1.0, device=dev), torch.full((B, mt), -1.0, device=dev)
         oc, ov = torch.full((B, mt), -1, dtype=torch.int32, device=dev), torch.full((B,), -1, dtype=torch.int32, device=dev)
         oa = torch.full((B, mt, 4), -1.0, device=dev)
-        ws = torch.empty(ops.nms_workspace_bytes(B, N, C, mpc, mt), dtype=torch.uint8, device=dev)
+        ws = torch.zeros(ops.nms_workspace_bytes(B, N, C, mpc, mt), dtype=torch.uint8, device=dev)
         if fused:
             ops.nms_combined_abs(boxes, scores, B, N, q, C, C, 0, mpc, mt, 0.7, 0.0, ob, os_, oc, ov, ws, oa, 1242.0, 375.0)
         else:
