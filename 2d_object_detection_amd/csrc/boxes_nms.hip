@@ -442,9 +442,20 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                 __syncthreads();
                 NMS_COUNT(14);
                 NMS_STAMP(1);
-                for (int i0 = 0; i0 < p.N; i0 += NMS_T) {         // (all lanes stay in the loop: ballots below)
-                    const int i = i0 + threadIdx.x;
-                    const unsigned int sk = i < p.N ? score_key(i) : 0u;
+                for (int i4 = 0; i4 < p.N; i4 += 4 * NMS_T) {     // (all lanes stay in the loop: ballots below)
+                  // four keys per thread in flight (a key per trip left every trip waiting for its own LDS / global round trip:
+                  // N / 1024 dependent latencies per pass -- 80 global ones for the pyramid's 82 k candidates)
+                  unsigned int sk4[4];
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                      const int i = i4 + u * NMS_T + threadIdx.x;
+                      sk4[u] = i < p.N ? score_key(i) : 0u;
+                  }
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                    if (i4 + u * NMS_T >= p.N) break;             // (uniform)
+                    const int i = i4 + u * NMS_T + threadIdx.x;
+                    const unsigned int sk = sk4[u];
                     const unsigned long long k = composite(sk, i);
                     const bool in = sk != 0u && k < prev && (pass == 0 || (k >> (shift + 8)) == prefix);
                     const int dg = (int)((k >> shift) & 255ull);
@@ -472,6 +483,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
 #else
                     if (in) atomicAdd(&hist[wave * 256 + dg], 1);
 #endif
+                  }
                 }
                 __syncthreads();
                 NMS_STAMP(15);
@@ -526,19 +538,27 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
         const int n_sort = K <= NMS_CH ? NMS_CH : K <= 512 ? 512 : NMS_RK;
         for (int t = threadIdx.x; t < n_sort; t += NMS_T) rkeys[t] = 0ull;
         __syncthreads();
-        for (int i0 = 0; i0 < p.N; i0 += NMS_T) {
-            const int i = i0 + threadIdx.x;
-            const unsigned int sk = i < p.N ? score_key(i) : 0u;
-            const unsigned long long k = composite(sk, i);
-            const bool take = sk != 0u && k >= T && k < prev;
-            const unsigned long long m = __ballot(take);      // one returning atomic per wave, not per candidate
-            if (m != 0ull) {
-                const int leader = __builtin_ctzll(m);
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&misc[6], __popcll(m));
-                base = __builtin_amdgcn_readlane(base, leader);
-                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (take && pos < NMS_RK) rkeys[pos] = k;     // (pos < K always; the guard keeps a logic error from corrupting LDS)
+        for (int i4 = 0; i4 < p.N; i4 += 4 * NMS_T) {
+            unsigned int sk4[4];                              // (four keys in flight, as in the select's sweeps)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i4 + u * NMS_T + threadIdx.x;
+                sk4[u] = i < p.N ? score_key(i) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i4 + u * NMS_T + threadIdx.x;
+                const unsigned long long k = composite(sk4[u], i);
+                const bool take = sk4[u] != 0u && k >= T && k < prev;
+                const unsigned long long m = __ballot(take);  // one returning atomic per wave, not per candidate
+                if (m != 0ull) {
+                    const int leader = __builtin_ctzll(m);
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(&misc[6], __popcll(m));
+                    base = __builtin_amdgcn_readlane(base, leader);
+                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (take && pos < NMS_RK) rkeys[pos] = k; // (pos < K always; the guard keeps a logic error from corrupting LDS)
+                }
             }
         }
         __syncthreads();
@@ -632,11 +652,12 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
             // ---- walk the round in score order (wave 0): the chunk loop's walk over NB row blocks instead of 4; the matrix words of
             // ONE row block at a time in registers (all 36 word pairs at once spilled to scratch: every phase of the kernel got slower)
             if (threadIdx.x < 64) {
-                unsigned long long alive[NBM], kmask[NBM];
+                unsigned long long alive[NBM];
+                unsigned long long* kmask_of = reinterpret_cast<unsigned long long*>(rows);     // [NBM] which candidates of a row block are kept (`rows` is idle in this round)
 #pragma unroll
                 for (int r = 0; r < NBM; ++r) {
                     alive[r] = __ballot(r < NB && dead[(r < NB ? r : 0) * 64 + lane] == 0);
-                    kmask[r] = 0ull;
+                    if (lane == 0) kmask_of[r] = 0ull;
                 }
                 int k_now = 0;
 #pragma unroll
@@ -652,6 +673,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                         wmask |= v != 0ull ? (1 << w) : 0;
                     }
                     const unsigned long long nz = __ballot(wmask != 0);
+                    unsigned long long kmask = 0ull;
                     while (alive[r] != 0ull && k_now < p.max_per_class) {
                         const unsigned long long az = alive[r] & nz;
                         const int pos = az != 0ull ? __builtin_ctzll(az) : 64;
@@ -666,11 +688,11 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                             run = sel;
                             cnt = __popcll(run);
                         }
-                        kmask[r] |= run;
+                        kmask |= run;
                         k_now += cnt;
                         alive[r] &= ~run;
                         if (pos == 64 || k_now >= p.max_per_class) continue;
-                        kmask[r] |= 1ull << pos;
+                        kmask |= 1ull << pos;
                         ++k_now;
                         alive[r] &= ~(1ull << pos);
                         const int wm = __builtin_amdgcn_readlane(wmask, pos);
@@ -682,12 +704,13 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                             alive[w] &= ~sp;
                         }
                     }
+                    if (lane == 0) kmask_of[r] = kmask;
                 }
                 int before = 0;
-#pragma unroll
-                for (int r = 0; r < NBM; ++r) {
-                    if ((kmask[r] >> lane) & 1ull) {
-                        const int slot = before + __popcll(kmask[r] & ((1ull << lane) - 1ull));
+                for (int r = 0; r < NB; ++r) {
+                    const unsigned long long km = kmask_of[r];        // (written by lane 0 of this wave: the LDS unit keeps a wave's order)
+                    if ((km >> lane) & 1ull) {
+                        const int slot = before + __popcll(km & ((1ull << lane) - 1ull));
                         kept_box[slot] = chunk_box[r * 64 + lane];
                         kept_area[slot] = chunk_area[r * 64 + lane];
                         const unsigned long long k = rkeys[r * 64 + lane];
@@ -696,7 +719,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                         p.kept_keys[o] = (k & 0xFFFFFFFF00000000ull) | (unsigned int)(~(unsigned int)(c * p.max_per_class + slot));
                         p.kept_idx[o] = (int)(~(unsigned int)(k & 0xFFFFFFFFull));
                     }
-                    before += __popcll(kmask[r]);
+                    before += __popcll(km);
                 }
                 if (lane == 0) misc[0] = k_now;
             }

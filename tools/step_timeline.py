@@ -1,6 +1,6 @@
 """One replayed training step as a timeline, from a rocprofv3 kernel trace (tools/prof_mode.sh keeps <tag>_<i>_kernel_trace.csv):
 start (us from the step's first kernel), duration, hardware queue, `||` where the kernel starts before its predecessor has ended (a
-side-stream branch), kernel name.  The step boundary is the plan's fill_zero_multi_kernel launch.
+side-stream branch), kernel name.  The step boundary is the plan's first fill_zero_multi_kernel launch.
 usage: python tools/step_timeline.py <kernel_trace.csv> [step index, default 20] > profiles/rNN_step_timeline.txt"""
 import csv
 import re
@@ -13,7 +13,10 @@ def main():
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""), int(r["Queue_Id"]))
             for r in csv.DictReader(open(path))]
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if r[2].startswith("fill_zero_multi_kernel")]
+    fills = [i for i, r in enumerate(rows) if r[2].startswith("fill_zero_multi_kernel")]
+    # (the backward pass's accumulation targets have a fill of their own on a side stream, a few us after the step's first one: a fill that
+    # starts within 300 us of the previous one does not open a step)
+    starts = [i for n, i in enumerate(fills) if n == 0 or rows[i][0] - rows[fills[n - 1]][0] > 300_000]
     a, b = starts[which], starts[which + 1]
     t0 = rows[a][0]
     prev_end, busy = t0, 0
