@@ -302,17 +302,30 @@ struct NmsParams {
     // team mode (nms_class_kernel<., true>): `team` workgroups per (image, class); the first round's suppression matrix is built by all
     // of them (rows split), exchanged through team_mat [B*C][NMS_TEAM_N][NMS_TEAM_N / 64] and the arrival words team_sync [B*C][16]
     int team; unsigned long long* team_mat; unsigned int* team_sync;
+    // split mode (nms_class_kernel<false, true, true>: lists whose score keys do not fit one workgroup's LDS): every workgroup of the team
+    // owns N / NMS_TEAM consecutive candidates; counts, digit histograms and the round's keys are exchanged through team_xch
+    int split_len; unsigned int* team_xflag; unsigned int* team_xch;
 };
+
+constexpr int NMS_XSTAGES = 10;              // exchanges of a split launch: valid counts, up to 8 select passes, the round's keys
+constexpr size_t NMS_XCH_WORDS = 8 /*counts*/ + (size_t)8 * 8 * 256 /*[pass][workgroup][digit]*/ + 8 /*key counts*/ + (size_t)8 * 512 * 2 /*[workgroup][key] as word pairs*/;
 
 constexpr int NMS_TEAM = 8;                  // workgroups per (image, class) in team mode
 constexpr int NMS_TEAM_N = 512;              // candidates of the team round (NMS_RK / 2: the first round's goal)
 
 // LDS of nms_class_kernel; *lds_keys: the 32-bit score keys of the N candidates are staged in LDS (else re-read from global)
-static size_t nms_class_lds(int n, int max_per_class, bool team, bool* lds_keys) {
+static size_t nms_class_lds(int n, int max_per_class, bool team, bool* lds_keys, int* split_len) {
     const size_t cap = team ? NMS_TEAM_N : NMS_CH;            // candidates whose boxes / matrix rows are resident at once
     const size_t fixed = (size_t)max_per_class * 28 + cap * (16 + 4 + 4 + 4) + cap * (cap / 64) * 8 + 64 + 16 + (size_t)NMS_HC * 256 * 4 + (size_t)NMS_RK * 8 + 16;
     *lds_keys = fixed + (size_t)n * 4 <= 150 * 1024;
-    return fixed + (*lds_keys ? (size_t)n * 4 : 0);
+    *split_len = 0;
+    if (*lds_keys) return fixed + (size_t)n * 4;
+    const int slice = ((n + 8 - 1) / 8 + 3) & ~3;              // a team member's candidates in split mode (NMS_TEAM = 8)
+    if (team && fixed + (size_t)slice * 4 <= 150 * 1024) {
+        *split_len = slice;
+        return fixed + (size_t)slice * 4;
+    }
+    return fixed;
 }
 
 // One workgroup per (image, class).  Greedy NMS visits candidates in descending score order and usually stops long before the
@@ -345,8 +358,15 @@ __device__ unsigned long long g_nms_stamps[2][8][16];
 // memory (release: __threadfence + arrival counter; acquire: the counter, then __threadfence).  Workgroup 0 walks the round in score
 // order from that matrix and, if the list does not end inside the round, continues alone with the rounds of the one-workgroup form.
 // Same visits in the same order: same results.  The helpers wait for nothing, so the counter is always reached.
-template <bool LDSK, bool TEAM>
+// SPLIT (TEAM, lists too long for LDSK: the pyramid's 82 k candidates, 57 k at 600 x 1987): one workgroup streaming such a list once takes
+// 20 us, and the select + compaction of a round stream it three or four times.  Every team member stages only ITS N / 8 candidates (in
+// LDS), sweeps only those, and the members exchange what the round needs -- valid counts, one 256-bin histogram per select pass, the
+// round's keys -- through global memory, all-to-all, with one arrival word per (exchange, member) holding the launch number (the hand-off
+// form of the matrix below).  Every member computes the same digit, threshold and key list from the same sums; from the sort on the
+// team round is unchanged.  Rounds after the team round (workgroup 0 alone) re-read the scores from global memory.
+template <bool LDSK, bool TEAM, bool SPLIT = false>
 __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
+    static_assert(!SPLIT || (TEAM && !LDSK), "split mode: a team without whole-list LDS keys");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef FRCNN_NMS_STAMPS
     unsigned long long st_acc[16] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
@@ -389,25 +409,47 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const IouThr thr = iou_thr_of(p.iou_thr);
 
+    unsigned int gen0 = 0u;                                   // team mode: this launch's number (see the hand-off below)
+    if (TEAM) gen0 = __hip_atomic_load(p.team_sync + (size_t)unit * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // split mode: this workgroup's candidates [lo, hi) while split_phase (the team round); afterwards, and in every other mode, all of them
+    bool split_phase = SPLIT;
+    const int s0 = SPLIT ? min(team_rank * p.split_len, p.N) : 0, s1 = SPLIT ? min(s0 + p.split_len, p.N) : p.N;
+    int lo = s0, hi = s1;
     auto score_key = [&](const int i) -> unsigned int {       // 0: not a candidate (score <= threshold)
         if (LDSK) return skeys[i];
+        if (SPLIT && split_phase) return skeys[i - s0];
         const float s = scores[(int64_t)i * p.score_stride];
         return s > p.score_thr ? float_key(s) : 0u;
+    };
+    // all-to-all exchange `stage` of a split launch: every member has published its part of team_xch (agent-scope relaxed atomic stores)
+    unsigned int* xch = SPLIT ? p.team_xch + (size_t)unit * NMS_XCH_WORDS : nullptr;
+    auto exchange = [&](const int stage) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned int* flags = p.team_xflag + ((size_t)unit * NMS_XSTAGES + stage) * NMS_TEAM;
+        if (threadIdx.x == 0) __hip_atomic_store(flags + team_rank, gen0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < NMS_TEAM) {
+            long spins = 0;
+            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen0 + 1u) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1l << 24)) __builtin_trap();   // (seconds: a member that never ran -- abort loudly rather than hang)
+            }
+        }
+        __syncthreads();
     };
     auto composite = [](const unsigned int sk, const int i) -> unsigned long long {
         return ((unsigned long long)sk << 32) | (unsigned int)(~(unsigned int)i);
     };
 
-    unsigned int gen0 = 0u;                                   // team mode: this launch's number (see the hand-off below)
-    if (TEAM) gen0 = __hip_atomic_load(p.team_sync + (size_t)unit * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < 16) misc[threadIdx.x] = 0;
     __syncthreads();
     {
         int valid = 0;
-        for (int i = threadIdx.x; i < p.N; i += NMS_T) {
+        for (int i = lo + threadIdx.x; i < hi; i += NMS_T) {
             const float s = scores[(int64_t)i * p.score_stride];
             const unsigned int sk = s > p.score_thr ? float_key(s) : 0u;
             if (LDSK) skeys[i] = sk;
+            if (SPLIT) skeys[i - s0] = sk;
             valid += sk != 0u;
         }
 #pragma unroll
@@ -415,6 +457,16 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
         if (lane == 0 && valid) atomicAdd(&misc[2], valid);
     }
     __syncthreads();
+    if (SPLIT) {                                              // exchange 0: the members' valid counts
+        if (threadIdx.x == 0) __hip_atomic_store(xch + team_rank, (unsigned int)misc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        exchange(0);
+        if (threadIdx.x == 0) {
+            int total = 0;
+            for (int g = 0; g < NMS_TEAM; ++g) total += (int)__hip_atomic_load(xch + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            misc[2] = total;
+        }
+        __syncthreads();
+    }
     NMS_STAMP(0);
     int remaining = misc[2];
     unsigned long long prev = ~0ull;                          // candidates with a composite key below prev are still unvisited
@@ -442,18 +494,18 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                 __syncthreads();
                 NMS_COUNT(14);
                 NMS_STAMP(1);
-                for (int i4 = 0; i4 < p.N; i4 += 4 * NMS_T) {     // (all lanes stay in the loop: ballots below)
+                for (int i4 = lo; i4 < hi; i4 += 4 * NMS_T) {     // (all lanes stay in the loop: ballots below)
                   // four keys per thread in flight (a key per trip left every trip waiting for its own LDS / global round trip:
                   // N / 1024 dependent latencies per pass -- 80 global ones for the pyramid's 82 k candidates)
                   unsigned int sk4[4];
 #pragma unroll
                   for (int u = 0; u < 4; ++u) {
                       const int i = i4 + u * NMS_T + threadIdx.x;
-                      sk4[u] = i < p.N ? score_key(i) : 0u;
+                      sk4[u] = i < hi ? score_key(i) : 0u;
                   }
 #pragma unroll
                   for (int u = 0; u < 4; ++u) {
-                    if (i4 + u * NMS_T >= p.N) break;             // (uniform)
+                    if (i4 + u * NMS_T >= hi) break;              // (uniform)
                     const int i = i4 + u * NMS_T + threadIdx.x;
                     const unsigned int sk = sk4[u];
                     const unsigned long long k = composite(sk, i);
@@ -486,6 +538,19 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                   }
                 }
                 __syncthreads();
+                if (SPLIT && split_phase) {                   // exchange 1 + pass: every member's 256 digit counts of this pass
+                    unsigned int* xh = xch + 8 + (size_t)pass * NMS_TEAM * 256;
+                    if (threadIdx.x < 256) {
+                        int sum = 0;
+#pragma unroll
+                        for (int h = 0; h < NMS_HC; ++h) sum += hist[h * 256 + threadIdx.x];
+                        __hip_atomic_store(xh + team_rank * 256 + threadIdx.x, (unsigned int)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    exchange(1 + pass);
+                    for (int t = threadIdx.x; t < NMS_HC * 256; t += NMS_T)      // the members' counts as the first 8 of the 16 copies
+                        hist[t] = t < NMS_TEAM * 256 ? (int)__hip_atomic_load(xh + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    __syncthreads();
+                }
                 NMS_STAMP(15);
                 if (threadIdx.x < 64) {                       // the digit d with  #(digits above d) < want <= #(digits >= d)
                     // (copy-major layout hist[wave][256]: a wave's atomics spread over the banks by digit, and a lane's four digits of
@@ -538,12 +603,12 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
         const int n_sort = K <= NMS_CH ? NMS_CH : K <= 512 ? 512 : NMS_RK;
         for (int t = threadIdx.x; t < n_sort; t += NMS_T) rkeys[t] = 0ull;
         __syncthreads();
-        for (int i4 = 0; i4 < p.N; i4 += 4 * NMS_T) {
+        for (int i4 = lo; i4 < hi; i4 += 4 * NMS_T) {
             unsigned int sk4[4];                              // (four keys in flight, as in the select's sweeps)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i4 + u * NMS_T + threadIdx.x;
-                sk4[u] = i < p.N ? score_key(i) : 0u;
+                sk4[u] = i < hi ? score_key(i) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -562,6 +627,30 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
             }
         }
         __syncthreads();
+        if (SPLIT && split_phase) {                           // exchange 9: every member's keys of the round
+            unsigned int* xk = xch + 8 + (size_t)8 * NMS_TEAM * 256;
+            const int mine_n = misc[6];
+            if (threadIdx.x == 0) __hip_atomic_store(xk + team_rank, (unsigned int)mine_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int t = threadIdx.x; t < mine_n; t += NMS_T) {
+                const unsigned long long k = rkeys[t];
+                __hip_atomic_store(xk + 8 + ((size_t)team_rank * NMS_TEAM_N + t) * 2, (unsigned int)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(xk + 8 + ((size_t)team_rank * NMS_TEAM_N + t) * 2 + 1, (unsigned int)(k >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            exchange(9);
+            for (int t = threadIdx.x; t < n_sort; t += NMS_T) rkeys[t] = 0ull;
+            __syncthreads();
+            int off = 0;
+            for (int g = 0; g < NMS_TEAM; ++g) {              // (uniform: every thread reads the eight counts)
+                const int ng = (int)__hip_atomic_load(xk + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int t = threadIdx.x; t < ng && off + t < NMS_RK; t += NMS_T) {
+                    const unsigned int klo = __hip_atomic_load(xk + 8 + ((size_t)g * NMS_TEAM_N + t) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned int khi = __hip_atomic_load(xk + 8 + ((size_t)g * NMS_TEAM_N + t) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    rkeys[off + t] = ((unsigned long long)khi << 32) | klo;
+                }
+                off += ng;
+            }
+            __syncthreads();
+        }
         NMS_STAMP(2);
         bitonic_desc_reg(rkeys, n_sort);
         NMS_STAMP(3);
@@ -728,6 +817,11 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
             kept = misc[0];
             prev = T;
             remaining -= K;
+            if (SPLIT) {                                          // later rounds (workgroup 0 alone): all N candidates, from global memory
+                split_phase = false;
+                lo = 0;
+                hi = p.N;
+            }
             __syncthreads();
             continue;
         }
@@ -1096,7 +1190,13 @@ static size_t nms_kept_bytes(int b, int c, int max_per_class) {
 extern "C" size_t frcnn_nms_workspace_bytes(int b, int n, int c, int max_per_class, int max_total) {
     (void)max_total;
     size_t bytes = nms_kept_bytes(b, c, max_per_class);
-    if (nms_team_mode(b, n, c)) bytes += (size_t)b * 64 + (size_t)b * NMS_TEAM_N * (NMS_TEAM_N / 64) * sizeof(unsigned long long);    // arrival words + matrices
+    if (nms_team_mode(b, n, c)) {
+        bytes += (size_t)b * 64 + (size_t)b * NMS_TEAM_N * (NMS_TEAM_N / 64) * sizeof(unsigned long long);    // arrival words + matrices
+        bool lds_keys;
+        int split_len;
+        nms_class_lds(n, max_per_class, true, &lds_keys, &split_len);
+        if (split_len) bytes += (size_t)b * (NMS_XSTAGES * NMS_TEAM + NMS_XCH_WORDS) * sizeof(unsigned int);     // split mode: arrival words + exchange buffers
+    }
     return bytes;
 }
 
@@ -1131,8 +1231,16 @@ static int nms_combined_impl(const float* boxes, const float* scores, int b, int
         p.team_mat = reinterpret_cast<unsigned long long*>(ws + nms_kept_bytes(b, c, max_per_class) + (size_t)b * 64);
     }
     bool lds_keys;
-    const size_t smem = nms_class_lds(n, max_per_class, team, &lds_keys);
+    int split_len;
+    const size_t smem = nms_class_lds(n, max_per_class, team, &lds_keys, &split_len);
+    if (getenv("FRCNN_NMS_NO_SPLIT")) split_len = 0;
     p.lds_keys = lds_keys ? 1 : 0;
+    p.split_len = split_len; p.team_xflag = nullptr; p.team_xch = nullptr;
+    if (split_len) {
+        unsigned char* x = reinterpret_cast<unsigned char*>(p.team_mat) + (size_t)b * NMS_TEAM_N * (NMS_TEAM_N / 64) * sizeof(unsigned long long);
+        p.team_xflag = reinterpret_cast<unsigned int*>(x);
+        p.team_xch = p.team_xflag + (size_t)b * NMS_XSTAGES * NMS_TEAM;
+    }
 #define FRCNN_NMS_LAUNCH(LDSK, TEAM, GRID)                                                                                                  \
     do {                                                                                                                                  \
         FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(nms_class_kernel<LDSK, TEAM>), smem) == 0,                      \
@@ -1141,7 +1249,11 @@ static int nms_combined_impl(const float* boxes, const float* scores, int b, int
     } while (0)
     if (team) {
         if (lds_keys) FRCNN_NMS_LAUNCH(true, true, b * c * NMS_TEAM);
-        else FRCNN_NMS_LAUNCH(false, true, b * c * NMS_TEAM);
+        else if (split_len) {
+            FRCNN_CHECK_ARG(frcnn_allow_big_lds(reinterpret_cast<const void*>(nms_class_kernel<false, true, true>), smem) == 0,
+                            "nms_combined: cannot reserve %zu B of LDS", smem);
+            hipLaunchKernelGGL((nms_class_kernel<false, true, true>), dim3(b * c * NMS_TEAM), dim3(NMS_T), smem, S_(stream), p);
+        } else FRCNN_NMS_LAUNCH(false, true, b * c * NMS_TEAM);
     } else {
         if (lds_keys) FRCNN_NMS_LAUNCH(true, false, b * c);
         else FRCNN_NMS_LAUNCH(false, false, b * c);

@@ -383,6 +383,9 @@ def _random_boxes(g, B, N, q):
     (1, 70, 3, 3, 100, 300, 0.5),        # fewer candidates than any cap
     (2, 8768, 1, 1, 1000, 1000, 0.7),    # BASELINE config 4: 1000-proposal stress (RPN)
     (2, 1000, 7, 7, 100, 300, 0.6),      # BASELINE config 4: RCNN NMS over 1000 proposals
+    (3, 81929, 1, 1, 300, 300, 0.7),     # BASELINE config 4: the pyramid's in-image anchors (team of workgroups, candidates split over it)
+    (2, 57000, 1, 1, 2000, 2000, 0.7),   # 600 x 1987 (the reference's config.json), more kept than the team round holds: rounds after it
+    (2, 600, 1, 1, 300, 300, 0.7),       # single class, one workgroup's round: a team without a select
 ])
 def test_nms_combined_bit_exact(ops, B, N, q, C, mpc, mt, thr):
     g = torch.Generator().manual_seed(N + C)
@@ -410,7 +413,8 @@ def test_nms_combined_bit_exact(ops, B, N, q, C, mpc, mt, thr):
     (8768, 16, 0.5, 300),        # many equal scores: the radix select of a round runs deep into the index bytes; IoUs of exactly 1/2
     (8768, 4096, 1.0 / 3.0, 300),
     (3000, 3, 0.5, 1000),        # almost all scores equal, more kept than one round holds
-    (22464, 64, 0.25, 300),      # score keys re-read from global memory (no LDS staging)
+    (22464, 64, 0.25, 300),      # score keys split over the team's workgroups (no whole-list LDS staging)
+    (57000, 8, 0.5, 300),        # ... with runs of equal scores longer than a member's slice
 ])
 def test_nms_equal_scores_and_ious_on_the_threshold(ops, N, levels, thr, mpc):
     """Boxes on a coarse grid (corners k/32, a few sizes): many pairs have an IoU that is EXACTLY a small rational -- 1/2, 1/3, 1/4 --
