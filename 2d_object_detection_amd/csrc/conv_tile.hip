@@ -139,22 +139,22 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
     for (int j = 0; j < NI; ++j) {
         const int c = n0 + wn * WTN + j * 16 + fchunk * 4;
         f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
-        if ((flags & FRCNN_CONV_BIAS) && c < p.Cout) b = *reinterpret_cast<const f32x4*>(p.bias + c);   // Cout % 8 == 0
+        if (!F8 && (flags & FRCNN_CONV_BIAS) && c < p.Cout) b = *reinterpret_cast<const f32x4*>(p.bias + c);   // Cout % 8 == 0
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[j][e] = b[e];
     }
 
-    float dq[F8 ? NI : 1][4];                     // F8: x_scale * w_scale[cout] of this lane's channels
+    // F8: x_scale * w_scale[cout] and the bias of the tile's BN channels wait in LDS for the epilogue (held in registers through the K
+    // loop they were the 8 VGPRs that made the fp8 forms spill: a scratch reload in front of every slice's DMA issue)
+    float* s_dq = reinterpret_cast<float*>(smem + BIG + 2 * BN * 4);           // F8: [BN] dequantisation factors, [BN] bias
     if (F8) {
         const float xs = *p.f8_x_scale;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int c = n0 + wn * WTN + j * 16 + fchunk * 4;
-            f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (c < p.Cout) w = *reinterpret_cast<const f32x4*>(p.f8_w_scale + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dq[F8 ? j : 0][e] = w[e] * xs;
+        if (tid < BN) {
+            const int c = n0 + tid;
+            s_dq[tid] = c < p.Cout ? p.f8_w_scale[c] * xs : 0.f;
+            s_dq[BN + tid] = ((flags & FRCNN_CONV_BIAS) && c < p.Cout) ? p.bias[c] : 0.f;
         }
+        __syncthreads();
     }
 
     // ------------------------------------------------------------------ loader (LDS-DMA) state
@@ -778,8 +778,9 @@ __global__ __launch_bounds__(512, 2 * OCC) void conv_tile_kernel(const ConvParam
                     for (int h = 0; h < 2; ++h) {
                         f32x2 v;
                         if (F8) {
-                            v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] * dq[F8 ? j : 0][2 * h] + bv[j][2 * h], lo, __builtin_inff());
-                            v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] * dq[F8 ? j : 0][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
+                            const f32x2 dqv = *reinterpret_cast<const f32x2*>(s_dq + cl + 2 * h), bvv = *reinterpret_cast<const f32x2*>(s_dq + BN + cl + 2 * h);
+                            v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] * dqv[0] + bvv[0], lo, __builtin_inff());
+                            v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] * dqv[1] + bvv[1], lo, __builtin_inff());
                         } else {
                             v[0] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h] + bv[j][2 * h], lo, __builtin_inff());
                             v[1] = __builtin_amdgcn_fmed3f(acc[i][j][2 * h + 1] + bv[j][2 * h + 1], lo, __builtin_inff());
@@ -2183,7 +2184,7 @@ unsigned long long* g_stamp_buffer = nullptr;    // FRCNN_STAMPS builds: set thr
 template <int BM, int BN, int BK, int S, bool LIN, int SMODE, int OCC, bool MULTI, bool F32 = false, bool KWS = false, bool FIX = false, int F8 = 0, bool BNIN = false>
 int launch_tile(const ConvParams& p, hipStream_t s) {
     constexpr int ring = KWS ? 2 * 3 * 8 * 1024 + S * BN * BK * 2 : S * (BM + BN) * BK * 2, stg = BM * (BN * 2 + 16), stg32 = BM * (BN * 4 + 16);
-    constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4 + (BNIN ? 2 * 512 * 4 : 0);   // BNIN: + scale / shift of <= 512 input channels
+    constexpr int smem = (F32 ? (ring > stg32 ? ring : stg32) : MULTI ? ring + stg : (ring > stg ? ring : stg)) + 2 * BN * 4 + (BNIN ? 2 * 512 * 4 : 0) + (F8 ? 2 * BN * 4 : 0);   // BNIN: + scale / shift of <= 512 input channels; F8: + dequantisation factors / bias
     static_assert(smem <= 163840, "LDS budget");
     static_assert(smem * OCC <= 163840, "occupancy target does not fit the LDS");
     if (!p.dry_run && frcnn_allow_big_lds(reinterpret_cast<const void*>(&conv_tile_kernel<BM, BN, BK, S, LIN, SMODE, OCC, MULTI, F32, KWS, FIX, F8, BNIN>), smem) != 0) {
