@@ -1223,7 +1223,10 @@ static int nms_combined_impl(const float* boxes, const float* scores, int b, int
     p.out_boxes = fused_merge ? out_boxes : nullptr; p.out_scores = out_scores; p.out_classes = out_classes; p.out_valid = out_valid;
     p.max_total = max_total;
     p.out_abs = out_abs; p.sx = sx; p.sy = sy;
-    const bool team = nms_team_mode(b, n, c) && !getenv("FRCNN_NMS_NO_TEAM");
+    bool team = nms_team_mode(b, n, c);
+#ifdef FRCNN_SWEEP
+    if (getenv("FRCNN_NMS_NO_TEAM")) team = false;            // (A/B switches of the kernel-development build: production reads no environment)
+#endif
     p.team = team ? NMS_TEAM : 1;
     p.team_sync = nullptr; p.team_mat = nullptr;
     if (team) {
@@ -1233,7 +1236,9 @@ static int nms_combined_impl(const float* boxes, const float* scores, int b, int
     bool lds_keys;
     int split_len;
     const size_t smem = nms_class_lds(n, max_per_class, team, &lds_keys, &split_len);
+#ifdef FRCNN_SWEEP
     if (getenv("FRCNN_NMS_NO_SPLIT")) split_len = 0;
+#endif
     p.lds_keys = lds_keys ? 1 : 0;
     p.split_len = split_len; p.team_xflag = nullptr; p.team_xch = nullptr;
     if (split_len) {
