@@ -625,7 +625,7 @@ class FeatureExtractor:
             else:
                 u[1].apply(plan, a["a1"], out8=a.get("a1_8") if f8 is not None else None, twin_only=f8 is not None and a.get("a1_twin_only", False))
                 u[2].forward(plan, a["a1"], training, a.get("a1_8") if f8 is not None else None)
-            if bnin and BN_IN_FUSED not in ("wres", "3x3") and ops.conv2d_bnin_supported(u[3].desc):
+            if bnin and (BN_IN_FUSED == "1" or (BN_IN_FUSED == "3x3c2" and u[3].cin == 64)) and ops.conv2d_bnin_supported(u[3].desc):
                 # ... and the block's third convolution (1x1) its second BatchNorm + ReLU (round 5: the tile kernel transforms every landed A slice)
                 u[3].forward_bnin(plan, u[2], a["a2"])
             else:
