@@ -674,7 +674,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
             NMS_STAMP(4);
             unsigned long long* mat = p.team_mat + (size_t)unit * NMS_TEAM_N * NBM;
             {
-                // this workgroup's rows: i = team_rank * rpw + (wave, wave + 16, ...); a lane's column candidates (j = 64 w + lane) in
+                // this workgroup's rows: i = team_rank + NMS_TEAM * (wave, wave + 16, ...); a lane's column candidates (j = 64 w + lane) in
                 // registers; lane w of the row's wave ends with word w and the row leaves as one 64-byte store
                 const int rpw = n_sort / NMS_TEAM;
 #pragma unroll 1
@@ -690,7 +690,11 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                         cdead[w4] = dead[j] != 0;
                     }
                     for (int ri = wave; ri < rpw; ri += NMS_T / 64) {
-                        const int i = team_rank * rpw + ri;       // (wave-uniform)
+                        // COLUMN form: word w of candidate i = which EARLIER candidates 64 w .. 64 w + 63 would suppress it (the overlap
+                        // test is symmetric, so this is the row form's test with the roles swapped): the walk below then needs no
+                        // cross-lane traffic at all -- a lane asks "does anybody kept so far suppress MY candidate"
+                        const int i = ri * NMS_TEAM + team_rank;  // (wave-uniform; interleaved: a candidate late in the round has up to 8 words
+                                                                  //  to test, an early one 1 -- every member and wave gets a mix)
                         const f32x4 rb = chunk_box[i];
                         const float ra = chunk_area[i];
                         const bool rdead = dead[i] != 0;
@@ -698,9 +702,9 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
 #pragma unroll
                         for (int w4 = 0; w4 < 4; ++w4) {
                             const int w = h * 4 + w4;
-                            if (w < (i >> 6)) continue;           // (uniform) every column of this word precedes the row
+                            if (w > (i >> 6)) continue;           // (uniform) every candidate of this word comes after i
                             const int j = w * 64 + lane;
-                            const bool sgt = !rdead && j > i && !cdead[w4] && nms_over(cb[w4], ca[w4], rb, ra, thr);
+                            const bool sgt = !rdead && j < i && !cdead[w4] && nms_over(cb[w4], ca[w4], rb, ra, thr);
                             const unsigned long long m = __ballot(sgt);
                             if (lane == w) mine = m;
                         }
@@ -738,11 +742,16 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
             for (int t = threadIdx.x; t < n_sort * NBM; t += NMS_T) sup_of[t] = __hip_atomic_load(mat + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             NMS_STAMP(12);
-            // ---- walk the round in score order (wave 0): the chunk loop's walk over NB row blocks instead of 4; the matrix words of
-            // ONE row block at a time in registers (all 36 word pairs at once spilled to scratch: every phase of the kernel got slower)
+            // ---- resolve the round in score order (wave 0), one block of 64 candidates at a time, from the column form: lane l of block r
+            // knows which earlier candidates of the block suppress its own (word r of its column).  "Kept" inside the block is the fixed
+            // point of  K <- alive & ~(somebody in K suppresses me)  started from K = alive: after t rounds the first t candidates of
+            // the block are final (a candidate depends on earlier ones only), so at most 64 rounds and in practice the depth of the
+            // longest suppression chain -- one ballot each, no cross-lane reads.  The kept set then strikes the later blocks' candidates
+            // the same way (one ballot per block).  (The row-form walk this replaces took one dependent scalar chain of ~150 cycles per
+            // KEPT candidate: 15 of the kernel's 50 us.)
             if (threadIdx.x < 64) {
                 unsigned long long alive[NBM];
-                unsigned long long* kmask_of = reinterpret_cast<unsigned long long*>(rows);     // [NBM] which candidates of a row block are kept (`rows` is idle in this round)
+                unsigned long long* kmask_of = reinterpret_cast<unsigned long long*>(rows);     // [NBM] which candidates of a block are kept (`rows` is idle in this round)
 #pragma unroll
                 for (int r = 0; r < NBM; ++r) {
                     alive[r] = __ballot(r < NB && dead[(r < NB ? r : 0) * 64 + lane] == 0);
@@ -752,48 +761,30 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
 #pragma unroll
                 for (int r = 0; r < NBM; ++r) {
                     if (r >= NB || alive[r] == 0ull || k_now >= p.max_per_class) continue;      // (uniform)
-                    unsigned int slo[NBM], shi[NBM];              // row r*64+lane, words w >= r
-                    int wmask = 0;                                // which of them are non-zero: a step reads only those from the row's lane
+                    unsigned long long col[NBM];                  // word r of the columns of this lane's candidates in blocks w >= r
 #pragma unroll
-                    for (int w = r; w < NBM; ++w) {
-                        const unsigned long long v = (w < NB && ((alive[r] >> lane) & 1ull)) ? sup_of[(size_t)(r * 64 + lane) * NBM + w] : 0ull;
-                        slo[w] = (unsigned int)v;
-                        shi[w] = (unsigned int)(v >> 32);
-                        wmask |= v != 0ull ? (1 << w) : 0;
+                    for (int w = r; w < NBM; ++w) col[w] = w < NB ? sup_of[(size_t)(w * 64 + lane) * NBM + r] : 0ull;
+                    const bool mine_alive = (alive[r] >> lane) & 1ull;
+                    unsigned long long K = alive[r];
+                    for (int it = 0; it < 64; ++it) {
+                        const unsigned long long Kn = __ballot(mine_alive && (col[r] & K) == 0ull);
+                        if (Kn == K) break;
+                        K = Kn;
                     }
-                    const unsigned long long nz = __ballot(wmask != 0);
-                    unsigned long long kmask = 0ull;
-                    while (alive[r] != 0ull && k_now < p.max_per_class) {
-                        const unsigned long long az = alive[r] & nz;
-                        const int pos = az != 0ull ? __builtin_ctzll(az) : 64;
-                        unsigned long long run = pos < 64 ? (alive[r] & ((1ull << pos) - 1ull)) : alive[r];
-                        int cnt = __popcll(run);
-                        if (k_now + cnt > p.max_per_class) {             // the cap falls inside the run: its first (cap - kept) members
-                            unsigned long long t = run, sel = 0ull;
-                            for (int need = p.max_per_class - k_now; need > 0; --need) {
-                                sel |= t & (~t + 1ull);
-                                t &= t - 1ull;
-                            }
-                            run = sel;
-                            cnt = __popcll(run);
+                    int cnt = __popcll(K);
+                    if (k_now + cnt > p.max_per_class) {          // the cap falls inside the block: its first (cap - kept) members
+                        unsigned long long t = K, sel = 0ull;
+                        for (int need = p.max_per_class - k_now; need > 0; --need) {
+                            sel |= t & (~t + 1ull);
+                            t &= t - 1ull;
                         }
-                        kmask |= run;
-                        k_now += cnt;
-                        alive[r] &= ~run;
-                        if (pos == 64 || k_now >= p.max_per_class) continue;
-                        kmask |= 1ull << pos;
-                        ++k_now;
-                        alive[r] &= ~(1ull << pos);
-                        const int wm = __builtin_amdgcn_readlane(wmask, pos);
+                        K = sel;
+                        cnt = __popcll(K);
+                    }
+                    k_now += cnt;
+                    if (lane == 0) kmask_of[r] = K;
 #pragma unroll
-                        for (int w = r; w < NBM; ++w) {
-                            if (!((wm >> w) & 1)) continue;       // (uniform)
-                            const unsigned long long sp = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)shi[w], pos) << 32) |
-                                                          (unsigned int)__builtin_amdgcn_readlane((int)slo[w], pos);
-                            alive[w] &= ~sp;
-                        }
-                    }
-                    if (lane == 0) kmask_of[r] = kmask;
+                    for (int w = r + 1; w < NBM; ++w) alive[w] &= ~__ballot((col[w] & K) != 0ull);
                 }
                 int before = 0;
                 for (int r = 0; r < NB; ++r) {
