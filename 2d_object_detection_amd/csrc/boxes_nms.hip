@@ -795,9 +795,11 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                         kept_area[slot] = chunk_area[r * 64 + lane];
                         const unsigned long long k = rkeys[r * 64 + lane];
                         kept_key[slot] = k;
-                        const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + slot;
-                        p.kept_keys[o] = (k & 0xFFFFFFFF00000000ull) | (unsigned int)(~(unsigned int)(c * p.max_per_class + slot));
-                        p.kept_idx[o] = (int)(~(unsigned int)(k & 0xFFFFFFFFull));
+                        if (!p.out_boxes) {                   // (a single class writes the final outputs itself, from kept_key: no merge launch reads these)
+                            const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + slot;
+                            p.kept_keys[o] = (k & 0xFFFFFFFF00000000ull) | (unsigned int)(~(unsigned int)(c * p.max_per_class + slot));
+                            p.kept_idx[o] = (int)(~(unsigned int)(k & 0xFFFFFFFFull));
+                        }
                     }
                     before += __popcll(km);
                 }
@@ -965,9 +967,11 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
                         kept_area[slot] = chunk_area[r * 64 + lane];
                         const unsigned long long k = rkeys[base + r * 64 + lane];
                         kept_key[slot] = k;
-                        const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + slot;
-                        p.kept_keys[o] = (k & 0xFFFFFFFF00000000ull) | (unsigned int)(~(unsigned int)(c * p.max_per_class + slot));
-                        p.kept_idx[o] = (int)(~(unsigned int)(k & 0xFFFFFFFFull));
+                        if (!p.out_boxes) {                   // (a single class writes the final outputs itself, from kept_key: no merge launch reads these)
+                            const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + slot;
+                            p.kept_keys[o] = (k & 0xFFFFFFFF00000000ull) | (unsigned int)(~(unsigned int)(c * p.max_per_class + slot));
+                            p.kept_idx[o] = (int)(~(unsigned int)(k & 0xFFFFFFFFull));
+                        }
                     }
                     before += __popcll(kmask[r]);
                 }
@@ -984,7 +988,7 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     }
     if (TEAM && team_rank != 0) return;                      // (a list without candidates: no round was run)
     // zero the unused kept slots of this (image, class)
-    for (int s = kept + threadIdx.x; s < p.max_per_class; s += blockDim.x) {
+    for (int s = kept + threadIdx.x; s < p.max_per_class && !p.out_boxes; s += blockDim.x) {
         const int64_t o = (int64_t)b * p.C * p.max_per_class + (int64_t)c * p.max_per_class + s;
         p.kept_keys[o] = 0ull;
         p.kept_idx[o] = 0;
