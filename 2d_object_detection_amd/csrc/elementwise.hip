@@ -565,6 +565,131 @@ __global__ __launch_bounds__(256) void bn_train_apply_pool_kernel(const bf16_t* 
     }
 }
 
+// The same operation, tiled: a workgroup owns 4 x 16 pooled cells of a 64-channel strip.  Its 9 x 33 input pixels are normalised ONCE
+// (the per-cell form above normalises every pixel of a 3 x 3 / 2 window again for each of the 2.25 cells that see it, and spends ~12
+// instructions per tap and channel on compare-and-select bookkeeping), stored as bf16 in LDS, and pooled from there with ONE v_max_u32 per
+// tap and channel: the activation is non-negative, so its bf16 pattern orders like an unsigned integer, and the key
+// (pattern << 16 | 15 - tap) makes the maximum of the keys the FIRST maximum of the window -- value and arg-max together.  Same bits as the
+// per-cell form (tests/test_gpu_kernels.py::test_stem_bn_relu_maxpool_fused) except that a -0.0 activation is stored as +0.0.
+constexpr int POOL_TH = 4, POOL_TW = 16, POOL_PH = 2 * POOL_TH + 1, POOL_PW = 2 * POOL_TW + 1, POOL_PITCH = 144;   // bytes per patch pixel (128 + pad)
+__global__ __launch_bounds__(256) void bn_train_apply_pool_tiled_kernel(const bf16_t* __restrict__ z, const double* __restrict__ part, int slots,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                        float* __restrict__ mm, float* __restrict__ mv, float momentum, float eps,
+                                                                        float inv_count, float unbias, bf16_t* __restrict__ pool,
+                                                                        uint8_t* __restrict__ amax, uint8_t* __restrict__ relu_mask,
+                                                                        float* __restrict__ mean_o, float* __restrict__ invstd_o, int N, int H,
+                                                                        int W, int C, int Ho, int Wo, int strips, int tiles_x, int tiles_y) {
+    __shared__ double red[2][4][64];
+    __shared__ float s_scale[64], s_shift[64];
+    __shared__ __attribute__((aligned(16))) unsigned char patch[POOL_PH * POOL_PW * POOL_PITCH];
+    const int strip = blockIdx.x % strips;
+    int tile = blockIdx.x / strips;
+    const int tx0 = (tile % tiles_x) * POOL_TW;
+    tile /= tiles_x;
+    const int ty0 = (tile % tiles_y) * POOL_TH, n = tile / tiles_y;
+    const int c0 = strip * 64;
+    {
+        const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        const int c = c0 + cl;
+        float ga = 0.f, be = 0.f;
+        if (sl == 0 && c < C) { ga = gamma[c]; be = beta[c]; }
+        double s = 0.0, ss = 0.0;
+        if (c < C) slot_sums(part, slots, sl, C, c, s, ss);
+        red[0][sl][cl] = s;
+        red[1][sl][cl] = ss;
+        __syncthreads();
+        if (sl == 0) {
+            float sc = 0.f, shf = 0.f;
+            if (c < C) {
+                s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+                ss = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+                const double mean = s * inv_count;
+                double var = ss * inv_count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+                sc = ga * invstd;
+                shf = be - (float)mean * sc;
+                if (blockIdx.x / strips == 0) {
+                    mean_o[c] = (float)mean;
+                    invstd_o[c] = invstd;
+                    mm[c] = mm[c] * momentum + (float)mean * (1.f - momentum);
+                    mv[c] = mv[c] * momentum + (float)(var * unbias) * (1.f - momentum);
+                }
+            }
+            s_scale[cl] = sc;
+            s_shift[cl] = shf;
+        }
+        __syncthreads();
+    }
+    const int C8 = C / 8;
+    const int v = threadIdx.x & 7;
+    const int cv = c0 / 8 + v;
+    const bool v_ok = cv < C8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = s_scale[v * 8 + e]; sh[e] = s_shift[v * 8 + e]; }
+    // ---- 1. the patch: pixel rows 2 ty0 - 1 .. 2 (ty0 + TH - 1) + 1, columns likewise; activation bf16 -> LDS, ReLU mask of the owned pixels
+    const int iy0 = 2 * ty0 - 1, ix0 = 2 * tx0 - 1;
+    for (int it = threadIdx.x >> 3; it < POOL_PH * POOL_PW; it += 32) {
+        const int py = it / POOL_PW, px = it - py * POOL_PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool in = v_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        u32x4 out = {0u, 0u, 0u, 0u};                                   // zero padding (and the channels beyond C)
+        if (in) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(z + ((((int64_t)n * H + iy) * W + ix) * C8 + cv) * 8);
+            float x[8];
+            unpack8(raw, x);
+            unsigned mbits = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x2 a2;
+                a2[0] = fmaxf(x[2 * q] * sc[2 * q] + sh[2 * q], 0.f);
+                a2[1] = fmaxf(x[2 * q + 1] * sc[2 * q + 1] + sh[2 * q + 1], 0.f);
+                const unsigned bits = __builtin_bit_cast(unsigned, __builtin_convertvector(a2, bf16x2_t)) & 0x7FFF7FFFu;   // (RNE; -0.0 -> +0.0)
+                out[q] = bits;
+                mbits |= ((bits & 0xFFFFu) ? 1u : 0u) << (2 * q);
+                mbits |= ((bits >> 16) ? 1u : 0u) << (2 * q + 1);
+            }
+            // every pixel's mask byte is written by the tile that OWNS it: pooled cell (iy / 2, ix / 2) -- the patch's first row and column
+            // belong to the neighbouring tiles, and so do rows / columns past this tile's cells
+            if (relu_mask && py >= 1 && px >= 1 && py <= 2 * POOL_TH && px <= 2 * POOL_TW)
+                relu_mask[(((int64_t)n * H + iy) * W + ix) * C8 + cv] = (uint8_t)mbits;
+        }
+        *reinterpret_cast<u32x4*>(patch + it * POOL_PITCH + v * 16) = out;
+    }
+    __syncthreads();
+    // ---- 2. pooling from LDS: one key maximum per tap and channel
+    for (int cell = threadIdx.x >> 3; cell < POOL_TH * POOL_TW; cell += 32) {
+        const int ty = cell / POOL_TW, tx = cell - ty * POOL_TW;
+        const int oy = ty0 + ty, ox = tx0 + tx;
+        if (oy >= Ho || ox >= Wo || !v_ok) continue;
+        unsigned key[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) key[e] = 0u;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(patch + ((2 * ty + k / 3) * POOL_PW + 2 * tx + k % 3) * POOL_PITCH + v * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned klo = (t[q] << 16) | (unsigned)(15 - k), khi = (t[q] & 0xFFFF0000u) | (unsigned)(15 - k);
+                key[2 * q] = key[2 * q] > klo ? key[2 * q] : klo;
+                key[2 * q + 1] = key[2 * q + 1] > khi ? key[2 * q + 1] : khi;
+            }
+        }
+        const int64_t o = ((int64_t)(n * Ho + oy) * Wo + ox) * C8 + cv;
+        u32x4 pv;
+        u32x2 av;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pv[q] = (key[2 * q] >> 16) | (key[2 * q + 1] & 0xFFFF0000u);
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf)
+            av[hlf] = (15u - (key[4 * hlf] & 15u)) | ((15u - (key[4 * hlf + 1] & 15u)) << 8) | ((15u - (key[4 * hlf + 2] & 15u)) << 16) |
+                      ((15u - (key[4 * hlf + 3] & 15u)) << 24);
+        *reinterpret_cast<u32x4*>(pool + o * 8) = pv;
+        *reinterpret_cast<u32x2*>(amax + o * 8) = av;
+    }
+}
+
 // fused BN backward finalize + apply: c1 = sum(g)/m, c2 = sum(g*xhat)/m of the workgroup's 64 channels from the reduce
 // kernel's slot partials; the row-chunk-0 workgroups publish dgamma / dbeta.
 // RED2 (frcnn_bn_bwd_apply_fused_red2): the same launch ALSO runs the backward reduce of a SECOND BatchNorm that receives the same masked
@@ -971,24 +1096,33 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bnreduce_kernel(const bf16_t*
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        const int oy_lo = (iy) / 2, oy_hi = (iy + 1) / 2;
-        const int ox_lo = (ix) / 2, ox_hi = (ix + 1) / 2;
-        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            if (oy >= Ho) continue;
-            const int ky = iy - (oy * 2 - 1);
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                if (ox >= Wo) continue;
-                const int kx = ix - (ox * 2 - 1);
-                const unsigned k = (unsigned)(ky * 3 + kx);
-                const int64_t o = (((int64_t)n * Ho + oy) * Wo + ox) * C8 + v;
-                const u32x2 a = *reinterpret_cast<const u32x2*>(amax + o * 8);
-                float g[8];
-                unpack8(*reinterpret_cast<const u32x4*>(gy + o * 8), g);
+        // the (at most four) pooled cells whose window holds this pixel: cell rows iy / 2 and (iy + 1) / 2, columns likewise.  All eight
+        // loads are issued before any of them is used (the nested loops with their early `continue`s waited for each cell's pair in turn:
+        // the kernel ran at 2.5 TB/s of its 146 MB); a cell that does not exist, or is the same as its neighbour, is read at a clamped
+        // index and masked out.  Same additions in the same order.
+        const int oy_c[2] = {iy / 2, (iy + 1) / 2}, ox_c[2] = {ix / 2, (ix + 1) / 2};
+        u32x2 a4[4];
+        u32x4 g4[4];
+        unsigned k4[4];
+        bool ok4[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const unsigned ak = (a[e >> 2] >> ((e & 3) * 8)) & 0xFFu;
-                    if (ak == k) acc[e] += g[e];
-                }
+        for (int q = 0; q < 4; ++q) {
+            const int oy = oy_c[q >> 1], ox = ox_c[q & 1];
+            ok4[q] = oy < Ho && ox < Wo && !((q >> 1) && oy_c[1] == oy_c[0]) && !((q & 1) && ox_c[1] == ox_c[0]);
+            const int oyc = oy < Ho ? oy : Ho - 1, oxc = ox < Wo ? ox : Wo - 1;
+            k4[q] = (unsigned)((iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1)));
+            const int64_t o = (((int64_t)n * Ho + oyc) * Wo + oxc) * C8 + v;
+            a4[q] = *reinterpret_cast<const u32x2*>(amax + o * 8);
+            g4[q] = *reinterpret_cast<const u32x4*>(gy + o * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float g[8];
+            unpack8(g4[q], g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned ak = (a4[q][e >> 2] >> ((e & 3) * 8)) & 0xFFu;
+                if (ok4[q] && ak == k4[q]) acc[e] += g[e];
             }
         }
         const u32x4 pk = pack8(acc);
@@ -1368,6 +1502,18 @@ extern "C" int frcnn_bn_train_apply_maxpool(const frcnn_bf16* z, const double* s
     const int64_t cells = (int64_t)n * ho * wo;
     const int per = strip_rows_per_block(cells, c);
     const int strips = (c + 63) / 64, chunks = (int)((cells + per - 1) / per);
+#ifndef FRCNN_POOL_PER_CELL
+    {
+        const int tiles_x = (wo + POOL_TW - 1) / POOL_TW, tiles_y = (ho + POOL_TH - 1) / POOL_TH;
+        const long long wgs = (long long)n * tiles_x * tiles_y * strips;
+        FRCNN_CHECK_ARG(wgs < (1ll << 31), "bn_train_apply_maxpool: grid too large");
+        hipLaunchKernelGGL(bn_train_apply_pool_tiled_kernel, dim3((unsigned)wgs), dim3(256), 0, S_(stream), CBF(z), stats_partial, slots, gamma, beta,
+                           moving_mean, moving_var, momentum, eps, (float)(1.0 / (double)count), unbias, BF(pooled), argmax, relu_mask, mean, invstd, n,
+                           h, w, c, ho, wo, strips, tiles_x, tiles_y);
+        FRCNN_CHECK_LAUNCH("bn_train_apply_maxpool");
+        return FRCNN_OK;
+    }
+#endif
     hipLaunchKernelGGL(bn_train_apply_pool_kernel, dim3((unsigned)(strips * 8 * ((chunks + 7) / 8))), dim3(256), 0, S_(stream), CBF(z),
                        stats_partial, slots, gamma, beta, moving_mean, moving_var, momentum, eps, (float)(1.0 / (double)count), unbias,
                        BF(pooled), argmax, relu_mask, mean, invstd, n, h, w, c, ho, wo, per, strips, chunks);
