@@ -34,6 +34,10 @@ struct WgradParams {
     int stem_unpack;                            // FRCNN_CONV_WGRAD_STEM_UNPACK: dw is the un-padded [cout][7][7][3] stem kernel gradient
     const float* f8_x_scale;                    // fp8 operands (x: e4m3, dz: e5m2, one byte per element): device scalars, the
     const float* f8_z_scale;                    // dequantisation scales of the two tensors; NULL for bf16 operands
+    // taps folded into the input-channel axis (kw == 1 filters with few channels per tap: the stem's 7 x 32): Cin = fold_taps * fold_cin,
+    // taps = 1; column c of the x operand is channel c % fold_cin of tap row c / fold_cin.  A tile then spans several taps and the dz
+    // slices it streams are shared by them (per-tap tiles re-read dz once per tap: 7 x 60 MB for the stem).  0: off
+    int fold_cin, fold_taps;
 };
 
 // 32-byte-chunk XOR swizzle of a pixel-major tile of W channels: the 4x16 blocks fetched by one
@@ -140,13 +144,13 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
     const long long halo = (long long)p.pad_h * p.in_row_stride32 + (long long)p.pad_w * p.in_pix_stride;
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.x) - halo * ES), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.dz_bytes, 0x00020000);
-    const unsigned soff_x = (unsigned)((kh * p.in_row_stride32 + kw * p.in_pix_stride + ci0) * ES);
+    const unsigned soff_x = p.fold_cin ? 0u : (unsigned)((kh * p.in_row_stride32 + kw * p.in_pix_stride + ci0) * ES);   // (folded taps: in x_col)
     const unsigned soff_z = (unsigned)(co0 * ES);
 
     // per-lane DMA state.  dz (and x when its rows are linear in the pixel index): a byte offset that advances by a
     // constant per slice; pixel rows beyond M fall outside the descriptor and read zeros.
     unsigned z_vo[Z_IT], x_vo[X_IT], x_col[X_IT];
-    int x_row[X_IT], x_n[X_IT], x_oy[X_IT], x_ox[X_IT];    // im2col walk of the lane's pixel (X_GENERAL)
+    int x_row[X_IT], x_n[X_IT], x_oy[X_IT], x_ox[X_IT], x_kh[X_IT];    // im2col walk of the lane's pixel (X_GENERAL); its tap row
     const unsigned z_step = (unsigned)(BKP * p.dz_stride * ES), x_step = (unsigned)(BKP * p.in_pix_stride * ES);
 #pragma unroll
     for (int i = 0; i < Z_IT; ++i) {
@@ -167,6 +171,12 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
         const bool col_ok = ins < X_INSTR && ci0 + col < p.Cin;
         x_row[i] = r;
         x_col[i] = col_ok ? (unsigned)(col * ES) : kColOob;
+        x_kh[i] = kh;
+        if (MODE == X_GENERAL && p.fold_cin) {     // folded taps: this lane's 16-byte chunk lies in tap row (ci0 + col) / fold_cin
+            const int gc = ci0 + col, t = gc / p.fold_cin;
+            x_kh[i] = t;
+            x_col[i] = col_ok ? (unsigned)((t * p.in_row_stride32 + (gc - t * p.fold_cin)) * ES) : kColOob;
+        }
         x_vo[i] = col_ok ? (unsigned)(pix0 + r) * (unsigned)(p.in_pix_stride * ES) + (unsigned)(col * ES) : kColOob;
         if (MODE == X_GENERAL) {
             const int m = pix0 + r;
@@ -200,7 +210,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
                     const int m = ld_pix0 + x_row[i];
                     vo = (m < p.M && x_col[i] != kColOob) ? (unsigned)p.row_index[m] * (unsigned)(p.in_pix_stride * ES) + x_col[i] : kOob;
                 } else {
-                    const int iy = x_oy[i] * p.stride - p.pad_h + kh, ix = x_ox[i] * p.stride - p.pad_w + kw;
+                    const int iy = x_oy[i] * p.stride - p.pad_h + x_kh[i], ix = x_ox[i] * p.stride - p.pad_w + kw;
                     const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi && x_n[i] * hw < p.M && x_col[i] != kColOob;
                     vo = ok ? (unsigned)(((x_n[i] * p.Hi + x_oy[i] * p.stride) * p.Wi + x_ox[i] * p.stride) * p.in_pix_stride * ES) + x_col[i] : kOob;
                     x_ox[i] += BKP;                          // advance this lane's pixel by BKP (division-free)
@@ -390,11 +400,12 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid) {
         if (co < p.Cout && ci < p.Cin) {
             float v = *reinterpret_cast<const float*>(stage + r * SROW + c * 4);
             if (F8) v *= dq;
-            long long off = ((long long)co * p.taps + tap) * p.Cin + ci;
+            long long off = ((long long)co * p.taps + tap) * p.Cin + ci;      // (folded taps: Cin = taps x channels, the same element)
             if (p.stem_unpack) {                 // ci = kw * 4 + c of the padded 8-pixel x 4-channel tap row: 7 x 3 of them are real
-                const int kw = ci >> 2, c4 = ci & 3;
+                const int t = p.fold_cin ? ci / p.fold_cin : tap, cc = p.fold_cin ? ci - t * p.fold_cin : ci;
+                const int kw = cc >> 2, c4 = cc & 3;
                 if (kw >= 7 || c4 == 3) continue;
-                off = ((long long)co * p.taps + tap) * 21 + kw * 3 + c4;
+                off = ((long long)co * (p.fold_cin ? p.fold_taps : p.taps) + t) * 21 + kw * 3 + c4;
             }
             float* dst = p.dw + off;
             if (p.plain_store) *dst = v;
@@ -783,6 +794,7 @@ static int wgrad_fill(const frcnn_conv_desc* d, const void* x, const void* dz, i
         p.dz_bytes = (unsigned)zb;
     }
     p.plain_store = 0;
+    p.fold_cin = p.fold_taps = 0;
     p.stem_unpack = (d->flags & FRCNN_CONV_WGRAD_STEM_UNPACK) ? 1 : 0;
     FRCNN_CHECK_ARG(!p.stem_unpack || (d->cin == 32 && d->in_pix_stride == 4 && d->kw == 1 && d->kh == 7 && es == 2),
                     "conv2d_wgrad: STEM_UNPACK is for the packed 7 x (8 px x 4 ch) stem descriptor");
@@ -877,6 +889,17 @@ static int wgrad_one(const frcnn_conv_desc* d, const void* x, const void* dz, in
 #endif
     const long long M = p.M;
     const int BKP = es == 1 ? 128 : 64;          // pixels per slice
+    int cin_eff = d->cin;
+#ifndef FRCNN_WGRAD_NOFOLD
+    if (es == 2 && !row_index && d->kw == 1 && d->kh > 1 && d->cin == 32 && d->pad_w == 0) {
+        // the stem (7 tap rows of 32 packed values): 64-wide tiles over the 224 folded columns -- dz is streamed 4 times instead of 7
+        p.fold_cin = d->cin;
+        p.fold_taps = d->kh;
+        p.Cin = cin_eff = d->kh * d->cin;
+        p.taps = 1;
+        p.KW = 1;
+    }
+#endif
 
     // measured on the R50-C4 layer shapes (tools/wgrad_sweep.py): 64 x 64 tiles with a 3-slot ring (three workgroups per
     // CU) win nearly everywhere -- small tiles need few pixel splits to fill the chip, and every split costs one fp32 tile
@@ -894,7 +917,8 @@ static int wgrad_one(const frcnn_conv_desc* d, const void* x, const void* dz, in
     const bool wide = d->kh * d->kw > 1 && d->cin % 128 == 0 && d->cout % 128 == 0 &&
                       (M >= wide_m || (long long)(d->cout / 128) * d->kh * d->kw * (d->cin / 128) >= 128);
     int bm = wide ? 128 : 64;
-    int bn = wide ? 128 : d->cin >= 64 ? 64 : 32;
+    int bn = wide ? 128 : cin_eff >= 64 ? 64 : 32;
+    // (the folded stem on 128-wide tiles -- dz streamed twice instead of four times -- measured 40.3 us against 34.9 for 64-wide and 46.0 unfolded)
     int stages = wide || bn == 32 ? 2 : 3, want_split = 0;
 #ifdef FRCNN_SWEEP
     if (const char* e = getenv("FRCNN_WGRAD")) {                // kernel development builds: "bm,bn,stages,split"
@@ -903,7 +927,7 @@ static int wgrad_one(const frcnn_conv_desc* d, const void* x, const void* dz, in
     }
 #endif
     p.tiles_co = (d->cout + bm - 1) / bm;
-    p.tiles_ci = (d->cin + bn - 1) / bn;
+    p.tiles_ci = (cin_eff + bn - 1) / bn;
     p.p_tiles = (int)((M + BKP - 1) / BKP);
     const int blocks_mn = p.tiles_co * p.taps * p.tiles_ci;
     // ~two workgroups per CU for 1x1 filters, four for multi-tap ones (same-box A/B in the step, ms: one / two per CU: batch 4
