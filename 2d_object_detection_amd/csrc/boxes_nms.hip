@@ -316,7 +316,7 @@ constexpr int NMS_TEAM_N = 512;              // candidates of the team round (NM
 // LDS of nms_class_kernel; *lds_keys: the 32-bit score keys of the N candidates are staged in LDS (else re-read from global)
 static size_t nms_class_lds(int n, int max_per_class, bool team, bool* lds_keys, int* split_len) {
     const size_t cap = team ? NMS_TEAM_N : NMS_CH;            // candidates whose boxes / matrix rows are resident at once
-    const size_t fixed = (size_t)max_per_class * 28 + cap * (16 + 4 + 4 + 4) + cap * (cap / 64) * 8 + 64 + 16 + (size_t)NMS_HC * 256 * 4 + (size_t)NMS_RK * 8 + 16;
+    const size_t fixed = (size_t)max_per_class * 28 + 16 + cap * (16 + 4 + 4 + 4) + cap * (cap / 64) * 8 + 64 + 16 + (size_t)NMS_HC * 256 * 4 + (size_t)NMS_RK * 8 + 16;
     *lds_keys = fixed + (size_t)n * 4 <= 150 * 1024;
     *split_len = 0;
     if (*lds_keys) return fixed + (size_t)n * 4;
@@ -377,10 +377,10 @@ __global__ __launch_bounds__(NMS_T) void nms_class_kernel(const NmsParams p) {
     // flat_load / flat_store / flat_atomic instructions: the bitonic network's 45-55 dependent stages each paid a flat round trip)
     constexpr size_t CAP = TEAM ? NMS_TEAM_N : NMS_CH;        // (the chunk loop uses the first NMS_CH entries of these arrays)
     const size_t o_kept_key = (size_t)p.max_per_class * 16;
-    const size_t o_chunk_box = o_kept_key + (size_t)p.max_per_class * 8;
+    const size_t o_chunk_box = (o_kept_key + (size_t)p.max_per_class * 8 + 15) & ~(size_t)15;     // (16-byte vectors: an odd max_per_class must not misalign them)
     const size_t o_sup = o_chunk_box + CAP * 16;
     const size_t o_kept_area = o_sup + CAP * (CAP / 64) * 8;
-    const size_t o_chunk_area = o_kept_area + (size_t)p.max_per_class * 4;
+    const size_t o_chunk_area = o_kept_area + (size_t)p.max_per_class * 4;                       // (4-byte entries from here to o_hist, which is re-aligned)
     const size_t o_dead = o_chunk_area + CAP * 4;
     const size_t o_rows = o_dead + CAP * 4;
     const size_t o_misc = o_rows + CAP * 4;

@@ -386,6 +386,8 @@ def _random_boxes(g, B, N, q):
     (3, 81929, 1, 1, 300, 300, 0.7),     # BASELINE config 4: the pyramid's in-image anchors (team of workgroups, candidates split over it)
     (2, 57000, 1, 1, 2000, 2000, 0.7),   # 600 x 1987 (the reference's config.json), more kept than the team round holds: rounds after it
     (2, 600, 1, 1, 300, 300, 0.7),       # single class, one workgroup's round: a team without a select
+    (2, 700, 1, 1, 25, 7, 0.5),          # odd max_per_class (the LDS arrays behind the kept lists must stay 16-byte aligned), team
+    (2, 300, 3, 3, 7, 10, 0.5),          # ... and without a team
 ])
 def test_nms_combined_bit_exact(ops, B, N, q, C, mpc, mt, thr):
     g = torch.Generator().manual_seed(N + C)
