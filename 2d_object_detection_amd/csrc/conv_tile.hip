@@ -1379,8 +1379,10 @@ __global__ __launch_bounds__(512 + 64 * LW, OCCW) void conv3x3_patch_kernel(cons
                 const u32x2 mk = pool_mask8(relu_bits8(pk), c8);      // the row's eight mask bytes of this chunk: one 8-byte store by its first lane
                 if (valid && py >= 1 && py <= TH && px >= 1 && px <= TW) {
                     const long long pix = ((long long)img * p.Hi + iy) * p.Wi + ix;
-                    *reinterpret_cast<u32x4*>(p.bnin_act + pix * p.Cin + s * 64 + c8 * 8) = pk;
-                    if (slot == 0) *reinterpret_cast<u32x2*>(p.bnin_mask + pix * (p.Cin >> 3) + s * 8) = mk;
+                    // (the activation and its ReLU mask are the BACKWARD pass's operands -- this kernel has consumed them already: non-temporal
+                    // stores; same-box A/B 3.798 -> 3.781, 3.802 -> 3.799)
+                    __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(p.bnin_act + pix * p.Cin + s * 64 + c8 * 8));
+                    if (slot == 0) __builtin_nontemporal_store(mk, reinterpret_cast<u32x2*>(p.bnin_mask + pix * (p.Cin >> 3) + s * 8));
                 }
             }
         }
@@ -1879,8 +1881,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wres_kernel(const ConvParams p
                     const u32x2 mk = pool_mask8(relu_bits8(pk), c8);      // the row's eight mask bytes: one 8-byte store by its first lane
                     if (valid && py >= 1 && py <= TH && px >= 1 && px <= TW) {
                         const long long pix = ((long long)img_t * p.Hi + iy) * p.Wi + ix;
-                        *reinterpret_cast<u32x4*>(p.bnin_act + pix * 64 + c8 * 8) = pk;
-                        if (slot == 0) *reinterpret_cast<u32x2*>(p.bnin_mask + pix * 8) = mk;
+                        __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(p.bnin_act + pix * 64 + c8 * 8));      // (as in the patch kernel)
+                        if (slot == 0) __builtin_nontemporal_store(mk, reinterpret_cast<u32x2*>(p.bnin_mask + pix * 8));
                     }
                 }
             }

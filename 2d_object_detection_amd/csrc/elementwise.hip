@@ -1192,10 +1192,12 @@ __global__ void sgd_fused_kernel(float* __restrict__ w, const float* __restrict_
     float stem_v = 0.f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float wi = w[i];
-        const float gi = g[i] * gscale + (i < f.decay_end ? l2x2 : 0.f) * wi;
-        const float vi = momentum * v[i] - lr * gi;
+        // the gradient and the momentum are touched once per step: streamed past the caches (the masters are read again by the next step's
+        // weight re-layouts, the bf16 copies by its convolutions); same-box A/B 3.805 -> 3.783, 3.808 -> 3.805
+        const float gi = __builtin_nontemporal_load(g + i) * gscale + (i < f.decay_end ? l2x2 : 0.f) * wi;
+        const float vi = momentum * __builtin_nontemporal_load(v + i) - lr * gi;
         const float wn = wi + vi;
-        v[i] = vi;
+        __builtin_nontemporal_store(vi, v + i);
         w[i] = wn;
         if (wb) wb[i] = (bf16_t)wn;
         const bool in_stem = i >= f.stem_begin && i < stem_end;
@@ -1711,6 +1713,7 @@ extern "C" int frcnn_copy_bytes_multi(const void* const* srcs, void* const* dsts
 // Zero n buffers in ONE launch.  table (device, int64 [n + 1][2]): row i = {pointer, first 16-byte chunk of buffer i in the concatenated
 // chunk space}; row n = {0, total chunks}.  A training step pre-zeroes seven accumulation targets (flat gradient, BatchNorm sums,
 // scatter targets, split-K outputs): one fill at HBM speed instead of seven launches of the framework's fill kernel.
+template <bool NT>
 __global__ __launch_bounds__(256) void fill_zero_multi_kernel(const int64_t* __restrict__ table, int n, int64_t chunks_per_block) {
     const int64_t total = table[2 * n + 1];
     int64_t c0 = (int64_t)blockIdx.x * chunks_per_block;
@@ -1721,7 +1724,10 @@ __global__ __launch_bounds__(256) void fill_zero_multi_kernel(const int64_t* __r
     while (c0 < c1) {
         const int64_t seg_end = table[2 * (seg + 1) + 1] < c1 ? table[2 * (seg + 1) + 1] : c1;
         u32x4* base = reinterpret_cast<u32x4*>(table[2 * seg]) - table[2 * seg + 1];
-        for (int64_t i = c0 + threadIdx.x; i < seg_end; i += 256) base[i] = z;
+        for (int64_t i = c0 + threadIdx.x; i < seg_end; i += 256) {
+            if (NT) __builtin_nontemporal_store(z, base + i);       // (a large fill whose buffers are first touched a millisecond later)
+            else base[i] = z;
+        }
         c0 = seg_end;
         ++seg;
     }
@@ -1733,7 +1739,10 @@ extern "C" int frcnn_fill_zero_multi(const int64_t* table, int n, int64_t total_
     int64_t per = 2048;                                       // 32 KiB per workgroup
     int64_t grid = (total_chunks + per - 1) / per;
     if (grid > 16384) { per = (total_chunks + 16383) / 16384; grid = (total_chunks + per - 1) / per; }
-    hipLaunchKernelGGL(fill_zero_multi_kernel, dim3((int)grid), dim3(256), 0, S_(stream), table, n, per);
+    // (a fill of more than 32 MB -- the train plan's late fill of the backward pass's accumulation targets -- streams past the caches;
+    // same-box A/B 3.802 -> 3.798, 3.798 -> 3.791)
+    if (total_chunks * 16 > (32ll << 20)) hipLaunchKernelGGL(fill_zero_multi_kernel<true>, dim3((int)grid), dim3(256), 0, S_(stream), table, n, per);
+    else hipLaunchKernelGGL(fill_zero_multi_kernel<false>, dim3((int)grid), dim3(256), 0, S_(stream), table, n, per);
     FRCNN_CHECK_LAUNCH("fill_zero_multi");
     return FRCNN_OK;
 }
