@@ -365,3 +365,44 @@ def test_late_zero_fill_precedes_every_use_of_its_buffers(monkeypatch):
                 continue
             assert not touches(args, kwargs), "%s (entry %d of the first segment) uses a late-zeroed buffer before the branch is joined" % (
                 getattr(fn, "__name__", fn), i)
+
+
+def test_nms_fixed_point_walk_equals_the_greedy_walk():
+    """csrc/boxes_nms.hip resolves a team round of <= 512 candidates block by block (64 candidates per block): inside a block the kept set is
+    the fixed point of  K <- alive & ~(somebody in K suppresses me)  started from K = alive, later blocks lose the candidates that the
+    block's kept set suppresses, and the cap (max_per_class) cuts inside a block.  The same procedure in numpy on random suppression
+    relations (`over[i, j]`: candidate i, if kept, suppresses the later candidate j) against the sequential greedy walk."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for n, density, cap in ((512, 0.002, 300), (512, 0.05, 300), (256, 0.3, 1000), (512, 0.9, 50), (320, 0.01, 7), (512, 0.0, 300)):
+        over = np.triu(rng.random((n, n)) < density, 1)
+        valid = rng.random(n) < 0.97
+        valid[n - 9:] = False                                   # (the padded tail of a round)
+        # greedy, in score order
+        kept_g, alive = [], valid.copy()
+        for i in range(n):
+            if alive[i] and len(kept_g) < cap:
+                kept_g.append(i)
+                alive[i + 1:] &= ~over[i, i + 1:]
+        # block-wise fixed point
+        kept_f, alive, rounds_max = [], valid.copy(), 0
+        for b0 in range(0, n, 64):
+            if len(kept_f) >= cap:
+                break
+            blk = slice(b0, min(n, b0 + 64))
+            al = alive[blk].copy()
+            sub = over[blk, blk]                                # sub[i, j]: i suppresses j, both inside the block
+            K = al.copy()
+            for rounds in range(1, 66):
+                Kn = al & ~(sub[K].any(axis=0) if K.any() else np.zeros_like(al))
+                if np.array_equal(Kn, K):
+                    break
+                K = Kn
+            assert rounds <= 65
+            rounds_max = max(rounds_max, rounds)
+            idx = np.flatnonzero(K) + b0
+            idx = idx[:cap - len(kept_f)]
+            kept_f.extend(idx.tolist())
+            alive[blk.stop:] &= ~over[idx, blk.stop:].any(axis=0) if idx.size else True
+        assert kept_f == kept_g, (n, density, cap, len(kept_f), len(kept_g))
+        assert rounds_max <= 64
