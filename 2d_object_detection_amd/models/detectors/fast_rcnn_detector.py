@@ -106,8 +106,11 @@ class FastRCNNDetector:
         self.deltas = torch.empty(batch, num_rois, self.num_classes, 4, device=dev)
         self.regions_abs = torch.empty(batch, num_rois, 4, device=dev)
         # K split of the Dense-head GEMM ([B*P] x 50176 x 64): every split adds one fp32 tile of float atomics (memory side,
-        # 1.3 TB/s); measured over 4..98 splits (tools/head_gemm_bench.py): 12-24 are fastest (29-30 us against 36 at 64)
-        split = max(1, min(int(os.environ.get("FRCNN_HEAD_SPLIT", "16")), self.flat // 64 // 8))
+        # 1.3 TB/s); measured over 4..98 splits back to back (tools/head_gemm_bench.py): 12-24 are fastest (29-30 us against 36 at 64).
+        # IN THE STEP the GEMM shares HBM with the write-back of what earlier kernels left in the caches and with the RPN's side stream
+        # (DESIGN 0.1b), and twice the workgroups hold their own better: same-box A/B, 16 -> 32, three alternations: 3.755 -> 3.746,
+        # 3.758 -> 3.742, 3.774 -> 3.760 ms (49: 3.759 / 3.780 / 3.755)
+        split = max(1, min(int(os.environ.get("FRCNN_HEAD_SPLIT", "32")), self.flat // 64 // 8))
         self.d_fwd = ops.conv_desc(1, 1, r, self.flat, 1, 1, 1, 0, 0, 1, r, HEAD_LD, flags=ops.CONV_SPLITK_ATOMIC, split_k=split)
         self.w_t = torch.zeros(self.flat, 1, 1, HEAD_LD, dtype=BF16, device=dev)
         if training:
