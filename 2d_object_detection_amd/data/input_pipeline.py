@@ -16,6 +16,7 @@ thread: a host allocation there would invalidate a hipGraph capture in progress)
 
 [TF-ext] `tf.image.resize` semantics restated from the public contract (bilinear, half-pixel centres, no antialias,
 float32 arithmetic, result truncated by the uint8 cast); unverified against TensorFlow here (not installed)."""
+import collections
 import io
 import os
 import queue
@@ -29,11 +30,14 @@ from . import kitti_classes, tfrecord
 
 
 def resize_bilinear(image, new_height, new_width):
-    """uint8/float [h,w,c] -> float32 [new_height,new_width,c]  (tf.image.resize(image, [new_height, new_width]))."""
+    """uint8/float [h,w,c] -> float32 [new_height,new_width,c]  (tf.image.resize(image, [new_height, new_width])).
+    Per output pixel: top = tl + (tr - tl) * x_lerp, bottom = bl + (br - bl) * x_lerp, out = top + (bottom - top) * y_lerp in float32.
+    The x interpolation runs once per SOURCE row (two column gathers, made in the source dtype: a quarter of the bytes for uint8) and the
+    y interpolation picks its two rows from that: the same operands in the same order as interpolating the four neighbours of every
+    output pixel (tests/test_data_metrics.py::test_resize_bilinear_equals_the_four_neighbour_form), at less than half the cost."""
     h, w = image.shape[:2]
-    img = image.astype(np.float32)
     if (h, w) == (new_height, new_width):
-        return img
+        return image.astype(np.float32)
 
     def weights(out_size, in_size):
         scale = np.float32(in_size) / np.float32(out_size)
@@ -45,11 +49,24 @@ def resize_bilinear(image, new_height, new_width):
 
     ylo, yhi, yl = weights(new_height, h)
     xlo, xhi, xl = weights(new_width, w)
-    xl = xl[None, :, None]
-    top_rows, bot_rows = img[ylo], img[yhi]
-    top = top_rows[:, xlo] + (top_rows[:, xhi] - top_rows[:, xlo]) * xl
-    bot = bot_rows[:, xlo] + (bot_rows[:, xhi] - bot_rows[:, xlo]) * xl
-    return top + (bot - top) * yl[:, None, None]
+    left = np.take(image, xlo, axis=1).astype(np.float32)
+    right = np.take(image, xhi, axis=1).astype(np.float32)
+    right -= left
+    right *= xl[None, :, None]
+    left += right                                    # [h, new_width, c]: every source row interpolated along x
+    top, bot = np.take(left, ylo, axis=0), np.take(left, yhi, axis=0)
+    bot -= top
+    bot *= yl[:, None, None]
+    top += bot
+    return top
+
+
+def resize_to_uint8(image, new_height, new_width):
+    """tf.cast(tf.image.resize(image, size), tf.uint8) (:116-117): truncation.  A uint8 image of the target size is returned as it is
+    (uint8 -> float32 -> uint8 is the identity)."""
+    if image.dtype == np.uint8 and image.shape[:2] == (new_height, new_width):
+        return image
+    return resize_bilinear(image, new_height, new_width).astype(np.uint8)
 
 
 def pad_or_clip(array, rows):
@@ -86,27 +103,52 @@ def example_from_files(image_file, label_file):
             "label/x_mins": boxes[:, 0], "label/y_mins": boxes[:, 1], "label/x_maxs": boxes[:, 2], "label/y_maxs": boxes[:, 3]}
 
 
+_PIXEL = np.dtype((np.void, 3))
+
+
+def _place_image(dst, image):
+    """dst[...] = image for uint8 [H,W,3]; a horizontally reversed view is copied pixel by pixel (3-byte items: 0.9 ms for a KITTI frame)
+    instead of byte by byte (2.3 ms)."""
+    if image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3 and image.strides[1] < 0 and dst.flags.c_contiguous:
+        base = image[:, ::-1]
+        if base.flags.c_contiguous and dst.dtype == np.uint8 and dst.shape == image.shape:
+            h, w = image.shape[:2]
+            dst.view(_PIXEL).reshape(h, w)[:] = base.view(_PIXEL).reshape(h, w)[:, ::-1]
+            return
+    dst[...] = image
+
+
 class _Dataset:
-    """Iterable of batches; `enumerate()` mirrors the tf.data method the reference driver calls (:153)."""
+    """Iterable of batches; `enumerate()` mirrors the tf.data method the reference driver calls (:153).
+
+    Throughput (tools/driver_rate.py): one KITTI frame costs 17-19 ms of PNG decoding and, when its size is not the configured one,
+    19 ms of resizing on a host core; the train step takes images at 1 ms each.  So (a) decoding runs ahead of the consumer in a window
+    of 2 x num_workers records ACROSS batch boundaries (the pool never drains between batches), and (b) the decoded, resized,
+    un-flipped records are kept in host memory up to `cache_bytes` (all of KITTI at 375 x 1242 is 10.4 GB): from the second epoch
+    on a batch is a flip and a copy into the pinned ring.  Neither changes what the pipeline yields."""
 
     def __init__(self, creator, sources, batch_size, training, rank, world_size, seed, device, num_workers, prefetch,
-                 shuffle_buffer):
+                 shuffle_buffer, cache_bytes=0):
         self.c, self.sources, self.batch_size, self.training = creator, sources, batch_size, training
         self.rank, self.world_size, self.seed, self.device = rank, world_size, seed, device
         self.num_workers, self.prefetch, self.shuffle_buffer = num_workers, prefetch, shuffle_buffer
+        self.cache_bytes = int(cache_bytes)
+        self._cache, self._cached_bytes, self._cache_lock = {}, 0, threading.Lock()
+        self.decoded = 0                                 # records decoded so far (cache misses): for tests and tools
 
-    # -- record stream of this rank (encoded examples or (image, label) file pairs)
+    # -- record stream of this rank: (key, encoded example or (image, label) file pair); the key names the record across epochs
     def _records(self):
         i = 0                                            # index of the next record in the concatenation of all sources
-        for kind, src in self.sources:
+        for n, (kind, src) in enumerate(self.sources):
             if kind == "tfrecord":                       # record i of the concatenation belongs to rank i % world
-                yield from tfrecord.read_records(src, start=(self.rank - i) % self.world_size, step=self.world_size)
+                for j, rec in enumerate(tfrecord.read_records(src, start=(self.rank - i) % self.world_size, step=self.world_size)):
+                    yield (n, j), rec
                 if len(self.sources) > 1:
                     i += self._scan(src)
             else:
-                for pair in src:
+                for j, pair in enumerate(src):
                     if i % self.world_size == self.rank:
-                        yield pair
+                        yield (n, j), pair
                     i += 1
 
     _counts = {}
@@ -151,35 +193,75 @@ class _Dataset:
                     yield buf[j]
                 buf = []
 
+    def _decode(self, key, value):
+        """The decoded, resized, un-flipped record (worker threads); kept for the next epochs while the budget lasts."""
+        item = self.c._decode(value)
+        with self._cache_lock:
+            self.decoded += 1
+            size = sum(a.nbytes for a in item)
+            if self._cached_bytes + size <= self.cache_bytes and key not in self._cache:
+                self._cache[key] = item
+                self._cached_bytes += size
+        return item
+
     def _batches(self, ring):
         """ring: pre-allocated pinned (images, classes, boxes) buffers to assemble the batches in, or None.  Nothing here calls
         the HIP runtime: this runs on a background thread, and a host allocation there would invalidate a stream capture
         (hipGraph) in progress on the training thread."""
         rng = np.random.default_rng([0x2D0D, self.rank] if self.seed is None else [self.seed, self.rank])
         flips = np.random.default_rng([0xF11B, self.rank] if self.seed is None else [self.seed, self.rank, 1])
-        pool = ThreadPoolExecutor(max_workers=max(1, self.num_workers))
+        workers = max(1, self.num_workers)
+        pool = ThreadPoolExecutor(max_workers=workers)
+        ring_np = None if ring is None else [tuple(t.numpy() for t in slot) for slot in ring]     # (views of the pinned memory)
+        window = collections.deque()                     # (key, decoded record or its future, flip coin) in stream order
+        pending = {}                                     # key -> future of a record being decoded
+        depth = max(self.batch_size, 2 * workers)
         k = 0
         try:
             stream = self._stream(rng)
+            more = True
             while True:
-                recs = []
-                for rec in stream:
-                    recs.append(rec)
-                    if len(recs) == self.batch_size:
+                while more and len(window) < depth:      # decode ahead, across batch boundaries
+                    try:
+                        key, rec = next(stream)
+                    except StopIteration:
+                        more = False
                         break
-                if not recs:
+                    coin = bool(flips.random() > 0.5) if self.training else False       # (one coin per record, in stream order)
+                    item = self._cache.get(key)
+                    if item is None:
+                        item = pending.get(key)          # (a data set shorter than the window: the record is being decoded already)
+                        if item is None:
+                            item = pending[key] = pool.submit(self._decode, key, rec)
+                    window.append((key, item, coin))
+                if not window:
                     return
-                do_flip = [bool(flips.random() > 0.5) if self.training else False for _ in recs]
-                items = list(pool.map(self.c._decode_and_preprocess, recs, do_flip))
-                parts = [torch.from_numpy(np.stack([it[j] for it in items])) for j in range(3)]
-                if ring is not None:
+                n = min(self.batch_size, len(window))
+                if ring_np is not None:
+                    out = ring_np[k % len(ring_np)]
                     slot = ring[k % len(ring)]
                     k += 1
-                    parts = [buf[:len(recs)].copy_(t) for buf, t in zip(slot, parts)]
-                yield tuple(parts)
-                if len(recs) < self.batch_size:
+                else:
+                    h, w = self.c.image_shape[0], self.c.image_shape[1]
+                    out = (np.empty((n, h, w, 3), np.uint8), np.empty((n, self.c.max_num_objects, self.c.num_classes + 1), np.float32),
+                           np.empty((n, self.c.max_num_objects, 4), np.float32))
+                    slot = tuple(torch.from_numpy(a) for a in out)
+                for i in range(n):
+                    key, item, coin = window.popleft()
+                    if not isinstance(item, tuple):
+                        if pending.get(key) is item:
+                            del pending[key]
+                        item = item.result()
+                    image, classes, boxes = self.c._augment(*item, coin)
+                    _place_image(out[0][i], image)                                      # (the flip's reversed view is copied here, once)
+                    out[1][i], out[2][i] = classes, boxes
+                yield tuple(buf[:n] for buf in slot)
+                if n < self.batch_size:
                     return
         finally:
+            for _, item, _ in window:
+                if not isinstance(item, tuple):
+                    item.cancel()
             pool.shutdown(wait=False)
 
     def __iter__(self):
@@ -248,9 +330,13 @@ class InputPipelineCreator(object):
         self.max_num_objects = max_num_objects
 
     def create_input_pipeline(self, filename, batch_size=1, training=False, rank=0, world_size=1, seed=None, device=None,
-                              num_workers=4, prefetch=4, shuffle_buffer=1024):
+                              num_workers=None, prefetch=4, shuffle_buffer=1024, cache_bytes=16 << 30):
         """data/input_pipeline.py:19-42.  `filename`: a TFRecord file, a list of them, or a KITTI directory holding
-        image_2/ and label_2/.  rank / world_size select this process's shard of the records."""
+        image_2/ and label_2/.  rank / world_size select this process's shard of the records.
+        num_workers: decode threads (default: the cores this process may run on, at most 16); cache_bytes: host memory for decoded
+        records that later epochs (and later iterators of the same pipeline: the validation pass of every epoch) reuse; 0 = none."""
+        if num_workers is None:
+            num_workers = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
         names = [filename] if isinstance(filename, (str, os.PathLike)) else list(filename)
         sources = []
         for name in names:
@@ -267,7 +353,7 @@ class InputPipelineCreator(object):
                 raise FileNotFoundError(name)
         if not (0 <= rank < world_size):
             raise ValueError("rank %d outside world of %d" % (rank, world_size))
-        return _Dataset(self, sources, batch_size, training, rank, world_size, seed, device, num_workers, prefetch, shuffle_buffer)
+        return _Dataset(self, sources, batch_size, training, rank, world_size, seed, device, num_workers, prefetch, shuffle_buffer, cache_bytes)
 
     def _augment(self, image, classes, boxes, do_flip):
         """:43-72 with the coin made by the caller (`do_flip = uniform() > 0.5`)."""
@@ -276,10 +362,16 @@ class InputPipelineCreator(object):
         flipped = boxes.copy()
         flipped[:, 0] = np.float32(1.0) - boxes[:, 2]
         flipped[:, 2] = np.float32(1.0) - boxes[:, 0]
-        return np.ascontiguousarray(image[:, ::-1]), classes, flipped
+        return image[:, ::-1], classes, flipped          # (a reversed VIEW: the batch assembly makes the one copy)
 
     def _decode_and_preprocess(self, value, do_flip=False):
-        """:83-130.  `value`: a serialized tf.train.Example, or an (image file, label file) pair of a raw KITTI directory."""
+        """:83-130 for one record: decode, resize, encode the labels, flip."""
+        image, classes, boxes = self._augment(*self._decode(value), do_flip)
+        return np.ascontiguousarray(image), classes, boxes
+
+    def _decode(self, value):
+        """:83-130 up to the augmentation.  `value`: a serialized tf.train.Example, or an (image file, label file) pair of a raw KITTI
+        directory.  Returns (image uint8 [H,W,3], classes f32 [100,C+1], boxes f32 [100,4]) -- what the pipeline's cache keeps."""
         from PIL import Image
         feats = example_from_files(*value) if isinstance(value, tuple) else tfrecord.parse_example(value)
         width, height = int(feats["image/width"][0]), int(feats["image/height"][0])
@@ -290,7 +382,7 @@ class InputPipelineCreator(object):
         if image.shape != (height, width, 3):
             raise ValueError("image is %s but the record says %dx%d" % (image.shape, height, width))
         new_height, new_width = self.image_shape[0], self.image_shape[1]
-        image = resize_bilinear(image, new_height, new_width).astype(np.uint8)           # tf.cast truncates
+        image = resize_to_uint8(image, new_height, new_width)                            # tf.cast truncates
 
         ids = np.asarray(feats["label/ids"], dtype=np.int64)
         classes = np.zeros((len(ids), self.num_classes + 1), dtype=np.float32)
@@ -303,4 +395,4 @@ class InputPipelineCreator(object):
                           np.asarray(feats["label/x_maxs"], np.float32) / w, np.asarray(feats["label/y_maxs"], np.float32) / h], axis=1)
         boxes = pad_or_clip(boxes.reshape(-1, 4).astype(np.float32), self.max_num_objects)
         # the flip of a padding row would turn [0,0,0,0] into [1,0,1,0] in the reference too (:58-62): kept
-        return self._augment(image, classes, boxes, do_flip)
+        return image, classes, boxes

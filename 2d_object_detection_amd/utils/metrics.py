@@ -91,12 +91,31 @@ class MeanAveragePrecision:
             ap.reset_states()
 
     def update_state(self, gt_boxes, gt_class_labels, pred_boxes, pred_scores, pred_classes):
-        labels = gt_class_labels[..., 1:]
-        for i, ap in enumerate(self.average_precisions):
-            mine = pred_classes == i
-            ap.update_state(gt_boxes=torch.where((labels[:, :, i] == 1.0)[..., None], gt_boxes, torch.zeros_like(gt_boxes)),
-                            pred_boxes=torch.where(mine[..., None], pred_boxes, torch.zeros_like(pred_boxes)),
-                            pred_scores=torch.where(mine, pred_scores, torch.zeros_like(pred_scores)))
+        """:107-130: class i's metric sees the ground-truth boxes labelled i and the predictions of class i, everything else zeroed.
+        A zeroed box has no intersection with anything, so class i's IoU matrix is the full matrix with the other classes' rows and
+        columns set to zero: ONE pass over [C,B,G,P] updates all the classes (the per-class form is 7 x 25 small launches per training
+        step -- 2.1 ms of host dispatch beside a 3.7 ms step, tools/driver_rate.py; equality with it:
+        tests/test_data_metrics.py::test_mean_average_precision_update_equals_the_per_class_form)."""
+        aps = self.average_precisions
+        gt_boxes, pred_boxes, pred_scores = gt_boxes.float(), pred_boxes.float(), pred_scores.float()
+        b, p = pred_scores.shape
+        cls = torch.arange(self.num_classes, device=pred_scores.device)
+        of_class = (gt_class_labels[..., 1:] == 1.0).permute(2, 0, 1)              # [C,B,G]
+        mine = pred_classes[None] == cls.view(-1, 1, 1).to(pred_classes.dtype)     # [C,B,P]
+        real = of_class & (gt_boxes.sum(-1) != 0.0)[None]                          # :68 on the zeroed boxes
+        ious = iou(gt_boxes, pred_boxes, pairwise=True)[None] * (of_class[..., :, None] & mine[..., None, :])   # [C,B,G,P]
+        best = ious.argmax(dim=3, keepdim=True)
+        hit = (ious.gather(3, best) > aps[0].iou_threshold) & real[..., None]
+        tp = torch.zeros(self.num_classes, b, p, dtype=torch.int32, device=pred_scores.device)
+        tp.scatter_reduce_(2, best[..., 0], hit[..., 0].to(torch.int32), reduce="amax")
+        true_count = real.sum(dim=(1, 2))
+        tp = tp.reshape(self.num_classes, -1)
+        scores = torch.where(mine, pred_scores[None], pred_scores.new_zeros(())).reshape(self.num_classes, -1)
+        for i, ap in enumerate(aps):
+            ap._true_count.append(true_count[i])
+            ap._pos_count += b * p
+            ap._true_pos.append(tp[i])
+            ap._scores.append(scores[i])
 
     def result(self):
         return sum(ap.result() for ap in self.average_precisions) / float(self.num_classes)

@@ -103,6 +103,28 @@ def test_metrics_match_loop_oracle():
 
 
 # ----------------------------------------------------------------------------------------------------------- TFRecord
+def test_mean_average_precision_update_equals_the_per_class_form():
+    """MeanAveragePrecision.update_state updates every class in one pass over [C,B,G,P]; the reference (:107-130) calls each class's
+    metric on inputs with the other classes' boxes zeroed.  Same state, element for element, after several updates."""
+    g = torch.Generator().manual_seed(7)
+    for B, G, P, C in ((4, 100, 300, 7), (2, 10, 40, 3), (1, 100, 300, 7)):
+        one_pass, per_class = MET.MeanAveragePrecision(C, 0.5), MET.MeanAveragePrecision(C, 0.5)
+        for _ in range(3):
+            gt, labels, pb, ps, pc = _random_case(g, B, G, P, C)
+            one_pass.update_state(gt, labels, pb, ps, pc)
+            for i, ap in enumerate(per_class.average_precisions):
+                mine = pc == i
+                ap.update_state(gt_boxes=torch.where((labels[..., 1:][:, :, i] == 1.0)[..., None], gt, torch.zeros_like(gt)),
+                                pred_boxes=torch.where(mine[..., None], pb, torch.zeros_like(pb)),
+                                pred_scores=torch.where(mine, ps, torch.zeros_like(ps)))
+        for a, b in zip(one_pass.average_precisions, per_class.average_precisions):
+            assert a._pos_count == b._pos_count and len(a._scores) == len(b._scores) == 3
+            assert all(torch.equal(x, y) for x, y in zip(a._true_pos, b._true_pos))
+            assert all(torch.equal(x, y) for x, y in zip(a._scores, b._scores))
+            assert [int(x) for x in a._true_count] == [int(y) for y in b._true_count]
+        assert one_pass.result() == per_class.result()
+
+
 def test_crc32c_and_record_framing(tmp_path):
     assert TFR._crc32c(b"123456789") == 0xE3069283                      # CRC-32C check value (RFC 3720 B.4)
     assert TFR._crc32c(b"") == 0 and TFR._crc32c(bytes(32)) == 0x8A9136AA
@@ -228,6 +250,87 @@ def test_pipeline_sharding_and_training_mode(kitti_dir):
     assert np.array_equal(a[0][:, ::-1], b[0]) and np.array_equal(a[1], b[1])
     with pytest.raises(ValueError):
         c.create_input_pipeline(path, rank=2, world_size=2)
+
+
+def test_resize_bilinear_equals_the_four_neighbour_form():
+    """resize_bilinear interpolates every source row along x once and takes its two rows from that; tf.image.resize is stated per output
+    pixel on its four neighbours (top = tl + (tr - tl) * x_lerp, bottom likewise, out = top + (bottom - top) * y_lerp).  Same
+    operands, same order: bit-identical float32, on KITTI's frame sizes and on a float input."""
+    def four_neighbours(image, nh, nw):
+        h, w = image.shape[:2]
+        img = image.astype(np.float32)
+        def weights(o, i):
+            scale = np.float32(i) / np.float32(o)
+            src = (np.arange(o, dtype=np.float32) + np.float32(0.5)) * scale - np.float32(0.5)
+            fl = np.floor(src)
+            return np.maximum(fl, 0).astype(np.int64), np.minimum(np.ceil(src), i - 1).astype(np.int64), (src - fl).astype(np.float32)
+        ylo, yhi, yl = weights(nh, h)
+        xlo, xhi, xl = weights(nw, w)
+        xl = xl[None, :, None]
+        tl, tr, bl, br = img[ylo][:, xlo], img[ylo][:, xhi], img[yhi][:, xlo], img[yhi][:, xhi]
+        top = tl + (tr - tl) * xl
+        bottom = bl + (br - bl) * xl
+        return top + (bottom - top) * yl[:, None, None]
+    rng = np.random.default_rng(5)
+    for h, w, nh, nw in ((370, 1224, 375, 1242), (376, 1241, 375, 1242), (374, 1238, 375, 1242), (24, 50, 20, 60), (75, 100, 600, 1987)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = IP.resize_bilinear(img, nh, nw)
+        assert got.dtype == np.float32 and np.array_equal(got, four_neighbours(img, nh, nw)), (h, w)
+        assert np.array_equal(IP.resize_to_uint8(img, nh, nw), four_neighbours(img, nh, nw).astype(np.uint8))
+    f = rng.random((37, 41, 3))
+    assert np.array_equal(IP.resize_bilinear(f, 50, 60), four_neighbours(f, 50, 60))
+    same = rng.integers(0, 256, (20, 60, 3), dtype=np.uint8)
+    assert IP.resize_to_uint8(same, 20, 60) is same                                      # nothing to do: not even a copy
+
+
+def test_pipeline_window_and_cache_do_not_change_the_batches(kitti_dir):
+    """The decode window (records decoded ahead, across batch boundaries) and the cache of decoded records are throughput devices: the
+    batches equal a record-by-record restatement with the same generators (shuffle picks, one flip coin per record in stream
+    order), for any number of workers, with and without the cache, in the first epoch and in later ones (cache hits); evaluation
+    iterators started again from the same pipeline are served from the cache and yield the same batches."""
+    c = IP.InputPipelineCreator(7, (20, 60, 3))
+    path = str(kitti_dir / "rec" / "train.tfrecord")
+    records = list(TFR.read_records(path))                                             # 5 records; 50 x 24 frames are resized
+    steps, B, seed = 9, 3, 11
+
+    def restated():
+        rng, flips = np.random.default_rng([seed, 0]), np.random.default_rng([seed, 0, 1])
+        out = []
+        while len(out) < steps * B:
+            for j in rng.permutation(len(records)):                                    # (smaller than the shuffle buffer: a permutation per epoch)
+                out.append(c._decode_and_preprocess(records[j], bool(flips.random() > 0.5)))
+        return [tuple(np.stack([r[k] for r in out[i * B:(i + 1) * B]]) for k in range(3)) for i in range(steps)]
+
+    want = restated()
+    for workers, cache in ((1, 0), (3, 0), (5, 1 << 30), (2, 9000)):                   # (9000 B: room for ONE 20 x 60 record of 8400 B)
+        pipe = c.create_input_pipeline(path, batch_size=B, training=True, seed=seed, num_workers=workers, cache_bytes=cache)
+        it = iter(pipe)
+        got = [tuple(t.numpy().copy() for t in next(it)) for _ in range(steps)]
+        it.close()
+        for g, w in zip(got, want):
+            assert all(np.array_equal(a, b) for a, b in zip(g, w)), (workers, cache)
+        if cache >= 1 << 30:
+            assert pipe.decoded == len(records)                                        # 27 records served, 5 decoded
+        elif cache:
+            assert len(pipe._cache) == 1 and pipe._cached_bytes <= cache
+        else:
+            assert pipe.decoded > 2 * len(records) and not pipe._cache                 # (only decodes in flight together are shared)
+    # evaluation: ordered, final partial batch kept; the second pass decodes nothing
+    ev = c.create_input_pipeline(path, batch_size=2)
+    first = [tuple(t.numpy().copy() for t in b) for b in ev]
+    assert [len(b[0]) for b in first] == [2, 2, 1] and ev.decoded == 5
+    second = [tuple(t.numpy().copy() for t in b) for b in ev]
+    assert ev.decoded == 5 and all(np.array_equal(x, y) for a, b in zip(first, second) for x, y in zip(a, b))
+    plain = [c._decode_and_preprocess(r) for r in records]
+    assert all(np.array_equal(first[i // 2][k][i % 2], plain[i][k]) for i in range(5) for k in range(3))
+    # the fast placement of a flipped frame equals the plain assignment
+    img = np.random.default_rng(0).integers(0, 256, (20, 60, 3), dtype=np.uint8)
+    a, b = np.empty_like(img), np.empty_like(img)
+    IP._place_image(a, img[:, ::-1])
+    b[...] = img[:, ::-1]
+    assert np.array_equal(a, b)
+    IP._place_image(a, img)
+    assert np.array_equal(a, img)
 
 
 # ------------------------------------------------------------------------------------------------------------- driver

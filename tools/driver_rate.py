@@ -1,0 +1,114 @@
+"""Rate of the training DRIVER's loop (train_faster_rcnn.py: TFRecord input pipeline -> train_step -> loss means and AP / mAP updates)
+beside the bare step that bench.py times -- the callers either side of the hot path.
+
+Generates a KITTI-shaped directory (PNG frames of 375x1242 and 370x1224, label_2 text files), writes TFRecords with
+data/build_records.py, and measures on one GPU:
+
+  pipeline_alone   images/s of the input pipeline with no consumer work (host batches): decoding every record (first epoch) with 1 / 4 /
+                   16 threads, and from the cache of decoded records (every later epoch)
+  driver_loop      train_faster_rcnn.main() on those records: seconds per step from the difference of two run lengths
+                   (start-up, plan build and graph capture cancel), with the metrics updated every step (the reference) and never
+
+    python tools/driver_rate.py [--frames 48] [--batch 4]   ->  one JSON line
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "2d_object_detection_amd"
+
+
+def make_kitti(root, frames, seed=0):
+    from PIL import Image
+    os.makedirs(os.path.join(root, "image_2"))
+    os.makedirs(os.path.join(root, "label_2"))
+    rng = np.random.default_rng(seed)
+    names = ("Car", "Van", "Truck", "Pedestrian", "Person_sitting", "Cyclist", "Tram")
+    for i in range(frames):
+        h, w = (375, 1242) if i % 3 else (370, 1224)
+        # street-scene-like statistics for the PNG coder: a smooth field + mild noise (pure noise would triple the file size)
+        low = rng.integers(0, 256, (h // 16 + 2, w // 16 + 2, 3), dtype=np.uint8)
+        img = np.asarray(Image.fromarray(low).resize((w, h), Image.BILINEAR)).astype(np.int16)
+        img = np.clip(img + rng.integers(-6, 7, img.shape), 0, 255).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(root, "image_2", "%06d.png" % i))
+        with open(os.path.join(root, "label_2", "%06d.txt" % i), "w") as fh:
+            for _ in range(int(rng.integers(1, 12))):
+                x0, y0 = float(rng.uniform(0, w - 120)), float(rng.uniform(100, h - 80))
+                bw, bh = float(rng.uniform(30, 300)), float(rng.uniform(25, 160))
+                fh.write("%s 0.00 0 -1.5 %.2f %.2f %.2f %.2f 1 1 1 1 1 1 0.1\n"
+                         % (names[int(rng.integers(0, 7))], x0, y0, min(w - 1.0, x0 + bw), min(h - 1.0, y0 + bh)))
+            fh.write("DontCare -1 -1 -10 1 1 5 5 -1 -1 -1 -1000 -1000 -1000 -10\n")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=48)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--short", type=int, default=100)
+    ap.add_argument("--long", type=int, default=1100)
+    args = ap.parse_args()
+    BR = importlib.import_module(PKG + ".data.build_records")
+    IP = importlib.import_module(PKG + ".data.input_pipeline")
+    C = importlib.import_module(PKG + ".config")
+    T = importlib.import_module("train_faster_rcnn")
+    cfg = C.default_config()
+    out = {"batch": args.batch, "frames": args.frames, "host_cores": len(os.sched_getaffinity(0))}
+    with tempfile.TemporaryDirectory() as tmp:
+        make_kitti(tmp, args.frames)
+        BR.main(["--images-dir", os.path.join(tmp, "image_2"), "--labels-dir", os.path.join(tmp, "label_2"),
+                 "--output-dir", os.path.join(tmp, "rec"), "--validation-set-size", "4"])
+        rec = os.path.join(tmp, "rec", "train.tfrecord")
+        out["png_bytes_per_frame"] = int(os.path.getsize(rec) / (args.frames - 4))
+        creator = IP.InputPipelineCreator(num_classes=cfg["num_classes"], image_shape=cfg["image_shape"])
+        out["pipeline_alone"] = {}
+        for workers, cache, name in ((1, 0, "decode_1_thread"), (4, 0, "decode_4_threads"), (16, 0, "decode_16_threads"),
+                                     (16, 16 << 30, "cached_records")):
+            pipe = creator.create_input_pipeline(rec, batch_size=args.batch, training=True, seed=1, num_workers=workers, cache_bytes=cache)
+            it = iter(pipe)
+            for _ in range(args.frames // args.batch + 12 if cache else 5):            # (cached: a whole epoch + the decode window first)
+                next(it)
+            n = 200 if cache else 40
+            before = pipe.decoded
+            t0 = time.perf_counter()
+            for _ in range(n):
+                next(it)
+            dt = time.perf_counter() - t0
+            it.close()
+            out["pipeline_alone"][name] = {"images_per_s": round(n * args.batch / dt, 1), "ms_per_batch": round(dt / n * 1e3, 2),
+                                           "records_decoded_in_the_timed_part": pipe.decoded - before}
+            print(json.dumps({"progress": "pipeline", name: out["pipeline_alone"][name]}), file=sys.stderr, flush=True)
+
+        def driver(steps, metrics_every, tag):
+            d = os.path.join(tmp, tag)
+            argv = ["--train-data-path", rec, "--valid-data-path", os.path.join(tmp, "rec", "valid.tfrecord"), "--logs-dir", os.path.join(d, "logs"),
+                    "--save-dir", os.path.join(d, "save"), "--checkpoints-dir", os.path.join(d, "ck"), "--num-steps", str(steps),
+                    "--num-steps-per-epoch", "1000000", "--batch-size", str(args.batch), "--learning-rates", "1e-5", "--decay-steps",
+                    "--metrics-every", str(metrics_every)]
+            t0 = time.perf_counter()
+            T.main(argv)
+            import torch
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        out["driver_loop"] = {}
+        for every, name in ((1, "metrics_every_step"), (1000000, "no_metrics")):
+            driver(args.short, every, "warm_%s" % name)                 # (first run of the process: image paging, allocator)
+            ts = driver(args.short, every, "s_%s" % name)
+            tl = driver(args.long, every, "l_%s" % name)
+            ms = (tl - ts) / (args.long - args.short) * 1e3
+            out["driver_loop"][name] = {"run_s": [round(ts, 2), round(tl, 2)], "steps": [args.short, args.long], "ms_per_step": round(ms, 3),
+                                        "images_per_s": round(args.batch / ms * 1e3, 1)}
+            print(json.dumps({"progress": "driver", name: out["driver_loop"][name]}), file=sys.stderr, flush=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
