@@ -99,6 +99,26 @@ class MetricStream:
         """Context in which result() / reset_states() of the metrics updated here are called."""
         return torch.cuda.stream(self.stream)
 
+    def wrap(self, metric):
+        """The metric behind its own call surface (update_state / result / reset_states), living on this stream."""
+        return _OnStream(metric, self)
+
+
+class _OnStream:
+    def __init__(self, metric, owner):
+        self.metric, self.owner, self.name = metric, owner, getattr(metric, "name", None)
+
+    def update_state(self, *tensors):
+        self.owner.update(self.metric.update_state, *tensors)
+
+    def result(self):
+        with self.owner.reading():
+            return self.metric.result()
+
+    def reset_states(self):
+        with self.owner.reading():
+            self.metric.reset_states()
+
 
 class ScalarWriter:
     """tf.summary.create_file_writer(directory) + tf.summary.scalar(tag, value, step) (reference train_faster_rcnn.py:102-106,
@@ -241,6 +261,8 @@ def main(argv=None):
     rpn_train_cls, rpn_train_reg, rpn_train_ap = Mean(), Mean(), MET.AveragePrecision(0.5, name="rpn_train_AP@IoU=.50")
     valid_cls, valid_reg, valid_map = Mean(), Mean(), MET.MeanAveragePrecision(nc, 0.5, name="valid_mAP@IoU=.50")
     rpn_valid_cls, rpn_valid_reg, rpn_valid_ap = Mean(), Mean(), MET.AveragePrecision(0.5, name="valid_AP@IoU=.50")
+    metric_stream = MetricStream(dev)                    # the AP / mAP updates of every step run under the next step
+    train_map, rpn_train_ap, valid_map, rpn_valid_ap = (metric_stream.wrap(m) for m in (train_map, rpn_train_ap, valid_map, rpn_valid_ap))
     every = (train_cls, train_reg, train_map, rpn_train_cls, rpn_train_reg, rpn_train_ap,
              valid_cls, valid_reg, valid_map, rpn_valid_cls, rpn_valid_reg, rpn_valid_ap)
 
@@ -263,8 +285,6 @@ def main(argv=None):
         print("Restored from {}".format(manager.latest_checkpoint) if step else "Initializing from scratch.", flush=True)
     sync = D.GradientSynchronizer(model.store.g, model.store.buckets) if world > 1 else None
     hook = sync.after_segment if sync is not None else None
-    metric_stream = MetricStream(dev)
-
     for images, gt_classes, gt_boxes in dataset_train():
         step += 1
         losses, preds = model.train_step(images, gt_classes, gt_boxes, optimizer, sync_fn=hook)
@@ -274,20 +294,15 @@ def main(argv=None):
         rpn_train_cls.update_state(losses["rpn_cls"])
         rpn_train_reg.update_state(losses["rpn_reg"])
         if step % args.metrics_every == 0:
-            metric_stream.update(lambda gb, gc, pb, ps, pc, rb, rs: (train_map.update_state(gb, gc, pb, ps, pc), rpn_train_ap.update_state(gb, rb, rs)),
-                                 gt_boxes, gt_classes, preds["rcnn_boxes"], preds["rcnn_scores"], preds["rcnn_classes"],
-                                 preds["rpn_boxes"], preds["rpn_scores"])
+            train_map.update_state(gt_boxes, gt_classes, preds["rcnn_boxes"], preds["rcnn_scores"], preds["rcnn_classes"])
+            rpn_train_ap.update_state(gt_boxes, preds["rpn_boxes"], preds["rpn_scores"])
 
         if step % args.num_steps_per_epoch == 0:
             epoch = step // args.num_steps_per_epoch
-            with metric_stream.reading():
-                train_metrics = {train_map: train_map.result(), rpn_train_ap: rpn_train_ap.result()}
-                train_map.reset_states()
-                rpn_train_ap.reset_states()
             for tag, m in (("Losses/Faster-RCNN/classification_loss", train_cls), ("Losses/Faster-RCNN/regression_loss", train_reg),
                            ("Metrics/Faster-RCNN/mAP@IoU=.50", train_map), ("Losses/RPN/classification_loss", rpn_train_cls),
                            ("Losses/RPN/regression_loss", rpn_train_reg), ("Metrics/RPN/AP@IoU=.50", rpn_train_ap)):
-                train_writer.scalar(tag, train_metrics[m] if m in train_metrics else m.result(), step)
+                train_writer.scalar(tag, m.result(), step)
 
             # validation: one ordered pass on rank 0 (the reference is single-device).  The other ranks wait in the barrier
             # behind it; a barrier is a collective under the process group's watchdog like the all-reduce it stands in front
@@ -315,11 +330,11 @@ def main(argv=None):
                 s += "\tFaster-RCNN: \n"
                 s += f"\t\tCls Loss       --> Train: {train_cls.result():.2f}, Valid: {valid_cls.result():.2f}\n"
                 s += f"\t\tReg Loss       --> Train: {train_reg.result():.2f}, Valid: {valid_reg.result():.2f}\n"
-                s += f"\t\tmAP at IoU=.50 --> Train: {train_metrics[train_map]:.2f}, Valid: {valid_map.result():.2f}\n"
+                s += f"\t\tmAP at IoU=.50 --> Train: {train_map.result():.2f}, Valid: {valid_map.result():.2f}\n"
                 s += "\tRPN: \n"
                 s += f"\t\tCls Loss       --> Train: {rpn_train_cls.result():.2f}, Valid: {rpn_valid_cls.result():.2f}\n"
                 s += f"\t\tReg Loss       --> Train: {rpn_train_reg.result():.2f}, Valid: {rpn_valid_reg.result():.2f}\n"
-                s += f"\t\tAP at IoU=.50  --> Train: {train_metrics[rpn_train_ap]:.2f}, Valid: {rpn_valid_ap.result():.2f}\n"
+                s += f"\t\tAP at IoU=.50  --> Train: {rpn_train_ap.result():.2f}, Valid: {rpn_valid_ap.result():.2f}\n"
                 print(s, flush=True)
             if world > 1:
                 torch.distributed.barrier()
