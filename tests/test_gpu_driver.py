@@ -95,3 +95,56 @@ def test_driver_on_tfrecords(tmp_path):
     va = _scalars(tmp_path / "logs", "valid")
     assert len(va) == 6 and all(np.isfinite(s["value"]) for s in va)
     assert os.path.exists(tmp_path / "saved" / "faster-rcnn" / "weights")
+
+
+def test_metrics_on_their_own_stream_equal_the_metrics_on_the_training_stream():
+    """train_faster_rcnn.MetricStream: the AP / mAP updates run on a side stream on clones of their inputs.  The inputs here live in
+    REUSED buffers that are overwritten right after every update (as the step's static prediction buffers are by the next replay),
+    with enough queued work on the training stream that a missing clone or a missing stream dependency would read the next update's
+    values: state and result must equal the same metrics updated in place on the training stream from private copies."""
+    sys.path.insert(0, ROOT)
+    T = importlib.import_module("train_faster_rcnn")
+    MET = importlib.import_module("2d_object_detection_amd.utils.metrics")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B, G, P, C = 2, 100, 300, 7
+    ms = T.MetricStream(dev)
+    side_map, side_ap = ms.wrap(MET.MeanAveragePrecision(C, 0.5)), ms.wrap(MET.AveragePrecision(0.5))
+    main_map, main_ap = MET.MeanAveragePrecision(C, 0.5), MET.AveragePrecision(0.5)
+    bufs = None
+    ballast = torch.zeros(64 << 20, device=dev)
+    for _ in range(6):
+        gt = torch.rand(B, G, 2, generator=g) * 0.5
+        gt = torch.cat([gt, gt + 0.05 + torch.rand(B, G, 2, generator=g) * 0.3], -1)
+        gt[:, 40:] = 0.0
+        labels = torch.zeros(B, G, C + 1)
+        labels.scatter_(2, torch.randint(1, C + 1, (B, G, 1), generator=g), 1.0)
+        labels[:, 40:] = 0.0
+        pb = torch.rand(B, P, 2, generator=g) * 0.5
+        pb = torch.cat([pb, pb + 0.05 + torch.rand(B, P, 2, generator=g) * 0.3], -1)
+        pb[:, :40] = gt[:, :40] + (torch.rand(B, 40, 4, generator=g) - 0.5) * 0.04
+        ps = torch.rand(B, P, generator=g)
+        pc = torch.randint(0, C, (B, P), generator=g).float()
+        fresh = [t.to(dev) for t in (gt, labels, pb, ps, pc)]
+        main_map.update_state(*[t.clone() for t in fresh])
+        main_ap.update_state(fresh[0].clone(), fresh[2].clone(), fresh[3].clone())
+        if bufs is None:
+            bufs = [torch.empty_like(t) for t in fresh]
+        for b, t in zip(bufs, fresh):
+            b.copy_(t)
+        ballast.add_(1.0)                                  # (work queued ahead of the updates on the training stream)
+        side_map.update_state(*bufs)
+        side_ap.update_state(bufs[0], bufs[2], bufs[3])
+        for b in bufs:                                     # the "next step" overwrites the buffers at once
+            b.fill_(0.25)
+    torch.cuda.synchronize()
+    for a, b in zip(side_map.metric.average_precisions + [side_ap.metric], main_map.average_precisions + [main_ap]):
+        with ms.reading():
+            assert a._pos_count == b._pos_count
+            assert all(torch.equal(x, y) for x, y in zip(a._true_pos, b._true_pos))
+            assert all(torch.equal(x, y) for x, y in zip(a._scores, b._scores))
+            assert [int(x) for x in a._true_count] == [int(y) for y in b._true_count]
+    assert side_map.result() == main_map.result() and side_ap.result() == main_ap.result()
+    assert 0.0 < main_ap.result() <= 1.0
+    side_map.reset_states()
+    assert side_map.result() == 0.0
