@@ -333,6 +333,25 @@ def test_pipeline_window_and_cache_do_not_change_the_batches(kitti_dir):
     assert np.array_equal(a, img)
 
 
+def test_records_with_uncompressed_frames_yield_the_same_batches(kitti_dir, tmp_path):
+    """build_records --image-format bmp re-encodes the frames without compression (a first epoch is bound by PNG inflate otherwise);
+    the pipeline yields the same batches from those records, and the stored bytes are a BMP file (what tf.io.decode_image, the
+    reference's decoder at data/input_pipeline.py:112, reads as well)."""
+    BR.main(["--images-dir", str(kitti_dir / "image_2"), "--labels-dir", str(kitti_dir / "label_2"), "--output-dir", str(tmp_path / "bmp"),
+             "--validation-set-size", "2", "--image-format", "bmp"])
+    c = IP.InputPipelineCreator(7, (20, 60, 3))
+    for split in ("train", "valid"):
+        png = [tuple(t.numpy().copy() for t in b) for b in c.create_input_pipeline(str(kitti_dir / "rec" / (split + ".tfrecord")), batch_size=2)]
+        bmp = [tuple(t.numpy().copy() for t in b) for b in c.create_input_pipeline(str(tmp_path / "bmp" / (split + ".tfrecord")), batch_size=2)]
+        assert len(png) == len(bmp) and all(np.array_equal(x, y) for a, b in zip(png, bmp) for x, y in zip(a, b))
+    first = TFR.parse_example(next(TFR.read_records(str(tmp_path / "bmp" / "train.tfrecord"))))
+    enc = first["image/encoded"]
+    enc = enc[0] if isinstance(enc, list) else enc
+    assert enc[:2] == b"BM" and len(enc) >= 20 * 60 * 3
+    with pytest.raises(SystemExit):
+        BR.parse_args(["--images-dir", "a", "--labels-dir", "b", "--image-format", "jpeg"])      # lossy: not offered
+
+
 # ------------------------------------------------------------------------------------------------------------- driver
 def test_driver_command_line_and_checkpoint_manager(tmp_path):
     sys.path.insert(0, ROOT)

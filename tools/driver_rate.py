@@ -86,6 +86,24 @@ def main():
                                            "records_decoded_in_the_timed_part": pipe.decoded - before}
             print(json.dumps({"progress": "pipeline", name: out["pipeline_alone"][name]}), file=sys.stderr, flush=True)
 
+        # the same frames stored without compression (build_records --image-format bmp): what a first epoch costs without the inflate
+        BR.main(["--images-dir", os.path.join(tmp, "image_2"), "--labels-dir", os.path.join(tmp, "label_2"),
+                 "--output-dir", os.path.join(tmp, "rec_bmp"), "--validation-set-size", "4", "--image-format", "bmp"])
+        for workers in (1, 16):
+            pipe = creator.create_input_pipeline(os.path.join(tmp, "rec_bmp", "train.tfrecord"), batch_size=args.batch, training=True, seed=1,
+                                                 num_workers=workers, cache_bytes=0)
+            it = iter(pipe)
+            for _ in range(5):
+                next(it)
+            t0 = time.perf_counter()
+            for _ in range(80):
+                next(it)
+            dt = time.perf_counter() - t0
+            it.close()
+            out["pipeline_alone"]["bmp_records_decode_%d_thread%s" % (workers, "s" if workers > 1 else "")] = {
+                "images_per_s": round(80 * args.batch / dt, 1), "ms_per_batch": round(dt / 80 * 1e3, 2)}
+        out["bmp_bytes_per_frame"] = int(os.path.getsize(os.path.join(tmp, "rec_bmp", "train.tfrecord")) / (args.frames - 4))
+
         def driver(steps, metrics_every, tag):
             d = os.path.join(tmp, tag)
             argv = ["--train-data-path", rec, "--valid-data-path", os.path.join(tmp, "rec", "valid.tfrecord"), "--logs-dir", os.path.join(d, "logs"),
