@@ -160,6 +160,7 @@ class FasterRCNN:
         if self._train.neck is not None:
             self._train.neck.init_weights(seed + 3)
         self._weights_dirty = True
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
 
     def set_weights(self, weights):
         """dict Keras-variable-name -> array in Keras layout (see oracle/faster_rcnn.py for the names)."""
@@ -169,6 +170,7 @@ class FasterRCNN:
         if self._train.neck is not None:
             self._train.neck.set_weights(weights)
         self._weights_dirty = True
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
 
     def get_weights(self):
         out = {}
@@ -615,6 +617,7 @@ class FasterRCNN:
         proposals_override (tests): fp32 CUDA [B,P,4] relative boxes that replace the proposal NMS's output inside the step
         (_inject_proposals_plan); a model steps either always with or always without one (the plan is rebuilt on a change)."""
         b = int(images.shape[0])
+        self._weights_epoch += 1                  # (test_step re-derives its modules' weight copies when this has moved)
         inject = proposals_override is not None
         if inject and not (proposals_override.is_cuda and proposals_override.dtype == torch.float32):
             raise TypeError("proposals_override: float32 CUDA tensor [B, P, 4] expected")
@@ -730,6 +733,7 @@ class FasterRCNN:
             st.stats[k].copy_(v)
         if fp8_scales and s.get("fp8") is not None:
             self.set_fp8_state(s["fp8"])
+        self._weights_epoch += 1
         self._sync_derived_weights(self._train)
 
     def get_fp8_state(self):
@@ -763,10 +767,25 @@ class FasterRCNN:
         if self._eval_plan is None or self._eval_plan["batch"] != b:
             self._eval_plan = self._build(self._eval, b, False, None)
         built = self._eval_plan
-        self._sync_derived_weights(self._eval)
+        if built.get("weights_version") != self._weights_version():
+            # once per change of the weights (a validation pass after an epoch of training), not per step: the evaluation modules' own
+            # re-laid-out copies (packed stem, transposed heads) from the masters the train step keeps current
+            self._sync_derived_weights(self._eval)
+            built["weights_version"] = self._weights_version()
         self._feed(built, images, gt_labels, gt_boxes)
-        built["plan"].run()
+        plan = built["plan"]
+        if plan.captured:
+            plan.replay()                        # the evaluation step as one hipGraph, like the train step (eager: 150 launches from
+        else:                                    # Python, 4.5 ms an image in the driver's validation pass against 1.x replayed)
+            plan.run()
+            if self.use_graphs and not built.get("capture_tried"):
+                built["capture_tried"] = True
+                plan.capture()                   # (capturing executes nothing: the eager run's results stay in the static buffers)
         return self._losses_dict(built), built["preds"]
+
+    def _weights_version(self):
+        """Changes whenever the masters may have: every train step, set_weights / init_weights, a restored snapshot."""
+        return self._weights_epoch
 
     def __call__(self, images, training=False):
         """reference faster_rcnn.py:39-57: returns (rpn_output, rcnn_output) dicts."""

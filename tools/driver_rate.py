@@ -104,11 +104,11 @@ def main():
                 "images_per_s": round(80 * args.batch / dt, 1), "ms_per_batch": round(dt / 80 * 1e3, 2)}
         out["bmp_bytes_per_frame"] = int(os.path.getsize(os.path.join(tmp, "rec_bmp", "train.tfrecord")) / (args.frames - 4))
 
-        def driver(steps, metrics_every, tag):
+        def driver(steps, metrics_every, tag, steps_per_epoch=1000000, valid=None):
             d = os.path.join(tmp, tag)
-            argv = ["--train-data-path", rec, "--valid-data-path", os.path.join(tmp, "rec", "valid.tfrecord"), "--logs-dir", os.path.join(d, "logs"),
+            argv = ["--train-data-path", rec, "--valid-data-path", valid or os.path.join(tmp, "rec", "valid.tfrecord"), "--logs-dir", os.path.join(d, "logs"),
                     "--save-dir", os.path.join(d, "save"), "--checkpoints-dir", os.path.join(d, "ck"), "--num-steps", str(steps),
-                    "--num-steps-per-epoch", "1000000", "--batch-size", str(args.batch), "--learning-rates", "1e-5", "--decay-steps",
+                    "--num-steps-per-epoch", str(steps_per_epoch), "--batch-size", str(args.batch), "--learning-rates", "1e-5", "--decay-steps",
                     "--metrics-every", str(metrics_every)]
             t0 = time.perf_counter()
             T.main(argv)
@@ -125,6 +125,15 @@ def main():
             out["driver_loop"][name] = {"run_s": [round(ts, 2), round(tl, 2)], "steps": [args.short, args.long], "ms_per_step": round(ms, 3),
                                         "images_per_s": round(args.batch / ms * 1e3, 1)}
             print(json.dumps({"progress": "driver", name: out["driver_loop"][name]}), file=sys.stderr, flush=True)
+        # the validation pass of an epoch (test_step at batch 1 + its metric updates + the first image's summaries) over the training
+        # records: 12 passes against 4 (the evaluation plan's build / capture and the first pass's decoding cancel), the 400 extra training
+        # steps taken off at the rate measured above
+        n_valid = args.frames - 4
+        t4 = driver(200, 1, "v4", steps_per_epoch=50, valid=rec)
+        t12 = driver(600, 1, "v12", steps_per_epoch=50, valid=rec)
+        train_s = 400 * out["driver_loop"]["metrics_every_step"]["ms_per_step"] * 1e-3
+        out["validation_pass"] = {"records": n_valid, "run_s": [round(t4, 2), round(t12, 2)], "passes": [4, 12],
+                                  "ms_per_image": round((t12 - t4 - train_s) / (8 * n_valid) * 1e3, 3)}
     print(json.dumps(out))
 
 
