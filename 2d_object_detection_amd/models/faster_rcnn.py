@@ -773,14 +773,10 @@ class FasterRCNN:
             self._sync_derived_weights(self._eval)
             built["weights_version"] = self._weights_version()
         self._feed(built, images, gt_labels, gt_boxes)
-        plan = built["plan"]
-        if plan.captured:
-            plan.replay()                        # the evaluation step as one hipGraph, like the train step (eager: 150 launches from
-        else:                                    # Python, 4.5 ms an image in the driver's validation pass against 1.x replayed)
-            plan.run()
-            if self.use_graphs and not built.get("capture_tried"):
-                built["capture_tried"] = True
-                plan.capture()                   # (capturing executes nothing: the eager run's results stay in the static buffers)
+        # (eager on purpose: replaying a captured evaluation plan was tried at the end of round 5 -- tools/driver_rate.py's validation leg
+        # then crashed in the NEXT model built in the same process, after the first model and its evaluation graph had been released;
+        # not understood, not kept)
+        built["plan"].run()
         return self._losses_dict(built), built["preds"]
 
     def _weights_version(self):
